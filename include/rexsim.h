@@ -1,0 +1,165 @@
+/*
+ * rexsim.h -- C ABI of the MI355X-native batched Rex simulator (librexsim_hip.so).
+ *
+ * This is the drop-in boundary for ONE hot path of nicrusso7/rex-gym: what the reference does
+ * per environment through `RexGymEnv.step()/reset()` (rex_gym/envs/rex_gym_env.py:296-414), i.e.
+ *   envs/gym/walk_env.py:246-324   action -> staged gait parameters -> 12 joint targets
+ *   model/gait_planner.py:96-134   Bezier/stance foot trajectories
+ *   model/kinematics.py:104-142    closed-form leg IK
+ *   model/rex.py:158-163,568-641   Step / ApplyAction (action_repeat x motor model + torque)
+ *   model/motor.py:76-143          DC-motor PD actuator
+ *   pybullet.stepSimulation        (third-party pybullet==2.8.3, requirements.txt:2)
+ *   model/rex.py:717-733           ReceiveObservation
+ *   envs/rex_gym_env.py:490-542    termination + reward, walk_env.py:356-362 observation
+ * is done here for N environments at once by hand-written gfx950 kernels, one env per lane.
+ *
+ * The reference has no FFI: its boundary is the Python Gym protocol.  The binding a maintainer
+ * adds is a ctypes stub; `rex_gym_amd/envs` is that stub plus the Gym surface.
+ *
+ * Conventions: every pointer named d_* is a DEVICE pointer (e.g. torch.Tensor.data_ptr()),
+ * owned by the caller.  `stream` is a hipStream_t passed as void* (NULL = default stream).
+ * All calls return 0 on success or a negative REX_E* code; nothing throws; `rex_last_error()`
+ * returns a thread-local message.  One host thread per RexSim.
+ */
+#ifndef REXSIM_H
+#define REXSIM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define REX_ABI_VERSION 1
+
+/* tasks (reference env classes) */
+#define REX_TASK_WALK   0   /* envs/gym/walk_env.py   RexWalkEnv      */
+#define REX_TASK_GALLOP 1   /* envs/gym/gallop_env.py RexReactiveEnv  */
+#define REX_TASK_TURN   2   /* envs/gym/turn_env.py   RexTurnEnv      */
+/* signal_type kwarg of the reference envs */
+#define REX_SIGNAL_IK 0
+#define REX_SIGNAL_OL 1
+
+#define REX_NUM_MOTORS 12
+
+/* error codes */
+#define REX_OK          0
+#define REX_EINVAL     -1   /* bad argument / config */
+#define REX_EHIP       -2   /* HIP runtime error (message in rex_last_error) */
+#define REX_ENODEV     -3   /* no usable gfx950 device */
+#define REX_ENOMEM     -4
+
+/*
+ * Per-env persistent state: SoA, float32 words, word-major ([REX_STATE_WORDS][num_envs]) so that
+ * lane i of a wavefront reads word w of env i at d_state[w * num_envs + i] (coalesced).
+ * Integer words are stored as raw int32 bits.
+ */
+enum RexStateWord {
+  REX_S_POS      = 0,   /* 3: base position, world [m]                   (getBasePositionAndOrientation) */
+  REX_S_QUAT     = 3,   /* 4: base orientation x,y,z,w                                                  */
+  REX_S_LINVEL   = 7,   /* 3: base linear velocity, world                (getBaseVelocity)               */
+  REX_S_ANGVEL   = 10,  /* 3: base angular velocity, world                                               */
+  REX_S_Q        = 13,  /* 12: motor angles, order of model/mark_constants.py:3-8                        */
+  REX_S_QD       = 25,  /* 12: motor velocities                                                          */
+  REX_S_PHI      = 37,  /* gait phase            (GaitPlanner._phi,       gait_planner.py:10)            */
+  REX_S_LASTT    = 38,  /* gait phase origin     (GaitPlanner._last_time, gait_planner.py:12)            */
+  REX_S_ALPHA    = 39,  /* gait rotation carry   (GaitPlanner._alpha,     gait_planner.py:13)            */
+  REX_S_TARGET   = 40,  /* episode target (x position, or yaw for turn)  (walk_env.py:143-147)           */
+  REX_S_ENDTIME  = 41,  /* time the goal was reached                     (walk_env.py:213)               */
+  REX_S_AUX      = 42,  /* task scratch (turn: start yaw)                                                */
+  REX_S_FLAGS    = 43,  /* int: REX_F_* bits                                                             */
+  REX_S_STEPS    = 44,  /* int: env steps this episode (RexGymEnv._env_step_counter)                     */
+  REX_S_EPISODE  = 45,  /* int: episodes started (RNG counter)                                           */
+  REX_S_MOTOR_EN = 46,  /* int: bit i = motor i enabled (Rex._motor_enabled_list, rex.py:302)            */
+  REX_S_OVERHEAT = 47,  /* 6 ints: 12 x u16 overheat counters, motor 2k in low half (rex.py:301,601-608) */
+  REX_STATE_WORDS = 53
+};
+
+#define REX_F_GOAL_REACHED   1u   /* walk_env.py:211 */
+#define REX_F_TERMINATING    2u   /* walk_env.py:214 */
+#define REX_F_STAY_STILL     4u   /* walk_env.py:280 */
+#define REX_F_BACKWARDS      8u   /* walk_env.py:133-136 (episode draw or fixed) */
+#define REX_F_DONE          16u   /* last step returned done; must be reset before the next step */
+#define REX_F_REWARD_ABS    32u   /* target already folded to abs() by _reward (rex_gym_env.py:510) */
+
+typedef struct RexConfig {
+  int32_t abi_version;        /* REX_ABI_VERSION */
+  int32_t num_envs;           /* envs in THIS shard */
+  int32_t env_index_base;     /* global index of local env 0 (multi-GPU shards): RNG streams are
+                                 keyed by the global index so results do not depend on sharding */
+  int32_t task;               /* REX_TASK_*   */
+  int32_t signal;             /* REX_SIGNAL_* */
+  int32_t action_repeat;      /* 5 (walk/turn) or 6 (gallop)  -- walk_env.py:35 */
+  int32_t solver_iterations;  /* int(300 / action_repeat)     -- rex_gym_env.py:25,184 */
+  float   sim_time_step;      /* control_time_step / action_repeat = 0.001 -- rex_gym_env.py:172 */
+  float   motor_kp;           /* 1.0  -- walk_env.py:39 */
+  float   motor_kd;           /* 0.02 -- walk_env.py:40 */
+  int32_t backwards;          /* -1: draw per episode (reference None), 0/1: fixed -- walk_env.py:133 */
+  float   target_position;    /* 0: draw per episode U(1,3) (or -U(2,3) backwards) -- walk_env.py:143 */
+  uint64_t seed;              /* Philox key */
+  int32_t auto_reset;         /* 1: an env that returns done is reset in the same launch and the
+                                 returned observation is the first one of the new episode */
+  int32_t max_episode_steps;  /* 0: off; else done at this many steps (LimitDuration, wrappers.py:268) */
+  /* reward weights -- rex_gym_env.py:56-59 */
+  float   distance_weight, energy_weight, drift_weight, shake_weight;
+  int32_t reserved[8];
+} RexConfig;
+
+typedef struct RexSim RexSim;
+
+/* Fill *cfg with the reference defaults of `task`/`signal` for `num_envs` envs. */
+int rex_default_config(int task, int signal, int num_envs, RexConfig* cfg);
+
+/* Dimensions implied by a config (action/observation vector lengths of the reference env). */
+int rex_action_dim(const RexConfig* cfg);
+int rex_obs_dim(const RexConfig* cfg);
+
+/* Create a simulator on HIP device `device`. `d_state` is a caller-owned device buffer of
+ * REX_STATE_WORDS * num_envs float32 words; the library never allocates per-env memory.
+ * Computes the settled reset snapshot (rex.py:314-323: 100 + 500 substeps holding the init
+ * pose) once, on the device, with the same kernels. */
+int rex_create(const RexConfig* cfg, int device, float* d_state, void* stream, RexSim** out);
+int rex_destroy(RexSim* sim);
+
+/* Reset envs. d_indices == NULL: all envs. Else n int32 env indices (device).  Writes the first
+ * observation of each reset env to d_obs[row * obs_dim] where row = position in d_indices (or the
+ * env index when d_indices is NULL).  Mirrors RexWalkEnv.reset (walk_env.py:125-154). */
+int rex_reset(RexSim* sim, const int32_t* d_indices, int n, float* d_obs, void* stream);
+
+/* One env.step() for every env (rex_gym_env.py:369-414):
+ *   d_action [N, action_dim] in  -- raw env action (NOT range-normalised)
+ *   d_obs    [N, obs_dim]    out
+ *   d_reward [N]             out
+ *   d_done   [N] uint8       out
+ *   d_motor_cmd [N, 12]      out, nullable -- info['action'], the 12 motor targets
+ */
+int rex_step(RexSim* sim, const float* d_action, float* d_obs, float* d_reward,
+             uint8_t* d_done, float* d_motor_cmd, void* stream);
+
+/* HIP event timing of the last rex_step launch on its own stream (ms); needs rex_set_timing(1). */
+int rex_set_timing(RexSim* sim, int enable);
+int rex_last_step_ms(RexSim* sim, float* ms);
+
+/* ---- controller-only entry points (parity tests of the controller half) ----
+ * n independent problems, row-major device arrays, all float32. */
+/* model/kinematics.py:104-142 -- orn[n,3], pos[n,3], frames[n,4,3] (FR,FL,RR,RL) ->
+ * angles[n,4,3] in the same leg order (theta, -alpha, -gamma) */
+int rex_ik_solve(int n, const float* d_orn, const float* d_pos, const float* d_frames,
+                 float* d_angles, void* stream);
+/* model/motor.py:76-143 -- cmd,q,qd,qd_true [n] -> actual, observed torque [n] */
+int rex_motor_torque(int n, const float* d_cmd, const float* d_q, const float* d_qd,
+                     const float* d_qd_true, float kp, float kd,
+                     float* d_actual, float* d_observed, void* stream);
+/* model/gait_planner.py:96-134 with the phase clock on explicit time `now`.
+ * mode: 0 walk, 1 gallop.  d_planner [n,3] = (phi, last_time, alpha) in/out; params[n,6] =
+ * (v, angle_deg, w_rot, period, direction, now); frames_out[n,4,3] (FR,FL,RR,RL). */
+int rex_gait_loop(int n, int mode, float* d_planner, const float* d_params,
+                  float* d_frames_out, void* stream);
+
+const char* rex_last_error(void);
+int rex_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REXSIM_H */

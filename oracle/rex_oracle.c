@@ -1,0 +1,1077 @@
+/*
+ * rex_oracle.c -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may load this library.
+ * The product path (rex_gym_amd + librexsim_hip.so) never imports, links or calls it.
+ *
+ * What it restates, function by function, of nicrusso7/rex-gym @ v0.2.7 (/root/reference):
+ *   orc_ik_*        rex_gym/model/kinematics.py:28-142
+ *   orc_gait_*      rex_gym/model/gait_planner.py:22-134 (phase clock moved from wall time to an
+ *                   explicit `now`)
+ *   orc_motor_*     rex_gym/model/motor.py:76-143
+ *   env logic       rex_gym/envs/gym/walk_env.py:125-154,207-324,326-362,
+ *                   rex_gym/envs/gym/gallop_env.py:142-160,212-329,349-356,
+ *                   rex_gym/envs/rex_gym_env.py:369-414,490-542, rex_gym/model/rex.py:158-163,
+ *                   296-324,568-641,717-733
+ *   physics         pybullet==2.8.3 (requirements.txt:2) is a third-party C++ dependency that is
+ *                   NOT vendored in the reference and NOT installable here.  Its published
+ *                   algorithm is restated: Featherstone articulated-body forward dynamics
+ *                   (btMultiBody::computeAccelerationsArticulatedBodyAlgorithmMultiDof), contact rows
+ *                   with ABA unit-impulse responses (calcAccelerationDeltasMultiDof) solved by
+ *                   projected Gauss-Seidel in Bullet's row order (btMultiBodyConstraintSolver),
+ *                   semi-implicit Euler.  SURVEY.md section 9.2 lists the Bullet behaviours assumed.
+ *
+ * PARITY STATUS: the controller half is pinned against golden vectors generated from the
+ * reference's own numpy code (tests/golden/).  The physics half is **parity unpinned**: no
+ * PyBullet here, no golden trajectories in the reference.
+ *
+ * Build: `make -C oracle` -> oracle/_build/librex_oracle_f64.so (REAL=double) and _f32.so (float).
+ * The physics deliberately uses a DIFFERENT formulation (body-coordinate spatial ABA, dense 18-dof
+ * delta-velocity PGS) from the HIP kernels (world-aligned CRBA + Cholesky-whitened PGS), so that
+ * agreement between the two is evidence for both.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/rexsim.h"              /* state-word layout + config struct (interface only) */
+#include "../rex_gym_amd/csrc/rex_model_gen.h" /* robot data compiled from rex.urdf */
+
+#ifndef REAL
+#define REAL double
+#endif
+typedef REAL real;
+
+#define NB REX_NB
+#define NJ REX_NJ
+#define NDOF (6 + NJ)
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* ---------- Bullet / PyBullet world parameters ---------- */
+#define GRAVITY_Z ((real)-10.0)          /* rex_gym_env.py:314 */
+static real MB_LINEAR_DAMPING = (real)0.04;  /* btMultiBody default, 9.2-4 */
+static real MB_ANGULAR_DAMPING = (real)0.04; /* (variables only so the conservation tests can zero them) */
+#define MB_MAX_COORD_VEL ((real)100.0)   /* btMultiBody::m_maxCoordinateVelocity */
+#define CONTACT_ERP ((real)0.2)          /* btContactSolverInfo::m_erp2 */
+#define CONTACT_BREAKING ((real)0.02)    /* gContactBreakingThreshold */
+static real FRICTION_MU = (real)0.5;      /* toe 0.5 x plane 1.0, 9.2-7 (variable for sensitivity probes) */
+#define ROBOT_INIT_Z ((real)0.21)        /* terrain.py:14-20 */
+
+static real DBG_JOINT_FRICTION = 0, DBG_JOINT_VISC = 0; /* sensitivity probe only (off by default) */
+static real clampr(real x, real lo, real hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+/* =====================================================================================
+ *                         controller: inverse kinematics
+ * ===================================================================================== */
+#define IK_L ((real)0.23)
+#define IK_W ((real)0.075)
+#define IK_HIP ((real)0.055)
+#define IK_LEG ((real)0.10652)
+#define IK_FOOT ((real)0.145)
+#define IK_YDIST ((real)0.185)
+#define IK_HEIGHT ((real)0.2)
+
+/* kinematics.py:48-68 : RT = Rx(roll) Ry(pitch) Rz(yaw) * Trans(pos); identity rotation when all
+ * three angles are exactly zero.  transform(coord) = RT * [coord;1] = R (coord + pos). */
+static void ik_transform(const real coord[3], const real orn[3], const real pos[3], real out[3]) {
+  real t[3] = {coord[0] + pos[0], coord[1] + pos[1], coord[2] + pos[2]};
+  if (orn[0] != 0 || orn[1] != 0 || orn[2] != 0) {
+    real cx = cos(orn[0]), sx = sin(orn[0]), cy = cos(orn[1]), sy = sin(orn[1]);
+    real cz = cos(orn[2]), sz = sin(orn[2]);
+    /* Rz */
+    real a0 = cz * t[0] - sz * t[1], a1 = sz * t[0] + cz * t[1], a2 = t[2];
+    /* Ry */
+    real b0 = cy * a0 + sy * a2, b1 = a1, b2 = -sy * a0 + cy * a2;
+    /* Rx */
+    out[0] = b0;
+    out[1] = cx * b1 - sx * b2;
+    out[2] = sx * b1 + cx * b2;
+  } else {
+    out[0] = t[0]; out[1] = t[1]; out[2] = t[2];
+  }
+}
+
+/* kinematics.py:80-102 */
+static void ik_leg(const real c[3], int right_side, real out[3]) {
+  const real hip = IK_HIP, leg = IK_LEG, foot = IK_FOOT;
+  real domain = (c[1] * c[1] + c[2] * c[2] - hip * hip + c[0] * c[0] - leg * leg - foot * foot) / (2 * foot * leg);
+  if (domain > 1) domain = (real)0.99;
+  else if (domain < -1) domain = (real)-0.99;
+  real gamma = atan2(-sqrt(1 - domain * domain), domain);
+  real sq = c[1] * c[1] + c[2] * c[2] - hip * hip;
+  if (sq < 0) sq = 0;
+  real alpha = atan2(-c[0], sqrt(sq)) - atan2(foot * sin(gamma), leg + foot * cos(gamma));
+  real hip_val = right_side ? -hip : hip;
+  real theta = -atan2(c[2], c[1]) - atan2(sqrt(sq), hip_val);
+  out[0] = theta; out[1] = -alpha; out[2] = -gamma;
+}
+
+/* kinematics.py:104-142.  frames: 4x3 rows FR,FL,RR,RL.  angles out: same leg order. */
+static void ik_solve(const real orn[3], const real pos[3], const real frames[12], real angles[12], real tframes[12]) {
+  const real hipv[4][3] = {{IK_L / 2, -IK_W / 2, 0}, {IK_L / 2, IK_W / 2, 0}, {-IK_L / 2, -IK_W / 2, 0}, {-IK_L / 2, IK_W / 2, 0}};
+  real inv_orn[3] = {-orn[0], -orn[1], -orn[2]}, inv_pos[3] = {-pos[0], -pos[1], -pos[2]};
+  for (int l = 0; l < 4; ++l) {
+    real hv[3], coord[3], tc[3];
+    ik_transform(hipv[l], orn, pos, hv);
+    for (int k = 0; k < 3; ++k) coord[k] = frames[3 * l + k] - hv[k];
+    ik_transform(coord, inv_orn, inv_pos, tc);
+    ik_leg(tc, (l % 2) == 0, &angles[3 * l]);
+    if (tframes) for (int k = 0; k < 3; ++k) tframes[3 * l + k] = hv[k] + tc[k];
+  }
+}
+
+ORC_API void orc_ik_solve(int n, const real* orn, const real* pos, const real* frames, real* angles, real* tframes) {
+  for (int i = 0; i < n; ++i)
+    ik_solve(orn + 3 * i, pos + 3 * i, frames + 12 * i, angles + 12 * i, tframes ? tframes + 12 * i : 0);
+}
+
+/* =====================================================================================
+ *                         controller: gait planner
+ * ===================================================================================== */
+typedef struct { real phi, last_time, alpha; } Gait;
+
+static real binom11(int k) { /* gait_planner.py:22-24 with n = 11 */
+  static const real f[12] = {1, 1, 2, 6, 24, 120, 720, 5040, 40320, 362880, 3628800, 39916800};
+  return f[11] / (f[k] * f[11 - k]);
+}
+
+/* gait_planner.py:30-40 */
+static void gait_stance(real phi_st, real v, real angle_deg, real out[3]) {
+  real c = cos(angle_deg * (real)(M_PI / 180.0)), s = sin(angle_deg * (real)(M_PI / 180.0));
+  const real A = (real)0.001, half_l = (real)0.05;
+  real p = half_l * (1 - 2 * phi_st);
+  out[0] = c * p * fabs(v);
+  out[1] = -s * p * fabs(v);
+  out[2] = -A * cos((real)M_PI / (2 * half_l) * p);
+}
+
+/* gait_planner.py:42-58: degree-11 Bernstein basis, only control points 0..9 are summed */
+static void gait_swing(real phi_sw, real v, real angle_deg, real direction, real out[3]) {
+  static const real PX[12] = {-0.04, -0.056, -0.06, -0.06, -0.06, 0., 0., 0., 0.06, 0.06, 0.056, 0.04};
+  static const real PZ[12] = {0., 0., 0.0405, 0.0405, 0.0405, 0.0405, 0.0405, 0.0495, 0.0495, 0.0495, 0., 0.};
+  real c = cos(angle_deg * (real)(M_PI / 180.0)), s = sin(angle_deg * (real)(M_PI / 180.0));
+  real av = fabs(v);
+  real sx = 0, sy = 0, sz = 0;
+  for (int i = 0; i < 10; ++i) {
+    real X = av * c * PX[i] * direction;
+    real Y = av * s * (-X);
+    real Z = av * PZ[i];
+    real b = binom11(i) * pow(phi_sw, (real)i) * pow(1 - phi_sw, (real)(11 - i));
+    sx += X * b; sy += Y * b; sz += Z * b;
+  }
+  out[0] = sx; out[1] = sy; out[2] = sz;
+}
+
+/* gait_planner.py:60-94 */
+static void gait_step_trajectory(Gait* g, real phi, real v, real angle, real w_rot, const real ctf[3], real direction, real coord[3]) {
+  const real step_offset = (real)0.5;
+  const real R2D = (real)(180.0 / M_PI);
+  if (phi >= 1) phi = phi - 1;
+  real r = sqrt(ctf[0] * ctf[0] + ctf[1] * ctf[1]);
+  real foot_angle = atan2(ctf[1], ctf[0]);
+  real circle;
+  if (w_rot >= 0) circle = 90 - (foot_angle - g->alpha) * R2D;
+  else circle = 270 - (foot_angle - g->alpha) * R2D;
+  real lng[3], rot[3];
+  if (phi <= step_offset) {
+    real ps = phi / step_offset;
+    gait_stance(ps, v, angle, lng);
+    gait_stance(ps, w_rot, circle, rot);
+  } else {
+    real ps = (phi - step_offset) / (1 - step_offset);
+    gait_swing(ps, v, angle, direction, lng);
+    gait_swing(ps, w_rot, circle, direction, rot);
+  }
+  real mag = atan2(sqrt(rot[0] * rot[0] + rot[1] * rot[1]), r);
+  if (ctf[1] > 0) g->alpha = (rot[0] < 0) ? -mag : mag;
+  else g->alpha = (rot[0] < 0) ? mag : -mag;
+  coord[0] = lng[0] + rot[0];
+  coord[1] = lng[1] + rot[1];
+  coord[2] = lng[2] + rot[2];
+}
+
+/* gait_planner.py:96-134; mode 0 = walk offsets, 1 = gallop offsets (gait_planner.py:15-20) */
+static void gait_loop(Gait* g, int mode, real v, real angle, real w_rot, real T, real direction, real now, real frame[12]) {
+  static const real OFF[2][4] = {{0., 0.5, 0.5, 0.}, {0., 0., 0.8, 0.8}};
+  const real base[4][3] = {{IK_L / 2, -IK_YDIST / 2, -IK_HEIGHT}, {IK_L / 2, IK_YDIST / 2, -IK_HEIGHT},
+                           {-IK_L / 2, -IK_YDIST / 2, -IK_HEIGHT}, {-IK_L / 2, IK_YDIST / 2, -IK_HEIGHT}};
+  if (T <= (real)0.01) T = (real)0.01;
+  if (g->phi >= (real)0.99) g->last_time = now;
+  g->phi = (now - g->last_time) / T;
+  for (int l = 0; l < 4; ++l) {
+    real sc[3];
+    gait_step_trajectory(g, g->phi + OFF[mode][l], v, angle, w_rot, base[l], direction, sc);
+    for (int k = 0; k < 3; ++k) frame[3 * l + k] = base[l][k] + sc[k];
+  }
+}
+
+/* planner: n x (phi,last_time,alpha) in/out; params: n x (v, angle, w_rot, T, direction, now) */
+ORC_API void orc_gait_loop(int n, int mode, real* planner, const real* params, real* frames) {
+  for (int i = 0; i < n; ++i) {
+    Gait g = {planner[3 * i], planner[3 * i + 1], planner[3 * i + 2]};
+    const real* p = params + 6 * i;
+    gait_loop(&g, mode, p[0], p[1], p[2], p[3], p[4], p[5], frames + 12 * i);
+    planner[3 * i] = g.phi; planner[3 * i + 1] = g.last_time; planner[3 * i + 2] = g.alpha;
+  }
+}
+
+/* =====================================================================================
+ *                         actuator model  (model/motor.py)
+ * ===================================================================================== */
+#define MOTOR_VOLTAGE ((real)32.0)
+#define MOTOR_RESISTANCE ((real)0.186)
+#define MOTOR_KT ((real)0.0954)
+#define MOTOR_VISCOUS ((real)0.0)
+#define MOTOR_VCLIP ((real)50.0)
+#define MOTOR_OBS_LIMIT ((real)5.7)
+#define OVERHEAT_TORQUE ((real)2.45) /* rex.py:13 */
+#define OVERHEAT_TIME ((real)1.0)    /* rex.py:14 */
+
+static void motor_torque(real cmd, real q, real qd, real qd_true, real kp, real kd, real* actual, real* observed) {
+  static const real CUR[7] = {0, 10, 20, 30, 40, 50, 60};
+  static const real TRQ[7] = {0, 1, 1.9, 2.45, 3.0, 3.25, 3.5};
+  real pwm = -1 * kp * (q - cmd) - kd * qd;                              /* motor.py:111 */
+  pwm = clampr(pwm, -1, 1);                                              /* :113 */
+  *observed = clampr(MOTOR_KT * (pwm * MOTOR_VOLTAGE / MOTOR_RESISTANCE), -MOTOR_OBS_LIMIT, MOTOR_OBS_LIMIT); /* :127-129 */
+  real vnet = clampr(pwm * MOTOR_VOLTAGE - (MOTOR_KT + MOTOR_VISCOUS) * qd_true, -MOTOR_VCLIP, MOTOR_VCLIP);  /* :132-135 */
+  real cur = vnet / MOTOR_RESISTANCE;
+  real sgn = (cur > 0) - (cur < 0);
+  real mag = fabs(cur);
+  real t;
+  if (mag >= CUR[6]) t = TRQ[6];                                          /* np.interp clamps */
+  else {
+    int k = 0;
+    while (k < 5 && mag >= CUR[k + 1]) ++k;
+    t = TRQ[k] + (TRQ[k + 1] - TRQ[k]) * (mag - CUR[k]) / (CUR[k + 1] - CUR[k]);
+  }
+  *actual = sgn * t;                                                      /* strength ratio 1.0 */
+}
+
+ORC_API void orc_motor_torque(int n, const real* cmd, const real* q, const real* qd, const real* qd_true,
+                              real kp, real kd, real* actual, real* observed) {
+  for (int i = 0; i < n; ++i) motor_torque(cmd[i], q[i], qd[i], qd_true[i], kp, kd, &actual[i], &observed[i]);
+}
+
+/* =====================================================================================
+ *                 quaternion helpers with PyBullet's conventions
+ * ===================================================================================== */
+static void quat_to_mat(const real q[4], real R[3][3]) { /* btMatrix3x3::setRotation */
+  real d = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+  real s = 2 / d;
+  real xs = q[0] * s, ys = q[1] * s, zs = q[2] * s;
+  real wx = q[3] * xs, wy = q[3] * ys, wz = q[3] * zs;
+  real xx = q[0] * xs, xy = q[0] * ys, xz = q[0] * zs;
+  real yy = q[1] * ys, yz = q[1] * zs, zz = q[2] * zs;
+  R[0][0] = 1 - (yy + zz); R[0][1] = xy - wz; R[0][2] = xz + wy;
+  R[1][0] = xy + wz; R[1][1] = 1 - (xx + zz); R[1][2] = yz - wx;
+  R[2][0] = xz - wy; R[2][1] = yz + wx; R[2][2] = 1 - (xx + yy);
+}
+
+static void quat_to_euler(const real q[4], real rpy[3]) { /* pybullet getEulerFromQuaternion */
+  real x = q[0], y = q[1], z = q[2], w = q[3];
+  real sqx = x * x, sqy = y * y, sqz = z * z, squ = w * w;
+  real sarg = -2 * (x * z - w * y);
+  if (sarg <= (real)-0.99999) {
+    rpy[1] = (real)(-0.5 * M_PI); rpy[0] = 0; rpy[2] = 2 * atan2(x, -y);
+  } else if (sarg >= (real)0.99999) {
+    rpy[1] = (real)(0.5 * M_PI); rpy[0] = 0; rpy[2] = 2 * atan2(-x, y);
+  } else {
+    rpy[1] = asin(sarg);
+    rpy[0] = atan2(2 * (y * z + w * x), squ - sqx - sqy + sqz);
+    rpy[2] = atan2(2 * (x * y + w * z), squ + sqx - sqy - sqz);
+  }
+}
+
+static void euler_to_quat(const real rpy[3], real q[4]) { /* btQuaternion::setEulerZYX + normalize */
+  real hr = rpy[0] * (real)0.5, hp = rpy[1] * (real)0.5, hy = rpy[2] * (real)0.5;
+  real cr = cos(hr), sr = sin(hr), cp = cos(hp), sp = sin(hp), cy = cos(hy), sy = sin(hy);
+  q[0] = sr * cp * cy - cr * sp * sy;
+  q[1] = cr * sp * cy + sr * cp * sy;
+  q[2] = cr * cp * sy - sr * sp * cy;
+  q[3] = cr * cp * cy + sr * sp * sy;
+  real n = 1 / sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  for (int k = 0; k < 4; ++k) q[k] *= n;
+}
+
+/* =====================================================================================
+ *       physics: articulated-body algorithm in body coordinates (spatial vectors [ang; lin])
+ * ===================================================================================== */
+typedef struct {
+  real pos[3], quat[4], linvel[3], angvel[3]; /* base, world frame */
+  real q[NJ], qd[NJ];
+} Phys;
+
+typedef struct {
+  real Rw[NB][3][3];   /* body -> world */
+  real pw[NB][3];      /* body origin, world */
+  real X[NB][6][6];    /* motion transform parent -> body */
+  real v[NB][6], c[NB][6];
+  real IA[NB][6][6], pA[NB][6];
+  real U[NB][6], Dinv[NB], u[NB];
+  real L0[6][6];       /* Cholesky factor of the base articulated inertia */
+  real a[NB][6];
+} Aba;
+
+static void cross3(const real a[3], const real b[3], real o[3]) {
+  o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
+}
+static real dot3(const real a[3], const real b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static void matvec3(const real R[3][3], const real v[3], real o[3]) {
+  for (int i = 0; i < 3; ++i) o[i] = R[i][0] * v[0] + R[i][1] * v[1] + R[i][2] * v[2];
+}
+static void matTvec3(const real R[3][3], const real v[3], real o[3]) {
+  for (int i = 0; i < 3; ++i) o[i] = R[0][i] * v[0] + R[1][i] * v[1] + R[2][i] * v[2];
+}
+
+/* spatial inertia of body i about its own origin, body axes */
+static void body_inertia6(int i, real I[6][6]) {
+  real m = (real)REX_MASS[i];
+  real c[3] = {(real)REX_COM[i][0], (real)REX_COM[i][1], (real)REX_COM[i][2]};
+  real Ic[3][3] = {{(real)REX_INERTIA[i][0], (real)REX_INERTIA[i][3], (real)REX_INERTIA[i][4]},
+                   {(real)REX_INERTIA[i][3], (real)REX_INERTIA[i][1], (real)REX_INERTIA[i][5]},
+                   {(real)REX_INERTIA[i][4], (real)REX_INERTIA[i][5], (real)REX_INERTIA[i][2]}};
+  real cc = dot3(c, c);
+  real hx[3][3] = {{0, -m * c[2], m * c[1]}, {m * c[2], 0, -m * c[0]}, {-m * c[1], m * c[0], 0}};
+  memset(I, 0, sizeof(real) * 36);
+  for (int r = 0; r < 3; ++r)
+    for (int s = 0; s < 3; ++s) {
+      I[r][s] = Ic[r][s] + m * ((r == s ? cc : 0) - c[r] * c[s]);
+      I[r][3 + s] = hx[r][s];
+      I[3 + r][s] = -hx[r][s];
+    }
+  for (int r = 0; r < 3; ++r) I[3 + r][3 + r] = m;
+}
+
+static void crf_apply(const real v[6], const real f[6], real o[6]) { /* v x* f */
+  real t1[3], t2[3];
+  cross3(v, f, t1); cross3(v + 3, f + 3, t2);
+  o[0] = t1[0] + t2[0]; o[1] = t1[1] + t2[1]; o[2] = t1[2] + t2[2];
+  cross3(v, f + 3, o + 3);
+}
+static void crm_apply(const real v[6], const real m[6], real o[6]) { /* v x m */
+  real t1[3], t2[3];
+  cross3(v, m, o);
+  cross3(v, m + 3, t1); cross3(v + 3, m, t2);
+  o[3] = t1[0] + t2[0]; o[4] = t1[1] + t2[1]; o[5] = t1[2] + t2[2];
+}
+static void mat6vec(const real M[6][6], const real v[6], real o[6]) {
+  for (int i = 0; i < 6; ++i) { real s = 0; for (int k = 0; k < 6; ++k) s += M[i][k] * v[k]; o[i] = s; }
+}
+static void mat6Tvec(const real M[6][6], const real v[6], real o[6]) {
+  for (int i = 0; i < 6; ++i) { real s = 0; for (int k = 0; k < 6; ++k) s += M[k][i] * v[k]; o[i] = s; }
+}
+
+/* Bullet's per-link damping, expressed as a bias force (force needed for zero acceleration) */
+static void add_damping(int i, const real v[6], real pA[6]) {
+  real m = (real)REX_MASS[i];
+  real c[3] = {(real)REX_COM[i][0], (real)REX_COM[i][1], (real)REX_COM[i][2]};
+  real wxc[3], vc[3];
+  cross3(v, c, wxc);
+  for (int k = 0; k < 3; ++k) vc[k] = v[3 + k] + wxc[k];
+  real sv = sqrt(dot3(vc, vc)), sw = sqrt(dot3(v, v));
+  real Iw[3] = {(real)REX_INERTIA[i][0] * v[0] + (real)REX_INERTIA[i][3] * v[1] + (real)REX_INERTIA[i][4] * v[2],
+                (real)REX_INERTIA[i][3] * v[0] + (real)REX_INERTIA[i][1] * v[1] + (real)REX_INERTIA[i][5] * v[2],
+                (real)REX_INERTIA[i][4] * v[0] + (real)REX_INERTIA[i][5] * v[1] + (real)REX_INERTIA[i][2] * v[2]};
+  real F[3], N[3], cxF[3];
+  for (int k = 0; k < 3; ++k) {
+    F[k] = m * vc[k] * (MB_LINEAR_DAMPING + MB_LINEAR_DAMPING * sv);
+    N[k] = Iw[k] * (MB_ANGULAR_DAMPING + MB_ANGULAR_DAMPING * sw);
+  }
+  cross3(c, F, cxF);
+  for (int k = 0; k < 3; ++k) { pA[k] += N[k] + cxF[k]; pA[3 + k] += F[k]; }
+}
+
+static int chol6(const real A[6][6], real L[6][6]) {
+  memset(L, 0, sizeof(real) * 36);
+  for (int j = 0; j < 6; ++j) {
+    real s = A[j][j];
+    for (int k = 0; k < j; ++k) s -= L[j][k] * L[j][k];
+    if (!(s > 0)) return -1;
+    L[j][j] = sqrt(s);
+    for (int i = j + 1; i < 6; ++i) {
+      real t = A[i][j];
+      for (int k = 0; k < j; ++k) t -= L[i][k] * L[j][k];
+      L[i][j] = t / L[j][j];
+    }
+  }
+  return 0;
+}
+static void chol6_solve(const real L[6][6], const real b[6], real x[6]) {
+  real y[6];
+  for (int i = 0; i < 6; ++i) { real s = b[i]; for (int k = 0; k < i; ++k) s -= L[i][k] * y[k]; y[i] = s / L[i][i]; }
+  for (int i = 5; i >= 0; --i) { real s = y[i]; for (int k = i + 1; k < 6; ++k) s -= L[k][i] * x[k]; x[i] = s / L[i][i]; }
+}
+
+/* forward kinematics + ABA; writes joint accelerations and base world accelerations */
+static void aba_forward(const Phys* s, const real tau[NJ], Aba* A, real qdd[NJ], real wdot_w[3], real vdot_w[3]) {
+  /* base */
+  quat_to_mat(s->quat, A->Rw[0]);
+  memcpy(A->pw[0], s->pos, sizeof(real) * 3);
+  matTvec3(A->Rw[0], s->angvel, A->v[0]);
+  matTvec3(A->Rw[0], s->linvel, A->v[0] + 3);
+  for (int i = 0; i < NB; ++i) {
+    if (i > 0) {
+      int p = REX_PARENT[i], ax = REX_JOINT_AXIS[i - 1];
+      real r[3] = {(real)REX_JOINT_POS[i - 1][0], (real)REX_JOINT_POS[i - 1][1], (real)REX_JOINT_POS[i - 1][2]};
+      real cq = cos(s->q[i - 1]), sq = sin(s->q[i - 1]);
+      real Rrel[3][3]; /* child -> parent rotation about the joint axis */
+      int a1 = (ax + 1) % 3, a2 = (ax + 2) % 3;
+      memset(Rrel, 0, sizeof(Rrel));
+      Rrel[ax][ax] = 1; Rrel[a1][a1] = cq; Rrel[a1][a2] = -sq; Rrel[a2][a1] = sq; Rrel[a2][a2] = cq;
+      real E[3][3];
+      for (int x = 0; x < 3; ++x) for (int y = 0; y < 3; ++y) E[x][y] = Rrel[y][x];
+      /* world pose */
+      for (int x = 0; x < 3; ++x)
+        for (int y = 0; y < 3; ++y) {
+          real t = 0; for (int k = 0; k < 3; ++k) t += A->Rw[p][x][k] * Rrel[k][y];
+          A->Rw[i][x][y] = t;
+        }
+      real rw[3]; matvec3(A->Rw[p], r, rw);
+      for (int k = 0; k < 3; ++k) A->pw[i][k] = A->pw[p][k] + rw[k];
+      /* X = [[E,0],[-E rx, E]] */
+      real rx[3][3] = {{0, -r[2], r[1]}, {r[2], 0, -r[0]}, {-r[1], r[0], 0}};
+      memset(A->X[i], 0, sizeof(real) * 36);
+      for (int x = 0; x < 3; ++x)
+        for (int y = 0; y < 3; ++y) {
+          A->X[i][x][y] = E[x][y];
+          A->X[i][3 + x][3 + y] = E[x][y];
+          real t = 0; for (int k = 0; k < 3; ++k) t += E[x][k] * rx[k][y];
+          A->X[i][3 + x][y] = -t;
+        }
+      mat6vec(A->X[i], A->v[p], A->v[i]);
+      real vJ[6] = {0, 0, 0, 0, 0, 0};
+      vJ[ax] = s->qd[i - 1];
+      A->v[i][ax] += s->qd[i - 1];
+      crm_apply(A->v[i], vJ, A->c[i]);
+    }
+    body_inertia6(i, A->IA[i]);
+    real Iv[6];
+    mat6vec(A->IA[i], A->v[i], Iv);
+    crf_apply(A->v[i], Iv, A->pA[i]);
+    add_damping(i, A->v[i], A->pA[i]);
+  }
+  for (int i = NB - 1; i >= 1; --i) {
+    int p = REX_PARENT[i], ax = REX_JOINT_AXIS[i - 1];
+    for (int k = 0; k < 6; ++k) A->U[i][k] = A->IA[i][k][ax];
+    real D = A->U[i][ax];
+    A->Dinv[i] = 1 / D;
+    A->u[i] = tau[i - 1] - A->pA[i][ax];
+    real Ia[6][6], pa[6], Iac[6];
+    for (int x = 0; x < 6; ++x) for (int y = 0; y < 6; ++y) Ia[x][y] = A->IA[i][x][y] - A->U[i][x] * A->U[i][y] * A->Dinv[i];
+    mat6vec(Ia, A->c[i], Iac);
+    for (int k = 0; k < 6; ++k) pa[k] = A->pA[i][k] + Iac[k] + A->U[i][k] * (A->u[i] * A->Dinv[i]);
+    /* IA_p += X^T Ia X ; pA_p += X^T pa */
+    real T[6][6];
+    for (int x = 0; x < 6; ++x) for (int y = 0; y < 6; ++y) { real t = 0; for (int k = 0; k < 6; ++k) t += Ia[x][k] * A->X[i][k][y]; T[x][y] = t; }
+    for (int x = 0; x < 6; ++x) for (int y = 0; y < 6; ++y) { real t = 0; for (int k = 0; k < 6; ++k) t += A->X[i][k][x] * T[k][y]; A->IA[p][x][y] += t; }
+    real pp[6]; mat6Tvec(A->X[i], pa, pp);
+    for (int k = 0; k < 6; ++k) A->pA[p][k] += pp[k];
+  }
+  chol6(A->IA[0], A->L0);
+  real nb[6];
+  for (int k = 0; k < 6; ++k) nb[k] = -A->pA[0][k];
+  chol6_solve(A->L0, nb, A->a[0]); /* acceleration relative to free fall (gravity handled as a field) */
+  for (int i = 1; i < NB; ++i) {
+    int p = REX_PARENT[i], ax = REX_JOINT_AXIS[i - 1];
+    mat6vec(A->X[i], A->a[p], A->a[i]);
+    for (int k = 0; k < 6; ++k) A->a[i][k] += A->c[i][k];
+    real Ua = 0; for (int k = 0; k < 6; ++k) Ua += A->U[i][k] * A->a[i][k];
+    qdd[i - 1] = A->Dinv[i] * (A->u[i] - Ua);
+    A->a[i][ax] += qdd[i - 1];
+  }
+  /* world-frame classical accelerations of the base */
+  real wxv[3], al[3];
+  cross3(A->v[0], A->v[0] + 3, wxv);
+  for (int k = 0; k < 3; ++k) al[k] = A->a[0][3 + k] + wxv[k];
+  matvec3(A->Rw[0], A->a[0], wdot_w);
+  matvec3(A->Rw[0], al, vdot_w);
+  vdot_w[2] += GRAVITY_Z;
+}
+
+/* impulse f_k (6, body-k coords) applied to body k -> generalized velocity change */
+static void impulse_response_at(const Aba* A, int kbody, const real fk[6], real out[NDOF]) {
+  real pA[NB][6], u[NB], da[NB][6];
+  memset(pA, 0, sizeof(pA));
+  for (int k = 0; k < 6; ++k) pA[kbody][k] = -fk[k];
+  for (int i = NB - 1; i >= 1; --i) {
+    int p = REX_PARENT[i], ax = REX_JOINT_AXIS[i - 1];
+    u[i] = -pA[i][ax];
+    real pa[6], pp[6];
+    for (int k = 0; k < 6; ++k) pa[k] = pA[i][k] + A->U[i][k] * (u[i] * A->Dinv[i]);
+    mat6Tvec(A->X[i], pa, pp);
+    for (int k = 0; k < 6; ++k) pA[p][k] += pp[k];
+  }
+  real nb[6];
+  for (int k = 0; k < 6; ++k) nb[k] = -pA[0][k];
+  chol6_solve(A->L0, nb, da[0]);
+  for (int k = 0; k < 6; ++k) out[k] = da[0][k];
+  for (int i = 1; i < NB; ++i) {
+    int p = REX_PARENT[i], ax = REX_JOINT_AXIS[i - 1];
+    mat6vec(A->X[i], da[p], da[i]);
+    real Ua = 0; for (int k = 0; k < 6; ++k) Ua += A->U[i][k] * da[i][k];
+    real dq = A->Dinv[i] * (u[i] - Ua);
+    out[6 + i - 1] = dq;
+    da[i][ax] += dq;
+  }
+}
+
+/* btPlaneSpace1 */
+static void plane_space(const real n[3], real p[3], real q[3]) {
+  if (fabs(n[2]) > (real)0.7071067811865475244) {
+    real a = n[1] * n[1] + n[2] * n[2], k = 1 / sqrt(a);
+    p[0] = 0; p[1] = -n[2] * k; p[2] = n[1] * k;
+    q[0] = a * k; q[1] = -n[0] * p[2]; q[2] = n[0] * p[1];
+  } else {
+    real a = n[0] * n[0] + n[1] * n[1], k = 1 / sqrt(a);
+    p[0] = -n[1] * k; p[1] = n[0] * k; p[2] = 0;
+    q[0] = -n[2] * p[1]; q[1] = n[2] * p[0]; q[2] = a * k;
+  }
+}
+
+#define MAX_POINTS 8
+#define MAX_ROWS (3 * MAX_POINTS)
+typedef struct {
+  real J[NDOF], resp[NDOF];
+  real rhs, invdiag, lo, hi, lambda;
+  int normal_row; /* for friction rows: index of the normal row that bounds them; -1 for normals */
+} Row;
+
+/* Jacobian row of world direction d at world point P on body kbody, in (base body coords, joints) */
+static void contact_jacobian(const Aba* A, int kbody, const real P[3], const real d[3], real J[NDOF], real fk[6]) {
+  real rel[3], pk[3], dk[3], phi[6];
+  for (int k = 0; k < 3; ++k) rel[k] = P[k] - A->pw[kbody][k];
+  matTvec3(A->Rw[kbody], rel, pk);
+  matTvec3(A->Rw[kbody], d, dk);
+  cross3(pk, dk, phi);
+  phi[3] = dk[0]; phi[4] = dk[1]; phi[5] = dk[2];
+  memcpy(fk, phi, sizeof(phi));
+  for (int k = 0; k < NDOF; ++k) J[k] = 0;
+  int i = kbody;
+  while (i > 0) {
+    J[6 + i - 1] = phi[REX_JOINT_AXIS[i - 1]];
+    real pp[6];
+    mat6Tvec(A->X[i], phi, pp);
+    memcpy(phi, pp, sizeof(pp));
+    i = REX_PARENT[i];
+  }
+  for (int k = 0; k < 6; ++k) J[k] = phi[k];
+}
+
+/* one 1 ms world step: the restated stepSimulation */
+static void physics_substep(Phys* s, const real tau[NJ], real dt, int iterations) {
+  static __thread Aba A;
+  real qdd[NJ], wdot[3], vdot[3];
+  aba_forward(s, tau, &A, qdd, wdot, vdot);
+  /* v <- v + dt a  (btMultiBodyDynamicsWorld::solveConstraints, before the constraint solve) */
+  for (int k = 0; k < 3; ++k) { s->angvel[k] += dt * wdot[k]; s->linvel[k] += dt * vdot[k]; }
+  for (int j = 0; j < NJ; ++j) s->qd[j] += dt * qdd[j];
+
+  /* generalized velocity in solver coordinates: base in body axes, then joints */
+  real nu[NDOF];
+  matTvec3(A.Rw[0], s->angvel, nu);
+  matTvec3(A.Rw[0], s->linvel, nu + 3);
+  for (int j = 0; j < NJ; ++j) nu[6 + j] = s->qd[j];
+
+  /* contact detection at the start-of-step pose: two end points of each toe cylinder vs z = 0 */
+  Row rows[MAX_ROWS];
+  int nrow = 0, npoint = 0;
+  int normal_of_point[MAX_POINTS];
+  real PtP[MAX_POINTS][3];
+  int PtBody[MAX_POINTS];
+  real PtDist[MAX_POINTS];
+  const real nrm[3] = {0, 0, 1};
+  const real rad = (real)REX_TOE_RADIUS + (real)REX_COLLISION_MARGIN;
+  for (int l = 0; l < REX_NLEG; ++l) {
+    int kb = REX_TOE_BODY[l];
+    real ctr[3] = {(real)REX_TOE_CENTER[l][0], (real)REX_TOE_CENTER[l][1], (real)REX_TOE_CENTER[l][2]};
+    real axl[3] = {(real)REX_TOE_AXIS[l][0], (real)REX_TOE_AXIS[l][1], (real)REX_TOE_AXIS[l][2]};
+    real cw[3], aw[3];
+    matvec3(A.Rw[kb], ctr, cw);
+    matvec3(A.Rw[kb], axl, aw);
+    for (int k = 0; k < 3; ++k) cw[k] += A.pw[kb][k];
+    real na = dot3(nrm, aw);
+    real dv[3] = {nrm[0] - na * aw[0], nrm[1] - na * aw[1], nrm[2] - na * aw[2]};
+    real dn = sqrt(dot3(dv, dv));
+    real inv = dn > (real)1e-9 ? 1 / dn : 0;
+    for (int e = 0; e < 2; ++e) {
+      real sgn = e == 0 ? (real)-1 : (real)1;
+      real P[3];
+      for (int k = 0; k < 3; ++k) P[k] = cw[k] + sgn * (real)REX_TOE_HALFLEN * aw[k] - rad * inv * dv[k];
+      real dist = P[2];
+      if (dist < CONTACT_BREAKING) {
+        memcpy(PtP[npoint], P, sizeof(P));
+        PtBody[npoint] = kb;
+        PtDist[npoint] = dist;
+        ++npoint;
+      }
+    }
+  }
+  /* rows: all normals first, then the friction pairs (Bullet's per-iteration order) */
+  real t1[3], t2[3];
+  plane_space(nrm, t1, t2);
+  for (int p = 0; p < npoint; ++p) {
+    Row* r = &rows[nrow];
+    real fk[6];
+    contact_jacobian(&A, PtBody[p], PtP[p], nrm, r->J, fk);
+    impulse_response_at(&A, PtBody[p], fk, r->resp);
+    real diag = 0, vel = 0;
+    for (int k = 0; k < NDOF; ++k) { diag += r->J[k] * r->resp[k]; vel += r->J[k] * nu[k]; }
+    r->invdiag = 1 / diag;
+    real pen = PtDist[p];
+    real poserr = 0, velerr = -vel;
+    if (pen > 0) velerr -= pen / dt; else poserr = -pen * CONTACT_ERP / dt;
+    r->rhs = (poserr + velerr) * r->invdiag;
+    r->lo = 0; r->hi = (real)1e10; r->lambda = 0; r->normal_row = -1;
+    normal_of_point[p] = nrow++;
+  }
+  for (int p = 0; p < npoint; ++p)
+    for (int d = 0; d < 2; ++d) {
+      Row* r = &rows[nrow];
+      real fk[6];
+      contact_jacobian(&A, PtBody[p], PtP[p], d == 0 ? t1 : t2, r->J, fk);
+      impulse_response_at(&A, PtBody[p], fk, r->resp);
+      real diag = 0, vel = 0;
+      for (int k = 0; k < NDOF; ++k) { diag += r->J[k] * r->resp[k]; vel += r->J[k] * nu[k]; }
+      r->invdiag = 1 / diag;
+      r->rhs = -vel * r->invdiag;
+      r->lambda = 0; r->normal_row = normal_of_point[p];
+      ++nrow;
+    }
+  /* projected Gauss-Seidel (btMultiBodyConstraintSolver::resolveSingleConstraintRowGeneric) */
+  real dv[NDOF];
+  for (int k = 0; k < NDOF; ++k) dv[k] = 0;
+  for (int it = 0; it < iterations; ++it) {
+    for (int i = 0; i < nrow; ++i) {
+      Row* r = &rows[i];
+      real lo = r->lo, hi = r->hi;
+      if (r->normal_row >= 0) { hi = FRICTION_MU * rows[r->normal_row].lambda; lo = -hi; }
+      real dvel = 0;
+      for (int k = 0; k < NDOF; ++k) dvel += r->J[k] * dv[k];
+      real dl = r->rhs - dvel * r->invdiag;
+      real sum = r->lambda + dl;
+      if (sum < lo) { dl = lo - r->lambda; sum = lo; }
+      else if (sum > hi) { dl = hi - r->lambda; sum = hi; }
+      r->lambda = sum;
+      for (int k = 0; k < NDOF; ++k) dv[k] += r->resp[k] * dl;
+    }
+  }
+  /* apply, clamp (btMultiBody::applyDeltaVeeMultiDof), integrate positions with the NEW velocities */
+  real dw[3], dl[3];
+  matvec3(A.Rw[0], dv, dw);
+  matvec3(A.Rw[0], dv + 3, dl);
+  for (int k = 0; k < 3; ++k) {
+    s->angvel[k] = clampr(s->angvel[k] + dw[k], -MB_MAX_COORD_VEL, MB_MAX_COORD_VEL);
+    s->linvel[k] = clampr(s->linvel[k] + dl[k], -MB_MAX_COORD_VEL, MB_MAX_COORD_VEL);
+  }
+  for (int j = 0; j < NJ; ++j) s->qd[j] = clampr(s->qd[j] + dv[6 + j], -MB_MAX_COORD_VEL, MB_MAX_COORD_VEL);
+  for (int k = 0; k < 3; ++k) s->pos[k] += dt * s->linvel[k];
+  for (int j = 0; j < NJ; ++j) s->q[j] += dt * s->qd[j];
+  /* orientation: q <- exp(w dt) * q  (world-frame angular velocity) */
+  real w = sqrt(dot3(s->angvel, s->angvel));
+  real ang = w * dt;
+  real sc;
+  if (w < (real)0.001) sc = (real)0.5 * dt - dt * dt * dt * (real)0.020833333333 * w * w;
+  else sc = sin((real)0.5 * ang) / w;
+  real dq[4] = {s->angvel[0] * sc, s->angvel[1] * sc, s->angvel[2] * sc, cos((real)0.5 * ang)};
+  real* q = s->quat;
+  real nq[4] = {dq[3] * q[0] + dq[0] * q[3] + dq[1] * q[2] - dq[2] * q[1],
+                dq[3] * q[1] - dq[0] * q[2] + dq[1] * q[3] + dq[2] * q[0],
+                dq[3] * q[2] + dq[0] * q[1] - dq[1] * q[0] + dq[2] * q[3],
+                dq[3] * q[3] - dq[0] * q[0] - dq[1] * q[1] - dq[2] * q[2]};
+  real nn = 1 / sqrt(nq[0] * nq[0] + nq[1] * nq[1] + nq[2] * nq[2] + nq[3] * nq[3]);
+  for (int k = 0; k < 4; ++k) q[k] = nq[k] * nn;
+}
+
+/* =====================================================================================
+ *                                   Philox4x32-10
+ * ===================================================================================== */
+static void philox4x32(uint32_t c[4], uint32_t k0, uint32_t k1) {
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+static float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+
+ORC_API void orc_philox(uint32_t* ctr4, uint32_t k0, uint32_t k1) { philox4x32(ctr4, k0, k1); }
+
+/* =====================================================================================
+ *                                   environments
+ * ===================================================================================== */
+static const real POSE_STAND[12] = {0., -0.88643435, 1.30197369, 0., -0.88643435, 1.30197369,
+                                    0., -0.88643435, 1.30197369, 0., -0.88643435, 1.30197369};
+static const real POSE_STAND_OL[12] = {0.15192765, -0.90412283, 1.48156545, -0.15192765, -0.90412283, 1.48156545,
+                                       0.15192765, -0.90412283, 1.48156545, -0.15192765, -0.90412283, 1.48156545};
+
+typedef struct {
+  Phys ph;
+  Gait gait;
+  real target, end_time, aux;
+  uint32_t flags;
+  int32_t steps, episode;
+  uint32_t motor_enabled;
+  uint16_t overheat[NJ];
+  real tau_obs[NJ]; /* Rex._observed_motor_torques (transient; not part of the persistent state) */
+} Env;
+
+typedef struct {
+  RexConfig cfg;
+  Env* envs;
+  Env snapshot; /* settled reset state (rex.py:296-324) */
+} Orc;
+
+static const real* init_pose(const RexConfig* c) { return c->signal == REX_SIGNAL_OL ? POSE_STAND_OL : POSE_STAND; }
+
+/* Rex.ApplyAction + stepSimulation + ReceiveObservation (rex.py:158-163,568-641) */
+static void rex_substep(const RexConfig* c, Env* e, const real cmd[NJ]) {
+  real tau[NJ];
+  for (int j = 0; j < NJ; ++j) {
+    real act, obs;
+    motor_torque(cmd[j], e->ph.q[j], e->ph.qd[j], e->ph.qd[j], (real)c->motor_kp, (real)c->motor_kd, &act, &obs);
+    if (fabs(act) > OVERHEAT_TORQUE) { if (e->overheat[j] < 65535) e->overheat[j]++; } else e->overheat[j] = 0;
+    if ((real)e->overheat[j] > OVERHEAT_TIME / (real)c->sim_time_step) e->motor_enabled &= ~(1u << j);
+    e->tau_obs[j] = obs;
+    tau[j] = ((e->motor_enabled >> j) & 1u) ? act : 0;
+    if (DBG_JOINT_FRICTION > 0 && (j % 3) != 1) tau[j] -= clampr(DBG_JOINT_VISC * e->ph.qd[j], -DBG_JOINT_FRICTION, DBG_JOINT_FRICTION);
+  }
+  physics_substep(&e->ph, tau, (real)c->sim_time_step, c->solver_iterations);
+}
+
+static void settle(Orc* o) {
+  Env* e = &o->snapshot;
+  memset(e, 0, sizeof(*e));
+  e->ph.pos[2] = ROBOT_INIT_Z;
+  e->ph.quat[3] = 1;
+  for (int j = 0; j < NJ; ++j) e->ph.q[j] = POSE_STAND[j]; /* ResetPose uses INIT_POSES[pose_id='stand'] */
+  e->motor_enabled = (1u << NJ) - 1;
+  for (int k = 0; k < 100; ++k) rex_substep(&o->cfg, e, POSE_STAND);      /* rex.py:315-318 */
+  int nreset = (int)((real)0.5 / (real)o->cfg.sim_time_step);             /* rex.py:319 */
+  for (int k = 0; k < nreset; ++k) rex_substep(&o->cfg, e, init_pose(&o->cfg));
+}
+
+static void env_observation(const RexConfig* c, const Env* e, real* obs) {
+  real rpy[3];
+  quat_to_euler(e->ph.quat, rpy);
+  obs[0] = rpy[0]; obs[1] = rpy[1]; obs[2] = e->ph.angvel[0]; obs[3] = e->ph.angvel[1];
+  if (c->task == REX_TASK_GALLOP) {
+    for (int j = 0; j < NJ; ++j) { /* MapToMinusPiToPi, rex.py:26-41 */
+      real a = fmod(e->ph.q[j], (real)(2 * M_PI));
+      if (a >= (real)M_PI) a -= (real)(2 * M_PI); else if (a < -(real)M_PI) a += (real)(2 * M_PI);
+      obs[4 + j] = a;
+    }
+  }
+}
+
+static void env_reset(Orc* o, int idx) {
+  const RexConfig* c = &o->cfg;
+  Env* e = &o->envs[idx];
+  int32_t episode = e->episode;
+  *e = o->snapshot;
+  e->episode = episode + 1;
+  e->gait.phi = 0; e->gait.last_time = 0; e->gait.alpha = 0;
+  uint32_t ctr[4] = {(uint32_t)e->episode, 0, 0, 0};
+  philox4x32(ctr, (uint32_t)c->seed ^ (uint32_t)(c->env_index_base + idx), (uint32_t)(c->seed >> 32));
+  e->flags = 0;
+  if (c->task == REX_TASK_WALK) {
+    int backwards = c->backwards < 0 ? (int)(ctr[0] >> 31) : c->backwards;     /* walk_env.py:133-136 */
+    if (backwards) e->flags |= REX_F_BACKWARDS;
+    if (c->target_position != 0.0f) e->target = (real)c->target_position;
+    else {                                                                      /* walk_env.py:143-147 */
+      float u = u01(ctr[1]);
+      e->target = backwards ? (real)(-2.0f - u) : (real)(1.0f + 2.0f * u);
+    }
+  } else if (c->task == REX_TASK_GALLOP) {
+    if (c->target_position != 0.0f) e->target = (real)c->target_position;
+    else e->target = (real)(1.0f + 2.0f * u01(ctr[1]));                         /* gallop_env.py:150-152 */
+  }
+  e->end_time = 0; e->aux = 0; e->steps = 0;
+}
+
+/* walk_env.py:229-244 */
+static real walk_gait_coeff(real t, real a0) { real p = (real)0.8 + a0; return (0 <= t && t <= p) ? t : (real)1.0; }
+static real walk_brake_coeff(real t, real a1, real end_t) {
+  real p = (real)0.8 + a1;
+  return (end_t <= t && t <= p + end_t) ? 1 - (t - end_t) : (real)0.0;
+}
+
+static void order_signal(const real ang[12], real cmd[12]) { /* FR,FL,RR,RL -> FL,FR,RL,RR (walk_env.py:284-289) */
+  for (int k = 0; k < 3; ++k) { cmd[k] = ang[3 + k]; cmd[3 + k] = ang[k]; cmd[6 + k] = ang[9 + k]; cmd[9 + k] = ang[6 + k]; }
+}
+
+static void walk_command(const RexConfig* c, Env* e, const real* action, real cmd[NJ]) {
+  const real* ip = init_pose(c);
+  if (e->flags & REX_F_STAY_STILL) { memcpy(cmd, ip, sizeof(real) * NJ); return; }       /* walk_env.py:318-319 */
+  real t = (real)(e->steps * c->action_repeat) * (real)c->sim_time_step;               /* rex.py:155-156 */
+  if (e->target != 0) {                                                                 /* walk_env.py:207-215 */
+    if (fabs(e->ph.pos[0]) >= fabs(e->target) - (real)0.15) {
+      e->flags |= REX_F_GOAL_REACHED;
+      if (!(e->flags & REX_F_TERMINATING)) { e->end_time = t; e->flags |= REX_F_TERMINATING; }
+    }
+  }
+  int backwards = (e->flags & REX_F_BACKWARDS) != 0;
+  if (c->signal == REX_SIGNAL_IK) {                                                     /* walk_env.py:252-290 */
+    real gait_coeff = walk_gait_coeff(t, action[0]);
+    real step = backwards ? (real)-0.3 : (real)0.6;
+    real period = backwards ? (real)0.5 : (real)0.65;
+    real base_x = backwards ? (real)0.0 : (real)0.01;
+    real pos[3] = {base_x, 0, 0}, orn[3] = {0, 0, 0};
+    real step_length = step * gait_coeff;
+    if (e->flags & REX_F_GOAL_REACHED) {
+      real b = walk_brake_coeff(t, action[1], e->end_time);
+      step_length *= b;
+      if (b == 0) e->flags |= REX_F_STAY_STILL;
+    }
+    real direction = step_length < 0 ? (real)-1.0 : (real)1.0;
+    real frames[12], ang[12];
+    gait_loop(&e->gait, 0, step_length, 0, 0, period, direction, t, frames);
+    ik_solve(orn, pos, frames, ang, 0);
+    order_signal(ang, cmd);
+  } else {                                                                              /* walk_env.py:292-315 */
+    real l_a = (real)0.1, f_a = (real)0.2;
+    const real period = (real)(1.0 / 8);
+    if (e->flags & REX_F_GOAL_REACHED) {
+      real b = walk_brake_coeff(t, 0, e->end_time);
+      l_a *= b; f_a *= b;
+      /* `coeff is 0.0` in the reference is an identity test that never holds for a computed
+       * float: _stay_still is never set on this branch */
+    }
+    real sc = walk_gait_coeff(t, 0);
+    l_a *= sc; f_a *= sc;
+    real l_ext = l_a * cos(2 * (real)M_PI / period * t), f_ext = f_a * cos(2 * (real)M_PI / period * t);
+    real pose[12] = {0, l_ext + action[0], f_ext + action[1], 0, -l_ext + action[2], -f_ext + action[3],
+                     0, -l_ext + action[4], -f_ext + action[5], 0, l_ext + action[6], f_ext + action[7]};
+    for (int j = 0; j < NJ; ++j) cmd[j] = ip[j] + pose[j];
+  }
+}
+
+/* gallop_env.py:234-249 */
+static real gallop_brake_coeff(real t, real a0, real end_t) {
+  real p = (real)1.0 + a0;
+  return (end_t <= t && t <= p + end_t) ? 1 - (t - end_t) : (real)0.0;
+}
+static real gallop_gait_coeff(real t, real a1) { real p = (real)1.0 + a1; return (0 <= t && t <= p) ? t : (real)1.0; }
+
+static void gallop_command(const RexConfig* c, Env* e, const real* action, real cmd[NJ]) {
+  if (e->flags & REX_F_STAY_STILL) { memcpy(cmd, POSE_STAND, sizeof(real) * NJ); return; } /* rex.initial_pose */
+  real t = (real)(e->steps * c->action_repeat) * (real)c->sim_time_step;
+  if (e->target != 0) {                                                                 /* gallop_env.py:212-220 */
+    if (fabs(e->ph.pos[0]) >= fabs(e->target)) {
+      e->flags |= REX_F_GOAL_REACHED;
+      if (!(e->flags & REX_F_TERMINATING)) { e->end_time = t; e->flags |= REX_F_TERMINATING; }
+    }
+  }
+  if (c->signal == REX_SIGNAL_IK) {                                                     /* gallop_env.py:257-285 */
+    real gait_coeff = gallop_gait_coeff(t, action[1]);
+    real pos[3] = {(real)0.01, 0, (real)-0.007}, orn[3] = {0, 0, 0};
+    real step_length = (real)1.3 * gait_coeff;
+    if (e->flags & REX_F_GOAL_REACHED) step_length *= gallop_brake_coeff(t, action[0], e->end_time);
+    real frames[12], ang[12];
+    gait_loop(&e->gait, 1, step_length, 0, 0, (real)0.3, (real)1.0, t, frames);
+    ik_solve(orn, pos, frames, ang, 0);
+    order_signal(ang, cmd);
+  } else {                                                                              /* gallop_env.py:287-304 */
+    real lp[4] = {action[0], action[1], action[2], action[3]};
+    if (e->flags & REX_F_GOAL_REACHED) {
+      real b = gallop_brake_coeff(t, 0, e->end_time);
+      for (int k = 0; k < 4; ++k) lp[k] *= b;
+    }
+    const real* ip = init_pose(c);
+    for (int l = 0; l < 4; ++l) {
+      cmd[3 * l] = ip[3 * l];
+      cmd[3 * l + 1] = ip[3 * l + 1] + (l < 2 ? lp[0] : lp[2]);
+      cmd[3 * l + 2] = ip[3 * l + 2] + (l < 2 ? lp[1] : lp[3]);
+    }
+  }
+}
+
+/* rex_gym_env.py:501-542 */
+static real base_reward(const RexConfig* c, Env* e) {
+  real x = -e->ph.pos[0];
+  if (c->backwards > 0) x = -x; /* `if self._backwards:` tests the constructor argument, not the episode draw */
+  real fwd;
+  e->target = fabs(e->target); /* rex_gym_env.py:510; _target_position is never None after reset() */
+  real T = e->target;
+  if (x > T + (real)0.15) fwd = T - x;
+  else if (T <= x && x <= T + (real)0.15) fwd = 1;
+  else if (x <= (real)0.05) fwd = 0;
+  else fwd = x / T;
+  real drift = -fabs(e->ph.pos[1]);
+  real rpy[3], qq[4], R[3][3];
+  quat_to_euler(e->ph.quat, rpy);  /* GetBaseOrientation: quat -> RPY -> quat (rex.py:530-537) */
+  euler_to_quat(rpy, qq);
+  quat_to_mat(qq, R);
+  real shake = -fabs(R[2][0] + R[2][1]);
+  real dotp = 0;
+  for (int j = 0; j < NJ; ++j) dotp += e->tau_obs[j] * e->ph.qd[j];
+  real energy = -fabs(dotp) * (real)c->sim_time_step;
+  return (real)c->distance_weight * fwd + (real)c->energy_weight * energy + (real)c->drift_weight * drift + (real)c->shake_weight * shake;
+}
+
+static int env_fallen(const RexConfig* c, const Env* e) {
+  real rpy[3];
+  quat_to_euler(e->ph.quat, rpy);
+  if (c->task == REX_TASK_GALLOP)                                       /* gallop_env.py:319-329 (true RPY) */
+    return fabs(rpy[0]) > (real)0.3 || fabs(rpy[1]) > (real)0.5;
+  real qq[4], R[3][3];                                                  /* walk_env.py:326-338 */
+  euler_to_quat(rpy, qq);
+  quat_to_mat(qq, R);
+  return R[2][2] < (real)0.85;
+}
+
+static void env_step(Orc* o, int idx, const real* action, real* obs, real* reward, uint8_t* done, real* motor_cmd) {
+  const RexConfig* c = &o->cfg;
+  Env* e = &o->envs[idx];
+  real cmd[NJ];
+  if (c->task == REX_TASK_GALLOP) gallop_command(c, e, action, cmd);
+  else walk_command(c, e, action, cmd);
+  for (int k = 0; k < c->action_repeat; ++k) rex_substep(c, e, cmd);    /* Rex.Step, rex.py:158-163 */
+  *reward = base_reward(c, e);
+  int d = env_fallen(c, e);
+  if (c->task == REX_TASK_GALLOP && e->ph.pos[1] > (real)0.3) d = 1;    /* gallop_env.py:315-317 */
+  e->steps += 1;
+  if (c->max_episode_steps > 0 && e->steps >= c->max_episode_steps) d = 1;
+  *done = (uint8_t)d;
+  if (motor_cmd) memcpy(motor_cmd, cmd, sizeof(real) * NJ);
+  if (d) e->flags |= REX_F_DONE;
+  if (d && c->auto_reset) env_reset(o, idx);
+  env_observation(c, e, obs);
+}
+
+/* ---------------------------------- batch API (mirrors include/rexsim.h) ---------------------------------- */
+ORC_API int orc_sizeof_real(void) { return (int)sizeof(real); }
+
+ORC_API int orc_obs_dim(const RexConfig* c) { return c->task == REX_TASK_GALLOP ? 16 : 4; }
+ORC_API int orc_action_dim(const RexConfig* c) {
+  if (c->task == REX_TASK_WALK) return c->signal == REX_SIGNAL_IK ? 2 : 8;
+  if (c->task == REX_TASK_GALLOP) return c->signal == REX_SIGNAL_IK ? 2 : 4;
+  return 2;
+}
+
+ORC_API void* orc_create(const RexConfig* cfg) {
+  Orc* o = (Orc*)calloc(1, sizeof(Orc));
+  o->cfg = *cfg;
+  o->envs = (Env*)calloc((size_t)cfg->num_envs, sizeof(Env));
+  settle(o);
+  return o;
+}
+ORC_API void orc_destroy(void* h) { Orc* o = (Orc*)h; free(o->envs); free(o); }
+
+ORC_API void orc_reset(void* h, const int32_t* indices, int n, real* obs) {
+  Orc* o = (Orc*)h;
+  int od = orc_obs_dim(&o->cfg);
+  int cnt = indices ? n : o->cfg.num_envs;
+  for (int r = 0; r < cnt; ++r) {
+    int idx = indices ? indices[r] : r;
+    env_reset(o, idx);
+    env_observation(&o->cfg, &o->envs[idx], obs + (size_t)r * od);
+  }
+}
+
+ORC_API void orc_step(void* h, const real* action, real* obs, real* reward, uint8_t* done, real* motor_cmd) {
+  Orc* o = (Orc*)h;
+  int od = orc_obs_dim(&o->cfg), ad = orc_action_dim(&o->cfg);
+  int n = o->cfg.num_envs;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+  for (int i = 0; i < n; ++i)
+    env_step(o, i, action + (size_t)i * ad, obs + (size_t)i * od, reward + i, done + i, motor_cmd ? motor_cmd + (size_t)i * NJ : 0);
+}
+
+/* state exchange: numeric values, word-major [REX_STATE_WORDS][N] as in rexsim.h (ints as numbers;
+ * overheat counters unpacked are NOT used here: words REX_S_OVERHEAT+k hold lo + 65536*hi) */
+ORC_API void orc_get_state(void* h, double* out) {
+  Orc* o = (Orc*)h;
+  int n = o->cfg.num_envs;
+  for (int i = 0; i < n; ++i) {
+    const Env* e = &o->envs[i];
+#define W(w) out[(size_t)(w) * n + i]
+    for (int k = 0; k < 3; ++k) { W(REX_S_POS + k) = e->ph.pos[k]; W(REX_S_LINVEL + k) = e->ph.linvel[k]; W(REX_S_ANGVEL + k) = e->ph.angvel[k]; }
+    for (int k = 0; k < 4; ++k) W(REX_S_QUAT + k) = e->ph.quat[k];
+    for (int j = 0; j < NJ; ++j) { W(REX_S_Q + j) = e->ph.q[j]; W(REX_S_QD + j) = e->ph.qd[j]; }
+    W(REX_S_PHI) = e->gait.phi; W(REX_S_LASTT) = e->gait.last_time; W(REX_S_ALPHA) = e->gait.alpha;
+    W(REX_S_TARGET) = e->target; W(REX_S_ENDTIME) = e->end_time; W(REX_S_AUX) = e->aux;
+    W(REX_S_FLAGS) = e->flags; W(REX_S_STEPS) = e->steps; W(REX_S_EPISODE) = e->episode;
+    W(REX_S_MOTOR_EN) = e->motor_enabled;
+    for (int k = 0; k < NJ / 2; ++k) W(REX_S_OVERHEAT + k) = (double)e->overheat[2 * k] + 65536.0 * (double)e->overheat[2 * k + 1];
+#undef W
+  }
+}
+
+ORC_API void orc_set_state(void* h, const double* in) {
+  Orc* o = (Orc*)h;
+  int n = o->cfg.num_envs;
+  for (int i = 0; i < n; ++i) {
+    Env* e = &o->envs[i];
+#define W(w) in[(size_t)(w) * n + i]
+    for (int k = 0; k < 3; ++k) { e->ph.pos[k] = (real)W(REX_S_POS + k); e->ph.linvel[k] = (real)W(REX_S_LINVEL + k); e->ph.angvel[k] = (real)W(REX_S_ANGVEL + k); }
+    for (int k = 0; k < 4; ++k) e->ph.quat[k] = (real)W(REX_S_QUAT + k);
+    for (int j = 0; j < NJ; ++j) { e->ph.q[j] = (real)W(REX_S_Q + j); e->ph.qd[j] = (real)W(REX_S_QD + j); }
+    e->gait.phi = (real)W(REX_S_PHI); e->gait.last_time = (real)W(REX_S_LASTT); e->gait.alpha = (real)W(REX_S_ALPHA);
+    e->target = (real)W(REX_S_TARGET); e->end_time = (real)W(REX_S_ENDTIME); e->aux = (real)W(REX_S_AUX);
+    e->flags = (uint32_t)W(REX_S_FLAGS); e->steps = (int32_t)W(REX_S_STEPS); e->episode = (int32_t)W(REX_S_EPISODE);
+    e->motor_enabled = (uint32_t)W(REX_S_MOTOR_EN);
+    for (int k = 0; k < NJ / 2; ++k) {
+      uint32_t v = (uint32_t)W(REX_S_OVERHEAT + k);
+      e->overheat[2 * k] = (uint16_t)(v & 0xFFFFu); e->overheat[2 * k + 1] = (uint16_t)(v >> 16);
+    }
+#undef W
+  }
+}
+
+ORC_API void orc_set_joint_friction(real f, real visc) { DBG_JOINT_FRICTION = f; DBG_JOINT_VISC = visc; }
+ORC_API void orc_set_friction(real mu) { FRICTION_MU = mu; }
+ORC_API void orc_set_damping(real lin, real ang) { MB_LINEAR_DAMPING = lin; MB_ANGULAR_DAMPING = ang; }
+
+/* ---- physics-only probes used by the oracle's own unit tests (tests/test_oracle_physics.py) ---- */
+/* state: pos3 quat4 linvel3 angvel3 q12 qd12 = 37 reals, in/out; tau 12 */
+ORC_API void orc_physics_substep(real* st, const real* tau, real dt, int iterations, int nsteps) {
+  Phys p;
+  memcpy(p.pos, st, sizeof(real) * 3); memcpy(p.quat, st + 3, sizeof(real) * 4);
+  memcpy(p.linvel, st + 7, sizeof(real) * 3); memcpy(p.angvel, st + 10, sizeof(real) * 3);
+  memcpy(p.q, st + 13, sizeof(real) * NJ); memcpy(p.qd, st + 25, sizeof(real) * NJ);
+  for (int k = 0; k < nsteps; ++k) physics_substep(&p, tau, dt, iterations);
+  memcpy(st, p.pos, sizeof(real) * 3); memcpy(st + 3, p.quat, sizeof(real) * 4);
+  memcpy(st + 7, p.linvel, sizeof(real) * 3); memcpy(st + 10, p.angvel, sizeof(real) * 3);
+  memcpy(st + 13, p.q, sizeof(real) * NJ); memcpy(st + 25, p.qd, sizeof(real) * NJ);
+}
+
+/* unconstrained accelerations (ABA) for a state: out = wdot_w3, vdot_w3, qdd12 */
+ORC_API void orc_forward_dynamics(const real* st, const real* tau, real* out) {
+  Phys p;
+  static __thread Aba A;
+  memcpy(p.pos, st, sizeof(real) * 3); memcpy(p.quat, st + 3, sizeof(real) * 4);
+  memcpy(p.linvel, st + 7, sizeof(real) * 3); memcpy(p.angvel, st + 10, sizeof(real) * 3);
+  memcpy(p.q, st + 13, sizeof(real) * NJ); memcpy(p.qd, st + 25, sizeof(real) * NJ);
+  aba_forward(&p, tau, &A, out + 6, out, out + 3);
+}
+
+/* total mechanical energy (kinetic + m g h) and world linear momentum, for conservation tests */
+ORC_API void orc_energy_momentum(const real* st, real* out /* E, px, py, pz */) {
+  Phys p;
+  static __thread Aba A;
+  real tau[NJ] = {0}, qdd[NJ], wd[3], vd[3];
+  memcpy(p.pos, st, sizeof(real) * 3); memcpy(p.quat, st + 3, sizeof(real) * 4);
+  memcpy(p.linvel, st + 7, sizeof(real) * 3); memcpy(p.angvel, st + 10, sizeof(real) * 3);
+  memcpy(p.q, st + 13, sizeof(real) * NJ); memcpy(p.qd, st + 25, sizeof(real) * NJ);
+  aba_forward(&p, tau, &A, qdd, wd, vd); /* fills Rw, pw, v (body spatial velocities) */
+  real E = 0, P[3] = {0, 0, 0};
+  for (int i = 0; i < NB; ++i) {
+    real I[6][6], Iv[6];
+    body_inertia6(i, I);
+    mat6vec(I, A.v[i], Iv);
+    real ke = 0; for (int k = 0; k < 6; ++k) ke += A.v[i][k] * Iv[k];
+    E += (real)0.5 * ke;
+    real c[3] = {(real)REX_COM[i][0], (real)REX_COM[i][1], (real)REX_COM[i][2]}, cw[3];
+    matvec3(A.Rw[i], c, cw);
+    E += (real)REX_MASS[i] * (-GRAVITY_Z) * (A.pw[i][2] + cw[2]);
+    real pl[3]; matvec3(A.Rw[i], Iv + 3, pl);
+    for (int k = 0; k < 3; ++k) P[k] += pl[k];
+  }
+  out[0] = E; out[1] = P[0]; out[2] = P[1]; out[3] = P[2];
+}
