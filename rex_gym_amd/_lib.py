@@ -1,0 +1,84 @@
+"""ctypes binding of the C ABI in include/rexsim.h (librexsim_hip.so).
+
+There is NO CPU fallback: if the HIP library is missing or a call fails, this raises.
+"""
+import ctypes
+import os
+
+from . import build as _build
+
+TASKS = {"walk": 0, "gallop": 1}
+SIGNALS = {"ik": 0, "ol": 1}
+STATE_WORDS = 53
+NUM_MOTORS = 12
+
+
+class RexConfig(ctypes.Structure):
+    """Mirror of `struct RexConfig` (include/rexsim.h)."""
+    _fields_ = [
+        ("abi_version", ctypes.c_int32), ("num_envs", ctypes.c_int32), ("env_index_base", ctypes.c_int32),
+        ("task", ctypes.c_int32), ("signal", ctypes.c_int32), ("action_repeat", ctypes.c_int32),
+        ("solver_iterations", ctypes.c_int32), ("sim_time_step", ctypes.c_float),
+        ("motor_kp", ctypes.c_float), ("motor_kd", ctypes.c_float), ("backwards", ctypes.c_int32),
+        ("target_position", ctypes.c_float), ("seed", ctypes.c_uint64), ("auto_reset", ctypes.c_int32),
+        ("max_episode_steps", ctypes.c_int32), ("distance_weight", ctypes.c_float),
+        ("energy_weight", ctypes.c_float), ("drift_weight", ctypes.c_float), ("shake_weight", ctypes.c_float),
+        ("reserved", ctypes.c_int32 * 8),
+    ]
+
+
+class RexSimError(RuntimeError):
+    pass
+
+
+_lib = None
+
+_SIGS = {
+    "rex_default_config": ([ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(RexConfig)], ctypes.c_int),
+    "rex_action_dim": ([ctypes.POINTER(RexConfig)], ctypes.c_int),
+    "rex_obs_dim": ([ctypes.POINTER(RexConfig)], ctypes.c_int),
+    "rex_create": ([ctypes.POINTER(RexConfig), ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                    ctypes.POINTER(ctypes.c_void_p)], ctypes.c_int),
+    "rex_destroy": ([ctypes.c_void_p], ctypes.c_int),
+    "rex_reset": ([ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p], ctypes.c_int),
+    "rex_step": ([ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                  ctypes.c_void_p, ctypes.c_void_p], ctypes.c_int),
+    "rex_set_timing": ([ctypes.c_void_p, ctypes.c_int], ctypes.c_int),
+    "rex_last_step_ms": ([ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)], ctypes.c_int),
+    "rex_ik_solve": ([ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                      ctypes.c_void_p], ctypes.c_int),
+    "rex_motor_torque": ([ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                          ctypes.c_float, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p],
+                         ctypes.c_int),
+    "rex_gait_loop": ([ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                       ctypes.c_void_p], ctypes.c_int),
+    "rex_last_error": ([], ctypes.c_char_p),
+    "rex_abi_version": ([], ctypes.c_int),
+}
+EXPORTED_SYMBOLS = tuple(_SIGS)
+
+
+def lib():
+    """Load (once) the HIP library. Raises RexSimError if it is not there -- never falls back."""
+    global _lib
+    if _lib is None:
+        path = _build.LIB_PATH
+        if not os.path.exists(path):
+            raise RexSimError(
+                f"{path} is missing: build it with `python -m rex_gym_amd.build` (needs hipcc). "
+                "rex_gym_amd has no CPU fallback.")
+        l = ctypes.CDLL(path)
+        for name, (argtypes, restype) in _SIGS.items():
+            fn = getattr(l, name)  # AttributeError if the ABI header and the library disagree
+            fn.argtypes = argtypes
+            fn.restype = restype
+        if l.rex_abi_version() != 1:
+            raise RexSimError("librexsim_hip.so ABI version mismatch")
+        _lib = l
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().rex_last_error().decode("utf-8", "replace")
+        raise RexSimError(f"{what} failed (code {rc}): {msg}")

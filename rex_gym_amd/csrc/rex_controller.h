@@ -1,0 +1,155 @@
+// rex_controller.h -- device restatement (fp32) of the reference controller and actuator:
+//   model/gait_planner.py:22-134, model/kinematics.py:28-142, model/motor.py:76-143.
+// Same maths as the numpy code; Bezier powers are built by repeated multiplication instead of
+// np.power + factorial, and the swing y component uses Y_i = -|v| s X_i (gait_planner.py:48).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace rex {
+
+// kinematics.py:6-13
+constexpr float kIkL = 0.23f, kIkW = 0.075f, kIkHip = 0.055f, kIkLeg = 0.10652f, kIkFoot = 0.145f;
+constexpr float kIkYDist = 0.185f, kIkHeight = 0.2f;
+constexpr float kPi = 3.14159265358979323846f;
+
+// kinematics.py:48-78 : R (coord + pos), R = Rx Ry Rz, identity when all angles are exactly 0
+__device__ __forceinline__ void ik_transform(const float* coord, const float* orn, const float* pos, float* out) {
+  const float t0 = coord[0] + pos[0], t1 = coord[1] + pos[1], t2 = coord[2] + pos[2];
+  if (orn[0] != 0.0f || orn[1] != 0.0f || orn[2] != 0.0f) {
+    float sx, cx, sy, cy, sz, cz;
+    sincosf(orn[0], &sx, &cx); sincosf(orn[1], &sy, &cy); sincosf(orn[2], &sz, &cz);
+    const float a0 = cz * t0 - sz * t1, a1 = sz * t0 + cz * t1, a2 = t2;
+    const float b0 = cy * a0 + sy * a2, b1 = a1, b2 = -sy * a0 + cy * a2;
+    out[0] = b0; out[1] = cx * b1 - sx * b2; out[2] = sx * b1 + cx * b2;
+  } else {
+    out[0] = t0; out[1] = t1; out[2] = t2;
+  }
+}
+
+// kinematics.py:80-102
+__device__ __forceinline__ void ik_leg(const float* c, bool right_side, float* out) {
+  const float hip = kIkHip, leg = kIkLeg, foot = kIkFoot;
+  float domain = (c[1] * c[1] + c[2] * c[2] - hip * hip + c[0] * c[0] - leg * leg - foot * foot) / (2.0f * foot * leg);
+  if (domain > 1.0f) domain = 0.99f;
+  else if (domain < -1.0f) domain = -0.99f;
+  const float gamma = atan2f(-sqrtf(1.0f - domain * domain), domain);
+  float sq = c[1] * c[1] + c[2] * c[2] - hip * hip;
+  if (sq < 0.0f) sq = 0.0f;
+  const float rs = sqrtf(sq);
+  float sg, cg;
+  sincosf(gamma, &sg, &cg);
+  const float alpha = atan2f(-c[0], rs) - atan2f(foot * sg, leg + foot * cg);
+  const float theta = -atan2f(c[2], c[1]) - atan2f(rs, right_side ? -hip : hip);
+  out[0] = theta; out[1] = -alpha; out[2] = -gamma;
+}
+
+// kinematics.py:104-142 ; frames/angles rows: FR, FL, RR, RL
+__device__ __forceinline__ void ik_solve(const float* orn, const float* pos, const float* frames, float* angles) {
+  const float hv[4][3] = {{kIkL / 2, -kIkW / 2, 0.f}, {kIkL / 2, kIkW / 2, 0.f}, {-kIkL / 2, -kIkW / 2, 0.f}, {-kIkL / 2, kIkW / 2, 0.f}};
+  const float iorn[3] = {-orn[0], -orn[1], -orn[2]}, ipos[3] = {-pos[0], -pos[1], -pos[2]};
+#pragma unroll
+  for (int l = 0; l < 4; ++l) {
+    float hvx[3], coord[3], tc[3];
+    ik_transform(hv[l], orn, pos, hvx);
+    coord[0] = frames[3 * l] - hvx[0]; coord[1] = frames[3 * l + 1] - hvx[1]; coord[2] = frames[3 * l + 2] - hvx[2];
+    ik_transform(coord, iorn, ipos, tc);
+    ik_leg(tc, (l & 1) == 0, angles + 3 * l);
+  }
+}
+
+// Sum_{i<10} P_i C(11,i) t^i (1-t)^(11-i) for the x and z control polygons (gait_planner.py:42-58)
+__device__ __forceinline__ void bezier_xz(float t, float& bx, float& bz) {
+  const float PX[10] = {-0.04f, -0.056f, -0.06f, -0.06f, -0.06f, 0.f, 0.f, 0.f, 0.06f, 0.06f};
+  const float PZ[10] = {0.f, 0.f, 0.0405f, 0.0405f, 0.0405f, 0.0405f, 0.0405f, 0.0495f, 0.0495f, 0.0495f};
+  const float BIN[10] = {1.f, 11.f, 55.f, 165.f, 330.f, 462.f, 462.f, 330.f, 165.f, 55.f};
+  const float u = 1.0f - t;
+  float up[12];
+  up[0] = 1.0f;
+#pragma unroll
+  for (int k = 1; k < 12; ++k) up[k] = up[k - 1] * u;
+  float tp = 1.0f;
+  bx = 0.0f; bz = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    const float b = BIN[i] * tp * up[11 - i];
+    bx += PX[i] * b; bz += PZ[i] * b;
+    tp *= t;
+  }
+}
+
+struct GaitState { float phi, last_time, alpha; };
+
+// gait_planner.py:30-40 and 42-58 for one (v, angle) pair at a given phase
+__device__ __forceinline__ void gait_component(bool stance, float ph, float bx, float bz, float v, float angle_deg,
+                                               float direction, float* out) {
+  float s, c;
+  sincosf(angle_deg * (kPi / 180.0f), &s, &c);
+  const float av = fabsf(v);
+  if (stance) {
+    const float p = 0.05f * (1.0f - 2.0f * ph);
+    out[0] = c * p * av;
+    out[1] = -s * p * av;
+    out[2] = -0.001f * cosf(kPi / (2.0f * 0.05f) * p);
+  } else {
+    const float X = av * c * direction * bx;
+    out[0] = X;
+    out[1] = av * s * (-X);
+    out[2] = av * bz;
+  }
+}
+
+// gait_planner.py:96-134 with the phase clock on `now`; mode 0 walk, 1 gallop (offsets :15-20)
+__device__ __forceinline__ void gait_loop(GaitState& g, int mode, float v, float angle, float w_rot, float T,
+                                          float direction, float now, float* frame) {
+  const float bx0[4] = {kIkL / 2, kIkL / 2, -kIkL / 2, -kIkL / 2};
+  const float by0[4] = {-kIkYDist / 2, kIkYDist / 2, -kIkYDist / 2, kIkYDist / 2};
+  if (T <= 0.01f) T = 0.01f;
+  if (g.phi >= 0.99f) g.last_time = now;
+  g.phi = (now - g.last_time) / T;
+#pragma unroll
+  for (int l = 0; l < 4; ++l) {
+    const float off = mode == 0 ? ((l == 1 || l == 2) ? 0.5f : 0.0f) : (l >= 2 ? 0.8f : 0.0f);
+    float phi = g.phi + off;
+    if (phi >= 1.0f) phi -= 1.0f;
+    const float r = sqrtf(bx0[l] * bx0[l] + by0[l] * by0[l]);
+    const float foot_angle = atan2f(by0[l], bx0[l]);
+    const float circle = (w_rot >= 0.0f ? 90.0f : 270.0f) - (foot_angle - g.alpha) * (180.0f / kPi);
+    const bool stance = phi <= 0.5f;
+    const float ph = stance ? phi / 0.5f : (phi - 0.5f) / (1.0f - 0.5f);
+    float bx = 0.f, bz = 0.f;
+    if (!stance) bezier_xz(ph, bx, bz);
+    float lng[3], rot[3];
+    gait_component(stance, ph, bx, bz, v, angle, direction, lng);
+    gait_component(stance, ph, bx, bz, w_rot, circle, direction, rot);
+    const float mag = atan2f(sqrtf(rot[0] * rot[0] + rot[1] * rot[1]), r);
+    if (by0[l] > 0.0f) g.alpha = rot[0] < 0.0f ? -mag : mag;
+    else g.alpha = rot[0] < 0.0f ? mag : -mag;
+    frame[3 * l + 0] = bx0[l] + lng[0] + rot[0];
+    frame[3 * l + 1] = by0[l] + lng[1] + rot[1];
+    frame[3 * l + 2] = -kIkHeight + lng[2] + rot[2];
+  }
+}
+
+// model/motor.py:76-143 (position-control branch, strength ratio 1)
+__device__ __forceinline__ void motor_torque(float cmd, float q, float qd, float qd_true, float kp, float kd,
+                                             float& actual, float& observed) {
+  constexpr float V = 32.0f, R = 0.186f, KT = 0.0954f;
+  float pwm = -1.0f * kp * (q - cmd) - kd * qd;
+  pwm = fminf(fmaxf(pwm, -1.0f), 1.0f);
+  observed = fminf(fmaxf(KT * (pwm * V / R), -5.7f), 5.7f);
+  const float vnet = fminf(fmaxf(pwm * V - (KT + 0.0f) * qd_true, -50.0f), 50.0f);
+  const float cur = vnet / R;
+  const float mag = fabsf(cur);
+  // np.interp(|I|, [0,10,...,60], [0,1,1.9,2.45,3.0,3.25,3.5]), clamped at the ends
+  float t;
+  if (mag >= 60.0f) t = 3.5f;
+  else if (mag >= 50.0f) t = 3.25f + (3.5f - 3.25f) * (mag - 50.0f) / 10.0f;
+  else if (mag >= 40.0f) t = 3.0f + (3.25f - 3.0f) * (mag - 40.0f) / 10.0f;
+  else if (mag >= 30.0f) t = 2.45f + (3.0f - 2.45f) * (mag - 30.0f) / 10.0f;
+  else if (mag >= 20.0f) t = 1.9f + (2.45f - 1.9f) * (mag - 20.0f) / 10.0f;
+  else if (mag >= 10.0f) t = 1.0f + (1.9f - 1.0f) * (mag - 10.0f) / 10.0f;
+  else t = 0.0f + (1.0f - 0.0f) * (mag - 0.0f) / 10.0f;
+  actual = cur > 0.0f ? t : (cur < 0.0f ? -t : 0.0f);
+}
+
+}  // namespace rex

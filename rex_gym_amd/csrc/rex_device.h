@@ -1,0 +1,556 @@
+// rex_device.h -- gfx950 device code of the batched Rex simulator: one environment per lane.
+//
+// Physics formulation (differs on purpose from the CPU oracle's body-coordinate ABA; the two must
+// agree to rounding -- tests/test_gpu_parity.py):
+//   * every spatial quantity is expressed in world-aligned axes about ONE reference point, the base
+//     origin, so composite inertias and subtree wrenches are plain sums (no per-joint transforms);
+//   * the star topology (floating base + 4 three-joint legs) is eliminated leg by leg:
+//       H_f  = leg joint-space inertia (3x3)        = G_f G_f^T        (Cholesky)
+//       B_f  = base/leg coupling (6x3),  Bw_f = G_f^-1 B_f^T
+//       A    = composite base inertia - sum_f Bw_f^T Bw_f = Lc Lc^T    (6x6 Cholesky)
+//     which is the articulated-body algorithm written as a sparse Cholesky factorisation of M(q);
+//   * in the whitened coordinates x = (y, z_0..z_3),  y = Lc^T nu_base,  z_f = G_f^T qd_f + Bw_f nu_base
+//     the mass matrix is the identity, so a constraint row is ONE 9-vector Jt (6 base + 3 own-leg
+//     entries) that serves as Jacobian AND unit-impulse response: per PGS row 9 FMAs to read the
+//     velocity, 9 to apply the impulse (Bullet's delta-velocity PGS costs 18 + 18 on 18 dofs).
+// Reference semantics restated here: SURVEY.md section 8(a) rows a1-a23 (file:line cited inline).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rexsim.h"
+#include "rex_model_gen.h"
+
+#define REX_WAVE 64
+#define REX_NPOINT 8                  /* 2 toe-cylinder end points per foot */
+#define REX_NROW (3 * REX_NPOINT)     /* normal + 2 pyramid friction rows per point */
+#define REX_ROW_F4 3                  /* float4 chunks per row in LDS */
+#define REX_LDS_FLOATS (REX_NROW * REX_ROW_F4 * 4 * REX_WAVE)
+
+namespace rex {
+
+// ---- world / solver constants (same values as oracle/rex_oracle.c) ----
+constexpr float kGravity = 10.0f;          // rex_gym_env.py:314 (0,0,-10)
+constexpr float kLinDamp = 0.04f;          // btMultiBody default damping
+constexpr float kAngDamp = 0.04f;
+constexpr float kMaxCoordVel = 100.0f;     // btMultiBody::m_maxCoordinateVelocity
+constexpr float kErp = 0.2f;               // btContactSolverInfo::m_erp2
+constexpr float kBreaking = 0.02f;         // contact breaking threshold
+constexpr float kMu = 0.5f;                // toe 0.5 x plane 1.0
+constexpr float kInitZ = 0.21f;            // terrain.py:14-20
+constexpr float kToeRad = (float)(REX_TOE_RADIUS + REX_COLLISION_MARGIN);
+constexpr float kToeHalf = (float)REX_TOE_HALFLEN;
+
+struct f3 { float x, y, z; };
+__device__ __forceinline__ f3 mk(float x, float y, float z) { return f3{x, y, z}; }
+__device__ __forceinline__ f3 operator+(f3 a, f3 b) { return f3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ f3 operator-(f3 a, f3 b) { return f3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ f3 operator*(float s, f3 a) { return f3{s * a.x, s * a.y, s * a.z}; }
+__device__ __forceinline__ float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ f3 cross(f3 a, f3 b) {
+  return f3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+
+// symmetric 3x3: xx yy zz xy xz yz
+struct s33 { float xx, yy, zz, xy, xz, yz; };
+__device__ __forceinline__ f3 mul(const s33& m, f3 v) {
+  return f3{m.xx * v.x + m.xy * v.y + m.xz * v.z, m.xy * v.x + m.yy * v.y + m.yz * v.z,
+            m.xz * v.x + m.yz * v.y + m.zz * v.z};
+}
+// R diag(ix,iy,iz) R^T with R = [ex ey ez] columns
+__device__ __forceinline__ s33 rot_inertia(f3 ex, f3 ey, f3 ez, float ix, float iy, float iz) {
+  s33 m;
+  m.xx = ix * ex.x * ex.x + iy * ey.x * ey.x + iz * ez.x * ez.x;
+  m.yy = ix * ex.y * ex.y + iy * ey.y * ey.y + iz * ez.y * ez.y;
+  m.zz = ix * ex.z * ex.z + iy * ey.z * ey.z + iz * ez.z * ez.z;
+  m.xy = ix * ex.x * ex.y + iy * ey.x * ey.y + iz * ez.x * ez.y;
+  m.xz = ix * ex.x * ex.z + iy * ey.x * ey.z + iz * ez.x * ez.z;
+  m.yz = ix * ex.y * ex.z + iy * ey.y * ey.z + iz * ez.y * ez.z;
+  return m;
+}
+// point-mass inertia about the origin: m (|c|^2 1 - c c^T)
+__device__ __forceinline__ void add_point(s33& m, float mass, f3 c) {
+  float cc = dot(c, c);
+  m.xx += mass * (cc - c.x * c.x); m.yy += mass * (cc - c.y * c.y); m.zz += mass * (cc - c.z * c.z);
+  m.xy -= mass * c.x * c.y; m.xz -= mass * c.x * c.z; m.yz -= mass * c.y * c.z;
+}
+__device__ __forceinline__ void add(s33& a, const s33& b) {
+  a.xx += b.xx; a.yy += b.yy; a.zz += b.zz; a.xy += b.xy; a.xz += b.xz; a.yz += b.yz;
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-substep shared quantities of the base
+struct BaseKin {
+  f3 ex, ey, ez;   // columns of the base rotation (body axes in world)
+  f3 w, v;         // base angular / linear velocity, world
+  float height;    // base origin z (flat ground at z = 0)
+};
+
+// what a leg leaves behind for the back-substitution after the constraint solve
+struct LegFactor {
+  float gi1, gi2, gi3;     // 1 / diag(G)
+  float g21, g31, g32;     // strict lower triangle of G
+  float Bw[3][6];          // G^-1 B^T
+  float z[3];              // whitened predicted velocity of the leg
+};
+
+// accumulators of the base block
+struct BaseAccum {
+  s33 Io;          // composite rotational inertia about the base origin
+  f3 h;            // composite first moment  sum m c
+  float m;         // composite mass
+  float S[21];     // sum_f Bw_f^T Bw_f, lower triangle row-major (i*(i+1)/2 + j)
+  f3 N, F;         // total bias wrench about the base origin
+  float bz[6];     // sum_f Bw_f^T zdot_f
+};
+
+__device__ __forceinline__ int tri(int i, int j) { return i * (i + 1) / 2 + j; }
+
+// LDS row store: row r, float4 chunk c, lane l  ->  ((r*3 + c)*64 + l) float4
+__device__ __forceinline__ float4& row_chunk(float4* lds, int r, int c, int lane) {
+  return lds[(r * REX_ROW_F4 + c) * REX_WAVE + lane];
+}
+
+// One leg: forward kinematics, Newton-Euler bias, composite inertia, leg Cholesky, Schur
+// contributions to the base, and the (unwhitened in the base part) contact rows of its toe.
+template <int LEG>
+__device__ __forceinline__ void leg_pass(const BaseKin& bk, const float* __restrict__ q, const float* __restrict__ qd,
+                                         const float* __restrict__ tau, float dt, LegFactor& L, BaseAccum& acc,
+                                         float4* lds, int lane, unsigned& active_mask) {
+  constexpr float SX = (float)REX_LEG_SX[LEG], SY = (float)REX_LEG_SY[LEG];
+  constexpr float HX = SX * (float)REX_HIP_X, HY = SY * (float)REX_HIP_Y, UY = SY * (float)REX_UPPER_Y;
+  constexpr float KX = (float)REX_KNEE_X, KZ = (float)REX_KNEE_Z, CZ = (float)REX_LOWER_COM_Z, TZ = (float)REX_TOE_Z;
+  constexpr float M1 = (float)REX_SHOULDER_MASS, M2 = (float)REX_UPPER_MASS, M3 = (float)REX_LOWER_MASS;
+
+  const float q1 = q[0], q2 = q[1], q3 = q[2];
+  const float qd1 = qd[0], qd2 = qd[1], qd3 = qd[2];
+  float s1, c1, s2, c2, s3, c3;
+  sincosf(q1, &s1, &c1);
+  sincosf(q2, &s2, &c2);
+  sincosf(q3, &s3, &c3);
+  const float s23 = s2 * c3 + c2 * s3, c23 = c2 * c3 - s2 * s3;
+
+  // --- forward kinematics (rotations as world columns; positions relative to the base origin) ---
+  const f3 x1 = bk.ex;                                  // R1 = R0 Rx(q1)
+  const f3 y1 = c1 * bk.ey + s1 * bk.ez;
+  const f3 z1 = c1 * bk.ez - s1 * bk.ey;
+  const f3 x2 = c2 * x1 - s2 * z1, z2 = s2 * x1 + c2 * z1;       // R2 = R1 Ry(q2)
+  const f3 x3 = c23 * x1 - s23 * z1, z3 = s23 * x1 + c23 * z1;   // R3 = R1 Ry(q2+q3)
+  const f3 a1 = x1, a2 = y1;                            // joint axes (a3 == a2)
+  const f3 o1 = HX * bk.ex + HY * bk.ey;
+  const f3 o2 = o1 + UY * y1;
+  const f3 d23 = KX * x2 + KZ * z2;
+  const f3 o3 = o2 + d23;
+  const f3 e3 = CZ * z3;
+  const f3 cm3 = o3 + e3;
+  const f3 d12 = UY * y1;
+
+  // --- velocities ---
+  const f3 w0 = bk.w;
+  const f3 w1 = w0 + qd1 * a1;
+  const f3 w2 = w1 + qd2 * a2;
+  const f3 w3 = w2 + qd3 * a2;
+  const f3 vo1 = bk.v + cross(w0, o1);
+  const f3 vo2 = vo1 + cross(w1, d12);
+  const f3 vo3 = vo2 + cross(w2, d23);
+  const f3 vc3 = vo3 + cross(w3, e3);
+
+  // --- Newton-Euler bias with zero generalized acceleration; gravity as +g on the base ---
+  const f3 al1 = cross(w0, qd1 * a1);
+  const f3 al2 = al1 + cross(w1, qd2 * a2);
+  const f3 al3 = al2 + cross(w2, qd3 * a2);
+  const f3 ao1 = mk(0.f, 0.f, kGravity) + cross(w0, cross(w0, o1));
+  const f3 ao2 = ao1 + cross(al1, d12) + cross(w1, cross(w1, d12));
+  const f3 ao3 = ao2 + cross(al2, d23) + cross(w2, cross(w2, d23));
+  const f3 ac3 = ao3 + cross(al3, e3) + cross(w3, cross(w3, e3));
+
+  const s33 I1 = rot_inertia(x1, y1, z1, (float)REX_SHOULDER_IXX, (float)REX_SHOULDER_IYY, (float)REX_SHOULDER_IZZ);
+  const s33 I2 = rot_inertia(x2, y1, z2, (float)REX_UPPER_IXX, (float)REX_UPPER_IYY, (float)REX_UPPER_IZZ);
+  const s33 I3 = rot_inertia(x3, y1, z3, (float)REX_LOWER_IXX, (float)REX_LOWER_IYY, (float)REX_LOWER_IZZ);
+
+  const f3 Iw1 = mul(I1, w1), Iw2 = mul(I2, w2), Iw3 = mul(I3, w3);
+  const float dl1 = kLinDamp + kLinDamp * sqrtf(dot(vo1, vo1));
+  const float dl2 = kLinDamp + kLinDamp * sqrtf(dot(vo2, vo2));
+  const float dl3 = kLinDamp + kLinDamp * sqrtf(dot(vc3, vc3));
+  const float da1 = kAngDamp + kAngDamp * sqrtf(dot(w1, w1));
+  const float da2 = kAngDamp + kAngDamp * sqrtf(dot(w2, w2));
+  const float da3 = kAngDamp + kAngDamp * sqrtf(dot(w3, w3));
+  const f3 f1 = M1 * ao1 + (M1 * dl1) * vo1;
+  const f3 f2 = M2 * ao2 + (M2 * dl2) * vo2;
+  const f3 f3_ = M3 * ac3 + (M3 * dl3) * vc3;
+  const f3 n1 = mul(I1, al1) + cross(w1, Iw1) + da1 * Iw1;
+  const f3 n2 = mul(I2, al2) + cross(w2, Iw2) + da2 * Iw2;
+  const f3 n3 = mul(I3, al3) + cross(w3, Iw3) + da3 * Iw3;
+  // subtree wrenches about the base origin
+  const f3 F3 = f3_, N3 = n3 + cross(cm3, f3_);
+  const f3 F2 = F3 + f2, N2 = N3 + n2 + cross(o2, f2);
+  const f3 F1 = F2 + f1, N1 = N2 + n1 + cross(o1, f1);
+  const float C1 = dot(a1, N1 - cross(o1, F1));
+  const float C2 = dot(a2, N2 - cross(o2, F2));
+  const float C3 = dot(a2, N3 - cross(o3, F3));
+  acc.N = acc.N + N1;
+  acc.F = acc.F + F1;
+
+  // --- composite inertias about the base origin ---
+  s33 Io3 = I3; add_point(Io3, M3, cm3);
+  const f3 h3 = M3 * cm3;
+  s33 Io2 = I2; add_point(Io2, M2, o2); add(Io2, Io3);
+  const f3 h2 = h3 + M2 * o2;
+  s33 Io1 = I1; add_point(Io1, M1, o1); add(Io1, Io2);
+  const f3 h1 = h2 + M1 * o1;
+  constexpr float m3c = M3, m2c = M3 + M2, m1c = M3 + M2 + M1;
+  add(acc.Io, Io1);
+  acc.h = acc.h + h1;
+  acc.m += m1c;
+
+  // --- joint columns F_j = I^c_j S_j,  S_j = [a_j ; o_j x a_j] ---
+  const f3 v1 = cross(o1, a1), v2 = cross(o2, a2), v3 = cross(o3, a2);
+  const f3 Fl1 = m1c * v1 + cross(a1, h1), Fa1 = mul(Io1, a1) + cross(h1, v1);
+  const f3 Fl2 = m2c * v2 + cross(a2, h2), Fa2 = mul(Io2, a2) + cross(h2, v2);
+  const f3 Fl3 = m3c * v3 + cross(a2, h3), Fa3 = mul(Io3, a2) + cross(h3, v3);
+  const float H11 = dot(a1, Fa1) + dot(v1, Fl1);
+  const float H21 = dot(a1, Fa2) + dot(v1, Fl2);
+  const float H31 = dot(a1, Fa3) + dot(v1, Fl3);
+  const float H22 = dot(a2, Fa2) + dot(v2, Fl2);
+  const float H32 = dot(a2, Fa3) + dot(v2, Fl3);
+  const float H33 = dot(a2, Fa3) + dot(v3, Fl3);
+
+  // --- G = chol(H) ---
+  const float gi1 = rsqrtf(H11);
+  const float g21 = H21 * gi1, g31 = H31 * gi1;
+  const float p22 = H22 - g21 * g21;
+  const float gi2 = rsqrtf(p22);
+  const float g32 = (H32 - g31 * g21) * gi2;
+  const float p33 = H33 - g31 * g31 - g32 * g32;
+  const float gi3 = rsqrtf(p33);
+  const float g11 = H11 * gi1, g22 = p22 * gi2, g33 = p33 * gi3;   // diag(G)
+  L.gi1 = gi1; L.gi2 = gi2; L.gi3 = gi3; L.g21 = g21; L.g31 = g31; L.g32 = g32;
+
+  // --- Bw = G^-1 B^T, columns k = (ang xyz, lin xyz) ---
+  const float B1[6] = {Fa1.x, Fa1.y, Fa1.z, Fl1.x, Fl1.y, Fl1.z};
+  const float B2[6] = {Fa2.x, Fa2.y, Fa2.z, Fl2.x, Fl2.y, Fl2.z};
+  const float B3[6] = {Fa3.x, Fa3.y, Fa3.z, Fl3.x, Fl3.y, Fl3.z};
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const float u1 = B1[k] * gi1;
+    const float u2 = (B2[k] - g21 * u1) * gi2;
+    const float u3 = (B3[k] - g31 * u1 - g32 * u2) * gi3;
+    L.Bw[0][k] = u1; L.Bw[1][k] = u2; L.Bw[2][k] = u3;
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j <= i; ++j)
+      acc.S[tri(i, j)] += L.Bw[0][i] * L.Bw[0][j] + L.Bw[1][i] * L.Bw[1][j] + L.Bw[2][i] * L.Bw[2][j];
+
+  // --- free whitened acceleration of the leg and its predicted whitened velocity ---
+  const float r1 = tau[0] - C1, r2 = tau[1] - C2, r3 = tau[2] - C3;
+  const float zd1 = r1 * gi1;
+  const float zd2 = (r2 - g21 * zd1) * gi2;
+  const float zd3 = (r3 - g31 * zd1 - g32 * zd2) * gi3;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) acc.bz[k] += L.Bw[0][k] * zd1 + L.Bw[1][k] * zd2 + L.Bw[2][k] * zd3;
+  const float nu0[6] = {bk.w.x, bk.w.y, bk.w.z, bk.v.x, bk.v.y, bk.v.z};
+  // z = G^T qd + Bw nu0
+  float zc1 = g11 * qd1 + g21 * qd2 + g31 * qd3;
+  float zc2 = g22 * qd2 + g32 * qd3;
+  float zc3 = g33 * qd3;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { zc1 += L.Bw[0][k] * nu0[k]; zc2 += L.Bw[1][k] * nu0[k]; zc3 += L.Bw[2][k] * nu0[k]; }
+  L.z[0] = zc1 + dt * zd1; L.z[1] = zc2 + dt * zd2; L.z[2] = zc3 + dt * zd3;
+
+  // --- toe contact points: both ends of the toe cylinder against z = 0 ---
+  const f3 tc = o3 + TZ * z3;
+  const f3 aw = y1;
+  const f3 dv = mk(-aw.z * aw.x, -aw.z * aw.y, 1.0f - aw.z * aw.z);   // n - (n.a) a, n = +z
+  const float dn2 = dot(dv, dv);
+  const float inv = dn2 > 1e-18f ? rsqrtf(dn2) : 0.0f;
+  const f3 nrm = mk(0.f, 0.f, 1.f), t1 = mk(0.f, -1.f, 0.f), t2 = mk(1.f, 0.f, 0.f);  // btPlaneSpace1(+z)
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const float sg = e == 0 ? -kToeHalf : kToeHalf;
+    const f3 P = tc + sg * aw - (kToeRad * inv) * dv;
+    const float dist = bk.height + P.z;
+    const bool act = dist < kBreaking;
+    const int p = 2 * LEG + e;
+    if (act) active_mask |= 1u << p;
+    const f3 r1v = P - o1, r2v = P - o2, r3v = P - o3;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const f3 dir = d == 0 ? nrm : (d == 1 ? t1 : t2);
+      const f3 Jw = cross(P, dir);
+      const float Jq1 = dot(a1, cross(r1v, dir));
+      const float Jq2 = dot(a2, cross(r2v, dir));
+      const float Jq3 = dot(a2, cross(r3v, dir));
+      const float j1 = Jq1 * gi1;
+      const float j2 = (Jq2 - g21 * j1) * gi2;
+      const float j3 = (Jq3 - g31 * j1 - g32 * j2) * gi3;
+      const float Jb[6] = {Jw.x, Jw.y, Jw.z, dir.x, dir.y, dir.z};
+      float g[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) g[k] = Jb[k] - (L.Bw[0][k] * j1 + L.Bw[1][k] * j2 + L.Bw[2][k] * j3);
+      float target = 0.0f;
+      if (d == 0) target = dist > 0.0f ? -dist / dt : -dist * (kErp / dt);
+      const int r = d == 0 ? p : (REX_NPOINT + 2 * p + (d - 1));
+      row_chunk(lds, r, 0, lane) = make_float4(g[0], g[1], g[2], g[3]);
+      row_chunk(lds, r, 1, lane) = make_float4(g[4], g[5], j1, j2);
+      row_chunk(lds, r, 2, lane) = make_float4(j3, target, act ? 1.0f : 0.0f, 0.0f);
+    }
+  }
+}
+
+// Lower-triangular 6x6 Cholesky factor, packed: off-diagonals + inverse diagonal
+struct Chol6 {
+  float l[15];   // strict lower triangle, row-major: (1,0) (2,0) (2,1) (3,0) ...
+  float di[6];   // 1 / L_ii
+  float d[6];    // L_ii
+};
+__device__ __forceinline__ int tri_s(int i, int j) { return i * (i - 1) / 2 + j; }  // i > j
+
+__device__ __forceinline__ void chol6(const float* A /*21 lower*/, Chol6& C) {
+  float Lf[6][6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    float s = A[tri(j, j)];
+#pragma unroll
+    for (int k = 0; k < j; ++k) s -= Lf[j][k] * Lf[j][k];
+    const float di = rsqrtf(s);
+    C.di[j] = di;
+    C.d[j] = s * di;
+#pragma unroll
+    for (int i = j + 1; i < 6; ++i) {
+      float t = A[tri(i, j)];
+#pragma unroll
+      for (int k = 0; k < j; ++k) t -= Lf[i][k] * Lf[j][k];
+      Lf[i][j] = t * di;
+      C.l[tri_s(i, j)] = Lf[i][j];
+    }
+  }
+}
+// x = Lc^-1 b
+__device__ __forceinline__ void fwd6(const Chol6& C, const float* b, float* x) {
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    float s = b[i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) s -= C.l[tri_s(i, k)] * x[k];
+    x[i] = s * C.di[i];
+  }
+}
+// x = Lc^-T b
+__device__ __forceinline__ void bwd6(const Chol6& C, const float* b, float* x) {
+#pragma unroll
+  for (int i = 5; i >= 0; --i) {
+    float s = b[i];
+#pragma unroll
+    for (int k = i + 1; k < 6; ++k) s -= C.l[tri_s(k, i)] * x[k];
+    x[i] = s * C.di[i];
+  }
+}
+// x = Lc^T b
+__device__ __forceinline__ void mulT6(const Chol6& C, const float* b, float* x) {
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    float s = b[i] * C.d[i];
+#pragma unroll
+    for (int k = i + 1; k < 6; ++k) s += C.l[tri_s(k, i)] * b[k];
+    x[i] = s;
+  }
+}
+
+struct PhysState {
+  float pos[3], quat[4], lin[3], ang[3];
+  float q[12], qd[12];
+};
+
+template <int LEG>
+__device__ __forceinline__ void pgs_point_normal(float4* lds, int lane, float* y, float* z, float* lam) {
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int p = 2 * LEG + e;
+    const float4 c0 = row_chunk(lds, p, 0, lane), c1 = row_chunk(lds, p, 1, lane), c2 = row_chunk(lds, p, 2, lane);
+    const float vel = c0.x * y[0] + c0.y * y[1] + c0.z * y[2] + c0.w * y[3] + c1.x * y[4] + c1.y * y[5] +
+                      c1.z * z[0] + c1.w * z[1] + c2.x * z[2];
+    float dl = c2.z * (c2.y - vel);
+    const float nl = fmaxf(lam[p] + dl, 0.0f);
+    dl = nl - lam[p];
+    lam[p] = nl;
+    y[0] += c0.x * dl; y[1] += c0.y * dl; y[2] += c0.z * dl; y[3] += c0.w * dl; y[4] += c1.x * dl; y[5] += c1.y * dl;
+    z[0] += c1.z * dl; z[1] += c1.w * dl; z[2] += c2.x * dl;
+  }
+}
+
+template <int LEG>
+__device__ __forceinline__ void pgs_point_friction(float4* lds, int lane, float* y, float* z, float* lam) {
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int p = 2 * LEG + e;
+    const float lim = kMu * lam[p];
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      const int r = REX_NPOINT + 2 * p + d;
+      const float4 c0 = row_chunk(lds, r, 0, lane), c1 = row_chunk(lds, r, 1, lane), c2 = row_chunk(lds, r, 2, lane);
+      const float vel = c0.x * y[0] + c0.y * y[1] + c0.z * y[2] + c0.w * y[3] + c1.x * y[4] + c1.y * y[5] +
+                        c1.z * z[0] + c1.w * z[1] + c2.x * z[2];
+      float dl = c2.z * (c2.y - vel);
+      const float nl = clampf(lam[r] + dl, -lim, lim);
+      dl = nl - lam[r];
+      lam[r] = nl;
+      y[0] += c0.x * dl; y[1] += c0.y * dl; y[2] += c0.z * dl; y[3] += c0.w * dl; y[4] += c1.x * dl; y[5] += c1.y * dl;
+      z[0] += c1.z * dl; z[1] += c1.w * dl; z[2] += c2.x * dl;
+    }
+  }
+}
+
+// The restated pybullet.stepSimulation for one env (one lane): tau is held for this substep.
+__device__ __forceinline__ void physics_substep(PhysState& s, const float* tau, float dt, int iterations,
+                                                float4* lds, int lane) {
+  // base rotation (btMatrix3x3::setRotation)
+  BaseKin bk;
+  {
+    const float x = s.quat[0], y = s.quat[1], z = s.quat[2], w = s.quat[3];
+    const float d = x * x + y * y + z * z + w * w, sc = 2.0f / d;
+    const float xs = x * sc, ys = y * sc, zs = z * sc;
+    const float wx = w * xs, wy = w * ys, wz = w * zs, xx = x * xs, xy = x * ys, xz = x * zs, yy = y * ys, yz = y * zs, zz = z * zs;
+    bk.ex = mk(1.0f - (yy + zz), xy + wz, xz - wy);
+    bk.ey = mk(xy - wz, 1.0f - (xx + zz), yz + wx);
+    bk.ez = mk(xz + wy, yz - wx, 1.0f - (xx + yy));
+  }
+  bk.w = mk(s.ang[0], s.ang[1], s.ang[2]);
+  bk.v = mk(s.lin[0], s.lin[1], s.lin[2]);
+  bk.height = s.pos[2];
+
+  BaseAccum acc;
+  acc.Io = rot_inertia(bk.ex, bk.ey, bk.ez, (float)REX_BASE_IXX, (float)REX_BASE_IYY, (float)REX_BASE_IZZ);
+  acc.h = mk(0.f, 0.f, 0.f);
+  acc.m = (float)REX_BASE_MASS;
+#pragma unroll
+  for (int k = 0; k < 21; ++k) acc.S[k] = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) acc.bz[k] = 0.0f;
+  {
+    const f3 Iw = mul(acc.Io, bk.w);
+    const float dl = kLinDamp + kLinDamp * sqrtf(dot(bk.v, bk.v));
+    const float da = kAngDamp + kAngDamp * sqrtf(dot(bk.w, bk.w));
+    acc.N = cross(bk.w, Iw) + da * Iw;
+    acc.F = mk(0.f, 0.f, (float)REX_BASE_MASS * kGravity) + ((float)REX_BASE_MASS * dl) * bk.v;
+  }
+
+  LegFactor L0, L1, L2, L3;
+  unsigned active = 0;
+  leg_pass<0>(bk, s.q + 0, s.qd + 0, tau + 0, dt, L0, acc, lds, lane, active);
+  leg_pass<1>(bk, s.q + 3, s.qd + 3, tau + 3, dt, L1, acc, lds, lane, active);
+  leg_pass<2>(bk, s.q + 6, s.qd + 6, tau + 6, dt, L2, acc, lds, lane, active);
+  leg_pass<3>(bk, s.q + 9, s.qd + 9, tau + 9, dt, L3, acc, lds, lane, active);
+
+  // base articulated inertia A = [[Io, hx],[hx^T, m]] - S, then A = Lc Lc^T
+  float A[21];
+  {
+    const s33& I = acc.Io; const f3 h = acc.h;
+    const float full[6][6] = {
+        {I.xx, I.xy, I.xz, 0.f, -h.z, h.y},
+        {I.xy, I.yy, I.yz, h.z, 0.f, -h.x},
+        {I.xz, I.yz, I.zz, -h.y, h.x, 0.f},
+        {0.f, h.z, -h.y, acc.m, 0.f, 0.f},
+        {-h.z, 0.f, h.x, 0.f, acc.m, 0.f},
+        {h.y, -h.x, 0.f, 0.f, 0.f, acc.m}};
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = 0; j <= i; ++j) A[tri(i, j)] = full[i][j] - acc.S[tri(i, j)];
+  }
+  Chol6 Lc;
+  chol6(A, Lc);
+
+  // predicted whitened base velocity  y = Lc^T nu0 + dt Lc^-1 (F_b - sum Bw^T zdot)
+  float y[6];
+  {
+    const float nu0[6] = {bk.w.x, bk.w.y, bk.w.z, bk.v.x, bk.v.y, bk.v.z};
+    const float rhs[6] = {-acc.N.x - acc.bz[0], -acc.N.y - acc.bz[1], -acc.N.z - acc.bz[2],
+                          -acc.F.x - acc.bz[3], -acc.F.y - acc.bz[4], -acc.F.z - acc.bz[5]};
+    float yd[6];
+    fwd6(Lc, rhs, yd);
+    mulT6(Lc, nu0, y);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) y[k] += dt * yd[k];
+  }
+
+  // finish the rows: whiten the base part, inverse diagonal (0 disables an inactive point)
+  for (int r = 0; r < REX_NROW; ++r) {
+    float4 c0 = row_chunk(lds, r, 0, lane), c1 = row_chunk(lds, r, 1, lane), c2 = row_chunk(lds, r, 2, lane);
+    const float g[6] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y};
+    float gw[6];
+    fwd6(Lc, g, gw);
+    const float diag = gw[0] * gw[0] + gw[1] * gw[1] + gw[2] * gw[2] + gw[3] * gw[3] + gw[4] * gw[4] + gw[5] * gw[5] +
+                       c1.z * c1.z + c1.w * c1.w + c2.x * c2.x;
+    const float invd = c2.z != 0.0f ? 1.0f / diag : 0.0f;
+    row_chunk(lds, r, 0, lane) = make_float4(gw[0], gw[1], gw[2], gw[3]);
+    row_chunk(lds, r, 1, lane) = make_float4(gw[4], gw[5], c1.z, c1.w);
+    row_chunk(lds, r, 2, lane) = make_float4(c2.x, c2.y, invd, 0.0f);
+  }
+
+  // projected Gauss-Seidel in Bullet's order: all normals, then all friction rows; a point that no
+  // lane of the wavefront has within the breaking distance is skipped for the whole wavefront
+  // (its rows could only ever produce zero impulses).
+  float lam[REX_NROW];
+#pragma unroll
+  for (int r = 0; r < REX_NROW; ++r) lam[r] = 0.0f;
+  const bool any0 = __builtin_amdgcn_ballot_w64((active & 0x03u) != 0) != 0;
+  const bool any1 = __builtin_amdgcn_ballot_w64((active & 0x0Cu) != 0) != 0;
+  const bool any2 = __builtin_amdgcn_ballot_w64((active & 0x30u) != 0) != 0;
+  const bool any3 = __builtin_amdgcn_ballot_w64((active & 0xC0u) != 0) != 0;
+  for (int it = 0; it < iterations; ++it) {
+    if (any0) pgs_point_normal<0>(lds, lane, y, L0.z, lam);
+    if (any1) pgs_point_normal<1>(lds, lane, y, L1.z, lam);
+    if (any2) pgs_point_normal<2>(lds, lane, y, L2.z, lam);
+    if (any3) pgs_point_normal<3>(lds, lane, y, L3.z, lam);
+    if (any0) pgs_point_friction<0>(lds, lane, y, L0.z, lam);
+    if (any1) pgs_point_friction<1>(lds, lane, y, L1.z, lam);
+    if (any2) pgs_point_friction<2>(lds, lane, y, L2.z, lam);
+    if (any3) pgs_point_friction<3>(lds, lane, y, L3.z, lam);
+  }
+
+  // back to generalized velocities: nu0 = Lc^-T y ;  qd_f = G^-T (z_f - Bw_f nu0)
+  float nu[6];
+  bwd6(Lc, y, nu);
+  auto leg_back = [&](const LegFactor& L, float* qd) {
+    float t1 = L.z[0], t2 = L.z[1], t3 = L.z[2];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { t1 -= L.Bw[0][k] * nu[k]; t2 -= L.Bw[1][k] * nu[k]; t3 -= L.Bw[2][k] * nu[k]; }
+    const float u3 = t3 * L.gi3;
+    const float u2 = (t2 - L.g32 * u3) * L.gi2;
+    const float u1 = (t1 - L.g21 * u2 - L.g31 * u3) * L.gi1;
+    qd[0] = clampf(u1, -kMaxCoordVel, kMaxCoordVel);
+    qd[1] = clampf(u2, -kMaxCoordVel, kMaxCoordVel);
+    qd[2] = clampf(u3, -kMaxCoordVel, kMaxCoordVel);
+  };
+  leg_back(L0, s.qd + 0); leg_back(L1, s.qd + 3); leg_back(L2, s.qd + 6); leg_back(L3, s.qd + 9);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    s.ang[k] = clampf(nu[k], -kMaxCoordVel, kMaxCoordVel);
+    s.lin[k] = clampf(nu[3 + k], -kMaxCoordVel, kMaxCoordVel);
+  }
+  // semi-implicit Euler with the NEW velocities
+#pragma unroll
+  for (int k = 0; k < 3; ++k) s.pos[k] += dt * s.lin[k];
+#pragma unroll
+  for (int j = 0; j < 12; ++j) s.q[j] += dt * s.qd[j];
+  {
+    const float wn = sqrtf(s.ang[0] * s.ang[0] + s.ang[1] * s.ang[1] + s.ang[2] * s.ang[2]);
+    const float angle = wn * dt;
+    float sc;
+    if (wn < 0.001f) sc = 0.5f * dt - dt * dt * dt * 0.020833333333f * wn * wn;
+    else sc = sinf(0.5f * angle) / wn;
+    const float dx = s.ang[0] * sc, dy = s.ang[1] * sc, dz = s.ang[2] * sc, dw = cosf(0.5f * angle);
+    const float qx = s.quat[0], qy = s.quat[1], qz = s.quat[2], qw = s.quat[3];
+    const float nx = dw * qx + dx * qw + dy * qz - dz * qy;
+    const float ny = dw * qy - dx * qz + dy * qw + dz * qx;
+    const float nz = dw * qz + dx * qy - dy * qx + dz * qw;
+    const float nw = dw * qw - dx * qx - dy * qy - dz * qz;
+    const float nn = rsqrtf(nx * nx + ny * ny + nz * nz + nw * nw);
+    s.quat[0] = nx * nn; s.quat[1] = ny * nn; s.quat[2] = nz * nn; s.quat[3] = nw * nn;
+  }
+}
+
+}  // namespace rex

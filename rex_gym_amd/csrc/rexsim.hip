@@ -1,0 +1,607 @@
+// rexsim.hip -- kernels + C ABI (include/rexsim.h) of the MI355X-native batched Rex simulator.
+// gfx950 only.  Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC rexsim.hip -o librexsim_hip.so
+//
+// Kernel map
+//   rex_step_kernel     one env.step() per lane: action -> staged gait -> Bezier/IK targets ->
+//                       action_repeat x (motor model + restated stepSimulation) -> reward / done /
+//                       observation (+ optional in-launch reset).  State is read once and written
+//                       once per env.step (SoA, coalesced); constraint rows live in LDS.
+//   rex_settle_kernel   the reference's 100 + 500 substep reset motion (rex.py:314-323), run once.
+//   rex_reset_kernel    snapshot restore + per-episode draws (walk_env.py:125-154).
+//   rex_ik/motor/gait   controller-only kernels for parity tests of the controller half.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "rex_controller.h"
+#include "rex_device.h"
+
+namespace rex {
+
+// INIT_POSES (model/rex_constants.py:10-22), motor order FL,FR,RL,RR x (shoulder, leg, foot)
+__device__ __forceinline__ float pose_stand(int j) {
+  const int k = j % 3;
+  return k == 0 ? 0.0f : (k == 1 ? -0.88643435f : 1.30197369f);
+}
+__device__ __forceinline__ float pose_stand_ol(int j) {
+  const int k = j % 3;
+  return k == 0 ? (((j / 3) & 1) ? -0.15192765f : 0.15192765f) : (k == 1 ? -0.90412283f : 1.48156545f);
+}
+
+struct EnvState {
+  PhysState ph;
+  GaitState gait;
+  float target, end_time, aux;
+  uint32_t flags;
+  int32_t steps, episode;
+  uint32_t motor_en;
+  uint32_t overheat[6];  // 12 x u16
+};
+
+__device__ __forceinline__ float ldw(const float* st, int n, int w, int i) { return st[(size_t)w * n + i]; }
+__device__ __forceinline__ uint32_t ldi(const float* st, int n, int w, int i) { return __float_as_uint(st[(size_t)w * n + i]); }
+__device__ __forceinline__ void stw(float* st, int n, int w, int i, float v) { st[(size_t)w * n + i] = v; }
+__device__ __forceinline__ void sti(float* st, int n, int w, int i, uint32_t v) { st[(size_t)w * n + i] = __uint_as_float(v); }
+
+__device__ __forceinline__ void load_env(const float* st, int n, int i, EnvState& e) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { e.ph.pos[k] = ldw(st, n, REX_S_POS + k, i); e.ph.lin[k] = ldw(st, n, REX_S_LINVEL + k, i); e.ph.ang[k] = ldw(st, n, REX_S_ANGVEL + k, i); }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) e.ph.quat[k] = ldw(st, n, REX_S_QUAT + k, i);
+#pragma unroll
+  for (int j = 0; j < 12; ++j) { e.ph.q[j] = ldw(st, n, REX_S_Q + j, i); e.ph.qd[j] = ldw(st, n, REX_S_QD + j, i); }
+  e.gait.phi = ldw(st, n, REX_S_PHI, i); e.gait.last_time = ldw(st, n, REX_S_LASTT, i); e.gait.alpha = ldw(st, n, REX_S_ALPHA, i);
+  e.target = ldw(st, n, REX_S_TARGET, i); e.end_time = ldw(st, n, REX_S_ENDTIME, i); e.aux = ldw(st, n, REX_S_AUX, i);
+  e.flags = ldi(st, n, REX_S_FLAGS, i); e.steps = (int32_t)ldi(st, n, REX_S_STEPS, i); e.episode = (int32_t)ldi(st, n, REX_S_EPISODE, i);
+  e.motor_en = ldi(st, n, REX_S_MOTOR_EN, i);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) e.overheat[k] = ldi(st, n, REX_S_OVERHEAT + k, i);
+}
+
+__device__ __forceinline__ void store_env(float* st, int n, int i, const EnvState& e) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { stw(st, n, REX_S_POS + k, i, e.ph.pos[k]); stw(st, n, REX_S_LINVEL + k, i, e.ph.lin[k]); stw(st, n, REX_S_ANGVEL + k, i, e.ph.ang[k]); }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) stw(st, n, REX_S_QUAT + k, i, e.ph.quat[k]);
+#pragma unroll
+  for (int j = 0; j < 12; ++j) { stw(st, n, REX_S_Q + j, i, e.ph.q[j]); stw(st, n, REX_S_QD + j, i, e.ph.qd[j]); }
+  stw(st, n, REX_S_PHI, i, e.gait.phi); stw(st, n, REX_S_LASTT, i, e.gait.last_time); stw(st, n, REX_S_ALPHA, i, e.gait.alpha);
+  stw(st, n, REX_S_TARGET, i, e.target); stw(st, n, REX_S_ENDTIME, i, e.end_time); stw(st, n, REX_S_AUX, i, e.aux);
+  sti(st, n, REX_S_FLAGS, i, e.flags); sti(st, n, REX_S_STEPS, i, (uint32_t)e.steps); sti(st, n, REX_S_EPISODE, i, (uint32_t)e.episode);
+  sti(st, n, REX_S_MOTOR_EN, i, e.motor_en);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) sti(st, n, REX_S_OVERHEAT + k, i, e.overheat[k]);
+}
+
+// ---- PyBullet quaternion conventions ----
+__device__ __forceinline__ void quat_to_euler(const float* q, float* rpy) {
+  const float x = q[0], y = q[1], z = q[2], w = q[3];
+  const float sqx = x * x, sqy = y * y, sqz = z * z, squ = w * w;
+  const float sarg = -2.0f * (x * z - w * y);
+  if (sarg <= -0.99999f) { rpy[1] = -0.5f * kPi; rpy[0] = 0.0f; rpy[2] = 2.0f * atan2f(x, -y); }
+  else if (sarg >= 0.99999f) { rpy[1] = 0.5f * kPi; rpy[0] = 0.0f; rpy[2] = 2.0f * atan2f(-x, y); }
+  else {
+    rpy[1] = asinf(sarg);
+    rpy[0] = atan2f(2.0f * (y * z + w * x), squ - sqx - sqy + sqz);
+    rpy[2] = atan2f(2.0f * (x * y + w * z), squ + sqx - sqy - sqz);
+  }
+}
+// third row (R20, R21, R22) of the matrix of the quaternion rebuilt from Euler angles
+// (Rex.GetBaseOrientation, rex.py:530-537, then getMatrixFromQuaternion)
+__device__ __forceinline__ void euler_to_row2(const float* rpy, float& r20, float& r21, float& r22) {
+  float sr, cr, sp, cp, sy, cy;
+  sincosf(rpy[0] * 0.5f, &sr, &cr); sincosf(rpy[1] * 0.5f, &sp, &cp); sincosf(rpy[2] * 0.5f, &sy, &cy);
+  float x = sr * cp * cy - cr * sp * sy, y = cr * sp * cy + sr * cp * sy;
+  float z = cr * cp * sy - sr * sp * cy, w = cr * cp * cy + sr * sp * sy;
+  const float nn = rsqrtf(x * x + y * y + z * z + w * w);
+  x *= nn; y *= nn; z *= nn; w *= nn;
+  const float d = x * x + y * y + z * z + w * w, s = 2.0f / d;
+  const float xs = x * s, ys = y * s, zs = z * s;
+  r20 = x * zs - w * ys; r21 = y * zs + w * xs; r22 = 1.0f - (x * xs + y * ys);
+}
+
+// ---- Philox4x32-10 ----
+__device__ __forceinline__ void philox4x32(uint32_t* c, uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t h0 = __umulhi(0xD2511F53u, c[0]), l0 = 0xD2511F53u * c[0];
+    const uint32_t h1 = __umulhi(0xCD9E8D57u, c[2]), l1 = 0xCD9E8D57u * c[2];
+    const uint32_t n0 = h1 ^ c[1] ^ k0, n1 = l1, n2 = h0 ^ c[3] ^ k1, n3 = l0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+__device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+
+struct DevCfg {
+  int32_t n, env_index_base, task, signal, action_repeat, iterations;
+  float dt, kp, kd;
+  int32_t backwards;
+  float target_position;
+  uint32_t seed_lo, seed_hi;
+  int32_t auto_reset, max_steps;
+  float w_dist, w_energy, w_drift, w_shake;
+  int32_t action_dim, obs_dim;
+};
+
+__device__ __forceinline__ float init_pose(const DevCfg& c, int j) { return c.signal == REX_SIGNAL_OL ? pose_stand_ol(j) : pose_stand(j); }
+
+// Rex.ApplyAction + stepSimulation + ReceiveObservation (rex.py:158-163, 568-641)
+__device__ __forceinline__ void rex_substep(const DevCfg& c, EnvState& e, const float* cmd, float* tau_obs, float4* lds, int lane) {
+  float tau[12];
+  const float limit = 1.0f / c.dt;  // OVERHEAT_SHUTDOWN_TIME / time_step, rex.py:607
+#pragma unroll
+  for (int j = 0; j < 12; ++j) {
+    float act, obs;
+    motor_torque(cmd[j], e.ph.q[j], e.ph.qd[j], e.ph.qd[j], c.kp, c.kd, act, obs);
+    uint32_t cnt = (e.overheat[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
+    if (fabsf(act) > 2.45f) { if (cnt < 65535u) cnt++; } else cnt = 0;          // rex.py:603-606
+    if ((float)cnt > limit) e.motor_en &= ~(1u << j);                            // rex.py:607-608
+    e.overheat[j >> 1] = (e.overheat[j >> 1] & ~(0xFFFFu << ((j & 1) * 16))) | (cnt << ((j & 1) * 16));
+    tau_obs[j] = obs;
+    tau[j] = ((e.motor_en >> j) & 1u) ? act : 0.0f;                              // rex.py:617-623
+  }
+  physics_substep(e.ph, tau, c.dt, c.iterations, lds, lane);
+}
+
+__device__ __forceinline__ void env_observation(const DevCfg& c, const EnvState& e, float* obs) {
+  float rpy[3];
+  quat_to_euler(e.ph.quat, rpy);
+  obs[0] = rpy[0]; obs[1] = rpy[1]; obs[2] = e.ph.ang[0]; obs[3] = e.ph.ang[1];   // walk_env.py:356-362
+  if (c.task == REX_TASK_GALLOP) {
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {                                                // MapToMinusPiToPi, rex.py:26-41
+      float a = fmodf(e.ph.q[j], 2.0f * kPi);
+      if (a >= kPi) a -= 2.0f * kPi; else if (a < -kPi) a += 2.0f * kPi;
+      obs[4 + j] = a;
+    }
+  }
+}
+
+// RexWalkEnv.reset / RexReactiveEnv.reset draws on top of the settled snapshot
+__device__ __forceinline__ void env_reset(const DevCfg& c, const float* snap, int gidx, EnvState& e) {
+  const int32_t episode = e.episode + 1;
+  load_env(snap, 1, 0, e);
+  e.episode = episode;
+  e.gait.phi = 0.0f; e.gait.last_time = 0.0f; e.gait.alpha = 0.0f;
+  uint32_t ctr[4] = {(uint32_t)episode, 0u, 0u, 0u};
+  philox4x32(ctr, c.seed_lo ^ (uint32_t)gidx, c.seed_hi);
+  e.flags = 0;
+  const float u = u01(ctr[1]);
+  if (c.task == REX_TASK_WALK) {
+    const int backwards = c.backwards < 0 ? (int)(ctr[0] >> 31) : c.backwards;   // walk_env.py:133-136
+    if (backwards) e.flags |= REX_F_BACKWARDS;
+    if (c.target_position != 0.0f) e.target = c.target_position;
+    else e.target = backwards ? (-2.0f - u) : (1.0f + 2.0f * u);                 // walk_env.py:143-147
+  } else {
+    e.target = c.target_position != 0.0f ? c.target_position : (1.0f + 2.0f * u); // gallop_env.py:150-152
+  }
+  e.end_time = 0.0f; e.aux = 0.0f; e.steps = 0;
+}
+
+__device__ __forceinline__ void order_signal(const float* ang, float* cmd) {  // FR,FL,RR,RL -> FL,FR,RL,RR
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { cmd[k] = ang[3 + k]; cmd[3 + k] = ang[k]; cmd[6 + k] = ang[9 + k]; cmd[9 + k] = ang[6 + k]; }
+}
+
+// RexWalkEnv._transform_action_to_motor_command (walk_env.py:207-324)
+__device__ __forceinline__ void walk_command(const DevCfg& c, EnvState& e, const float* action, float* cmd) {
+  if (e.flags & REX_F_STAY_STILL) {
+#pragma unroll
+    for (int j = 0; j < 12; ++j) cmd[j] = init_pose(c, j);
+    return;
+  }
+  const float t = (float)(e.steps * c.action_repeat) * c.dt;                     // rex.py:155-156
+  if (e.target != 0.0f && fabsf(e.ph.pos[0]) >= fabsf(e.target) - 0.15f) {       // walk_env.py:207-215
+    e.flags |= REX_F_GOAL_REACHED;
+    if (!(e.flags & REX_F_TERMINATING)) { e.end_time = t; e.flags |= REX_F_TERMINATING; }
+  }
+  const bool backwards = (e.flags & REX_F_BACKWARDS) != 0;
+  if (c.signal == REX_SIGNAL_IK) {                                               // walk_env.py:252-290
+    const float p = 0.8f + action[0];
+    const float gait_coeff = (0.0f <= t && t <= p) ? t : 1.0f;
+    const float period = backwards ? 0.5f : 0.65f;
+    const float pos[3] = {backwards ? 0.0f : 0.01f, 0.0f, 0.0f}, orn[3] = {0.0f, 0.0f, 0.0f};
+    float step_length = (backwards ? -0.3f : 0.6f) * gait_coeff;
+    if (e.flags & REX_F_GOAL_REACHED) {
+      const float pb = 0.8f + action[1];
+      const float b = (e.end_time <= t && t <= pb + e.end_time) ? 1.0f - (t - e.end_time) : 0.0f;
+      step_length *= b;
+      if (b == 0.0f) e.flags |= REX_F_STAY_STILL;
+    }
+    const float direction = step_length < 0.0f ? -1.0f : 1.0f;
+    float frames[12], ang[12];
+    gait_loop(e.gait, 0, step_length, 0.0f, 0.0f, period, direction, t, frames);
+    ik_solve(orn, pos, frames, ang);
+    order_signal(ang, cmd);
+  } else {                                                                       // walk_env.py:292-315
+    float l_a = 0.1f, f_a = 0.2f;
+    if (e.flags & REX_F_GOAL_REACHED) {
+      const float b = (e.end_time <= t && t <= 0.8f + e.end_time) ? 1.0f - (t - e.end_time) : 0.0f;
+      l_a *= b; f_a *= b;   // `coeff is 0.0` never holds for a computed float: no _stay_still here
+    }
+    const float sc = (0.0f <= t && t <= 0.8f) ? t : 1.0f;
+    l_a *= sc; f_a *= sc;
+    const float cph = cosf(2.0f * kPi / 0.125f * t);
+    const float le = l_a * cph, fe = f_a * cph;
+    const float pose[12] = {0.f, le + action[0], fe + action[1], 0.f, -le + action[2], -fe + action[3],
+                            0.f, -le + action[4], -fe + action[5], 0.f, le + action[6], fe + action[7]};
+#pragma unroll
+    for (int j = 0; j < 12; ++j) cmd[j] = pose_stand_ol(j) + pose[j];
+  }
+}
+
+// RexReactiveEnv._transform_action_to_motor_command (gallop_env.py:212-313)
+__device__ __forceinline__ void gallop_command(const DevCfg& c, EnvState& e, const float* action, float* cmd) {
+  if (e.flags & REX_F_STAY_STILL) {
+#pragma unroll
+    for (int j = 0; j < 12; ++j) cmd[j] = pose_stand(j);                         // rex.initial_pose
+    return;
+  }
+  const float t = (float)(e.steps * c.action_repeat) * c.dt;
+  if (e.target != 0.0f && fabsf(e.ph.pos[0]) >= fabsf(e.target)) {               // gallop_env.py:212-220
+    e.flags |= REX_F_GOAL_REACHED;
+    if (!(e.flags & REX_F_TERMINATING)) { e.end_time = t; e.flags |= REX_F_TERMINATING; }
+  }
+  if (c.signal == REX_SIGNAL_IK) {                                               // gallop_env.py:257-285
+    const float pg = 1.0f + action[1];
+    const float gait_coeff = (0.0f <= t && t <= pg) ? t : 1.0f;
+    const float pos[3] = {0.01f, 0.0f, -0.007f}, orn[3] = {0.0f, 0.0f, 0.0f};
+    float step_length = 1.3f * gait_coeff;
+    if (e.flags & REX_F_GOAL_REACHED) {
+      const float pb = 1.0f + action[0];
+      step_length *= (e.end_time <= t && t <= pb + e.end_time) ? 1.0f - (t - e.end_time) : 0.0f;
+    }
+    float frames[12], ang[12];
+    gait_loop(e.gait, 1, step_length, 0.0f, 0.0f, 0.3f, 1.0f, t, frames);
+    ik_solve(orn, pos, frames, ang);
+    order_signal(ang, cmd);
+  } else {                                                                       // gallop_env.py:287-304
+    float lp[4] = {action[0], action[1], action[2], action[3]};
+    if (e.flags & REX_F_GOAL_REACHED) {
+      const float b = (e.end_time <= t && t <= 1.0f + e.end_time) ? 1.0f - (t - e.end_time) : 0.0f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) lp[k] *= b;
+    }
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+      cmd[3 * l] = init_pose(c, 3 * l);
+      cmd[3 * l + 1] = init_pose(c, 3 * l + 1) + (l < 2 ? lp[0] : lp[2]);
+      cmd[3 * l + 2] = init_pose(c, 3 * l + 2) + (l < 2 ? lp[1] : lp[3]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __restrict__ state, const float* __restrict__ snap,
+                                                            const float* __restrict__ action, float* __restrict__ obs_out,
+                                                            float* __restrict__ reward_out, uint8_t* __restrict__ done_out,
+                                                            float* __restrict__ cmd_out) {
+  __shared__ float4 lds[REX_LDS_FLOATS / 4];
+  const int lane = threadIdx.x;
+  const int gi = blockIdx.x * REX_WAVE + lane;
+  const bool live = gi < c.n;
+  const int i = live ? gi : c.n - 1;   // tail lanes shadow the last env (keeps the wave convergent)
+
+  EnvState e;
+  load_env(state, c.n, i, e);
+  float act[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) act[k] = k < c.action_dim ? action[(size_t)i * c.action_dim + k] : 0.0f;
+
+  float cmd[12];
+  if (c.task == REX_TASK_GALLOP) gallop_command(c, e, act, cmd);
+  else walk_command(c, e, act, cmd);
+
+  float tau_obs[12];
+  for (int k = 0; k < c.action_repeat; ++k) rex_substep(c, e, cmd, tau_obs, lds, lane);   // Rex.Step
+
+  // ---- reward (rex_gym_env.py:501-542) ----
+  float rpy[3], r20, r21, r22;
+  quat_to_euler(e.ph.quat, rpy);
+  euler_to_row2(rpy, r20, r21, r22);
+  float x = -e.ph.pos[0];
+  if (c.backwards > 0) x = -x;      // `if self._backwards:` is the constructor argument, not the draw
+  e.target = fabsf(e.target);       // rex_gym_env.py:510
+  const float T = e.target;
+  float fwd;
+  if (x > T + 0.15f) fwd = T - x;
+  else if (T <= x && x <= T + 0.15f) fwd = 1.0f;
+  else if (x <= 0.05f) fwd = 0.0f;
+  else fwd = x / T;
+  const float drift = -fabsf(e.ph.pos[1]);
+  const float shake = -fabsf(r20 + r21);
+  float dp = 0.0f;
+#pragma unroll
+  for (int j = 0; j < 12; ++j) dp += tau_obs[j] * e.ph.qd[j];
+  const float energy = -fabsf(dp) * c.dt;
+  const float reward = c.w_dist * fwd + c.w_energy * energy + c.w_drift * drift + c.w_shake * shake;
+
+  // ---- termination (rex_gym_env.py:490-499, walk_env.py:326-338, gallop_env.py:315-329) ----
+  bool done;
+  if (c.task == REX_TASK_GALLOP) done = fabsf(rpy[0]) > 0.3f || fabsf(rpy[1]) > 0.5f || e.ph.pos[1] > 0.3f;
+  else done = r22 < 0.85f;
+  e.steps += 1;
+  if (c.max_steps > 0 && e.steps >= c.max_steps) done = true;
+  if (done) e.flags |= REX_F_DONE;
+  if (done && c.auto_reset) env_reset(c, snap, c.env_index_base + i, e);
+
+  float obs[16];
+  env_observation(c, e, obs);
+  if (live) {
+    store_env(state, c.n, i, e);
+    for (int k = 0; k < c.obs_dim; ++k) obs_out[(size_t)i * c.obs_dim + k] = obs[k];
+    reward_out[i] = reward;
+    done_out[i] = done ? 1 : 0;
+    if (cmd_out) {
+#pragma unroll
+      for (int j = 0; j < 12; ++j) cmd_out[(size_t)i * 12 + j] = cmd[j];
+    }
+  }
+}
+
+// The reset motion of Rex.Reset (rex.py:296-324) for ONE robot; lane 0 writes the snapshot.
+__global__ __launch_bounds__(REX_WAVE) void rex_settle_kernel(DevCfg c, float* __restrict__ snap) {
+  __shared__ float4 lds[REX_LDS_FLOATS / 4];
+  const int lane = threadIdx.x;
+  EnvState e;
+  memset(&e, 0, sizeof(e));
+  e.ph.pos[2] = kInitZ;
+  e.ph.quat[3] = 1.0f;
+#pragma unroll
+  for (int j = 0; j < 12; ++j) e.ph.q[j] = pose_stand(j);       // ResetPose: INIT_POSES[pose_id = 'stand']
+  e.motor_en = (1u << 12) - 1u;
+  float cmd[12], tau_obs[12];
+#pragma unroll
+  for (int j = 0; j < 12; ++j) cmd[j] = pose_stand(j);
+  for (int k = 0; k < 100; ++k) rex_substep(c, e, cmd, tau_obs, lds, lane);   // rex.py:315-318
+#pragma unroll
+  for (int j = 0; j < 12; ++j) cmd[j] = init_pose(c, j);
+  const int nreset = (int)(0.5f / c.dt);                                       // rex.py:319
+  for (int k = 0; k < nreset; ++k) rex_substep(c, e, cmd, tau_obs, lds, lane);
+  if (lane == 0) store_env(snap, 1, 0, e);
+}
+
+__global__ void rex_reset_kernel(DevCfg c, float* __restrict__ state, const float* __restrict__ snap,
+                                 const int32_t* __restrict__ indices, int count, float* __restrict__ obs_out) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= count) return;
+  const int i = indices ? indices[r] : r;
+  if (i < 0 || i >= c.n) return;
+  EnvState e;
+  e.episode = (int32_t)ldi(state, c.n, REX_S_EPISODE, i);
+  env_reset(c, snap, c.env_index_base + i, e);
+  store_env(state, c.n, i, e);
+  float obs[16];
+  env_observation(c, e, obs);
+  if (obs_out) for (int k = 0; k < c.obs_dim; ++k) obs_out[(size_t)r * c.obs_dim + k] = obs[k];
+}
+
+// ---- controller-only kernels ----
+__global__ void rex_ik_kernel(int n, const float* __restrict__ orn, const float* __restrict__ pos,
+                              const float* __restrict__ frames, float* __restrict__ angles) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float o[3], p[3], f[12], a[12];
+  for (int k = 0; k < 3; ++k) { o[k] = orn[3 * i + k]; p[k] = pos[3 * i + k]; }
+  for (int k = 0; k < 12; ++k) f[k] = frames[12 * i + k];
+  ik_solve(o, p, f, a);
+  for (int k = 0; k < 12; ++k) angles[12 * i + k] = a[k];
+}
+
+__global__ void rex_motor_kernel(int n, const float* __restrict__ cmd, const float* __restrict__ q, const float* __restrict__ qd,
+                                 const float* __restrict__ qdt, float kp, float kd, float* __restrict__ actual,
+                                 float* __restrict__ observed) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float a, o;
+  motor_torque(cmd[i], q[i], qd[i], qdt[i], kp, kd, a, o);
+  actual[i] = a; observed[i] = o;
+}
+
+__global__ void rex_gait_kernel(int n, int mode, float* __restrict__ planner, const float* __restrict__ params,
+                                float* __restrict__ frames) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  GaitState g{planner[3 * i], planner[3 * i + 1], planner[3 * i + 2]};
+  const float* p = params + 6 * i;
+  float f[12];
+  gait_loop(g, mode, p[0], p[1], p[2], p[3], p[4], p[5], f);
+  planner[3 * i] = g.phi; planner[3 * i + 1] = g.last_time; planner[3 * i + 2] = g.alpha;
+  for (int k = 0; k < 12; ++k) frames[12 * i + k] = f[k];
+}
+
+}  // namespace rex
+
+// =================================================================================================
+//                                          host side: C ABI
+// =================================================================================================
+struct RexSim {
+  RexConfig cfg;
+  rex::DevCfg dev;
+  int device;
+  float* d_state;   // caller-owned
+  float* d_snap;    // REX_STATE_WORDS floats
+  hipEvent_t ev0, ev1;
+  int timing;
+  int have_timing;
+};
+
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, const char* detail) {
+  snprintf(g_err, sizeof(g_err), fmt, detail ? detail : "");
+  return code;
+}
+#define HIPCHK(expr)                                                                  \
+  do {                                                                                \
+    hipError_t _e = (expr);                                                           \
+    if (_e != hipSuccess) return fail(REX_EHIP, #expr ": %s", hipGetErrorString(_e)); \
+  } while (0)
+
+extern "C" {
+
+const char* rex_last_error(void) { return g_err; }
+int rex_abi_version(void) { return REX_ABI_VERSION; }
+
+int rex_default_config(int task, int signal, int num_envs, RexConfig* cfg) {
+  if (!cfg || num_envs <= 0) return fail(REX_EINVAL, "rex_default_config: bad arguments%s", "");
+  if (task != REX_TASK_WALK && task != REX_TASK_GALLOP) return fail(REX_EINVAL, "rex_default_config: unsupported task%s", "");
+  if (signal != REX_SIGNAL_IK && signal != REX_SIGNAL_OL) return fail(REX_EINVAL, "rex_default_config: unsupported signal%s", "");
+  memset(cfg, 0, sizeof(*cfg));
+  cfg->abi_version = REX_ABI_VERSION;
+  cfg->num_envs = num_envs;
+  cfg->task = task;
+  cfg->signal = signal;
+  cfg->action_repeat = task == REX_TASK_GALLOP ? 6 : 5;          /* gallop_env.py:47-48, walk_env.py:34-35 */
+  cfg->solver_iterations = 300 / cfg->action_repeat;             /* rex_gym_env.py:25,184 */
+  cfg->sim_time_step = 0.001f;
+  cfg->motor_kp = 1.0f;
+  cfg->motor_kd = 0.02f;
+  cfg->backwards = -1;
+  cfg->target_position = 0.0f;
+  cfg->seed = 0;
+  cfg->auto_reset = 0;
+  cfg->max_episode_steps = 0;
+  cfg->distance_weight = 1.0f;                                   /* rex_gym_env.py:56-59 */
+  cfg->energy_weight = task == REX_TASK_GALLOP ? 0.005f : 0.0005f;   /* gallop_env.py:45 */
+  cfg->drift_weight = 2.0f;
+  cfg->shake_weight = 0.005f;
+  return REX_OK;
+}
+
+int rex_action_dim(const RexConfig* c) {
+  if (!c) return REX_EINVAL;
+  if (c->task == REX_TASK_WALK) return c->signal == REX_SIGNAL_IK ? 2 : 8;      /* walk_env.py:104-112 */
+  if (c->task == REX_TASK_GALLOP) return c->signal == REX_SIGNAL_IK ? 2 : 4;    /* gallop_env.py:119-130 */
+  return REX_EINVAL;
+}
+int rex_obs_dim(const RexConfig* c) {
+  if (!c) return REX_EINVAL;
+  return c->task == REX_TASK_GALLOP ? 16 : 4;                                    /* gallop_env.py:349-356 */
+}
+
+static int validate(const RexConfig* c) {
+  if (!c) return fail(REX_EINVAL, "null config%s", "");
+  if (c->abi_version != REX_ABI_VERSION) return fail(REX_EINVAL, "RexConfig.abi_version mismatch%s", "");
+  if (c->num_envs <= 0) return fail(REX_EINVAL, "num_envs must be positive%s", "");
+  if (rex_action_dim(c) < 0) return fail(REX_EINVAL, "unsupported task/signal%s", "");
+  if (c->action_repeat <= 0 || c->solver_iterations <= 0 || !(c->sim_time_step > 0.0f))
+    return fail(REX_EINVAL, "action_repeat, solver_iterations and sim_time_step must be positive%s", "");
+  return REX_OK;
+}
+
+int rex_create(const RexConfig* cfg, int device, float* d_state, void* stream, RexSim** out) {
+  if (!out || !d_state) return fail(REX_EINVAL, "rex_create: null pointer%s", "");
+  int rc = validate(cfg);
+  if (rc) return rc;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(REX_ENODEV, "no HIP device visible%s", "");
+  if (device < 0 || device >= ndev) return fail(REX_EINVAL, "device index out of range%s", "");
+  HIPCHK(hipSetDevice(device));
+  RexSim* s = new RexSim();
+  s->cfg = *cfg;
+  s->device = device;
+  s->d_state = d_state;
+  s->timing = 0;
+  s->have_timing = 0;
+  rex::DevCfg& d = s->dev;
+  d.n = cfg->num_envs; d.env_index_base = cfg->env_index_base; d.task = cfg->task; d.signal = cfg->signal;
+  d.action_repeat = cfg->action_repeat; d.iterations = cfg->solver_iterations; d.dt = cfg->sim_time_step;
+  d.kp = cfg->motor_kp; d.kd = cfg->motor_kd; d.backwards = cfg->backwards; d.target_position = cfg->target_position;
+  d.seed_lo = (uint32_t)cfg->seed; d.seed_hi = (uint32_t)(cfg->seed >> 32);
+  d.auto_reset = cfg->auto_reset; d.max_steps = cfg->max_episode_steps;
+  d.w_dist = cfg->distance_weight; d.w_energy = cfg->energy_weight; d.w_drift = cfg->drift_weight; d.w_shake = cfg->shake_weight;
+  d.action_dim = rex_action_dim(cfg); d.obs_dim = rex_obs_dim(cfg);
+  hipError_t e = hipMalloc(&s->d_snap, sizeof(float) * REX_STATE_WORDS);
+  if (e != hipSuccess) { delete s; return fail(REX_ENOMEM, "hipMalloc(snapshot): %s", hipGetErrorString(e)); }
+  (void)hipEventCreate(&s->ev0);
+  (void)hipEventCreate(&s->ev1);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(rex::rex_settle_kernel, dim3(1), dim3(REX_WAVE), 0, st, s->dev, s->d_snap);
+  e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemsetAsync(d_state, 0, sizeof(float) * (size_t)REX_STATE_WORDS * cfg->num_envs, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) {
+    (void)hipFree(s->d_snap);
+    delete s;
+    return fail(REX_EHIP, "settle kernel: %s", hipGetErrorString(e));
+  }
+  *out = s;
+  return REX_OK;
+}
+
+int rex_destroy(RexSim* s) {
+  if (!s) return REX_OK;
+  (void)hipSetDevice(s->device);
+  (void)hipFree(s->d_snap);
+  (void)hipEventDestroy(s->ev0);
+  (void)hipEventDestroy(s->ev1);
+  delete s;
+  return REX_OK;
+}
+
+int rex_reset(RexSim* s, const int32_t* d_indices, int n, float* d_obs, void* stream) {
+  if (!s) return fail(REX_EINVAL, "rex_reset: null sim%s", "");
+  const int count = d_indices ? n : s->cfg.num_envs;
+  if (count <= 0) return d_indices ? REX_OK : fail(REX_EINVAL, "rex_reset: empty%s", "");
+  HIPCHK(hipSetDevice(s->device));
+  const int block = 256;
+  hipLaunchKernelGGL(rex::rex_reset_kernel, dim3((count + block - 1) / block), dim3(block), 0, (hipStream_t)stream, s->dev,
+                     s->d_state, s->d_snap, d_indices, count, d_obs);
+  HIPCHK(hipGetLastError());
+  return REX_OK;
+}
+
+int rex_step(RexSim* s, const float* d_action, float* d_obs, float* d_reward, uint8_t* d_done, float* d_motor_cmd, void* stream) {
+  if (!s || !d_action || !d_obs || !d_reward || !d_done) return fail(REX_EINVAL, "rex_step: null pointer%s", "");
+  HIPCHK(hipSetDevice(s->device));
+  hipStream_t st = (hipStream_t)stream;
+  const int blocks = (s->cfg.num_envs + REX_WAVE - 1) / REX_WAVE;
+  if (s->timing) HIPCHK(hipEventRecord(s->ev0, st));
+  hipLaunchKernelGGL(rex::rex_step_kernel, dim3(blocks), dim3(REX_WAVE), 0, st, s->dev, s->d_state, s->d_snap, d_action, d_obs,
+                     d_reward, d_done, d_motor_cmd);
+  HIPCHK(hipGetLastError());
+  if (s->timing) { HIPCHK(hipEventRecord(s->ev1, st)); s->have_timing = 1; }
+  return REX_OK;
+}
+
+int rex_set_timing(RexSim* s, int enable) {
+  if (!s) return fail(REX_EINVAL, "rex_set_timing: null sim%s", "");
+  s->timing = enable ? 1 : 0;
+  s->have_timing = 0;
+  return REX_OK;
+}
+
+int rex_last_step_ms(RexSim* s, float* ms) {
+  if (!s || !ms) return fail(REX_EINVAL, "rex_last_step_ms: null pointer%s", "");
+  if (!s->have_timing) return fail(REX_EINVAL, "rex_last_step_ms: no timed step recorded%s", "");
+  HIPCHK(hipEventSynchronize(s->ev1));
+  HIPCHK(hipEventElapsedTime(ms, s->ev0, s->ev1));
+  return REX_OK;
+}
+
+int rex_ik_solve(int n, const float* d_orn, const float* d_pos, const float* d_frames, float* d_angles, void* stream) {
+  if (n <= 0 || !d_orn || !d_pos || !d_frames || !d_angles) return fail(REX_EINVAL, "rex_ik_solve: bad arguments%s", "");
+  hipLaunchKernelGGL(rex::rex_ik_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, d_orn, d_pos, d_frames, d_angles);
+  HIPCHK(hipGetLastError());
+  return REX_OK;
+}
+
+int rex_motor_torque(int n, const float* d_cmd, const float* d_q, const float* d_qd, const float* d_qd_true, float kp, float kd,
+                     float* d_actual, float* d_observed, void* stream) {
+  if (n <= 0 || !d_cmd || !d_q || !d_qd || !d_qd_true || !d_actual || !d_observed) return fail(REX_EINVAL, "rex_motor_torque: bad arguments%s", "");
+  hipLaunchKernelGGL(rex::rex_motor_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, d_cmd, d_q, d_qd, d_qd_true,
+                     kp, kd, d_actual, d_observed);
+  HIPCHK(hipGetLastError());
+  return REX_OK;
+}
+
+int rex_gait_loop(int n, int mode, float* d_planner, const float* d_params, float* d_frames_out, void* stream) {
+  if (n <= 0 || (mode != 0 && mode != 1) || !d_planner || !d_params || !d_frames_out) return fail(REX_EINVAL, "rex_gait_loop: bad arguments%s", "");
+  hipLaunchKernelGGL(rex::rex_gait_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, mode, d_planner, d_params, d_frames_out);
+  HIPCHK(hipGetLastError());
+  return REX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,169 @@
+"""RexBatchEnv: N reference environments stepped by one HIP launch.
+
+Stands where the reference puts `BatchEnv` over N `ExternalProcess`-wrapped envs
+(rex_gym/agents/tools/batch_env.py:18-115, wrappers.py:294-458): same call shapes
+(`len(env)`, `env[i]`, `step(actions[N,A]) -> (obs[N,O], reward[N], done[N], infos)`,
+`reset(indices=None)`), but the state never leaves HBM and there is no IPC.
+
+PyTorch is used for device memory and streams only; all compute is in librexsim_hip.so.
+"""
+import ctypes
+import math
+
+import numpy as np
+
+from .. import _lib
+from .spaces import Box
+
+OBSERVATION_EPS = 0.01  # rex_gym_env.py:20
+
+
+def _spaces(task, signal, sim_dt):
+    """Box bounds of the reference envs (part of the drop-in contract)."""
+    if task == "walk":      # walk_env.py:104-114
+        hi = {"ik": 0.4, "ol": 0.01}[signal]
+        dim = {"ik": 2, "ol": 8}[signal]
+        action = Box(-np.full(dim, hi), np.full(dim, hi))
+        ub = np.array([2 * math.pi, 2 * math.pi, 2 * math.pi / sim_dt, 2 * math.pi / sim_dt])   # walk_env.py:364-378
+    elif task == "gallop":  # gallop_env.py:119-130 -- low/high are inverted in the reference
+        hi = {"ik": 0.4, "ol": 0.3}[signal]
+        dim = {"ik": 2, "ol": 4}[signal]
+        action = Box(np.full(dim, hi), -np.full(dim, hi))
+        ub = np.array([2 * math.pi, 2 * math.pi, 2 * math.pi / sim_dt, 2 * math.pi / sim_dt] + [2 * math.pi] * 12)
+    else:
+        raise ValueError(f"unsupported task {task!r}")
+    obs = Box(-(ub + OBSERVATION_EPS), ub + OBSERVATION_EPS)  # rex_gym_env.py:277-278
+    return action, obs
+
+
+class _EnvView:
+    """`batch_env[i]`: attribute access to one env, as BatchEnv.__getitem__ gives (batch_env.py:44-46)."""
+
+    def __init__(self, batch, index):
+        self._batch, self.index = batch, index
+        self.action_space, self.observation_space = batch.action_space, batch.observation_space
+
+    def state(self):
+        return self._batch.state[:, self.index].clone()
+
+
+class RexBatchEnv:
+    metadata = {"render.modes": []}
+
+    def __init__(self, num_envs, task="walk", signal_type="ik", device=0, seed=0, env_index_base=0,
+                 auto_reset=False, max_episode_steps=0, backwards=None, target_position=None,
+                 motor_kp=1.0, motor_kd=0.02, control_time_step=None, action_repeat=None,
+                 check_actions=False, terrain_type="plane", mark="base", render=False, stream=None, **unused):
+        import torch
+        if terrain_type != "plane" or mark != "base" or render:
+            raise NotImplementedError("this round covers terrain_type='plane', mark='base', render=False")
+        if task not in _lib.TASKS or signal_type not in _lib.SIGNALS:
+            raise ValueError(f"unsupported task/signal {task}/{signal_type}")
+        self._torch = torch
+        self._L = _lib.lib()   # raises if the HIP library is absent: no fallback
+        if not torch.cuda.is_available():
+            raise _lib.RexSimError("no HIP device visible to PyTorch: RexBatchEnv needs an MI355X (no CPU fallback)")
+        self.num_envs = int(num_envs)
+        self.task, self.signal_type = task, signal_type
+        self.device = torch.device("cuda", device if isinstance(device, int) else torch.device(device).index or 0)
+        cfg = _lib.RexConfig()
+        _lib.check(self._L.rex_default_config(_lib.TASKS[task], _lib.SIGNALS[signal_type], self.num_envs,
+                                             ctypes.byref(cfg)), "rex_default_config")
+        if action_repeat is not None:
+            cfg.action_repeat = int(action_repeat)
+            cfg.solver_iterations = int(300 / cfg.action_repeat)        # rex_gym_env.py:184
+        if control_time_step is not None:
+            cfg.sim_time_step = float(control_time_step) / cfg.action_repeat  # rex_gym_env.py:172
+        cfg.motor_kp, cfg.motor_kd = float(motor_kp), float(motor_kd)
+        cfg.backwards = -1 if backwards is None else int(bool(backwards))
+        cfg.target_position = 0.0 if not target_position else float(target_position)
+        cfg.seed = int(seed) & (2 ** 64 - 1)
+        cfg.env_index_base = int(env_index_base)
+        cfg.auto_reset = int(bool(auto_reset))
+        cfg.max_episode_steps = int(max_episode_steps)
+        self.config = cfg
+        self.action_dim = self._L.rex_action_dim(ctypes.byref(cfg))
+        self.obs_dim = self._L.rex_obs_dim(ctypes.byref(cfg))
+        self.action_space, self.observation_space = _spaces(task, signal_type, cfg.sim_time_step)
+        self.control_time_step = cfg.sim_time_step * cfg.action_repeat
+        self.check_actions = bool(check_actions)
+        self._stream = stream
+        with torch.cuda.device(self.device):
+            self.state = torch.zeros((_lib.STATE_WORDS, self.num_envs), dtype=torch.float32, device=self.device)
+            self._obs = torch.zeros((self.num_envs, self.obs_dim), dtype=torch.float32, device=self.device)
+            self._reward = torch.zeros(self.num_envs, dtype=torch.float32, device=self.device)
+            self._done = torch.zeros(self.num_envs, dtype=torch.uint8, device=self.device)
+            self._cmd = torch.zeros((self.num_envs, _lib.NUM_MOTORS), dtype=torch.float32, device=self.device)
+            handle = ctypes.c_void_p()
+            _lib.check(self._L.rex_create(ctypes.byref(cfg), self.device.index, self.state.data_ptr(),
+                                          self._stream_ptr(), ctypes.byref(handle)), "rex_create")
+        self._h = handle
+        self._needs_reset = True
+
+    # ---- plumbing ----
+    def _stream_ptr(self):
+        s = self._stream if self._stream is not None else self._torch.cuda.current_stream(self.device)
+        return ctypes.c_void_p(s.cuda_stream)
+
+    def __len__(self):
+        return self.num_envs
+
+    def __getitem__(self, index):
+        return _EnvView(self, index)
+
+    def seed(self, seed=None):
+        return [seed]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._torch.cuda.synchronize(self.device)
+            self._L.rex_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_timing(self, enable=True):
+        _lib.check(self._L.rex_set_timing(self._h, int(enable)), "rex_set_timing")
+
+    def last_step_ms(self):
+        ms = ctypes.c_float()
+        _lib.check(self._L.rex_last_step_ms(self._h, ctypes.byref(ms)), "rex_last_step_ms")
+        return ms.value
+
+    # ---- Gym / BatchEnv surface ----
+    def reset(self, indices=None):
+        """Reset all envs (indices=None) or the given ones; returns their first observations."""
+        torch = self._torch
+        if indices is None:
+            _lib.check(self._L.rex_reset(self._h, None, 0, self._obs.data_ptr(), self._stream_ptr()), "rex_reset")
+            self._needs_reset = False
+            return self._obs.clone()
+        idx = torch.as_tensor(indices, dtype=torch.int32, device=self.device).contiguous()
+        obs = torch.empty((idx.numel(), self.obs_dim), dtype=torch.float32, device=self.device)
+        if idx.numel():
+            _lib.check(self._L.rex_reset(self._h, idx.data_ptr(), idx.numel(), obs.data_ptr(), self._stream_ptr()),
+                       "rex_reset")
+        return obs
+
+    def step(self, actions):
+        """actions [N, action_dim] (device float32 tensor, or array-like). Returns device tensors
+        (obs [N,O], reward [N], done [N] bool) and info {'action': motor command [N,12]}."""
+        torch = self._torch
+        if self._needs_reset:
+            raise RuntimeError("Must reset environment.")   # wrappers.py:286-288 semantics
+        a = torch.as_tensor(actions, dtype=torch.float32, device=self.device)
+        if a.shape != (self.num_envs, self.action_dim):
+            raise ValueError(f"actions must have shape {(self.num_envs, self.action_dim)}, got {tuple(a.shape)}")
+        a = a.contiguous()
+        if self.check_actions:   # batch_env.py:76-79
+            lo = torch.as_tensor(np.minimum(self.action_space.low, self.action_space.high), device=self.device)
+            hi = torch.as_tensor(np.maximum(self.action_space.low, self.action_space.high), device=self.device)
+            if bool(((a < lo) | (a > hi) | ~torch.isfinite(a)).any()):
+                raise ValueError("Invalid action")
+        _lib.check(self._L.rex_step(self._h, a.data_ptr(), self._obs.data_ptr(), self._reward.data_ptr(),
+                                    self._done.data_ptr(), self._cmd.data_ptr(), self._stream_ptr()), "rex_step")
+        return self._obs, self._reward, self._done.bool(), {"action": self._cmd}

@@ -1,0 +1,16 @@
+"""RexReactiveEnv (gallop) -- rex_gym/envs/gym/gallop_env.py:25-381 on the batched HIP simulator."""
+from .walk_env import _SingleEnv
+
+
+class RexReactiveEnv(_SingleEnv):
+    _TASK = "gallop"
+
+    def __init__(self, debug=False, urdf_version=None, energy_weight=0.005, control_time_step=0.006, action_repeat=6,
+                 control_latency=0.0, pd_latency=0.0, on_rack=False, motor_kp=1.0, motor_kd=0.02, render=False,
+                 num_steps_to_log=2000, use_angle_in_observation=True, env_randomizer=None, log_path=None,
+                 target_position=None, signal_type="ik", terrain_type="plane", terrain_id=None, mark="base", **kw):
+        if control_latency or pd_latency or on_rack or env_randomizer or not use_angle_in_observation:
+            raise NotImplementedError("latency / on_rack / env_randomizer / angle-less observation are not covered")
+        super().__init__(signal_type=signal_type, control_time_step=control_time_step, action_repeat=action_repeat,
+                         motor_kp=motor_kp, motor_kd=motor_kd, render=render, target_position=target_position,
+                         terrain_type=terrain_type, mark=mark, **kw)

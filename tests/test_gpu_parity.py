@@ -1,0 +1,226 @@
+"""GPU parity tests proper: every call goes through the C ABI of librexsim_hip.so (via rex_gym_amd),
+and is checked against the CPU oracle / the golden vectors.  Tolerances are written next to each check.
+Run on the MI355X box: python -m pytest tests -m gpu"""
+import ctypes
+
+import numpy as np
+import pytest
+
+import orclib
+from helpers import joint_rmse, make_pair, numeric_to_product_state, product_state_to_numeric
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch as t
+    assert t.cuda.is_available(), "gpu tests need an MI355X"
+    return t
+
+
+@pytest.fixture(scope="module")
+def L():
+    from rex_gym_amd import _lib
+    return _lib
+
+
+def _dev(torch, a):
+    return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device="cuda")
+
+
+# ------------------------------------------------------------------ controller half (pinned to the reference)
+def test_ik_kernel_vs_reference_golden(torch, L, golden):
+    g = golden["ik"]
+    n = len(g["orn"])
+    orn, pos, fr = _dev(torch, g["orn"]), _dev(torch, g["pos"]), _dev(torch, np.array(g["frames"]).reshape(n, 12))
+    out = torch.zeros((n, 12), device="cuda")
+    L.check(L.lib().rex_ik_solve(n, orn.data_ptr(), pos.data_ptr(), fr.data_ptr(), out.data_ptr(), None), "rex_ik_solve")
+    torch.cuda.synchronize()
+    ref = np.array(g["angles"])
+    err = np.abs(out.cpu().numpy() - ref)
+    # fp32 kernel vs fp64 reference: 1e-5 rad typical; the clamped-domain / sqrt(0) edge cases are
+    # ill-conditioned (d acos / dx -> inf), allow 2e-3 there
+    assert np.median(err) < 2e-6
+    assert np.mean(err < 2e-5) > 0.97
+    assert err.max() < 2e-3
+
+
+def test_motor_kernel_vs_reference_golden(torch, L, golden):
+    g = golden["motor"]
+    cmd, q, qd, qdt = (_dev(torch, np.array(g[k]).ravel()) for k in ("cmd", "q", "qd", "qd_true"))
+    n = cmd.numel()
+    act, obs = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    L.check(L.lib().rex_motor_torque(n, cmd.data_ptr(), q.data_ptr(), qd.data_ptr(), qdt.data_ptr(), g["kp"], g["kd"],
+                                     act.data_ptr(), obs.data_ptr(), None), "rex_motor_torque")
+    torch.cuda.synchronize()
+    # tolerance 1e-5 N m, relative to the 3.5 / 5.7 N m full scale
+    np.testing.assert_allclose(act.cpu().numpy(), np.array(g["actual"]).ravel(), atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(obs.cpu().numpy(), np.array(g["observed"]).ravel(), atol=2e-5, rtol=1e-5)
+
+
+def test_gait_kernel_vs_reference_golden(torch, L, golden):
+    for seq in golden["gait"]:
+        mode = 0 if seq["mode"] == "walk" else 1
+        planner = torch.zeros((1, 3), device="cuda")
+        frames = torch.zeros((1, 12), device="cuda")
+        errs = []
+        for c in seq["calls"]:
+            params = _dev(torch, [[c["v"], c["angle"], c["w_rot"], c["T"], c["direction"], c["now"]]])
+            L.check(L.lib().rex_gait_loop(1, mode, planner.data_ptr(), params.data_ptr(), frames.data_ptr(), None), "rex_gait_loop")
+            errs.append(np.abs(frames.cpu().numpy()[0] - np.array(c["frames"])).max())
+        errs = np.array(errs)
+        # fp32 vs fp64: the handful of calls that land exactly on a phase threshold may take the other branch
+        assert np.median(errs) < 1e-6
+        if min(c["T"] for c in seq["calls"]) < 0.01:
+            continue  # period clamps to 0.01 s: EVERY 5 ms call lands exactly on a phase threshold (0.5 / 1.0)
+        assert np.mean(errs < 2e-5) > 0.97, (seq["mode"], np.sort(errs)[-10:])
+
+
+# ------------------------------------------------------------------ full step vs oracle
+def test_settled_snapshot_matches_oracle(torch):
+    env, orc = make_pair("walk", "ik", 4, np.float64, seed=3)
+    obs = env.reset().cpu().numpy()
+    oobs = orc.reset()
+    ps, os_ = product_state_to_numeric(env.state), orc.get_state()
+    # 600 substeps of contact dynamics, fp32 kernel vs fp64 oracle: 1e-4 on positions/angles
+    np.testing.assert_allclose(ps[:37], os_[:37], atol=2e-4)
+    np.testing.assert_allclose(obs, oobs, atol=2e-3)
+    # episode draws are integer/fp32-exact: identical
+    np.testing.assert_array_equal(ps[orclib.S_TARGET], os_[orclib.S_TARGET].astype(np.float32))
+    np.testing.assert_array_equal(ps[orclib.S_FLAGS], os_[orclib.S_FLAGS])
+    np.testing.assert_array_equal(ps[orclib.S_EPISODE], os_[orclib.S_EPISODE])
+    env.close()
+
+
+@pytest.mark.parametrize("task,signal", [("walk", "ik"), ("walk", "ol"), ("gallop", "ol"), ("gallop", "ik")])
+def test_single_step_parity_from_common_states(torch, task, signal):
+    """One env.step() from identical states: isolates per-step error from chaotic divergence.
+    Tolerance: 1e-4 rad / 1e-4 m / 2e-2 rad/s over 5-6 substeps x 50-60 PGS iterations.
+    The oracle runs in fp32 here so that the controller's discrete phase decisions (phi <= 0.5,
+    phi >= 0.99, ramp ends), which sit exactly on control-step multiples, round the same way; the
+    fp64 oracle is compared in test_single_step_parity_fp64_walk_ik."""
+    n = 64
+    env, orc = make_pair(task, signal, n, np.float32, seed=11)
+    env.reset(); orc.reset()
+    rng = np.random.RandomState(5)
+    lo, hi = np.minimum(env.action_space.low, env.action_space.high), np.maximum(env.action_space.low, env.action_space.high)
+    # walk a few steps on the oracle to get diverse, physically consistent states
+    for k in range(30):
+        a = rng.uniform(lo, hi, (n, env.action_dim))
+        orc.step(a)
+    for k in range(10):
+        st = orc.get_state()
+        env.state.copy_(numeric_to_product_state(st, torch, env.state.device))
+        a = rng.uniform(lo, hi, (n, env.action_dim)).astype(np.float32)
+        obs, rew, done, info = env.step(torch.as_tensor(a, device="cuda"))
+        oobs, orew, odone, ocmd = orc.step(a.astype(np.float64))
+        ps, os_ = product_state_to_numeric(env.state), orc.get_state()
+        np.testing.assert_allclose(info["action"].cpu().numpy(), ocmd, atol=3e-5)
+        np.testing.assert_allclose(ps[orclib.S_Q:orclib.S_Q + 12], os_[orclib.S_Q:orclib.S_Q + 12], atol=1e-4)
+        np.testing.assert_allclose(ps[:7], os_[:7], atol=1e-4)
+        np.testing.assert_allclose(ps[7:13], os_[7:13], atol=5e-3)
+        np.testing.assert_allclose(ps[orclib.S_QD:orclib.S_QD + 12], os_[orclib.S_QD:orclib.S_QD + 12], atol=2e-2)
+        np.testing.assert_allclose(rew.cpu().numpy(), orew, atol=1e-4)
+        np.testing.assert_array_equal(done.cpu().numpy(), odone)
+        np.testing.assert_allclose(obs.cpu().numpy(), oobs, atol=5e-3)
+    env.close()
+
+
+def test_single_step_parity_fp64_walk_ik(torch):
+    """Same as above against the fp64 oracle (what fp32 costs): walk-IK, 1e-4 rad / 1e-4 m."""
+    n = 64
+    env, orc = make_pair("walk", "ik", n, np.float64, seed=12)
+    env.reset(); orc.reset()
+    rng = np.random.RandomState(6)
+    for k in range(37):
+        orc.step(rng.uniform(-0.4, 0.4, (n, 2)))
+    for k in range(5):
+        st = orc.get_state()
+        env.state.copy_(numeric_to_product_state(st, torch, env.state.device))
+        a = rng.uniform(-0.4, 0.4, (n, 2)).astype(np.float32)
+        env.step(torch.as_tensor(a, device="cuda"))
+        orc.step(a.astype(np.float64))
+        ps, os_ = product_state_to_numeric(env.state), orc.get_state()
+        np.testing.assert_allclose(ps[orclib.S_Q:orclib.S_Q + 12], os_[orclib.S_Q:orclib.S_Q + 12], atol=1e-4)
+        np.testing.assert_allclose(ps[:7], os_[:7], atol=1e-4)
+    env.close()
+
+
+def test_walk_ik_trajectory_rmse(torch):
+    """first 200 control steps (1 s) from the settled reset state, same actions:
+    joint-angle RMSE vs the oracle <= 1e-3 rad (target of BASELINE.json) on the median env."""
+    n = 256
+    env, orc = make_pair("walk", "ik", n, np.float32, seed=1)
+    env.reset(); orc.reset()
+    rng = np.random.RandomState(0)
+    worst = np.zeros(n)
+    for k in range(200):
+        a = rng.uniform(-0.4, 0.4, (n, 2)).astype(np.float32)
+        env.step(torch.as_tensor(a, device="cuda"))
+        orc.step(a)
+        r = joint_rmse(product_state_to_numeric(env.state), orc.get_state())
+        worst = np.maximum(worst, r)
+    print("walk-ik 200-step joint RMSE vs f32 oracle: median %.3e max %.3e" % (np.median(worst), worst.max()))
+    assert np.median(worst) < 1e-3
+    env.close()
+
+
+def test_auto_reset_and_episode_limit(torch):
+    n = 128
+    env, orc = make_pair("walk", "ik", n, np.float32, seed=9, auto_reset=1, max_episode_steps=20)
+    env.reset(); orc.reset()
+    rng = np.random.RandomState(2)
+    for k in range(45):
+        a = rng.uniform(-0.4, 0.4, (n, 2)).astype(np.float32)
+        obs, rew, done, _ = env.step(torch.as_tensor(a, device="cuda"))
+        oobs, orew, odone, _ = orc.step(a)
+        np.testing.assert_array_equal(done.cpu().numpy(), odone)
+        if (k + 1) % 20 == 0:
+            assert odone.all()
+    ps, os_ = product_state_to_numeric(env.state), orc.get_state()
+    np.testing.assert_array_equal(ps[orclib.S_EPISODE], os_[orclib.S_EPISODE])
+    np.testing.assert_array_equal(ps[orclib.S_STEPS], os_[orclib.S_STEPS])
+    np.testing.assert_array_equal(ps[orclib.S_TARGET], os_[orclib.S_TARGET])
+    env.close()
+
+
+def test_reset_indices_and_sharding_invariance(torch):
+    """Env g of a 2-shard run equals env g of a single run (RNG keyed by global index)."""
+    from rex_gym_amd import RexBatchEnv
+    whole = RexBatchEnv(128, seed=5)
+    a, b = RexBatchEnv(64, seed=5, env_index_base=0), RexBatchEnv(64, seed=5, env_index_base=64)
+    whole.reset(); a.reset(); b.reset()
+    act = torch.rand((128, 2), device="cuda") * 0.8 - 0.4
+    for k in range(5):
+        ow = whole.step(act)[0].clone()
+        oa, ob = a.step(act[:64])[0], b.step(act[64:])[0]
+        assert torch.equal(ow[:64], oa) and torch.equal(ow[64:], ob)
+    assert torch.equal(whole.state[:, :64], a.state) and torch.equal(whole.state[:, 64:], b.state)
+    idx = torch.tensor([3, 17, 60], dtype=torch.int32)
+    o = a.reset(idx)
+    assert o.shape == (3, 4)
+    st = product_state_to_numeric(a.state)
+    assert (st[orclib.S_EPISODE][[3, 17, 60]] == 2).all() and st[orclib.S_EPISODE][0] == 1
+    for e in (whole, a, b):
+        e.close()
+
+
+def test_gym_surface_single_env(torch):
+    from rex_gym_amd.envs.gym import RexWalkEnv
+    env = RexWalkEnv(render=False, signal_type="ik", terrain_type="plane", mark="base")
+    obs = env.reset()
+    assert obs.shape == (4,) and env.observation_space.contains(obs.astype(np.float32))
+    o, r, d, info = env.step(env.action_space.sample())
+    assert o.shape == (4,) and isinstance(r, float) and isinstance(d, bool) and info["action"].shape == (12,)
+    env.close()
+
+
+def test_step_before_reset_raises(torch):
+    from rex_gym_amd import RexBatchEnv
+    env = RexBatchEnv(8)
+    with pytest.raises(RuntimeError):
+        env.step(torch.zeros((8, 2), device="cuda"))
+    with pytest.raises(ValueError):
+        env.reset(); env.step(torch.zeros((8, 3), device="cuda"))
+    env.close()

@@ -272,6 +272,11 @@ def main():
     w("// URDF_USE_INERTIA_FROM_FILE is absent (rex_gym/model/rex.py:276-287); fixed links are merged.")
     w("#ifndef REX_MODEL_GEN_H")
     w("#define REX_MODEL_GEN_H")
+    w("#ifdef __cplusplus")
+    w("#define REX_CONST static constexpr")
+    w("#else")
+    w("#define REX_CONST static const")
+    w("#endif")
     w("")
     w(f"#define REX_NB {nb}            /* bodies: base + 12 motor links, motor order of mark_constants.py:3-8 */")
     w(f"#define REX_NJ {nb - 1}            /* actuated revolute joints */")
@@ -279,7 +284,7 @@ def main():
     w(f"#define REX_TOTAL_MASS {fmt(total_mass)}")
     w("")
     w("/* body i>=1 hangs off REX_PARENT[i] through joint i-1; joint frames have no fixed rotation */")
-    w("static const int REX_PARENT[REX_NB] = {" + ", ".join(str(b["parent"]) for b in bodies) + "};")
+    w("REX_CONST int REX_PARENT[REX_NB] = {" + ", ".join(str(b["parent"]) for b in bodies) + "};")
     axes = []
     for b in bodies[1:]:
         j = b["joint"]
@@ -289,22 +294,22 @@ def main():
         assert np.allclose(np.abs(a), np.eye(3)[k]) and a[k] > 0
         axes.append(k)
     w("/* joint axis index in the child frame: 0 = x, 1 = y, 2 = z */")
-    w("static const int REX_JOINT_AXIS[REX_NJ] = {" + ", ".join(str(a) for a in axes) + "};")
+    w("REX_CONST int REX_JOINT_AXIS[REX_NJ] = {" + ", ".join(str(a) for a in axes) + "};")
     w("/* joint origin in the parent BODY frame [m] */")
-    w("static const double REX_JOINT_POS[REX_NJ][3] = {")
+    w("REX_CONST double REX_JOINT_POS[REX_NJ][3] = {")
     for b in bodies[1:]:
         w("  {" + ", ".join(fmt(v) for v in b["joint"]["xyz_in_body"]) + "},  /* " + b["joint"]["name"] + " */")
     w("};")
-    w("static const double REX_JOINT_LOWER[REX_NJ] = {" + ", ".join(fmt(b["joint"]["lower"]) for b in bodies[1:]) + "};")
-    w("static const double REX_JOINT_UPPER[REX_NJ] = {" + ", ".join(fmt(b["joint"]["upper"]) for b in bodies[1:]) + "};")
+    w("REX_CONST double REX_JOINT_LOWER[REX_NJ] = {" + ", ".join(fmt(b["joint"]["lower"]) for b in bodies[1:]) + "};")
+    w("REX_CONST double REX_JOINT_UPPER[REX_NJ] = {" + ", ".join(fmt(b["joint"]["upper"]) for b in bodies[1:]) + "};")
     w("/* merged-body mass [kg], COM in body frame [m], rotational inertia about the COM, body axes")
     w("   (xx, yy, zz, xy, xz, yz) [kg m^2] */")
-    w("static const double REX_MASS[REX_NB] = {" + ", ".join(fmt(b["mass"]) for b in bodies) + "};")
-    w("static const double REX_COM[REX_NB][3] = {")
+    w("REX_CONST double REX_MASS[REX_NB] = {" + ", ".join(fmt(b["mass"]) for b in bodies) + "};")
+    w("REX_CONST double REX_COM[REX_NB][3] = {")
     for b in bodies:
         w("  {" + ", ".join(fmt(v) for v in b["com"]) + "},  /* " + b["name"] + " */")
     w("};")
-    w("static const double REX_INERTIA[REX_NB][6] = {")
+    w("REX_CONST double REX_INERTIA[REX_NB][6] = {")
     for b in bodies:
         I = b["I"]
         w("  {" + ", ".join(fmt(v) for v in (I[0, 0], I[1, 1], I[2, 2], I[0, 1], I[0, 2], I[1, 2])) + "},")
@@ -314,12 +319,12 @@ def main():
     w(f"#define REX_TOE_RADIUS {fmt(toe_radius)}       /* hull radius [m]; the solver adds the 1 mm Bullet margin */")
     w(f"#define REX_TOE_HALFLEN {fmt(toe_halflen)}")
     w(f"#define REX_COLLISION_MARGIN {fmt(URDF_COLLISION_MARGIN)}")
-    w("static const int REX_TOE_BODY[REX_NLEG] = {" + ", ".join(str(t[0]) for t in toes) + "};")
-    w("static const double REX_TOE_CENTER[REX_NLEG][3] = {")
+    w("REX_CONST int REX_TOE_BODY[REX_NLEG] = {" + ", ".join(str(t[0]) for t in toes) + "};")
+    w("REX_CONST double REX_TOE_CENTER[REX_NLEG][3] = {")
     for t in toes:
         w("  {" + ", ".join(fmt(v) for v in t[1]) + "},")
     w("};")
-    w("static const double REX_TOE_AXIS[REX_NLEG][3] = {")
+    w("REX_CONST double REX_TOE_AXIS[REX_NLEG][3] = {")
     for t in toes:
         w("  {" + ", ".join(fmt(v if abs(v) > 1e-15 else 0.0) for v in t[2]) + "},")
     w("};")
@@ -351,8 +356,8 @@ def main():
     w("/* ---- leg-structured view (asserted mirror-symmetric by the compiler) ---- */")
     w("/* hip joint at (SX*HIP_X, SY*HIP_Y, 0) in base; upper-leg joint at (0, SY*UPPER_Y, 0) in shoulder;")
     w("   knee at (KNEE_X, 0, KNEE_Z) in upper leg; axes x, y, y */")
-    w("static const int REX_LEG_SX[REX_NLEG] = {" + ", ".join(str(v) for v in sx) + "};")
-    w("static const int REX_LEG_SY[REX_NLEG] = {" + ", ".join(str(v) for v in sy) + "};")
+    w("REX_CONST int REX_LEG_SX[REX_NLEG] = {" + ", ".join(str(v) for v in sx) + "};")
+    w("REX_CONST int REX_LEG_SY[REX_NLEG] = {" + ", ".join(str(v) for v in sy) + "};")
     w(f"#define REX_HIP_X {fmt(abs(s0['joint']['xyz_in_body'][0]))}")
     w(f"#define REX_HIP_Y {fmt(abs(s0['joint']['xyz_in_body'][1]))}")
     w(f"#define REX_UPPER_Y {fmt(abs(u0['joint']['xyz_in_body'][1]))}")
