@@ -31,6 +31,7 @@ extern "C" {
 #endif
 
 #define REX_ABI_VERSION 1
+#define REX_API __attribute__((visibility("default")))
 
 /* tasks (reference env classes) */
 #define REX_TASK_WALK   0   /* envs/gym/walk_env.py   RexWalkEnv      */
@@ -108,23 +109,23 @@ typedef struct RexConfig {
 typedef struct RexSim RexSim;
 
 /* Fill *cfg with the reference defaults of `task`/`signal` for `num_envs` envs. */
-int rex_default_config(int task, int signal, int num_envs, RexConfig* cfg);
+REX_API int rex_default_config(int task, int signal, int num_envs, RexConfig* cfg);
 
 /* Dimensions implied by a config (action/observation vector lengths of the reference env). */
-int rex_action_dim(const RexConfig* cfg);
-int rex_obs_dim(const RexConfig* cfg);
+REX_API int rex_action_dim(const RexConfig* cfg);
+REX_API int rex_obs_dim(const RexConfig* cfg);
 
 /* Create a simulator on HIP device `device`. `d_state` is a caller-owned device buffer of
  * REX_STATE_WORDS * num_envs float32 words; the library never allocates per-env memory.
  * Computes the settled reset snapshot (rex.py:314-323: 100 + 500 substeps holding the init
  * pose) once, on the device, with the same kernels. */
-int rex_create(const RexConfig* cfg, int device, float* d_state, void* stream, RexSim** out);
-int rex_destroy(RexSim* sim);
+REX_API int rex_create(const RexConfig* cfg, int device, float* d_state, void* stream, RexSim** out);
+REX_API int rex_destroy(RexSim* sim);
 
 /* Reset envs. d_indices == NULL: all envs. Else n int32 env indices (device).  Writes the first
  * observation of each reset env to d_obs[row * obs_dim] where row = position in d_indices (or the
  * env index when d_indices is NULL).  Mirrors RexWalkEnv.reset (walk_env.py:125-154). */
-int rex_reset(RexSim* sim, const int32_t* d_indices, int n, float* d_obs, void* stream);
+REX_API int rex_reset(RexSim* sim, const int32_t* d_indices, int n, float* d_obs, void* stream);
 
 /* One env.step() for every env (rex_gym_env.py:369-414):
  *   d_action [N, action_dim] in  -- raw env action (NOT range-normalised)
@@ -133,31 +134,31 @@ int rex_reset(RexSim* sim, const int32_t* d_indices, int n, float* d_obs, void* 
  *   d_done   [N] uint8       out
  *   d_motor_cmd [N, 12]      out, nullable -- info['action'], the 12 motor targets
  */
-int rex_step(RexSim* sim, const float* d_action, float* d_obs, float* d_reward,
+REX_API int rex_step(RexSim* sim, const float* d_action, float* d_obs, float* d_reward,
              uint8_t* d_done, float* d_motor_cmd, void* stream);
 
 /* HIP event timing of the last rex_step launch on its own stream (ms); needs rex_set_timing(1). */
-int rex_set_timing(RexSim* sim, int enable);
-int rex_last_step_ms(RexSim* sim, float* ms);
+REX_API int rex_set_timing(RexSim* sim, int enable);
+REX_API int rex_last_step_ms(RexSim* sim, float* ms);
 
 /* ---- controller-only entry points (parity tests of the controller half) ----
  * n independent problems, row-major device arrays, all float32. */
 /* model/kinematics.py:104-142 -- orn[n,3], pos[n,3], frames[n,4,3] (FR,FL,RR,RL) ->
  * angles[n,4,3] in the same leg order (theta, -alpha, -gamma) */
-int rex_ik_solve(int n, const float* d_orn, const float* d_pos, const float* d_frames,
+REX_API int rex_ik_solve(int n, const float* d_orn, const float* d_pos, const float* d_frames,
                  float* d_angles, void* stream);
 /* model/motor.py:76-143 -- cmd,q,qd,qd_true [n] -> actual, observed torque [n] */
-int rex_motor_torque(int n, const float* d_cmd, const float* d_q, const float* d_qd,
+REX_API int rex_motor_torque(int n, const float* d_cmd, const float* d_q, const float* d_qd,
                      const float* d_qd_true, float kp, float kd,
                      float* d_actual, float* d_observed, void* stream);
 /* model/gait_planner.py:96-134 with the phase clock on explicit time `now`.
  * mode: 0 walk, 1 gallop.  d_planner [n,3] = (phi, last_time, alpha) in/out; params[n,6] =
  * (v, angle_deg, w_rot, period, direction, now); frames_out[n,4,3] (FR,FL,RR,RL). */
-int rex_gait_loop(int n, int mode, float* d_planner, const float* d_params,
+REX_API int rex_gait_loop(int n, int mode, float* d_planner, const float* d_params,
                   float* d_frames_out, void* stream);
 
-const char* rex_last_error(void);
-int rex_abi_version(void);
+REX_API const char* rex_last_error(void);
+REX_API int rex_abi_version(void);
 
 #ifdef __cplusplus
 }

@@ -8,8 +8,7 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "librexsim_hip.so")
 SOURCES = ["rexsim.hip"]
 HEADERS = ["rex_device.h", "rex_controller.h", "rex_model_gen.h"]
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-fvisibility=hidden",
-               "-fgpu-rdc" if False else "-fno-gpu-rdc"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-fvisibility=hidden"]
 
 
 def _hipcc():
