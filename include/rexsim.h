@@ -103,7 +103,11 @@ typedef struct RexConfig {
   int32_t max_episode_steps;  /* 0: off; else done at this many steps (LimitDuration, wrappers.py:268) */
   /* reward weights -- rex_gym_env.py:56-59 */
   float   distance_weight, energy_weight, drift_weight, shake_weight;
-  int32_t reserved[8];
+  float   solver_residual_threshold; /* Bullet's m_leastSquaresResidualThreshold: the PGS sweep loop ends
+                                        early once max_row (delta_impulse / invdiag)^2 <= this; PyBullet's
+                                        default is 1e-7 and the reference never changes it. 0 = always run
+                                        solver_iterations sweeps. */
+  int32_t reserved[7];
 } RexConfig;
 
 typedef struct RexSim RexSim;

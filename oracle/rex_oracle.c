@@ -59,6 +59,8 @@ static real MB_ANGULAR_DAMPING = (real)0.04; /* (variables only so the conservat
 static real FRICTION_MU = (real)0.5;      /* toe 0.5 x plane 1.0, 9.2-7 (variable for sensitivity probes) */
 #define ROBOT_INIT_Z ((real)0.21)        /* terrain.py:14-20 */
 
+static long DBG_HIST[64] = {0};
+static long DBG_SWEEPS = 0, DBG_SUBSTEPS = 0; /* solver statistics (tests / tuning) */
 static real DBG_JOINT_FRICTION = 0, DBG_JOINT_VISC = 0; /* sensitivity probe only (off by default) */
 static real clampr(real x, real lo, real hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
@@ -560,7 +562,7 @@ static void contact_jacobian(const Aba* A, int kbody, const real P[3], const rea
 }
 
 /* one 1 ms world step: the restated stepSimulation */
-static void physics_substep(Phys* s, const real tau[NJ], real dt, int iterations) {
+static void physics_substep(Phys* s, const real tau[NJ], real dt, int iterations, real residual_threshold) {
   static __thread Aba A;
   real qdd[NJ], wdot[3], vdot[3];
   aba_forward(s, tau, &A, qdd, wdot, vdot);
@@ -643,6 +645,7 @@ static void physics_substep(Phys* s, const real tau[NJ], real dt, int iterations
   real dv[NDOF];
   for (int k = 0; k < NDOF; ++k) dv[k] = 0;
   for (int it = 0; it < iterations; ++it) {
+    real worst = 0; /* btMultiBodyConstraintSolver::solveSingleIteration: max squared velocity residual */
     for (int i = 0; i < nrow; ++i) {
       Row* r = &rows[i];
       real lo = r->lo, hi = r->hi;
@@ -655,8 +658,16 @@ static void physics_substep(Phys* s, const real tau[NJ], real dt, int iterations
       else if (sum > hi) { dl = hi - r->lambda; sum = hi; }
       r->lambda = sum;
       for (int k = 0; k < NDOF; ++k) dv[k] += r->resp[k] * dl;
+      real resid = dl / r->invdiag;
+      if (resid * resid > worst) worst = resid * resid;
     }
+    /* btSequentialImpulseConstraintSolver::solveGroupCacheFriendlyIterations: leave the sweep loop once
+     * the residual is below m_leastSquaresResidualThreshold (PyBullet default 1e-7) */
+    ++DBG_SWEEPS;
+    if (worst <= residual_threshold) { DBG_HIST[it < 63 ? it : 63]++; break; }
+    if (it == iterations - 1) DBG_HIST[63]++;
   }
+  ++DBG_SUBSTEPS;
   /* apply, clamp (btMultiBody::applyDeltaVeeMultiDof), integrate positions with the NEW velocities */
   real dw[3], dl[3];
   matvec3(A.Rw[0], dv, dw);
@@ -739,7 +750,7 @@ static void rex_substep(const RexConfig* c, Env* e, const real cmd[NJ]) {
     tau[j] = ((e->motor_enabled >> j) & 1u) ? act : 0;
     if (DBG_JOINT_FRICTION > 0 && (j % 3) != 1) tau[j] -= clampr(DBG_JOINT_VISC * e->ph.qd[j], -DBG_JOINT_FRICTION, DBG_JOINT_FRICTION);
   }
-  physics_substep(&e->ph, tau, (real)c->sim_time_step, c->solver_iterations);
+  physics_substep(&e->ph, tau, (real)c->sim_time_step, c->solver_iterations, (real)c->solver_residual_threshold);
 }
 
 static void settle(Orc* o) {
@@ -1025,17 +1036,19 @@ ORC_API void orc_set_state(void* h, const double* in) {
 }
 
 ORC_API void orc_set_joint_friction(real f, real visc) { DBG_JOINT_FRICTION = f; DBG_JOINT_VISC = visc; }
+ORC_API void orc_solver_hist(long* h) { for (int i = 0; i < 64; ++i) { h[i] = DBG_HIST[i]; DBG_HIST[i] = 0; } }
+ORC_API void orc_solver_stats(long* sweeps, long* substeps, int reset) { *sweeps = DBG_SWEEPS; *substeps = DBG_SUBSTEPS; if (reset) { DBG_SWEEPS = 0; DBG_SUBSTEPS = 0; } }
 ORC_API void orc_set_friction(real mu) { FRICTION_MU = mu; }
 ORC_API void orc_set_damping(real lin, real ang) { MB_LINEAR_DAMPING = lin; MB_ANGULAR_DAMPING = ang; }
 
 /* ---- physics-only probes used by the oracle's own unit tests (tests/test_oracle_physics.py) ---- */
 /* state: pos3 quat4 linvel3 angvel3 q12 qd12 = 37 reals, in/out; tau 12 */
-ORC_API void orc_physics_substep(real* st, const real* tau, real dt, int iterations, int nsteps) {
+ORC_API void orc_physics_substep(real* st, const real* tau, real dt, int iterations, int nsteps, real residual_threshold) {
   Phys p;
   memcpy(p.pos, st, sizeof(real) * 3); memcpy(p.quat, st + 3, sizeof(real) * 4);
   memcpy(p.linvel, st + 7, sizeof(real) * 3); memcpy(p.angvel, st + 10, sizeof(real) * 3);
   memcpy(p.q, st + 13, sizeof(real) * NJ); memcpy(p.qd, st + 25, sizeof(real) * NJ);
-  for (int k = 0; k < nsteps; ++k) physics_substep(&p, tau, dt, iterations);
+  for (int k = 0; k < nsteps; ++k) physics_substep(&p, tau, dt, iterations, residual_threshold);
   memcpy(st, p.pos, sizeof(real) * 3); memcpy(st + 3, p.quat, sizeof(real) * 4);
   memcpy(st + 7, p.linvel, sizeof(real) * 3); memcpy(st + 10, p.angvel, sizeof(real) * 3);
   memcpy(st + 13, p.q, sizeof(real) * NJ); memcpy(st + 25, p.qd, sizeof(real) * NJ);

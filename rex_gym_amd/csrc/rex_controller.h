@@ -5,6 +5,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "rex_device.h"
+
 namespace rex {
 
 // kinematics.py:6-13
@@ -17,7 +19,7 @@ __device__ __forceinline__ void ik_transform(const float* coord, const float* or
   const float t0 = coord[0] + pos[0], t1 = coord[1] + pos[1], t2 = coord[2] + pos[2];
   if (orn[0] != 0.0f || orn[1] != 0.0f || orn[2] != 0.0f) {
     float sx, cx, sy, cy, sz, cz;
-    sincosf(orn[0], &sx, &cx); sincosf(orn[1], &sy, &cy); sincosf(orn[2], &sz, &cz);
+    sincos_fast(orn[0], sx, cx); sincos_fast(orn[1], sy, cy); sincos_fast(orn[2], sz, cz);
     const float a0 = cz * t0 - sz * t1, a1 = sz * t0 + cz * t1, a2 = t2;
     const float b0 = cy * a0 + sy * a2, b1 = a1, b2 = -sy * a0 + cy * a2;
     out[0] = b0; out[1] = cx * b1 - sx * b2; out[2] = sx * b1 + cx * b2;
@@ -37,7 +39,7 @@ __device__ __forceinline__ void ik_leg(const float* c, bool right_side, float* o
   if (sq < 0.0f) sq = 0.0f;
   const float rs = sqrtf(sq);
   float sg, cg;
-  sincosf(gamma, &sg, &cg);
+  sincos_fast(gamma, sg, cg);
   const float alpha = atan2f(-c[0], rs) - atan2f(foot * sg, leg + foot * cg);
   const float theta = -atan2f(c[2], c[1]) - atan2f(rs, right_side ? -hip : hip);
   out[0] = theta; out[1] = -alpha; out[2] = -gamma;
@@ -83,13 +85,15 @@ struct GaitState { float phi, last_time, alpha; };
 __device__ __forceinline__ void gait_component(bool stance, float ph, float bx, float bz, float v, float angle_deg,
                                                float direction, float* out) {
   float s, c;
-  sincosf(angle_deg * (kPi / 180.0f), &s, &c);
+  sincos_fast(angle_deg * (kPi / 180.0f), s, c);
   const float av = fabsf(v);
   if (stance) {
     const float p = 0.05f * (1.0f - 2.0f * ph);
     out[0] = c * p * av;
     out[1] = -s * p * av;
-    out[2] = -0.001f * cosf(kPi / (2.0f * 0.05f) * p);
+    float sp, cp;
+    sincos_fast(kPi / (2.0f * 0.05f) * p, sp, cp);
+    out[2] = -0.001f * cp;
   } else {
     const float X = av * c * direction * bx;
     out[0] = X;

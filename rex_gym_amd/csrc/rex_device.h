@@ -25,7 +25,9 @@
 #define REX_NPOINT 8                  /* 2 toe-cylinder end points per foot */
 #define REX_NROW (3 * REX_NPOINT)     /* normal + 2 pyramid friction rows per point */
 #define REX_ROW_F4 3                  /* float4 chunks per row in LDS */
-#define REX_LDS_FLOATS (REX_NROW * REX_ROW_F4 * 4 * REX_WAVE)
+#define REX_LEG_F4 6                  /* float4 chunks per leg kept for the back-substitution (Bw 18 + G 6) */
+#define REX_LDS_ROW_F4 (REX_NROW * REX_ROW_F4 * REX_WAVE)
+#define REX_LDS_FLOATS ((REX_NROW * REX_ROW_F4 + REX_NLEG * REX_LEG_F4) * 4 * REX_WAVE)
 
 namespace rex {
 
@@ -51,6 +53,34 @@ __device__ __forceinline__ f3 cross(f3 a, f3 b) {
   return f3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
 __device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+
+typedef float v2 __attribute__((ext_vector_type(2)));
+
+// sin and cos to ~1 ulp for |x| < ~1e4: Cody-Waite reduction by pi/2 (3-term split) + minimax
+// polynomials on [-pi/4, pi/4].  Joint angles never leave a few radians, so the Payne-Hanek path of
+// the libm sincosf (hundreds of instructions, divergent) is dead weight here.
+__device__ __forceinline__ void sincos_fast(float x, float& s, float& c) {
+  const float k = rintf(x * 0.636619772367581343f);      // x * 2/pi
+  float r = fmaf(k, -1.57079601287841796875f, x);        // pi/2 = hi + mid + lo
+  r = fmaf(k, -3.1391647326017846353352069854736328125e-07f, r);
+  r = fmaf(k, -5.390302529957764765e-15f, r);
+  const float r2 = r * r;
+  // least-squares minimax fits on r^2 in [0, (pi/4)^2] (tools: numpy Chebyshev nodes; max abs error 9e-8)
+  float ps = fmaf(r2, 2.7243820799024522e-06f, -1.9840039244367917e-04f);
+  ps = fmaf(ps, r2, 8.33333178609531e-03f);
+  ps = fmaf(ps, r2, -1.6666666663625898e-01f);
+  const float sr = fmaf(ps * r2, r, r);
+  float pc = fmaf(r2, 2.4542922330261397e-05f, -1.3888279652923955e-03f);
+  pc = fmaf(pc, r2, 4.16666645388584e-02f);
+  const float cr = fmaf(pc * r2, r2, fmaf(r2, -0.5f, 1.0f));
+  const int q = (int)k;
+  const float s0 = (q & 1) ? cr : sr;
+  const float c0 = (q & 1) ? sr : cr;
+  s = (q & 2) ? -s0 : s0;
+  c = ((q + 1) & 2) ? -c0 : c0;
+}
+
+__device__ __forceinline__ float cos_half(float a) { float s, c; sincos_fast(a, s, c); return c; }
 
 // symmetric 3x3: xx yy zz xy xz yz
 struct s33 { float xx, yy, zz, xy, xz, yz; };
@@ -94,6 +124,26 @@ struct LegFactor {
   float Bw[3][6];          // G^-1 B^T
   float z[3];              // whitened predicted velocity of the leg
 };
+// the part of LegFactor that is only needed again after the constraint solve is parked in LDS
+__device__ __forceinline__ float4& leg_chunk(float4* lds, int leg, int c, int lane) {
+  return lds[REX_LDS_ROW_F4 + (leg * REX_LEG_F4 + c) * REX_WAVE + lane];
+}
+__device__ __forceinline__ void leg_park(float4* lds, int leg, int lane, const LegFactor& L) {
+  leg_chunk(lds, leg, 0, lane) = make_float4(L.Bw[0][0], L.Bw[0][1], L.Bw[0][2], L.Bw[0][3]);
+  leg_chunk(lds, leg, 1, lane) = make_float4(L.Bw[0][4], L.Bw[0][5], L.Bw[1][0], L.Bw[1][1]);
+  leg_chunk(lds, leg, 2, lane) = make_float4(L.Bw[1][2], L.Bw[1][3], L.Bw[1][4], L.Bw[1][5]);
+  leg_chunk(lds, leg, 3, lane) = make_float4(L.Bw[2][0], L.Bw[2][1], L.Bw[2][2], L.Bw[2][3]);
+  leg_chunk(lds, leg, 4, lane) = make_float4(L.Bw[2][4], L.Bw[2][5], L.gi1, L.gi2);
+  leg_chunk(lds, leg, 5, lane) = make_float4(L.gi3, L.g21, L.g31, L.g32);
+}
+__device__ __forceinline__ void leg_unpark(float4* lds, int leg, int lane, LegFactor& L) {
+  const float4 a = leg_chunk(lds, leg, 0, lane), b = leg_chunk(lds, leg, 1, lane), c = leg_chunk(lds, leg, 2, lane);
+  const float4 d = leg_chunk(lds, leg, 3, lane), e = leg_chunk(lds, leg, 4, lane), f = leg_chunk(lds, leg, 5, lane);
+  L.Bw[0][0] = a.x; L.Bw[0][1] = a.y; L.Bw[0][2] = a.z; L.Bw[0][3] = a.w; L.Bw[0][4] = b.x; L.Bw[0][5] = b.y;
+  L.Bw[1][0] = b.z; L.Bw[1][1] = b.w; L.Bw[1][2] = c.x; L.Bw[1][3] = c.y; L.Bw[1][4] = c.z; L.Bw[1][5] = c.w;
+  L.Bw[2][0] = d.x; L.Bw[2][1] = d.y; L.Bw[2][2] = d.z; L.Bw[2][3] = d.w; L.Bw[2][4] = e.x; L.Bw[2][5] = e.y;
+  L.gi1 = e.z; L.gi2 = e.w; L.gi3 = f.x; L.g21 = f.y; L.g31 = f.z; L.g32 = f.w;
+}
 
 // accumulators of the base block
 struct BaseAccum {
@@ -126,9 +176,9 @@ __device__ __forceinline__ void leg_pass(const BaseKin& bk, const float* __restr
   const float q1 = q[0], q2 = q[1], q3 = q[2];
   const float qd1 = qd[0], qd2 = qd[1], qd3 = qd[2];
   float s1, c1, s2, c2, s3, c3;
-  sincosf(q1, &s1, &c1);
-  sincosf(q2, &s2, &c2);
-  sincosf(q3, &s3, &c3);
+  sincos_fast(q1, s1, c1);
+  sincos_fast(q2, s2, c2);
+  sincos_fast(q3, s3, c3);
   const float s23 = s2 * c3 + c2 * s3, c23 = c2 * c3 - s2 * s3;
 
   // --- forward kinematics (rotations as world columns; positions relative to the base origin) ---
@@ -364,48 +414,65 @@ struct PhysState {
   float q[12], qd[12];
 };
 
-template <int LEG>
-__device__ __forceinline__ void pgs_point_normal(float4* lds, int lane, float* y, float* z, float* lam) {
-#pragma unroll
-  for (int e = 0; e < 2; ++e) {
-    const int p = 2 * LEG + e;
-    const float4 c0 = row_chunk(lds, p, 0, lane), c1 = row_chunk(lds, p, 1, lane), c2 = row_chunk(lds, p, 2, lane);
-    const float vel = c0.x * y[0] + c0.y * y[1] + c0.z * y[2] + c0.w * y[3] + c1.x * y[4] + c1.y * y[5] +
-                      c1.z * z[0] + c1.w * z[1] + c2.x * z[2];
-    float dl = c2.z * (c2.y - vel);
-    const float nl = fmaxf(lam[p] + dl, 0.0f);
-    dl = nl - lam[p];
-    lam[p] = nl;
-    y[0] += c0.x * dl; y[1] += c0.y * dl; y[2] += c0.z * dl; y[3] += c0.w * dl; y[4] += c1.x * dl; y[5] += c1.y * dl;
-    z[0] += c1.z * dl; z[1] += c1.w * dl; z[2] += c2.x * dl;
-  }
+// whitened solver state: y = 3 packed pairs, per leg z = (pair, scalar)
+struct PgsX {
+  v2 y01, y23, y45;
+  v2 z01[4];
+  float z2[4];
+};
+
+// one constraint row: vel = Jt . x ; impulse step ; x += Jt dl.   Packed fp32 (v_pk_fma_f32) on the pairs.
+// Row chunk 2 = (j2, invd * target, invd, diag): nl = lam + invd (target - vel) is evaluated as
+// fma(-invd, vel, lam + invd*target) so that only one fma sits between vel and the clamp, and the
+// 9-term dot runs as two independent packed accumulators (shorter dependent chain for a lone wave).
+template <int LEG, bool FRICTION>
+__device__ __forceinline__ void pgs_row(const float4 c0, const float4 c1, const float4 c2, PgsX& x, float& lam, float lim, float& worst) {
+  const v2 a = {c0.x, c0.y}, b = {c0.z, c0.w}, c = {c1.x, c1.y}, d = {c1.z, c1.w};
+  const v2 acc0 = __builtin_elementwise_fma(c, x.y45, a * x.y01);
+  const v2 acc1 = __builtin_elementwise_fma(d, x.z01[LEG], b * x.y23);
+  const float base = lam + c2.y;
+  const v2 acc = acc0 + acc1;
+  const float vel = fmaf(c2.x, x.z2[LEG], acc.x + acc.y);
+  float nl = fmaf(-c2.z, vel, base);
+  if (FRICTION) nl = __builtin_amdgcn_fmed3f(nl, -lim, lim);
+  else nl = fmaxf(nl, 0.0f);
+  const float dl = nl - lam;
+  lam = nl;
+  worst = fmaxf(worst, fabsf(dl * c2.w));   // velocity residual |dl / invdiag|
+  const v2 dl2 = {dl, dl};
+  x.y01 = __builtin_elementwise_fma(a, dl2, x.y01);
+  x.y23 = __builtin_elementwise_fma(b, dl2, x.y23);
+  x.y45 = __builtin_elementwise_fma(c, dl2, x.y45);
+  x.z01[LEG] = __builtin_elementwise_fma(d, dl2, x.z01[LEG]);
+  x.z2[LEG] = fmaf(c2.x, dl, x.z2[LEG]);
 }
 
 template <int LEG>
-__device__ __forceinline__ void pgs_point_friction(float4* lds, int lane, float* y, float* z, float* lam) {
+__device__ __forceinline__ void pgs_leg_normals(float4* lds, int lane, PgsX& x, float* lam, float& worst) {
+  const int p0 = 2 * LEG, p1 = 2 * LEG + 1;
+  const float4 a0 = row_chunk(lds, p0, 0, lane), a1 = row_chunk(lds, p0, 1, lane), a2 = row_chunk(lds, p0, 2, lane);
+  const float4 b0 = row_chunk(lds, p1, 0, lane), b1 = row_chunk(lds, p1, 1, lane), b2 = row_chunk(lds, p1, 2, lane);
+  pgs_row<LEG, false>(a0, a1, a2, x, lam[p0], 0.0f, worst);
+  pgs_row<LEG, false>(b0, b1, b2, x, lam[p1], 0.0f, worst);
+}
+
+template <int LEG>
+__device__ __forceinline__ void pgs_leg_friction(float4* lds, int lane, PgsX& x, float* lam, float& worst) {
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
     const int p = 2 * LEG + e;
     const float lim = kMu * lam[p];
-#pragma unroll
-    for (int d = 0; d < 2; ++d) {
-      const int r = REX_NPOINT + 2 * p + d;
-      const float4 c0 = row_chunk(lds, r, 0, lane), c1 = row_chunk(lds, r, 1, lane), c2 = row_chunk(lds, r, 2, lane);
-      const float vel = c0.x * y[0] + c0.y * y[1] + c0.z * y[2] + c0.w * y[3] + c1.x * y[4] + c1.y * y[5] +
-                        c1.z * z[0] + c1.w * z[1] + c2.x * z[2];
-      float dl = c2.z * (c2.y - vel);
-      const float nl = clampf(lam[r] + dl, -lim, lim);
-      dl = nl - lam[r];
-      lam[r] = nl;
-      y[0] += c0.x * dl; y[1] += c0.y * dl; y[2] += c0.z * dl; y[3] += c0.w * dl; y[4] += c1.x * dl; y[5] += c1.y * dl;
-      z[0] += c1.z * dl; z[1] += c1.w * dl; z[2] += c2.x * dl;
-    }
+    const int r0 = REX_NPOINT + 2 * p, r1 = r0 + 1;
+    const float4 a0 = row_chunk(lds, r0, 0, lane), a1 = row_chunk(lds, r0, 1, lane), a2 = row_chunk(lds, r0, 2, lane);
+    const float4 b0 = row_chunk(lds, r1, 0, lane), b1 = row_chunk(lds, r1, 1, lane), b2 = row_chunk(lds, r1, 2, lane);
+    pgs_row<LEG, true>(a0, a1, a2, x, lam[r0], lim, worst);
+    pgs_row<LEG, true>(b0, b1, b2, x, lam[r1], lim, worst);
   }
 }
 
 // The restated pybullet.stepSimulation for one env (one lane): tau is held for this substep.
 __device__ __forceinline__ void physics_substep(PhysState& s, const float* tau, float dt, int iterations,
-                                                float4* lds, int lane) {
+                                                float sqrt_res_thr, float4* lds, int lane) {
   // base rotation (btMatrix3x3::setRotation)
   BaseKin bk;
   {
@@ -437,12 +504,19 @@ __device__ __forceinline__ void physics_substep(PhysState& s, const float* tau, 
     acc.F = mk(0.f, 0.f, (float)REX_BASE_MASS * kGravity) + ((float)REX_BASE_MASS * dl) * bk.v;
   }
 
-  LegFactor L0, L1, L2, L3;
   unsigned active = 0;
-  leg_pass<0>(bk, s.q + 0, s.qd + 0, tau + 0, dt, L0, acc, lds, lane, active);
-  leg_pass<1>(bk, s.q + 3, s.qd + 3, tau + 3, dt, L1, acc, lds, lane, active);
-  leg_pass<2>(bk, s.q + 6, s.qd + 6, tau + 6, dt, L2, acc, lds, lane, active);
-  leg_pass<3>(bk, s.q + 9, s.qd + 9, tau + 9, dt, L3, acc, lds, lane, active);
+  PgsX x;
+  {
+    LegFactor L;
+    leg_pass<0>(bk, s.q + 0, s.qd + 0, tau + 0, dt, L, acc, lds, lane, active);
+    leg_park(lds, 0, lane, L); x.z01[0] = v2{L.z[0], L.z[1]}; x.z2[0] = L.z[2];
+    leg_pass<1>(bk, s.q + 3, s.qd + 3, tau + 3, dt, L, acc, lds, lane, active);
+    leg_park(lds, 1, lane, L); x.z01[1] = v2{L.z[0], L.z[1]}; x.z2[1] = L.z[2];
+    leg_pass<2>(bk, s.q + 6, s.qd + 6, tau + 6, dt, L, acc, lds, lane, active);
+    leg_park(lds, 2, lane, L); x.z01[2] = v2{L.z[0], L.z[1]}; x.z2[2] = L.z[2];
+    leg_pass<3>(bk, s.q + 9, s.qd + 9, tau + 9, dt, L, acc, lds, lane, active);
+    leg_park(lds, 3, lane, L); x.z01[3] = v2{L.z[0], L.z[1]}; x.z2[3] = L.z[2];
+  }
 
   // base articulated inertia A = [[Io, hx],[hx^T, m]] - S, then A = Lc Lc^T
   float A[21];
@@ -484,10 +558,10 @@ __device__ __forceinline__ void physics_substep(PhysState& s, const float* tau, 
     fwd6(Lc, g, gw);
     const float diag = gw[0] * gw[0] + gw[1] * gw[1] + gw[2] * gw[2] + gw[3] * gw[3] + gw[4] * gw[4] + gw[5] * gw[5] +
                        c1.z * c1.z + c1.w * c1.w + c2.x * c2.x;
-    const float invd = c2.z != 0.0f ? 1.0f / diag : 0.0f;
+    const float invd = c2.z != 0.0f ? __builtin_amdgcn_rcpf(diag) : 0.0f;
     row_chunk(lds, r, 0, lane) = make_float4(gw[0], gw[1], gw[2], gw[3]);
     row_chunk(lds, r, 1, lane) = make_float4(gw[4], gw[5], c1.z, c1.w);
-    row_chunk(lds, r, 2, lane) = make_float4(c2.x, c2.y, invd, 0.0f);
+    row_chunk(lds, r, 2, lane) = make_float4(c2.x, c2.y * invd, invd, diag);
   }
 
   // projected Gauss-Seidel in Bullet's order: all normals, then all friction rows; a point that no
@@ -500,22 +574,35 @@ __device__ __forceinline__ void physics_substep(PhysState& s, const float* tau, 
   const bool any1 = __builtin_amdgcn_ballot_w64((active & 0x0Cu) != 0) != 0;
   const bool any2 = __builtin_amdgcn_ballot_w64((active & 0x30u) != 0) != 0;
   const bool any3 = __builtin_amdgcn_ballot_w64((active & 0xC0u) != 0) != 0;
+  x.y01 = v2{y[0], y[1]}; x.y23 = v2{y[2], y[3]}; x.y45 = v2{y[4], y[5]};
+  // Bullet leaves the sweep loop as soon as the largest velocity residual of a sweep is below
+  // m_leastSquaresResidualThreshold; each lane (env) stops on its own sweep, the wavefront leaves the
+  // loop when its last lane has stopped.
+  bool running = true;
   for (int it = 0; it < iterations; ++it) {
-    if (any0) pgs_point_normal<0>(lds, lane, y, L0.z, lam);
-    if (any1) pgs_point_normal<1>(lds, lane, y, L1.z, lam);
-    if (any2) pgs_point_normal<2>(lds, lane, y, L2.z, lam);
-    if (any3) pgs_point_normal<3>(lds, lane, y, L3.z, lam);
-    if (any0) pgs_point_friction<0>(lds, lane, y, L0.z, lam);
-    if (any1) pgs_point_friction<1>(lds, lane, y, L1.z, lam);
-    if (any2) pgs_point_friction<2>(lds, lane, y, L2.z, lam);
-    if (any3) pgs_point_friction<3>(lds, lane, y, L3.z, lam);
+    if (running) {
+      float worst = 0.0f;
+      if (any0) pgs_leg_normals<0>(lds, lane, x, lam, worst);
+      if (any1) pgs_leg_normals<1>(lds, lane, x, lam, worst);
+      if (any2) pgs_leg_normals<2>(lds, lane, x, lam, worst);
+      if (any3) pgs_leg_normals<3>(lds, lane, x, lam, worst);
+      if (any0) pgs_leg_friction<0>(lds, lane, x, lam, worst);
+      if (any1) pgs_leg_friction<1>(lds, lane, x, lam, worst);
+      if (any2) pgs_leg_friction<2>(lds, lane, x, lam, worst);
+      if (any3) pgs_leg_friction<3>(lds, lane, x, lam, worst);
+      running = worst > sqrt_res_thr;
+    }
+    if (__builtin_amdgcn_ballot_w64(running) == 0) break;
   }
+  y[0] = x.y01.x; y[1] = x.y01.y; y[2] = x.y23.x; y[3] = x.y23.y; y[4] = x.y45.x; y[5] = x.y45.y;
 
   // back to generalized velocities: nu0 = Lc^-T y ;  qd_f = G^-T (z_f - Bw_f nu0)
   float nu[6];
   bwd6(Lc, y, nu);
-  auto leg_back = [&](const LegFactor& L, float* qd) {
-    float t1 = L.z[0], t2 = L.z[1], t3 = L.z[2];
+  auto leg_back = [&](int leg, float* qd) {
+    LegFactor L;
+    leg_unpark(lds, leg, lane, L);
+    float t1 = x.z01[leg].x, t2 = x.z01[leg].y, t3 = x.z2[leg];
 #pragma unroll
     for (int k = 0; k < 6; ++k) { t1 -= L.Bw[0][k] * nu[k]; t2 -= L.Bw[1][k] * nu[k]; t3 -= L.Bw[2][k] * nu[k]; }
     const float u3 = t3 * L.gi3;
@@ -525,7 +612,7 @@ __device__ __forceinline__ void physics_substep(PhysState& s, const float* tau, 
     qd[1] = clampf(u2, -kMaxCoordVel, kMaxCoordVel);
     qd[2] = clampf(u3, -kMaxCoordVel, kMaxCoordVel);
   };
-  leg_back(L0, s.qd + 0); leg_back(L1, s.qd + 3); leg_back(L2, s.qd + 6); leg_back(L3, s.qd + 9);
+  leg_back(0, s.qd + 0); leg_back(1, s.qd + 3); leg_back(2, s.qd + 6); leg_back(3, s.qd + 9);
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     s.ang[k] = clampf(nu[k], -kMaxCoordVel, kMaxCoordVel);
@@ -541,8 +628,8 @@ __device__ __forceinline__ void physics_substep(PhysState& s, const float* tau, 
     const float angle = wn * dt;
     float sc;
     if (wn < 0.001f) sc = 0.5f * dt - dt * dt * dt * 0.020833333333f * wn * wn;
-    else sc = sinf(0.5f * angle) / wn;
-    const float dx = s.ang[0] * sc, dy = s.ang[1] * sc, dz = s.ang[2] * sc, dw = cosf(0.5f * angle);
+    else { float sh, ch; sincos_fast(0.5f * angle, sh, ch); sc = sh / wn; }
+    const float dx = s.ang[0] * sc, dy = s.ang[1] * sc, dz = s.ang[2] * sc, dw = cos_half(0.5f * angle);
     const float qx = s.quat[0], qy = s.quat[1], qz = s.quat[2], qw = s.quat[3];
     const float nx = dw * qx + dx * qw + dy * qz - dz * qy;
     const float ny = dw * qy - dx * qz + dy * qw + dz * qx;

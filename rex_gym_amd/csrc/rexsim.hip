@@ -13,9 +13,10 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <math.h>
 
-#include "rex_controller.h"
 #include "rex_device.h"
+#include "rex_controller.h"
 
 namespace rex {
 
@@ -91,7 +92,7 @@ __device__ __forceinline__ void quat_to_euler(const float* q, float* rpy) {
 // (Rex.GetBaseOrientation, rex.py:530-537, then getMatrixFromQuaternion)
 __device__ __forceinline__ void euler_to_row2(const float* rpy, float& r20, float& r21, float& r22) {
   float sr, cr, sp, cp, sy, cy;
-  sincosf(rpy[0] * 0.5f, &sr, &cr); sincosf(rpy[1] * 0.5f, &sp, &cp); sincosf(rpy[2] * 0.5f, &sy, &cy);
+  sincos_fast(rpy[0] * 0.5f, sr, cr); sincos_fast(rpy[1] * 0.5f, sp, cp); sincos_fast(rpy[2] * 0.5f, sy, cy);
   float x = sr * cp * cy - cr * sp * sy, y = cr * sp * cy + sr * cp * sy;
   float z = cr * cp * sy - sr * sp * cy, w = cr * cp * cy + sr * sp * sy;
   const float nn = rsqrtf(x * x + y * y + z * z + w * w);
@@ -116,7 +117,7 @@ __device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * (1.0
 
 struct DevCfg {
   int32_t n, env_index_base, task, signal, action_repeat, iterations;
-  float dt, kp, kd;
+  float dt, kp, kd, res_thr;
   int32_t backwards;
   float target_position;
   uint32_t seed_lo, seed_hi;
@@ -142,7 +143,7 @@ __device__ __forceinline__ void rex_substep(const DevCfg& c, EnvState& e, const 
     tau_obs[j] = obs;
     tau[j] = ((e.motor_en >> j) & 1u) ? act : 0.0f;                              // rex.py:617-623
   }
-  physics_substep(e.ph, tau, c.dt, c.iterations, lds, lane);
+  physics_substep(e.ph, tau, c.dt, c.iterations, c.res_thr, lds, lane);
 }
 
 __device__ __forceinline__ void env_observation(const DevCfg& c, const EnvState& e, float* obs) {
@@ -223,7 +224,8 @@ __device__ __forceinline__ void walk_command(const DevCfg& c, EnvState& e, const
     }
     const float sc = (0.0f <= t && t <= 0.8f) ? t : 1.0f;
     l_a *= sc; f_a *= sc;
-    const float cph = cosf(2.0f * kPi / 0.125f * t);
+    float sph, cph;
+    sincos_fast(2.0f * kPi / 0.125f * t, sph, cph);
     const float le = l_a * cph, fe = f_a * cph;
     const float pose[12] = {0.f, le + action[0], fe + action[1], 0.f, -le + action[2], -fe + action[3],
                             0.f, -le + action[4], -fe + action[5], 0.f, le + action[6], fe + action[7]};
@@ -467,6 +469,7 @@ int rex_default_config(int task, int signal, int num_envs, RexConfig* cfg) {
   cfg->energy_weight = task == REX_TASK_GALLOP ? 0.005f : 0.0005f;   /* gallop_env.py:45 */
   cfg->drift_weight = 2.0f;
   cfg->shake_weight = 0.005f;
+  cfg->solver_residual_threshold = 1e-7f;                        /* PyBullet default solverResidualThreshold */
   return REX_OK;
 }
 
@@ -508,7 +511,7 @@ int rex_create(const RexConfig* cfg, int device, float* d_state, void* stream, R
   rex::DevCfg& d = s->dev;
   d.n = cfg->num_envs; d.env_index_base = cfg->env_index_base; d.task = cfg->task; d.signal = cfg->signal;
   d.action_repeat = cfg->action_repeat; d.iterations = cfg->solver_iterations; d.dt = cfg->sim_time_step;
-  d.kp = cfg->motor_kp; d.kd = cfg->motor_kd; d.backwards = cfg->backwards; d.target_position = cfg->target_position;
+  d.kp = cfg->motor_kp; d.kd = cfg->motor_kd; d.res_thr = sqrtf(fmaxf(cfg->solver_residual_threshold, 0.0f)); d.backwards = cfg->backwards; d.target_position = cfg->target_position;
   d.seed_lo = (uint32_t)cfg->seed; d.seed_hi = (uint32_t)(cfg->seed >> 32);
   d.auto_reset = cfg->auto_reset; d.max_steps = cfg->max_episode_steps;
   d.w_dist = cfg->distance_weight; d.w_energy = cfg->energy_weight; d.w_drift = cfg->drift_weight; d.w_shake = cfg->shake_weight;

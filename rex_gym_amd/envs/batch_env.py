@@ -53,6 +53,7 @@ class RexBatchEnv:
     def __init__(self, num_envs, task="walk", signal_type="ik", device=0, seed=0, env_index_base=0,
                  auto_reset=False, max_episode_steps=0, backwards=None, target_position=None,
                  motor_kp=1.0, motor_kd=0.02, control_time_step=None, action_repeat=None,
+                 solver_iterations=None, solver_residual_threshold=None,
                  check_actions=False, terrain_type="plane", mark="base", render=False, stream=None, **unused):
         import torch
         if terrain_type != "plane" or mark != "base" or render:
@@ -74,6 +75,10 @@ class RexBatchEnv:
             cfg.solver_iterations = int(300 / cfg.action_repeat)        # rex_gym_env.py:184
         if control_time_step is not None:
             cfg.sim_time_step = float(control_time_step) / cfg.action_repeat  # rex_gym_env.py:172
+        if solver_iterations is not None:
+            cfg.solver_iterations = int(solver_iterations)
+        if solver_residual_threshold is not None:
+            cfg.solver_residual_threshold = float(solver_residual_threshold)
         cfg.motor_kp, cfg.motor_kd = float(motor_kp), float(motor_kd)
         cfg.backwards = -1 if backwards is None else int(bool(backwards))
         cfg.target_position = 0.0 if not target_position else float(target_position)
@@ -166,4 +171,4 @@ class RexBatchEnv:
                 raise ValueError("Invalid action")
         _lib.check(self._L.rex_step(self._h, a.data_ptr(), self._obs.data_ptr(), self._reward.data_ptr(),
                                     self._done.data_ptr(), self._cmd.data_ptr(), self._stream_ptr()), "rex_step")
-        return self._obs, self._reward, self._done.bool(), {"action": self._cmd}
+        return self._obs, self._reward, self._done.view(self._torch.bool), {"action": self._cmd}

@@ -28,7 +28,7 @@ class RexConfig(ctypes.Structure):
         ("target_position", ctypes.c_float), ("seed", ctypes.c_uint64), ("auto_reset", ctypes.c_int32),
         ("max_episode_steps", ctypes.c_int32), ("distance_weight", ctypes.c_float),
         ("energy_weight", ctypes.c_float), ("drift_weight", ctypes.c_float), ("shake_weight", ctypes.c_float),
-        ("reserved", ctypes.c_int32 * 8),
+        ("solver_residual_threshold", ctypes.c_float), ("reserved", ctypes.c_int32 * 7),
     ]
 
 
@@ -43,7 +43,7 @@ def default_config(task="walk", signal="ik", num_envs=1, **kw):
                   action_repeat=repeat, solver_iterations=300 // repeat, sim_time_step=0.001,
                   motor_kp=1.0, motor_kd=0.02, backwards=-1, target_position=0.0, seed=0, auto_reset=0,
                   max_episode_steps=0, distance_weight=1.0, energy_weight=0.005 if task == "gallop" else 0.0005, drift_weight=2.0,
-                  shake_weight=0.005)
+                  shake_weight=0.005, solver_residual_threshold=1e-7)
     for k, v in kw.items():
         setattr(c, k, v)
     return c
@@ -101,10 +101,11 @@ class Oracle:
         return planner, frames
 
     # ---- physics probes ----
-    def physics_substep(self, st, tau, dt=0.001, iterations=60, nsteps=1):
+    def physics_substep(self, st, tau, dt=0.001, iterations=60, nsteps=1, residual_threshold=1e-7):
         st = self._arr(st).ravel().copy()
         tau = self._arr(tau).ravel()
-        self.lib.orc_physics_substep(self._p(st), self._p(tau), self.creal(dt), int(iterations), int(nsteps))
+        self.lib.orc_physics_substep(self._p(st), self._p(tau), self.creal(dt), int(iterations), int(nsteps),
+                                     self.creal(residual_threshold))
         return st
 
     def forward_dynamics(self, st, tau):
