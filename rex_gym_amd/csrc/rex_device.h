@@ -25,7 +25,7 @@
 #define REX_NPOINT 8                  /* 2 toe-cylinder end points per foot */
 #define REX_NROW (3 * REX_NPOINT)     /* normal + 2 pyramid friction rows per point */
 #define REX_ROW_F4 3                  /* float4 chunks per row in LDS */
-#define REX_LEG_F4 6                  /* float4 chunks per leg kept for the back-substitution (Bw 18 + G 6) */
+#define REX_LEG_F4 7                  /* float4 chunks per leg parked in LDS (Bw 18 + G 6 + z 3) */
 #define REX_LDS_ROW_F4 (REX_NROW * REX_ROW_F4 * REX_WAVE)
 #define REX_LDS_FLOATS ((REX_NROW * REX_ROW_F4 + REX_NLEG * REX_LEG_F4) * 4 * REX_WAVE)
 
@@ -135,6 +135,7 @@ __device__ __forceinline__ void leg_park(float4* lds, int leg, int lane, const L
   leg_chunk(lds, leg, 3, lane) = make_float4(L.Bw[2][0], L.Bw[2][1], L.Bw[2][2], L.Bw[2][3]);
   leg_chunk(lds, leg, 4, lane) = make_float4(L.Bw[2][4], L.Bw[2][5], L.gi1, L.gi2);
   leg_chunk(lds, leg, 5, lane) = make_float4(L.gi3, L.g21, L.g31, L.g32);
+  leg_chunk(lds, leg, 6, lane) = make_float4(L.z[0], L.z[1], L.z[2], 0.0f);
 }
 __device__ __forceinline__ void leg_unpark(float4* lds, int leg, int lane, LegFactor& L) {
   const float4 a = leg_chunk(lds, leg, 0, lane), b = leg_chunk(lds, leg, 1, lane), c = leg_chunk(lds, leg, 2, lane);
@@ -164,12 +165,16 @@ __device__ __forceinline__ float4& row_chunk(float4* lds, int r, int c, int lane
 
 // One leg: forward kinematics, Newton-Euler bias, composite inertia, leg Cholesky, Schur
 // contributions to the base, and the (unwhitened in the base part) contact rows of its toe.
-template <int LEG>
-__device__ __forceinline__ void leg_pass(const BaseKin& bk, const float* __restrict__ q, const float* __restrict__ qd,
+// `leg` is a run-time index: the four legs share ONE copy of this code (the caller's leg loop is kept
+// rolled so that a substep's instruction stream stays inside the instruction cache); only the mirror
+// signs of the hip offsets differ between legs.
+__device__ __forceinline__ void leg_pass(int leg, const BaseKin& bk, const float* __restrict__ q, const float* __restrict__ qd,
                                          const float* __restrict__ tau, float dt, LegFactor& L, BaseAccum& acc,
                                          float4* lds, int lane, unsigned& active_mask) {
-  constexpr float SX = (float)REX_LEG_SX[LEG], SY = (float)REX_LEG_SY[LEG];
-  constexpr float HX = SX * (float)REX_HIP_X, HY = SY * (float)REX_HIP_Y, UY = SY * (float)REX_UPPER_Y;
+  static_assert(REX_LEG_SX[0] == -1 && REX_LEG_SX[1] == -1 && REX_LEG_SX[2] == 1 && REX_LEG_SX[3] == 1, "leg mirror table");
+  static_assert(REX_LEG_SY[0] == -1 && REX_LEG_SY[1] == 1 && REX_LEG_SY[2] == -1 && REX_LEG_SY[3] == 1, "leg mirror table");
+  const float SX = leg < 2 ? -1.0f : 1.0f, SY = (leg & 1) ? 1.0f : -1.0f;
+  const float HX = SX * (float)REX_HIP_X, HY = SY * (float)REX_HIP_Y, UY = SY * (float)REX_UPPER_Y;
   constexpr float KX = (float)REX_KNEE_X, KZ = (float)REX_KNEE_Z, CZ = (float)REX_LOWER_COM_Z, TZ = (float)REX_TOE_Z;
   constexpr float M1 = (float)REX_SHOULDER_MASS, M2 = (float)REX_UPPER_MASS, M3 = (float)REX_LOWER_MASS;
 
@@ -323,7 +328,7 @@ __device__ __forceinline__ void leg_pass(const BaseKin& bk, const float* __restr
     const f3 P = tc + sg * aw - (kToeRad * inv) * dv;
     const float dist = bk.height + P.z;
     const bool act = dist < kBreaking;
-    const int p = 2 * LEG + e;
+    const int p = 2 * leg + e;
     if (act) active_mask |= 1u << p;
     const f3 r1v = P - o1, r2v = P - o2, r3v = P - o3;
 #pragma unroll
@@ -471,7 +476,15 @@ __device__ __forceinline__ void pgs_leg_friction(float4* lds, int lane, PgsX& x,
 }
 
 // The restated pybullet.stepSimulation for one env (one lane): tau is held for this substep.
-__device__ __forceinline__ void physics_substep(PhysState& s, const float* tau, float dt, int iterations,
+template <class T>
+__device__ __forceinline__ void rotate_leg(T* a) {   // 12-entry per-joint array: leg k+1 moves into leg k's slots
+  const T t0 = a[0], t1 = a[1], t2 = a[2];
+#pragma unroll
+  for (int j = 0; j < 9; ++j) a[j] = a[j + 3];
+  a[9] = t0; a[10] = t1; a[11] = t2;
+}
+
+__device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float dt, int iterations,
                                                 float sqrt_res_thr, float4* lds, int lane) {
   // base rotation (btMatrix3x3::setRotation)
   BaseKin bk;
@@ -506,16 +519,19 @@ __device__ __forceinline__ void physics_substep(PhysState& s, const float* tau, 
 
   unsigned active = 0;
   PgsX x;
-  {
+#pragma unroll 1
+  for (int leg = 0; leg < REX_NLEG; ++leg) {
+    // the current leg always sits in slots 0..2: q / qd / tau are rotated by one leg per iteration,
+    // which keeps every register index static inside the rolled loop
     LegFactor L;
-    leg_pass<0>(bk, s.q + 0, s.qd + 0, tau + 0, dt, L, acc, lds, lane, active);
-    leg_park(lds, 0, lane, L); x.z01[0] = v2{L.z[0], L.z[1]}; x.z2[0] = L.z[2];
-    leg_pass<1>(bk, s.q + 3, s.qd + 3, tau + 3, dt, L, acc, lds, lane, active);
-    leg_park(lds, 1, lane, L); x.z01[1] = v2{L.z[0], L.z[1]}; x.z2[1] = L.z[2];
-    leg_pass<2>(bk, s.q + 6, s.qd + 6, tau + 6, dt, L, acc, lds, lane, active);
-    leg_park(lds, 2, lane, L); x.z01[2] = v2{L.z[0], L.z[1]}; x.z2[2] = L.z[2];
-    leg_pass<3>(bk, s.q + 9, s.qd + 9, tau + 9, dt, L, acc, lds, lane, active);
-    leg_park(lds, 3, lane, L); x.z01[3] = v2{L.z[0], L.z[1]}; x.z2[3] = L.z[2];
+    leg_pass(leg, bk, s.q, s.qd, tau, dt, L, acc, lds, lane, active);
+    leg_park(lds, leg, lane, L);
+    rotate_leg(s.q); rotate_leg(s.qd); rotate_leg(tau);
+  }
+#pragma unroll
+  for (int k = 0; k < REX_NLEG; ++k) {
+    const float4 zc = leg_chunk(lds, k, 6, lane);
+    x.z01[k] = v2{zc.x, zc.y}; x.z2[k] = zc.z;
   }
 
   // base articulated inertia A = [[Io, hx],[hx^T, m]] - S, then A = Lc Lc^T
@@ -599,20 +615,24 @@ __device__ __forceinline__ void physics_substep(PhysState& s, const float* tau, 
   // back to generalized velocities: nu0 = Lc^-T y ;  qd_f = G^-T (z_f - Bw_f nu0)
   float nu[6];
   bwd6(Lc, y, nu);
-  auto leg_back = [&](int leg, float* qd) {
+  float zt[12];
+#pragma unroll
+  for (int k = 0; k < REX_NLEG; ++k) { zt[3 * k] = x.z01[k].x; zt[3 * k + 1] = x.z01[k].y; zt[3 * k + 2] = x.z2[k]; }
+#pragma unroll 1
+  for (int leg = 0; leg < REX_NLEG; ++leg) {
     LegFactor L;
     leg_unpark(lds, leg, lane, L);
-    float t1 = x.z01[leg].x, t2 = x.z01[leg].y, t3 = x.z2[leg];
+    float t1 = zt[0], t2 = zt[1], t3 = zt[2];
 #pragma unroll
     for (int k = 0; k < 6; ++k) { t1 -= L.Bw[0][k] * nu[k]; t2 -= L.Bw[1][k] * nu[k]; t3 -= L.Bw[2][k] * nu[k]; }
     const float u3 = t3 * L.gi3;
     const float u2 = (t2 - L.g32 * u3) * L.gi2;
     const float u1 = (t1 - L.g21 * u2 - L.g31 * u3) * L.gi1;
-    qd[0] = clampf(u1, -kMaxCoordVel, kMaxCoordVel);
-    qd[1] = clampf(u2, -kMaxCoordVel, kMaxCoordVel);
-    qd[2] = clampf(u3, -kMaxCoordVel, kMaxCoordVel);
-  };
-  leg_back(0, s.qd + 0); leg_back(1, s.qd + 3); leg_back(2, s.qd + 6); leg_back(3, s.qd + 9);
+    s.qd[0] = clampf(u1, -kMaxCoordVel, kMaxCoordVel);
+    s.qd[1] = clampf(u2, -kMaxCoordVel, kMaxCoordVel);
+    s.qd[2] = clampf(u3, -kMaxCoordVel, kMaxCoordVel);
+    rotate_leg(s.qd); rotate_leg(zt);
+  }
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     s.ang[k] = clampf(nu[k], -kMaxCoordVel, kMaxCoordVel);

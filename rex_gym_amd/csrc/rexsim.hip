@@ -37,7 +37,7 @@ struct EnvState {
   uint32_t flags;
   int32_t steps, episode;
   uint32_t motor_en;
-  uint32_t overheat[6];  // 12 x u16
+  uint32_t overheat[12]; // one counter per motor in registers; packed 2 x u16 per state word in HBM
 };
 
 __device__ __forceinline__ float ldw(const float* st, int n, int w, int i) { return st[(size_t)w * n + i]; }
@@ -57,7 +57,10 @@ __device__ __forceinline__ void load_env(const float* st, int n, int i, EnvState
   e.flags = ldi(st, n, REX_S_FLAGS, i); e.steps = (int32_t)ldi(st, n, REX_S_STEPS, i); e.episode = (int32_t)ldi(st, n, REX_S_EPISODE, i);
   e.motor_en = ldi(st, n, REX_S_MOTOR_EN, i);
 #pragma unroll
-  for (int k = 0; k < 6; ++k) e.overheat[k] = ldi(st, n, REX_S_OVERHEAT + k, i);
+  for (int k = 0; k < 6; ++k) {
+    const uint32_t w = ldi(st, n, REX_S_OVERHEAT + k, i);
+    e.overheat[2 * k] = w & 0xFFFFu; e.overheat[2 * k + 1] = w >> 16;
+  }
 }
 
 __device__ __forceinline__ void store_env(float* st, int n, int i, const EnvState& e) {
@@ -72,7 +75,7 @@ __device__ __forceinline__ void store_env(float* st, int n, int i, const EnvStat
   sti(st, n, REX_S_FLAGS, i, e.flags); sti(st, n, REX_S_STEPS, i, (uint32_t)e.steps); sti(st, n, REX_S_EPISODE, i, (uint32_t)e.episode);
   sti(st, n, REX_S_MOTOR_EN, i, e.motor_en);
 #pragma unroll
-  for (int k = 0; k < 6; ++k) sti(st, n, REX_S_OVERHEAT + k, i, e.overheat[k]);
+  for (int k = 0; k < 6; ++k) sti(st, n, REX_S_OVERHEAT + k, i, e.overheat[2 * k] | (e.overheat[2 * k + 1] << 16));
 }
 
 // ---- PyBullet quaternion conventions ----
@@ -129,19 +132,23 @@ struct DevCfg {
 __device__ __forceinline__ float init_pose(const DevCfg& c, int j) { return c.signal == REX_SIGNAL_OL ? pose_stand_ol(j) : pose_stand(j); }
 
 // Rex.ApplyAction + stepSimulation + ReceiveObservation (rex.py:158-163, 568-641)
-__device__ __forceinline__ void rex_substep(const DevCfg& c, EnvState& e, const float* cmd, float* tau_obs, float4* lds, int lane) {
+__device__ __forceinline__ void rex_substep(const DevCfg& c, EnvState& e, float* cmd, float* tau_obs, float4* lds, int lane) {
   float tau[12];
   const float limit = 1.0f / c.dt;  // OVERHEAT_SHUTDOWN_TIME / time_step, rex.py:607
+#pragma unroll 1
+  for (int leg = 0; leg < 4; ++leg) {   // rolled (code size); the current leg sits in slots 0..2
 #pragma unroll
-  for (int j = 0; j < 12; ++j) {
-    float act, obs;
-    motor_torque(cmd[j], e.ph.q[j], e.ph.qd[j], e.ph.qd[j], c.kp, c.kd, act, obs);
-    uint32_t cnt = (e.overheat[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
-    if (fabsf(act) > 2.45f) { if (cnt < 65535u) cnt++; } else cnt = 0;          // rex.py:603-606
-    if ((float)cnt > limit) e.motor_en &= ~(1u << j);                            // rex.py:607-608
-    e.overheat[j >> 1] = (e.overheat[j >> 1] & ~(0xFFFFu << ((j & 1) * 16))) | (cnt << ((j & 1) * 16));
-    tau_obs[j] = obs;
-    tau[j] = ((e.motor_en >> j) & 1u) ? act : 0.0f;                              // rex.py:617-623
+    for (int k = 0; k < 3; ++k) {
+      float act, obs;
+      motor_torque(cmd[k], e.ph.q[k], e.ph.qd[k], e.ph.qd[k], c.kp, c.kd, act, obs);
+      uint32_t cnt = e.overheat[k];
+      cnt = fabsf(act) > 2.45f ? min(cnt + 1u, 65535u) : 0u;                      // rex.py:603-606
+      if ((float)cnt > limit) e.motor_en &= ~(1u << (3 * leg + k));               // rex.py:607-608
+      e.overheat[k] = cnt;
+      tau_obs[k] = obs;
+      tau[k] = ((e.motor_en >> (3 * leg + k)) & 1u) ? act : 0.0f;                 // rex.py:617-623
+    }
+    rotate_leg(cmd); rotate_leg(e.ph.q); rotate_leg(e.ph.qd); rotate_leg(e.overheat); rotate_leg(tau_obs); rotate_leg(tau);
   }
   physics_substep(e.ph, tau, c.dt, c.iterations, c.res_thr, lds, lane);
 }
