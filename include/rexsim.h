@@ -81,7 +81,7 @@ enum RexStateWord {
 #define REX_F_STAY_STILL     4u   /* walk_env.py:280 */
 #define REX_F_BACKWARDS      8u   /* walk_env.py:133-136 (episode draw or fixed) */
 #define REX_F_DONE          16u   /* last step returned done; must be reset before the next step */
-#define REX_F_REWARD_ABS    32u   /* target already folded to abs() by _reward (rex_gym_env.py:510) */
+#define REX_F_ENV_GOAL      32u   /* RexGymEnv.env_goal_reached (turn_env.py:338-340) */
 
 typedef struct RexConfig {
   int32_t abi_version;        /* REX_ABI_VERSION */
@@ -107,7 +107,11 @@ typedef struct RexConfig {
                                         early once max_row (delta_impulse / invdiag)^2 <= this; PyBullet's
                                         default is 1e-7 and the reference never changes it. 0 = always run
                                         solver_iterations sweeps. */
-  int32_t reserved[7];
+  /* RexTurnEnv (envs/gym/turn_env.py:129-160): yaw targets; bit 0 of orient_fixed = target_orient is
+     given (else drawn U(0.2, 6) per episode), bit 1 = init_orient is given */
+  float   target_orient, init_orient;
+  int32_t orient_fixed;
+  int32_t reserved[4];
 } RexConfig;
 
 typedef struct RexSim RexSim;

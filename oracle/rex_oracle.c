@@ -801,6 +801,14 @@ static void env_reset(Orc* o, int idx) {
     else e->target = (real)(1.0f + 2.0f * u01(ctr[1]));                         /* gallop_env.py:150-152 */
   }
   e->end_time = 0; e->aux = 0; e->steps = 0;
+  if (c->task == REX_TASK_TURN) {                                               /* turn_env.py:129-160 */
+    float tgt = (c->orient_fixed & 1) ? c->target_orient : fmaf(5.8f, u01(ctr[1]), 0.2f);
+    float ini = (c->orient_fixed & 2) ? c->init_orient : fmaf(5.8f, u01(ctr[2]), 0.2f);
+    e->target = (real)tgt; e->aux = (real)ini;
+    real rpy[3] = {0, 0, (real)ini};
+    euler_to_quat(rpy, e->ph.quat);                                             /* resetBasePositionAndOrientation */
+    e->ph.pos[0] = 0; e->ph.pos[1] = 0; e->ph.pos[2] = ROBOT_INIT_Z;
+  }
 }
 
 /* walk_env.py:229-244 */
@@ -900,6 +908,54 @@ static void gallop_command(const RexConfig* c, Env* e, const real* action, real 
   }
 }
 
+/* turn_env.py:313-322 */
+static int turn_clockwise(const Env* e) {
+  real diff = fabs(e->aux - e->target);
+  if (e->aux < e->target) return diff > (real)3.14;
+  return diff < (real)3.14;
+}
+
+/* RexTurnEnv._transform_action_to_motor_command (turn_env.py:239-347) */
+static void turn_command(const RexConfig* c, Env* e, const real* action, real cmd[NJ]) {
+  const real* ip = init_pose(c);
+  real t = (real)(e->steps * c->action_repeat) * (real)c->sim_time_step;
+  if (e->flags & REX_F_STAY_STILL) {
+    if (t - e->end_time >= 1) e->flags |= REX_F_ENV_GOAL;                          /* _terminate_with_delay */
+    memcpy(cmd, ip, sizeof(real) * NJ);
+    return;
+  }
+  {                                                                                 /* _check_target_position */
+    real rpy[3];
+    quat_to_euler(e->ph.quat, rpy);
+    real cz = rpy[2];
+    if (cz < 0) cz += (real)6.28;
+    if (fabs(e->target - cz) <= (real)0.01) {
+      e->flags |= REX_F_GOAL_REACHED;
+      if (!(e->flags & REX_F_TERMINATING)) { e->end_time = t; e->flags |= REX_F_TERMINATING; }
+    }
+  }
+  int clockwise = turn_clockwise(e);
+  if (e->flags & REX_F_GOAL_REACHED) e->flags |= REX_F_STAY_STILL;                  /* turn_env.py:259-260,272-273 */
+  if (c->signal == REX_SIGNAL_IK) {
+    real coeff = (0 <= t && t <= (real)0.8) ? t : (real)1.0;
+    real dirv = (real)-0.5 * coeff;
+    if (clockwise) dirv = -dirv;
+    real pos[3] = {(real)0.009, 0, 0}, orn[3] = {0, 0, 0};
+    real frames[12], ang[12];
+    gait_loop(&e->gait, 0, (real)0.02, 0, dirv + action[0], (real)0.75 + action[1], (real)1.0, t, frames);
+    ik_solve(orn, pos, frames, ang, 0);
+    order_signal(ang, cmd);
+  } else {
+    const real ext = (real)0.1, swing = (real)0.03 + action[0], swipe = (real)0.05 + action[1];
+    int ith = ((int)(t / (real)0.1)) % 2;
+    real m = clockwise ? (real)1 : (real)-1;   /* right_* poses (clockwise) = left_* with the swing sign flipped, turn_env.py:280-297 */
+    real ms = m * swing;
+    real first[12] = {swipe, ext, ms, -swipe, ext, -ms, swipe, -ext, -ms, -swipe, -ext, ms};
+    real second[12] = {-swipe, 0, -ms, swipe, 0, ms, -swipe, 0, ms, swipe, 0, -ms};
+    for (int j = 0; j < NJ; ++j) cmd[j] = POSE_STAND_OL[j] + (ith ? second[j] : first[j]);
+  }
+}
+
 /* rex_gym_env.py:501-542 */
 static real base_reward(const RexConfig* c, Env* e) {
   real x = -e->ph.pos[0];
@@ -939,10 +995,13 @@ static void env_step(Orc* o, int idx, const real* action, real* obs, real* rewar
   Env* e = &o->envs[idx];
   real cmd[NJ];
   if (c->task == REX_TASK_GALLOP) gallop_command(c, e, action, cmd);
+  else if (c->task == REX_TASK_TURN) turn_command(c, e, action, cmd);
   else walk_command(c, e, action, cmd);
   for (int k = 0; k < c->action_repeat; ++k) rex_substep(c, e, cmd);    /* Rex.Step, rex.py:158-163 */
-  *reward = base_reward(c, e);
+  if (c->task == REX_TASK_TURN) *reward = (real)0.035 - fabs(e->ph.pos[0]) - fabs(e->ph.pos[1]);  /* turn_env.py:362-367 */
+  else *reward = base_reward(c, e);
   int d = env_fallen(c, e);
+  if (e->flags & REX_F_ENV_GOAL) d = 1;                                 /* rex_gym_env.py:495 */
   if (c->task == REX_TASK_GALLOP && e->ph.pos[1] > (real)0.3) d = 1;    /* gallop_env.py:315-317 */
   e->steps += 1;
   if (c->max_episode_steps > 0 && e->steps >= c->max_episode_steps) d = 1;

@@ -127,6 +127,8 @@ struct DevCfg {
   int32_t auto_reset, max_steps;
   float w_dist, w_energy, w_drift, w_shake;
   int32_t action_dim, obs_dim;
+  float target_orient, init_orient;
+  int32_t orient_fixed;
 };
 
 __device__ __forceinline__ float init_pose(const DevCfg& c, int j) { return c.signal == REX_SIGNAL_OL ? pose_stand_ol(j) : pose_stand(j); }
@@ -186,6 +188,16 @@ __device__ __forceinline__ void env_reset(const DevCfg& c, const float* snap, in
     e.target = c.target_position != 0.0f ? c.target_position : (1.0f + 2.0f * u); // gallop_env.py:150-152
   }
   e.end_time = 0.0f; e.aux = 0.0f; e.steps = 0;
+  if (c.task == REX_TASK_TURN) {                                                 // turn_env.py:129-160
+    const float tgt = (c.orient_fixed & 1) ? c.target_orient : fmaf(5.8f, u, 0.2f);
+    const float ini = (c.orient_fixed & 2) ? c.init_orient : fmaf(5.8f, u01(ctr[2]), 0.2f);
+    e.target = tgt; e.aux = ini;
+    float sh, ch;
+    sincos_fast(0.5f * ini, sh, ch);                                             // getQuaternionFromEuler([0, 0, yaw])
+    const float nn = rsqrtf(sh * sh + ch * ch);
+    e.ph.quat[0] = 0.0f; e.ph.quat[1] = 0.0f; e.ph.quat[2] = sh * nn; e.ph.quat[3] = ch * nn;
+    e.ph.pos[0] = 0.0f; e.ph.pos[1] = 0.0f; e.ph.pos[2] = kInitZ;                // resetBasePositionAndOrientation
+  }
 }
 
 __device__ __forceinline__ void order_signal(const float* ang, float* cmd) {  // FR,FL,RR,RL -> FL,FR,RL,RR
@@ -282,6 +294,48 @@ __device__ __forceinline__ void gallop_command(const DevCfg& c, EnvState& e, con
   }
 }
 
+// RexTurnEnv._transform_action_to_motor_command (turn_env.py:239-347)
+__device__ __forceinline__ void turn_command(const DevCfg& c, EnvState& e, const float* action, float* cmd) {
+  const float t = (float)(e.steps * c.action_repeat) * c.dt;
+  if (e.flags & REX_F_STAY_STILL) {
+    if (t - e.end_time >= 1.0f) e.flags |= REX_F_ENV_GOAL;                       // _terminate_with_delay
+#pragma unroll
+    for (int j = 0; j < 12; ++j) cmd[j] = init_pose(c, j);
+    return;
+  }
+  {                                                                              // _check_target_position
+    float rpy[3];
+    quat_to_euler(e.ph.quat, rpy);
+    float cz = rpy[2];
+    if (cz < 0.0f) cz += 6.28f;
+    if (fabsf(e.target - cz) <= 0.01f) {
+      e.flags |= REX_F_GOAL_REACHED;
+      if (!(e.flags & REX_F_TERMINATING)) { e.end_time = t; e.flags |= REX_F_TERMINATING; }
+    }
+  }
+  const float diff = fabsf(e.aux - e.target);                                    // _solve_direction
+  const bool clockwise = e.aux < e.target ? diff > 3.14f : diff < 3.14f;
+  if (e.flags & REX_F_GOAL_REACHED) e.flags |= REX_F_STAY_STILL;
+  if (c.signal == REX_SIGNAL_IK) {
+    const float coeff = (0.0f <= t && t <= 0.8f) ? t : 1.0f;
+    float dirv = -0.5f * coeff;
+    if (clockwise) dirv = -dirv;
+    const float pos[3] = {0.009f, 0.0f, 0.0f}, orn[3] = {0.0f, 0.0f, 0.0f};
+    float frames[12], ang[12];
+    gait_loop(e.gait, 0, 0.02f, 0.0f, dirv + action[0], 0.75f + action[1], 1.0f, t, frames);
+    ik_solve(orn, pos, frames, ang);
+    order_signal(ang, cmd);
+  } else {
+    const float ext = 0.1f, swing = 0.03f + action[0], swipe = 0.05f + action[1];
+    const int ith = ((int)(t / 0.1f)) % 2;
+    const float ms = clockwise ? swing : -swing;     // right_* = left_* with the swing sign flipped
+    const float first[12] = {swipe, ext, ms, -swipe, ext, -ms, swipe, -ext, -ms, -swipe, -ext, ms};
+    const float second[12] = {-swipe, 0.f, -ms, swipe, 0.f, ms, -swipe, 0.f, ms, swipe, 0.f, -ms};
+#pragma unroll
+    for (int j = 0; j < 12; ++j) cmd[j] = pose_stand_ol(j) + (ith ? second[j] : first[j]);
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __restrict__ state, const float* __restrict__ snap,
                                                             const float* __restrict__ action, float* __restrict__ obs_out,
@@ -301,6 +355,7 @@ __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __r
 
   float cmd[12];
   if (c.task == REX_TASK_GALLOP) gallop_command(c, e, act, cmd);
+  else if (c.task == REX_TASK_TURN) turn_command(c, e, act, cmd);
   else walk_command(c, e, act, cmd);
 
   float tau_obs[12];
@@ -325,12 +380,14 @@ __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __r
 #pragma unroll
   for (int j = 0; j < 12; ++j) dp += tau_obs[j] * e.ph.qd[j];
   const float energy = -fabsf(dp) * c.dt;
-  const float reward = c.w_dist * fwd + c.w_energy * energy + c.w_drift * drift + c.w_shake * shake;
+  float reward = c.w_dist * fwd + c.w_energy * energy + c.w_drift * drift + c.w_shake * shake;
+  if (c.task == REX_TASK_TURN) reward = 0.035f - fabsf(e.ph.pos[0]) - fabsf(e.ph.pos[1]);   // turn_env.py:362-367
 
   // ---- termination (rex_gym_env.py:490-499, walk_env.py:326-338, gallop_env.py:315-329) ----
   bool done;
   if (c.task == REX_TASK_GALLOP) done = fabsf(rpy[0]) > 0.3f || fabsf(rpy[1]) > 0.5f || e.ph.pos[1] > 0.3f;
   else done = r22 < 0.85f;
+  if (e.flags & REX_F_ENV_GOAL) done = true;                                     // rex_gym_env.py:495
   e.steps += 1;
   if (c.max_steps > 0 && e.steps >= c.max_steps) done = true;
   if (done) e.flags |= REX_F_DONE;
@@ -455,7 +512,7 @@ int rex_abi_version(void) { return REX_ABI_VERSION; }
 
 int rex_default_config(int task, int signal, int num_envs, RexConfig* cfg) {
   if (!cfg || num_envs <= 0) return fail(REX_EINVAL, "rex_default_config: bad arguments%s", "");
-  if (task != REX_TASK_WALK && task != REX_TASK_GALLOP) return fail(REX_EINVAL, "rex_default_config: unsupported task%s", "");
+  if (task != REX_TASK_WALK && task != REX_TASK_GALLOP && task != REX_TASK_TURN) return fail(REX_EINVAL, "rex_default_config: unsupported task%s", "");
   if (signal != REX_SIGNAL_IK && signal != REX_SIGNAL_OL) return fail(REX_EINVAL, "rex_default_config: unsupported signal%s", "");
   memset(cfg, 0, sizeof(*cfg));
   cfg->abi_version = REX_ABI_VERSION;
@@ -484,6 +541,7 @@ int rex_action_dim(const RexConfig* c) {
   if (!c) return REX_EINVAL;
   if (c->task == REX_TASK_WALK) return c->signal == REX_SIGNAL_IK ? 2 : 8;      /* walk_env.py:104-112 */
   if (c->task == REX_TASK_GALLOP) return c->signal == REX_SIGNAL_IK ? 2 : 4;    /* gallop_env.py:119-130 */
+  if (c->task == REX_TASK_TURN) return 2;                                       /* turn_env.py:100-110 */
   return REX_EINVAL;
 }
 int rex_obs_dim(const RexConfig* c) {
@@ -523,6 +581,7 @@ int rex_create(const RexConfig* cfg, int device, float* d_state, void* stream, R
   d.auto_reset = cfg->auto_reset; d.max_steps = cfg->max_episode_steps;
   d.w_dist = cfg->distance_weight; d.w_energy = cfg->energy_weight; d.w_drift = cfg->drift_weight; d.w_shake = cfg->shake_weight;
   d.action_dim = rex_action_dim(cfg); d.obs_dim = rex_obs_dim(cfg);
+  d.target_orient = cfg->target_orient; d.init_orient = cfg->init_orient; d.orient_fixed = cfg->orient_fixed;
   hipError_t e = hipMalloc(&s->d_snap, sizeof(float) * REX_STATE_WORDS);
   if (e != hipSuccess) { delete s; return fail(REX_ENOMEM, "hipMalloc(snapshot): %s", hipGetErrorString(e)); }
   (void)hipEventCreate(&s->ev0);

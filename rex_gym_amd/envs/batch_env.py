@@ -30,6 +30,9 @@ def _spaces(task, signal, sim_dt):
         dim = {"ik": 2, "ol": 4}[signal]
         action = Box(np.full(dim, hi), -np.full(dim, hi))
         ub = np.array([2 * math.pi, 2 * math.pi, 2 * math.pi / sim_dt, 2 * math.pi / sim_dt] + [2 * math.pi] * 12)
+    elif task == "turn":    # turn_env.py:100-110
+        action = Box(-np.full(2, 0.01), np.full(2, 0.01))
+        ub = np.array([2 * math.pi, 2 * math.pi, 2 * math.pi / sim_dt, 2 * math.pi / sim_dt])
     else:
         raise ValueError(f"unsupported task {task!r}")
     obs = Box(-(ub + OBSERVATION_EPS), ub + OBSERVATION_EPS)  # rex_gym_env.py:277-278
@@ -52,6 +55,7 @@ class RexBatchEnv:
 
     def __init__(self, num_envs, task="walk", signal_type="ik", device=0, seed=0, env_index_base=0,
                  auto_reset=False, max_episode_steps=0, backwards=None, target_position=None,
+                 target_orient=None, init_orient=None,
                  motor_kp=1.0, motor_kd=0.02, control_time_step=None, action_repeat=None,
                  solver_iterations=None, solver_residual_threshold=None,
                  check_actions=False, terrain_type="plane", mark="base", render=False, stream=None, **unused):
@@ -82,6 +86,10 @@ class RexBatchEnv:
         cfg.motor_kp, cfg.motor_kd = float(motor_kp), float(motor_kd)
         cfg.backwards = -1 if backwards is None else int(bool(backwards))
         cfg.target_position = 0.0 if not target_position else float(target_position)
+        if target_orient:                      # `if not self._target_orient` -> drawn (turn_env.py:137)
+            cfg.target_orient = float(target_orient); cfg.orient_fixed |= 1
+        if init_orient is not None:            # `if self._init_orient is None` -> drawn (turn_env.py:146)
+            cfg.init_orient = float(init_orient); cfg.orient_fixed |= 2
         cfg.seed = int(seed) & (2 ** 64 - 1)
         cfg.env_index_base = int(env_index_base)
         cfg.auto_reset = int(bool(auto_reset))

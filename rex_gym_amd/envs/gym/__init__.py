@@ -1,2 +1,3 @@
 from .walk_env import RexWalkEnv  # noqa: F401
 from .gallop_env import RexReactiveEnv  # noqa: F401
+from .turn_env import RexTurnEnv  # noqa: F401

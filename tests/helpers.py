@@ -36,6 +36,10 @@ def make_pair(task, signal, n, dtype=np.float32, **kw):
     if "backwards" in okw:
         b = okw.pop("backwards")
         cfg_kw["backwards"] = -1 if b is None else int(b)
+    for k in ("target_orient", "init_orient"):
+        if k in okw and okw[k] is not None:
+            cfg_kw[k] = float(okw.pop(k))
+            cfg_kw["orient_fixed"] = cfg_kw.get("orient_fixed", 0) | (1 if k == "target_orient" else 2)
     if "target_position" in okw:
         t = okw.pop("target_position")
         cfg_kw["target_position"] = 0.0 if not t else float(t)

@@ -28,7 +28,8 @@ class RexConfig(ctypes.Structure):
         ("target_position", ctypes.c_float), ("seed", ctypes.c_uint64), ("auto_reset", ctypes.c_int32),
         ("max_episode_steps", ctypes.c_int32), ("distance_weight", ctypes.c_float),
         ("energy_weight", ctypes.c_float), ("drift_weight", ctypes.c_float), ("shake_weight", ctypes.c_float),
-        ("solver_residual_threshold", ctypes.c_float), ("reserved", ctypes.c_int32 * 7),
+        ("solver_residual_threshold", ctypes.c_float), ("target_orient", ctypes.c_float),
+        ("init_orient", ctypes.c_float), ("orient_fixed", ctypes.c_int32), ("reserved", ctypes.c_int32 * 4),
     ]
 
 

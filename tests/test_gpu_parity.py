@@ -97,7 +97,8 @@ def test_settled_snapshot_matches_oracle(torch):
     env.close()
 
 
-@pytest.mark.parametrize("task,signal", [("walk", "ik"), ("walk", "ol"), ("gallop", "ol"), ("gallop", "ik")])
+@pytest.mark.parametrize("task,signal", [("walk", "ik"), ("walk", "ol"), ("gallop", "ol"), ("gallop", "ik"),
+                                         ("turn", "ik"), ("turn", "ol")])
 def test_single_step_parity_from_common_states(torch, task, signal):
     """One env.step() from identical states: isolates per-step error from chaotic divergence.
     Tolerance: 1e-4 rad / 1e-4 m / 2e-2 rad/s over 5-6 substeps x 50-60 PGS iterations.
@@ -167,6 +168,32 @@ def test_walk_ik_trajectory_rmse(torch):
         worst = np.maximum(worst, r)
     print("walk-ik 200-step joint RMSE vs f32 oracle: median %.3e max %.3e" % (np.median(worst), worst.max()))
     assert np.median(worst) < 1e-3
+    env.close()
+
+
+def test_turn_env_reset_and_goal_logic(torch):
+    """RexTurnEnv: yaw draws, teleport to the start heading, goal detection -> hold pose -> done 1 s later
+    (turn_env.py:129-160,324-347). Discrete outcomes must match the fp32 oracle exactly."""
+    n = 64
+    env, orc = make_pair("turn", "ol", n, np.float32, seed=21)
+    obs, oobs = env.reset().cpu().numpy(), orc.reset()
+    ps, os_ = product_state_to_numeric(env.state), orc.get_state()
+    np.testing.assert_array_equal(ps[orclib.S_TARGET], os_[orclib.S_TARGET])
+    np.testing.assert_array_equal(ps[orclib.S_AUX], os_[orclib.S_AUX])
+    np.testing.assert_allclose(ps[3:7], os_[3:7], atol=1e-6)
+    assert np.all(ps[2] == np.float32(0.21))
+    np.testing.assert_allclose(obs, oobs, atol=2e-3)
+    rng = np.random.RandomState(4)
+    ndone = 0
+    for k in range(500):
+        a = rng.uniform(-0.01, 0.01, (n, 2)).astype(np.float32)
+        o, r, d, _ = env.step(torch.as_tensor(a, device="cuda"))
+        oo, orr, od, _ = orc.step(a)
+        agree = np.mean(d.cpu().numpy() == od)
+        assert agree > 0.95, (k, agree)       # chaotic contact dynamics: a few envs may cross a threshold a step apart
+        ndone += int(od.sum())
+    flags = product_state_to_numeric(env.state)[orclib.S_FLAGS].astype(int)
+    assert (flags & 1).sum() > 0              # some envs reached their target heading
     env.close()
 
 
