@@ -37,6 +37,7 @@ extern "C" {
 #define REX_TASK_WALK   0   /* envs/gym/walk_env.py   RexWalkEnv      */
 #define REX_TASK_GALLOP 1   /* envs/gym/gallop_env.py RexReactiveEnv  */
 #define REX_TASK_TURN   2   /* envs/gym/turn_env.py   RexTurnEnv      */
+#define REX_TASK_POSES  3   /* envs/gym/poses_env.py  RexPosesEnv     */
 /* signal_type kwarg of the reference envs */
 #define REX_SIGNAL_IK 0
 #define REX_SIGNAL_OL 1
@@ -111,7 +112,12 @@ typedef struct RexConfig {
      given (else drawn U(0.2, 6) per episode), bit 1 = init_orient is given */
   float   target_orient, init_orient;
   int32_t orient_fixed;
-  int32_t reserved[4];
+  /* RexPosesEnv (envs/gym/poses_env.py:153-192): pose_index -1 = cycle base_y, base_z, roll, pitch, yaw
+     per episode with a value drawn in the reference's ranges (rex_gym_env.py:258-265); 0..4 = that
+     component held at pose_value (the base_y/base_z/base_roll/base_pitch/base_yaw kwargs) */
+  int32_t pose_index;
+  float   pose_value;
+  int32_t reserved[2];
 } RexConfig;
 
 typedef struct RexSim RexSim;

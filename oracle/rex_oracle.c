@@ -760,6 +760,9 @@ static void settle(Orc* o) {
   e->ph.quat[3] = 1;
   for (int j = 0; j < NJ; ++j) e->ph.q[j] = POSE_STAND[j]; /* ResetPose uses INIT_POSES[pose_id='stand'] */
   e->motor_enabled = (1u << NJ) - 1;
+  /* RexPosesEnv.reset() calls the base reset with initial_motor_angles=None: the reset motion is
+   * skipped (rex.py:308), the robot starts at the drop height in the 'stand' pose */
+  if (o->cfg.task == REX_TASK_POSES) return;
   for (int k = 0; k < 100; ++k) rex_substep(&o->cfg, e, POSE_STAND);      /* rex.py:315-318 */
   int nreset = (int)((real)0.5 / (real)o->cfg.sim_time_step);             /* rex.py:319 */
   for (int k = 0; k < nreset; ++k) rex_substep(&o->cfg, e, init_pose(&o->cfg));
@@ -801,6 +804,17 @@ static void env_reset(Orc* o, int idx) {
     else e->target = (real)(1.0f + 2.0f * u01(ctr[1]));                         /* gallop_env.py:150-152 */
   }
   e->end_time = 0; e->aux = 0; e->steps = 0;
+  if (c->task == REX_TASK_POSES) {                                              /* poses_env.py:153-192 */
+    /* _ranges (rex_gym_env.py:258-265): base_y, base_z, roll, pitch, yaw */
+    static const float LO[5] = {-0.007f, -0.048f, -0.78539816339744830962f, -0.78539816339744830962f, -0.78539816339744830962f};
+    static const float HI[5] = {0.007f, 0.021f, 0.78539816339744830962f, 0.78539816339744830962f, 0.78539816339744830962f};
+    if (c->pose_index >= 0) { e->aux = (real)c->pose_index; e->target = (real)c->pose_value; }
+    else {
+      int k = e->episode % 5;               /* deque rotation: one pop per reset() */
+      e->aux = (real)k;
+      e->target = (real)fmaf(HI[k] - LO[k], u01(ctr[1]), LO[k]);
+    }
+  }
   if (c->task == REX_TASK_TURN) {                                               /* turn_env.py:129-160 */
     float tgt = (c->orient_fixed & 1) ? c->target_orient : fmaf(5.8f, u01(ctr[1]), 0.2f);
     float ini = (c->orient_fixed & 2) ? c->init_orient : fmaf(5.8f, u01(ctr[2]), 0.2f);
@@ -956,6 +970,23 @@ static void turn_command(const RexConfig* c, Env* e, const real* action, real cm
   }
 }
 
+/* RexPosesEnv._signal (poses_env.py:186-225): one body-pose component ramps to its target, IK on the
+ * default foot frames */
+static void poses_command(const RexConfig* c, Env* e, const real* action, real cmd[NJ]) {
+  real t = (real)(e->steps * c->action_repeat) * (real)c->sim_time_step;
+  real p = (real)0.8 + action[0];
+  real coeff = (0 <= t && t <= p) ? t : (real)1.0;
+  real staged = e->target * coeff;
+  real pos[3] = {(real)0.01, 0, 0}, orn[3] = {0, 0, 0};
+  int k = (int)e->aux;
+  if (k == 0) pos[1] = staged; else if (k == 1) pos[2] = staged; else orn[k - 2] = staged;
+  const real frames[12] = {IK_L / 2, -IK_YDIST / 2, -IK_HEIGHT, IK_L / 2, IK_YDIST / 2, -IK_HEIGHT,
+                           -IK_L / 2, -IK_YDIST / 2, -IK_HEIGHT, -IK_L / 2, IK_YDIST / 2, -IK_HEIGHT};
+  real ang[12];
+  ik_solve(orn, pos, frames, ang, 0);
+  order_signal(ang, cmd);
+}
+
 /* rex_gym_env.py:501-542 */
 static real base_reward(const RexConfig* c, Env* e) {
   real x = -e->ph.pos[0];
@@ -996,11 +1027,14 @@ static void env_step(Orc* o, int idx, const real* action, real* obs, real* rewar
   real cmd[NJ];
   if (c->task == REX_TASK_GALLOP) gallop_command(c, e, action, cmd);
   else if (c->task == REX_TASK_TURN) turn_command(c, e, action, cmd);
+  else if (c->task == REX_TASK_POSES) poses_command(c, e, action, cmd);
   else walk_command(c, e, action, cmd);
   for (int k = 0; k < c->action_repeat; ++k) rex_substep(c, e, cmd);    /* Rex.Step, rex.py:158-163 */
   if (c->task == REX_TASK_TURN) *reward = (real)0.035 - fabs(e->ph.pos[0]) - fabs(e->ph.pos[1]);  /* turn_env.py:362-367 */
+  else if (c->task == REX_TASK_POSES) { *reward = 1; for (int j = 0; j < NJ; ++j) (void)e->tau_obs[j]; } /* poses_env.py:267-269 */
   else *reward = base_reward(c, e);
   int d = env_fallen(c, e);
+  if (c->task == REX_TASK_POSES) d = 0;                                 /* is_fallen() returns False, poses_env.py:265 */
   if (e->flags & REX_F_ENV_GOAL) d = 1;                                 /* rex_gym_env.py:495 */
   if (c->task == REX_TASK_GALLOP && e->ph.pos[1] > (real)0.3) d = 1;    /* gallop_env.py:315-317 */
   e->steps += 1;
@@ -1019,6 +1053,7 @@ ORC_API int orc_obs_dim(const RexConfig* c) { return c->task == REX_TASK_GALLOP 
 ORC_API int orc_action_dim(const RexConfig* c) {
   if (c->task == REX_TASK_WALK) return c->signal == REX_SIGNAL_IK ? 2 : 8;
   if (c->task == REX_TASK_GALLOP) return c->signal == REX_SIGNAL_IK ? 2 : 4;
+  if (c->task == REX_TASK_POSES) return 1;
   return 2;
 }
 

@@ -7,7 +7,7 @@ import os
 
 from . import build as _build
 
-TASKS = {"walk": 0, "gallop": 1, "turn": 2}
+TASKS = {"walk": 0, "gallop": 1, "turn": 2, "poses": 3}
 SIGNALS = {"ik": 0, "ol": 1}
 STATE_WORDS = 53
 NUM_MOTORS = 12
@@ -24,7 +24,8 @@ class RexConfig(ctypes.Structure):
         ("max_episode_steps", ctypes.c_int32), ("distance_weight", ctypes.c_float),
         ("energy_weight", ctypes.c_float), ("drift_weight", ctypes.c_float), ("shake_weight", ctypes.c_float),
         ("solver_residual_threshold", ctypes.c_float), ("target_orient", ctypes.c_float),
-        ("init_orient", ctypes.c_float), ("orient_fixed", ctypes.c_int32), ("reserved", ctypes.c_int32 * 4),
+        ("init_orient", ctypes.c_float), ("orient_fixed", ctypes.c_int32), ("pose_index", ctypes.c_int32),
+        ("pose_value", ctypes.c_float), ("reserved", ctypes.c_int32 * 2),
     ]
 
 

@@ -129,6 +129,8 @@ struct DevCfg {
   int32_t action_dim, obs_dim;
   float target_orient, init_orient;
   int32_t orient_fixed;
+  int32_t pose_index;
+  float pose_value;
 };
 
 __device__ __forceinline__ float init_pose(const DevCfg& c, int j) { return c.signal == REX_SIGNAL_OL ? pose_stand_ol(j) : pose_stand(j); }
@@ -188,6 +190,14 @@ __device__ __forceinline__ void env_reset(const DevCfg& c, const float* snap, in
     e.target = c.target_position != 0.0f ? c.target_position : (1.0f + 2.0f * u); // gallop_env.py:150-152
   }
   e.end_time = 0.0f; e.aux = 0.0f; e.steps = 0;
+  if (c.task == REX_TASK_POSES) {                                                // poses_env.py:153-192
+    const int k = c.pose_index >= 0 ? c.pose_index : episode % 5;               // deque rotation: one pop per reset()
+    // _ranges (rex_gym_env.py:258-265): base_y, base_z, roll, pitch, yaw
+    const float lo = k == 0 ? -0.007f : (k == 1 ? -0.048f : -0.78539816339744830962f);
+    const float hi = k == 0 ? 0.007f : (k == 1 ? 0.021f : 0.78539816339744830962f);
+    e.aux = (float)k;
+    e.target = c.pose_index >= 0 ? c.pose_value : fmaf(hi - lo, u, lo);
+  }
   if (c.task == REX_TASK_TURN) {                                                 // turn_env.py:129-160
     const float tgt = (c.orient_fixed & 1) ? c.target_orient : fmaf(5.8f, u, 0.2f);
     const float ini = (c.orient_fixed & 2) ? c.init_orient : fmaf(5.8f, u01(ctr[2]), 0.2f);
@@ -294,6 +304,22 @@ __device__ __forceinline__ void gallop_command(const DevCfg& c, EnvState& e, con
   }
 }
 
+// RexPosesEnv._signal (poses_env.py:186-225)
+__device__ __forceinline__ void poses_command(const DevCfg& c, EnvState& e, const float* action, float* cmd) {
+  const float t = (float)(e.steps * c.action_repeat) * c.dt;
+  const float p = 0.8f + action[0];
+  const float coeff = (0.0f <= t && t <= p) ? t : 1.0f;
+  const float staged = e.target * coeff;
+  const int k = (int)e.aux;
+  const float pos[3] = {0.01f, k == 0 ? staged : 0.0f, k == 1 ? staged : 0.0f};
+  const float orn[3] = {k == 2 ? staged : 0.0f, k == 3 ? staged : 0.0f, k == 4 ? staged : 0.0f};
+  const float frames[12] = {kIkL / 2, -kIkYDist / 2, -kIkHeight, kIkL / 2, kIkYDist / 2, -kIkHeight,
+                            -kIkL / 2, -kIkYDist / 2, -kIkHeight, -kIkL / 2, kIkYDist / 2, -kIkHeight};
+  float ang[12];
+  ik_solve(orn, pos, frames, ang);
+  order_signal(ang, cmd);
+}
+
 // RexTurnEnv._transform_action_to_motor_command (turn_env.py:239-347)
 __device__ __forceinline__ void turn_command(const DevCfg& c, EnvState& e, const float* action, float* cmd) {
   const float t = (float)(e.steps * c.action_repeat) * c.dt;
@@ -356,6 +382,7 @@ __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __r
   float cmd[12];
   if (c.task == REX_TASK_GALLOP) gallop_command(c, e, act, cmd);
   else if (c.task == REX_TASK_TURN) turn_command(c, e, act, cmd);
+  else if (c.task == REX_TASK_POSES) poses_command(c, e, act, cmd);
   else walk_command(c, e, act, cmd);
 
   float tau_obs[12];
@@ -382,12 +409,14 @@ __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __r
   const float energy = -fabsf(dp) * c.dt;
   float reward = c.w_dist * fwd + c.w_energy * energy + c.w_drift * drift + c.w_shake * shake;
   if (c.task == REX_TASK_TURN) reward = 0.035f - fabsf(e.ph.pos[0]) - fabsf(e.ph.pos[1]);   // turn_env.py:362-367
+  if (c.task == REX_TASK_POSES) reward = 1.0f;                                                // poses_env.py:267-269
 
   // ---- termination (rex_gym_env.py:490-499, walk_env.py:326-338, gallop_env.py:315-329) ----
   bool done;
   if (c.task == REX_TASK_GALLOP) done = fabsf(rpy[0]) > 0.3f || fabsf(rpy[1]) > 0.5f || e.ph.pos[1] > 0.3f;
   else done = r22 < 0.85f;
   if (e.flags & REX_F_ENV_GOAL) done = true;                                     // rex_gym_env.py:495
+  if (c.task == REX_TASK_POSES) done = false;                                    // is_fallen() returns False, poses_env.py:265
   e.steps += 1;
   if (c.max_steps > 0 && e.steps >= c.max_steps) done = true;
   if (done) e.flags |= REX_F_DONE;
@@ -418,6 +447,10 @@ __global__ __launch_bounds__(REX_WAVE) void rex_settle_kernel(DevCfg c, float* _
 #pragma unroll
   for (int j = 0; j < 12; ++j) e.ph.q[j] = pose_stand(j);       // ResetPose: INIT_POSES[pose_id = 'stand']
   e.motor_en = (1u << 12) - 1u;
+  if (c.task == REX_TASK_POSES) {   // base reset() with initial_motor_angles=None skips the reset motion (rex.py:308)
+    if (lane == 0) store_env(snap, 1, 0, e);
+    return;
+  }
   float cmd[12], tau_obs[12];
 #pragma unroll
   for (int j = 0; j < 12; ++j) cmd[j] = pose_stand(j);
@@ -512,14 +545,14 @@ int rex_abi_version(void) { return REX_ABI_VERSION; }
 
 int rex_default_config(int task, int signal, int num_envs, RexConfig* cfg) {
   if (!cfg || num_envs <= 0) return fail(REX_EINVAL, "rex_default_config: bad arguments%s", "");
-  if (task != REX_TASK_WALK && task != REX_TASK_GALLOP && task != REX_TASK_TURN) return fail(REX_EINVAL, "rex_default_config: unsupported task%s", "");
+  if (task != REX_TASK_WALK && task != REX_TASK_GALLOP && task != REX_TASK_TURN && task != REX_TASK_POSES) return fail(REX_EINVAL, "rex_default_config: unsupported task%s", "");
   if (signal != REX_SIGNAL_IK && signal != REX_SIGNAL_OL) return fail(REX_EINVAL, "rex_default_config: unsupported signal%s", "");
   memset(cfg, 0, sizeof(*cfg));
   cfg->abi_version = REX_ABI_VERSION;
   cfg->num_envs = num_envs;
   cfg->task = task;
   cfg->signal = signal;
-  cfg->action_repeat = task == REX_TASK_GALLOP ? 6 : 5;          /* gallop_env.py:47-48, walk_env.py:34-35 */
+  cfg->action_repeat = (task == REX_TASK_GALLOP || task == REX_TASK_POSES) ? 6 : 5;          /* gallop_env.py:47-48, walk_env.py:34-35 */
   cfg->solver_iterations = 300 / cfg->action_repeat;             /* rex_gym_env.py:25,184 */
   cfg->sim_time_step = 0.001f;
   cfg->motor_kp = 1.0f;
@@ -533,6 +566,7 @@ int rex_default_config(int task, int signal, int num_envs, RexConfig* cfg) {
   cfg->energy_weight = task == REX_TASK_GALLOP ? 0.005f : 0.0005f;   /* gallop_env.py:45 */
   cfg->drift_weight = 2.0f;
   cfg->shake_weight = 0.005f;
+  cfg->pose_index = -1;
   cfg->solver_residual_threshold = 1e-7f;                        /* PyBullet default solverResidualThreshold */
   return REX_OK;
 }
@@ -542,6 +576,7 @@ int rex_action_dim(const RexConfig* c) {
   if (c->task == REX_TASK_WALK) return c->signal == REX_SIGNAL_IK ? 2 : 8;      /* walk_env.py:104-112 */
   if (c->task == REX_TASK_GALLOP) return c->signal == REX_SIGNAL_IK ? 2 : 4;    /* gallop_env.py:119-130 */
   if (c->task == REX_TASK_TURN) return 2;                                       /* turn_env.py:100-110 */
+  if (c->task == REX_TASK_POSES) return 1;                                      /* poses_env.py:115-117 */
   return REX_EINVAL;
 }
 int rex_obs_dim(const RexConfig* c) {
@@ -581,6 +616,7 @@ int rex_create(const RexConfig* cfg, int device, float* d_state, void* stream, R
   d.auto_reset = cfg->auto_reset; d.max_steps = cfg->max_episode_steps;
   d.w_dist = cfg->distance_weight; d.w_energy = cfg->energy_weight; d.w_drift = cfg->drift_weight; d.w_shake = cfg->shake_weight;
   d.action_dim = rex_action_dim(cfg); d.obs_dim = rex_obs_dim(cfg);
+  d.pose_index = cfg->pose_index; d.pose_value = cfg->pose_value;
   d.target_orient = cfg->target_orient; d.init_orient = cfg->init_orient; d.orient_fixed = cfg->orient_fixed;
   hipError_t e = hipMalloc(&s->d_snap, sizeof(float) * REX_STATE_WORDS);
   if (e != hipSuccess) { delete s; return fail(REX_ENOMEM, "hipMalloc(snapshot): %s", hipGetErrorString(e)); }

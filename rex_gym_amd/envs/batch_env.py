@@ -33,6 +33,9 @@ def _spaces(task, signal, sim_dt):
     elif task == "turn":    # turn_env.py:100-110
         action = Box(-np.full(2, 0.01), np.full(2, 0.01))
         ub = np.array([2 * math.pi, 2 * math.pi, 2 * math.pi / sim_dt, 2 * math.pi / sim_dt])
+    elif task == "poses":   # poses_env.py:115-117
+        action = Box(-np.full(1, 0.1), np.full(1, 0.1))
+        ub = np.array([2 * math.pi, 2 * math.pi, 2 * math.pi / sim_dt, 2 * math.pi / sim_dt])
     else:
         raise ValueError(f"unsupported task {task!r}")
     obs = Box(-(ub + OBSERVATION_EPS), ub + OBSERVATION_EPS)  # rex_gym_env.py:277-278
@@ -55,7 +58,8 @@ class RexBatchEnv:
 
     def __init__(self, num_envs, task="walk", signal_type="ik", device=0, seed=0, env_index_base=0,
                  auto_reset=False, max_episode_steps=0, backwards=None, target_position=None,
-                 target_orient=None, init_orient=None,
+                 target_orient=None, init_orient=None, base_y=None, base_z=None, base_roll=None, base_pitch=None,
+                 base_yaw=None,
                  motor_kp=1.0, motor_kd=0.02, control_time_step=None, action_repeat=None,
                  solver_iterations=None, solver_residual_threshold=None,
                  check_actions=False, terrain_type="plane", mark="base", render=False, stream=None, **unused):
@@ -90,6 +94,11 @@ class RexBatchEnv:
             cfg.target_orient = float(target_orient); cfg.orient_fixed |= 1
         if init_orient is not None:            # `if self._init_orient is None` -> drawn (turn_env.py:146)
             cfg.init_orient = float(init_orient); cfg.orient_fixed |= 2
+        pose_kw = (base_y, base_z, base_roll, base_pitch, base_yaw)
+        if task == "poses" and any(v is not None for v in pose_kw):   # fill_next_pose_and_target, poses_env.py:172-187
+            vals = [0.0 if v is None else float(v) for v in pose_kw]
+            k = next((i for i, v in enumerate(vals[:4]) if v != 0.0), 4)
+            cfg.pose_index, cfg.pose_value = k, vals[k]
         cfg.seed = int(seed) & (2 ** 64 - 1)
         cfg.env_index_base = int(env_index_base)
         cfg.auto_reset = int(bool(auto_reset))

@@ -40,6 +40,8 @@ def make_pair(task, signal, n, dtype=np.float32, **kw):
         if k in okw and okw[k] is not None:
             cfg_kw[k] = float(okw.pop(k))
             cfg_kw["orient_fixed"] = cfg_kw.get("orient_fixed", 0) | (1 if k == "target_orient" else 2)
+    if "base_roll" in okw:
+        cfg_kw["pose_index"], cfg_kw["pose_value"] = 2, float(okw.pop("base_roll"))
     if "target_position" in okw:
         t = okw.pop("target_position")
         cfg_kw["target_position"] = 0.0 if not t else float(t)

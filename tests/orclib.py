@@ -29,22 +29,23 @@ class RexConfig(ctypes.Structure):
         ("max_episode_steps", ctypes.c_int32), ("distance_weight", ctypes.c_float),
         ("energy_weight", ctypes.c_float), ("drift_weight", ctypes.c_float), ("shake_weight", ctypes.c_float),
         ("solver_residual_threshold", ctypes.c_float), ("target_orient", ctypes.c_float),
-        ("init_orient", ctypes.c_float), ("orient_fixed", ctypes.c_int32), ("reserved", ctypes.c_int32 * 4),
+        ("init_orient", ctypes.c_float), ("orient_fixed", ctypes.c_int32), ("pose_index", ctypes.c_int32),
+        ("pose_value", ctypes.c_float), ("reserved", ctypes.c_int32 * 2),
     ]
 
 
-TASKS = {"walk": 0, "gallop": 1, "turn": 2}
+TASKS = {"walk": 0, "gallop": 1, "turn": 2, "poses": 3}
 SIGNALS = {"ik": 0, "ol": 1}
 
 
 def default_config(task="walk", signal="ik", num_envs=1, **kw):
     """Reference defaults."""
-    repeat = 6 if task == "gallop" else 5
+    repeat = 6 if task in ("gallop", "poses") else 5
     c = RexConfig(abi_version=1, num_envs=num_envs, env_index_base=0, task=TASKS[task], signal=SIGNALS[signal],
                   action_repeat=repeat, solver_iterations=300 // repeat, sim_time_step=0.001,
                   motor_kp=1.0, motor_kd=0.02, backwards=-1, target_position=0.0, seed=0, auto_reset=0,
                   max_episode_steps=0, distance_weight=1.0, energy_weight=0.005 if task == "gallop" else 0.0005, drift_weight=2.0,
-                  shake_weight=0.005, solver_residual_threshold=1e-7)
+                  shake_weight=0.005, solver_residual_threshold=1e-7, pose_index=-1)
     for k, v in kw.items():
         setattr(c, k, v)
     return c

@@ -98,7 +98,7 @@ def test_settled_snapshot_matches_oracle(torch):
 
 
 @pytest.mark.parametrize("task,signal", [("walk", "ik"), ("walk", "ol"), ("gallop", "ol"), ("gallop", "ik"),
-                                         ("turn", "ik"), ("turn", "ol")])
+                                         ("turn", "ik"), ("turn", "ol"), ("poses", "ik")])
 def test_single_step_parity_from_common_states(torch, task, signal):
     """One env.step() from identical states: isolates per-step error from chaotic divergence.
     Tolerance: 1e-4 rad / 1e-4 m / 2e-2 rad/s over 5-6 substeps x 50-60 PGS iterations.
