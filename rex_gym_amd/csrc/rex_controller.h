@@ -134,25 +134,25 @@ __device__ __forceinline__ void gait_loop(GaitState& g, int mode, float v, float
   }
 }
 
-// model/motor.py:76-143 (position-control branch, strength ratio 1)
+// model/motor.py:76-143 (position-control branch, strength ratio 1).  Divisions by the constants R and 10
+// are written as multiplications by their reciprocals (1 ulp from the numpy result, far inside the 1e-5 N m
+// parity tolerance) -- an IEEE fp32 division is a ~15-instruction sequence on gfx950.
 __device__ __forceinline__ void motor_torque(float cmd, float q, float qd, float qd_true, float kp, float kd,
                                              float& actual, float& observed) {
-  constexpr float V = 32.0f, R = 0.186f, KT = 0.0954f;
+  constexpr float V = 32.0f, RINV = 1.0f / 0.186f, KT = 0.0954f;
   float pwm = -1.0f * kp * (q - cmd) - kd * qd;
-  pwm = fminf(fmaxf(pwm, -1.0f), 1.0f);
-  observed = fminf(fmaxf(KT * (pwm * V / R), -5.7f), 5.7f);
-  const float vnet = fminf(fmaxf(pwm * V - (KT + 0.0f) * qd_true, -50.0f), 50.0f);
-  const float cur = vnet / R;
+  pwm = __builtin_amdgcn_fmed3f(pwm, -1.0f, 1.0f);
+  observed = __builtin_amdgcn_fmed3f(KT * (pwm * V * RINV), -5.7f, 5.7f);
+  const float vnet = __builtin_amdgcn_fmed3f(pwm * V - (KT + 0.0f) * qd_true, -50.0f, 50.0f);
+  const float cur = vnet * RINV;
   const float mag = fabsf(cur);
-  // np.interp(|I|, [0,10,...,60], [0,1,1.9,2.45,3.0,3.25,3.5]), clamped at the ends
-  float t;
-  if (mag >= 60.0f) t = 3.5f;
-  else if (mag >= 50.0f) t = 3.25f + (3.5f - 3.25f) * (mag - 50.0f) / 10.0f;
-  else if (mag >= 40.0f) t = 3.0f + (3.25f - 3.0f) * (mag - 40.0f) / 10.0f;
-  else if (mag >= 30.0f) t = 2.45f + (3.0f - 2.45f) * (mag - 30.0f) / 10.0f;
-  else if (mag >= 20.0f) t = 1.9f + (2.45f - 1.9f) * (mag - 20.0f) / 10.0f;
-  else if (mag >= 10.0f) t = 1.0f + (1.9f - 1.0f) * (mag - 10.0f) / 10.0f;
-  else t = 0.0f + (1.0f - 0.0f) * (mag - 0.0f) / 10.0f;
+  // np.interp(|I|, [0,10,...,60], [0,1,1.9,2.45,3.0,3.25,3.5]), clamped at the ends: segment k = floor(|I|/10)
+  const float kf = fminf(floorf(mag * 0.1f), 5.0f);
+  const int k = (int)kf;
+  const float t0 = k == 0 ? 0.0f : (k == 1 ? 1.0f : (k == 2 ? 1.9f : (k == 3 ? 2.45f : (k == 4 ? 3.0f : 3.25f))));
+  const float sl = k == 0 ? 0.1f : (k == 1 ? 0.09f : (k == 2 ? 0.055f : (k == 3 ? 0.055f : 0.025f)));
+  float t = fmaf(sl, mag - 10.0f * kf, t0);
+  t = fminf(t, 3.5f);
   actual = cur > 0.0f ? t : (cur < 0.0f ? -t : 0.0f);
 }
 

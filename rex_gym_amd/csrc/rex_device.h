@@ -468,6 +468,9 @@ __device__ __forceinline__ void pgs_leg_friction(float4* lds, int lane, PgsX& x,
     const int p = 2 * LEG + e;
     const float lim = kMu * lam[p];
     const int r0 = REX_NPOINT + 2 * p, r1 = r0 + 1;
+    // a point that carries no normal impulse (and no friction impulse left from an earlier sweep) in ANY
+    // lane can only produce zero friction steps this sweep: skip its two rows for the wavefront (exact)
+    if (__builtin_amdgcn_ballot_w64(lim > 0.0f || lam[r0] != 0.0f || lam[r1] != 0.0f) == 0) continue;
     const float4 a0 = row_chunk(lds, r0, 0, lane), a1 = row_chunk(lds, r0, 1, lane), a2 = row_chunk(lds, r0, 2, lane);
     const float4 b0 = row_chunk(lds, r1, 0, lane), b1 = row_chunk(lds, r1, 1, lane), b2 = row_chunk(lds, r1, 2, lane);
     pgs_row<LEG, true>(a0, a1, a2, x, lam[r0], lim, worst);

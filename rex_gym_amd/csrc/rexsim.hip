@@ -136,23 +136,19 @@ struct DevCfg {
 __device__ __forceinline__ float init_pose(const DevCfg& c, int j) { return c.signal == REX_SIGNAL_OL ? pose_stand_ol(j) : pose_stand(j); }
 
 // Rex.ApplyAction + stepSimulation + ReceiveObservation (rex.py:158-163, 568-641)
-__device__ __forceinline__ void rex_substep(const DevCfg& c, EnvState& e, float* cmd, float* tau_obs, float4* lds, int lane) {
+__device__ __forceinline__ void rex_substep(const DevCfg& c, EnvState& e, const float* cmd, float* tau_obs, float4* lds, int lane) {
   float tau[12];
   const float limit = 1.0f / c.dt;  // OVERHEAT_SHUTDOWN_TIME / time_step, rex.py:607
-#pragma unroll 1
-  for (int leg = 0; leg < 4; ++leg) {   // rolled (code size); the current leg sits in slots 0..2
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      float act, obs;
-      motor_torque(cmd[k], e.ph.q[k], e.ph.qd[k], e.ph.qd[k], c.kp, c.kd, act, obs);
-      uint32_t cnt = e.overheat[k];
-      cnt = fabsf(act) > 2.45f ? min(cnt + 1u, 65535u) : 0u;                      // rex.py:603-606
-      if ((float)cnt > limit) e.motor_en &= ~(1u << (3 * leg + k));               // rex.py:607-608
-      e.overheat[k] = cnt;
-      tau_obs[k] = obs;
-      tau[k] = ((e.motor_en >> (3 * leg + k)) & 1u) ? act : 0.0f;                 // rex.py:617-623
-    }
-    rotate_leg(cmd); rotate_leg(e.ph.q); rotate_leg(e.ph.qd); rotate_leg(e.overheat); rotate_leg(tau_obs); rotate_leg(tau);
+  for (int j = 0; j < 12; ++j) {
+    float act, obs;
+    motor_torque(cmd[j], e.ph.q[j], e.ph.qd[j], e.ph.qd[j], c.kp, c.kd, act, obs);
+    uint32_t cnt = e.overheat[j];
+    cnt = fabsf(act) > 2.45f ? min(cnt + 1u, 65535u) : 0u;                      // rex.py:603-606
+    if ((float)cnt > limit) e.motor_en &= ~(1u << j);                           // rex.py:607-608
+    e.overheat[j] = cnt;
+    tau_obs[j] = obs;
+    tau[j] = ((e.motor_en >> j) & 1u) ? act : 0.0f;                             // rex.py:617-623
   }
   physics_substep(e.ph, tau, c.dt, c.iterations, c.res_thr, lds, lane);
 }
