@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to smoke-test the "
+                                                      "multi-rank path on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
 
     import torch
@@ -79,8 +81,15 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        ngpu = torch.cuda.device_count()
+        if args.backend == "nccl" and ngpu < world:
+            raise SystemExit(f"{world} ranks need {world} GPUs with the nccl backend (found {ngpu})")
+        local_rank = local_rank % max(ngpu, 1)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -109,7 +118,7 @@ def main():
     elapsed = time.perf_counter() - t0
     barrier()
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

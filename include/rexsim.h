@@ -117,7 +117,12 @@ typedef struct RexConfig {
      component held at pose_value (the base_y/base_z/base_roll/base_pitch/base_yaw kwargs) */
   int32_t pose_index;
   float   pose_value;
-  int32_t reserved[2];
+  /* 1: fold the reference's per-env wrapper stack into the launch (playground/trainer.py:48-52,
+     agents/tools/wrappers.py:183-265): ClipAction to [-1,1], RangeNormalize of the action
+     ((a+1)/2 (high-low)+low with the env's Box) and of the returned observation (2(o-low)/(high-low)-1).
+     d_motor_cmd is unaffected. */
+  int32_t range_normalize;
+  int32_t reserved[1];
 } RexConfig;
 
 typedef struct RexSim RexSim;

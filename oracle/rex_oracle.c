@@ -736,6 +736,14 @@ typedef struct {
   Env snapshot; /* settled reset state (rex.py:296-324) */
 } Orc;
 
+ORC_API int orc_obs_dim(const RexConfig* c) { return c->task == REX_TASK_GALLOP ? 16 : 4; }
+ORC_API int orc_action_dim(const RexConfig* c) {
+  if (c->task == REX_TASK_WALK) return c->signal == REX_SIGNAL_IK ? 2 : 8;
+  if (c->task == REX_TASK_GALLOP) return c->signal == REX_SIGNAL_IK ? 2 : 4;
+  if (c->task == REX_TASK_POSES) return 1;
+  return 2;
+}
+
 static const real* init_pose(const RexConfig* c) { return c->signal == REX_SIGNAL_OL ? POSE_STAND_OL : POSE_STAND; }
 
 /* Rex.ApplyAction + stepSimulation + ReceiveObservation (rex.py:158-163,568-641) */
@@ -1021,10 +1029,40 @@ static int env_fallen(const RexConfig* c, const Env* e) {
   return R[2][2] < (real)0.85;
 }
 
-static void env_step(Orc* o, int idx, const real* action, real* obs, real* reward, uint8_t* done, real* motor_cmd) {
+/* Box bounds of the reference envs (walk_env.py:104-114,364-378; gallop_env.py:119-130,358-376;
+ * turn_env.py:100-110; poses_env.py:115-117; rex_gym_env.py:277-278) for the folded wrappers */
+static void action_bounds(const RexConfig* c, real* lo, real* hi) {
+  real b;
+  if (c->task == REX_TASK_WALK) b = c->signal == REX_SIGNAL_IK ? (real)0.4 : (real)0.01;
+  else if (c->task == REX_TASK_GALLOP) b = c->signal == REX_SIGNAL_IK ? (real)-0.4 : (real)-0.3; /* low=+b, high=-b */
+  else if (c->task == REX_TASK_TURN) b = (real)0.01;
+  else b = (real)0.1;
+  *lo = -b; *hi = b;
+}
+static real obs_bound(const RexConfig* c, int k) {
+  real two_pi = (real)(2 * M_PI);
+  if (k == 2 || k == 3) return two_pi / (real)c->sim_time_step + (real)0.01;
+  return two_pi + (real)0.01;
+}
+static void normalize_obs(const RexConfig* c, real* obs, int n) {
+  for (int k = 0; k < n; ++k) { real hi = obs_bound(c, k), lo = -hi; obs[k] = 2 * (obs[k] - lo) / (hi - lo) - 1; }
+}
+
+static void env_step(Orc* o, int idx, const real* action_in, real* obs, real* reward, uint8_t* done, real* motor_cmd) {
   const RexConfig* c = &o->cfg;
   Env* e = &o->envs[idx];
   real cmd[NJ];
+  real action[8];
+  {
+    int ad = orc_action_dim(c);
+    real lo, hi;
+    action_bounds(c, &lo, &hi);
+    for (int k = 0; k < ad; ++k) {
+      real a = action_in[k];
+      if (c->range_normalize) { a = clampr(a, -1, 1); a = (a + 1) / 2 * (hi - lo) + lo; }   /* ClipAction, RangeNormalize */
+      action[k] = a;
+    }
+  }
   if (c->task == REX_TASK_GALLOP) gallop_command(c, e, action, cmd);
   else if (c->task == REX_TASK_TURN) turn_command(c, e, action, cmd);
   else if (c->task == REX_TASK_POSES) poses_command(c, e, action, cmd);
@@ -1044,18 +1082,11 @@ static void env_step(Orc* o, int idx, const real* action, real* obs, real* rewar
   if (d) e->flags |= REX_F_DONE;
   if (d && c->auto_reset) env_reset(o, idx);
   env_observation(c, e, obs);
+  if (c->range_normalize) normalize_obs(c, obs, orc_obs_dim(c));
 }
 
 /* ---------------------------------- batch API (mirrors include/rexsim.h) ---------------------------------- */
 ORC_API int orc_sizeof_real(void) { return (int)sizeof(real); }
-
-ORC_API int orc_obs_dim(const RexConfig* c) { return c->task == REX_TASK_GALLOP ? 16 : 4; }
-ORC_API int orc_action_dim(const RexConfig* c) {
-  if (c->task == REX_TASK_WALK) return c->signal == REX_SIGNAL_IK ? 2 : 8;
-  if (c->task == REX_TASK_GALLOP) return c->signal == REX_SIGNAL_IK ? 2 : 4;
-  if (c->task == REX_TASK_POSES) return 1;
-  return 2;
-}
 
 ORC_API void* orc_create(const RexConfig* cfg) {
   Orc* o = (Orc*)calloc(1, sizeof(Orc));
@@ -1074,6 +1105,7 @@ ORC_API void orc_reset(void* h, const int32_t* indices, int n, real* obs) {
     int idx = indices ? indices[r] : r;
     env_reset(o, idx);
     env_observation(&o->cfg, &o->envs[idx], obs + (size_t)r * od);
+    if (o->cfg.range_normalize) normalize_obs(&o->cfg, obs + (size_t)r * od, od);
   }
 }
 

@@ -25,7 +25,7 @@ class RexConfig(ctypes.Structure):
         ("energy_weight", ctypes.c_float), ("drift_weight", ctypes.c_float), ("shake_weight", ctypes.c_float),
         ("solver_residual_threshold", ctypes.c_float), ("target_orient", ctypes.c_float),
         ("init_orient", ctypes.c_float), ("orient_fixed", ctypes.c_int32), ("pose_index", ctypes.c_int32),
-        ("pose_value", ctypes.c_float), ("reserved", ctypes.c_int32 * 2),
+        ("pose_value", ctypes.c_float), ("range_normalize", ctypes.c_int32), ("reserved", ctypes.c_int32 * 1),
     ]
 
 

@@ -131,6 +131,9 @@ struct DevCfg {
   int32_t orient_fixed;
   int32_t pose_index;
   float pose_value;
+  int32_t range_normalize;
+  float act_lo, act_hi;      // Box bounds of the env's action space (host: rex_create)
+  float obs_hi_ang, obs_hi_rate;
 };
 
 __device__ __forceinline__ float init_pose(const DevCfg& c, int j) { return c.signal == REX_SIGNAL_OL ? pose_stand_ol(j) : pose_stand(j); }
@@ -151,6 +154,17 @@ __device__ __forceinline__ void rex_substep(const DevCfg& c, EnvState& e, const 
     tau[j] = ((e.motor_en >> j) & 1u) ? act : 0.0f;                             // rex.py:617-623
   }
   physics_substep(e.ph, tau, c.dt, c.iterations, c.res_thr, lds, lane);
+}
+
+// RangeNormalize of the observation (wrappers.py:236-240); bounds are symmetric (rex_gym_env.py:277-278)
+__device__ __forceinline__ void normalize_obs(const DevCfg& c, float* obs) {
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    if (k < c.obs_dim) {
+      const float hi = (k == 2 || k == 3) ? c.obs_hi_rate : c.obs_hi_ang, lo = -hi;
+      obs[k] = 2.0f * (obs[k] - lo) / (hi - lo) - 1.0f;
+    }
+  }
 }
 
 __device__ __forceinline__ void env_observation(const DevCfg& c, const EnvState& e, float* obs) {
@@ -373,7 +387,14 @@ __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __r
   load_env(state, c.n, i, e);
   float act[8];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) act[k] = k < c.action_dim ? action[(size_t)i * c.action_dim + k] : 0.0f;
+  for (int k = 0; k < 8; ++k) {
+    float a = k < c.action_dim ? action[(size_t)i * c.action_dim + k] : 0.0f;
+    if (c.range_normalize) {                       // ClipAction + RangeNormalize (wrappers.py:229-234,261-265)
+      a = fminf(fmaxf(a, -1.0f), 1.0f);
+      a = (a + 1.0f) / 2.0f * (c.act_hi - c.act_lo) + c.act_lo;
+    }
+    act[k] = a;
+  }
 
   float cmd[12];
   if (c.task == REX_TASK_GALLOP) gallop_command(c, e, act, cmd);
@@ -420,6 +441,7 @@ __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __r
 
   float obs[16];
   env_observation(c, e, obs);
+  if (c.range_normalize) normalize_obs(c, obs);
   if (live) {
     store_env(state, c.n, i, e);
     for (int k = 0; k < c.obs_dim; ++k) obs_out[(size_t)i * c.obs_dim + k] = obs[k];
@@ -470,6 +492,7 @@ __global__ void rex_reset_kernel(DevCfg c, float* __restrict__ state, const floa
   store_env(state, c.n, i, e);
   float obs[16];
   env_observation(c, e, obs);
+  if (c.range_normalize) normalize_obs(c, obs);
   if (obs_out) for (int k = 0; k < c.obs_dim; ++k) obs_out[(size_t)r * c.obs_dim + k] = obs[k];
 }
 
@@ -613,6 +636,17 @@ int rex_create(const RexConfig* cfg, int device, float* d_state, void* stream, R
   d.w_dist = cfg->distance_weight; d.w_energy = cfg->energy_weight; d.w_drift = cfg->drift_weight; d.w_shake = cfg->shake_weight;
   d.action_dim = rex_action_dim(cfg); d.obs_dim = rex_obs_dim(cfg);
   d.pose_index = cfg->pose_index; d.pose_value = cfg->pose_value;
+  d.range_normalize = cfg->range_normalize;
+  {
+    float b;   /* walk_env.py:104-114, gallop_env.py:119-130 (low=+b, high=-b), turn_env.py:100-110, poses_env.py:115-117 */
+    if (cfg->task == REX_TASK_WALK) b = cfg->signal == REX_SIGNAL_IK ? 0.4f : 0.01f;
+    else if (cfg->task == REX_TASK_GALLOP) b = cfg->signal == REX_SIGNAL_IK ? -0.4f : -0.3f;
+    else if (cfg->task == REX_TASK_TURN) b = 0.01f;
+    else b = 0.1f;
+    d.act_lo = -b; d.act_hi = b;
+    d.obs_hi_ang = (float)(2.0 * M_PI) + 0.01f;                      /* walk_env.py:364-378 + OBSERVATION_EPS */
+    d.obs_hi_rate = (float)(2.0 * M_PI) / cfg->sim_time_step + 0.01f;
+  }
   d.target_orient = cfg->target_orient; d.init_orient = cfg->init_orient; d.orient_fixed = cfg->orient_fixed;
   hipError_t e = hipMalloc(&s->d_snap, sizeof(float) * REX_STATE_WORDS);
   if (e != hipSuccess) { delete s; return fail(REX_ENOMEM, "hipMalloc(snapshot): %s", hipGetErrorString(e)); }

@@ -62,7 +62,7 @@ class RexBatchEnv:
                  base_yaw=None,
                  motor_kp=1.0, motor_kd=0.02, control_time_step=None, action_repeat=None,
                  solver_iterations=None, solver_residual_threshold=None,
-                 check_actions=False, terrain_type="plane", mark="base", render=False, stream=None, **unused):
+                 range_normalize=False, check_actions=False, terrain_type="plane", mark="base", render=False, stream=None, **unused):
         import torch
         if terrain_type != "plane" or mark != "base" or render:
             raise NotImplementedError("this round covers terrain_type='plane', mark='base', render=False")
@@ -99,6 +99,7 @@ class RexBatchEnv:
             vals = [0.0 if v is None else float(v) for v in pose_kw]
             k = next((i for i, v in enumerate(vals[:4]) if v != 0.0), 4)
             cfg.pose_index, cfg.pose_value = k, vals[k]
+        cfg.range_normalize = int(bool(range_normalize))
         cfg.seed = int(seed) & (2 ** 64 - 1)
         cfg.env_index_base = int(env_index_base)
         cfg.auto_reset = int(bool(auto_reset))
@@ -107,6 +108,10 @@ class RexBatchEnv:
         self.action_dim = self._L.rex_action_dim(ctypes.byref(cfg))
         self.obs_dim = self._L.rex_obs_dim(ctypes.byref(cfg))
         self.action_space, self.observation_space = _spaces(task, signal_type, cfg.sim_time_step)
+        if range_normalize:   # RangeNormalize / ClipAction expose [-1, 1] boxes (wrappers.py:205-219)
+            self.inner_action_space, self.inner_observation_space = self.action_space, self.observation_space
+            self.action_space = Box(-np.ones(self.action_space.shape), np.ones(self.action_space.shape))
+            self.observation_space = Box(-np.ones(self.observation_space.shape), np.ones(self.observation_space.shape))
         self.control_time_step = cfg.sim_time_step * cfg.action_repeat
         self.check_actions = bool(check_actions)
         self._stream = stream

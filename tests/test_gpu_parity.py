@@ -197,6 +197,30 @@ def test_turn_env_reset_and_goal_logic(torch):
     env.close()
 
 
+def test_folded_wrappers_match_explicit_wrappers(torch):
+    """ClipAction + RangeNormalize folded into the launch == the same wrappers applied around the raw env
+    (agents/tools/wrappers.py:183-265), incl. gallop's inverted Box."""
+    from rex_gym_amd import RexBatchEnv
+    for task, sig in (("walk", "ik"), ("gallop", "ol")):
+        raw = RexBatchEnv(32, task=task, signal_type=sig, seed=4)
+        fold = RexBatchEnv(32, task=task, signal_type=sig, seed=4, range_normalize=True)
+        o_raw, o_fold = raw.reset(), fold.reset()
+        lo = torch.as_tensor(raw.action_space.low, device="cuda"); hi = torch.as_tensor(raw.action_space.high, device="cuda")
+        olo = torch.as_tensor(raw.observation_space.low, device="cuda"); ohi = torch.as_tensor(raw.observation_space.high, device="cuda")
+        torch.testing.assert_close(o_fold, 2 * (o_raw - olo) / (ohi - olo) - 1, atol=1e-6, rtol=1e-5)
+        assert fold.action_space.contains(np.zeros(raw.action_dim, np.float32)) and np.all(fold.action_space.high == 1)
+        g = torch.Generator(device="cuda"); g.manual_seed(0)
+        for k in range(8):
+            a = torch.rand((32, raw.action_dim), device="cuda", generator=g) * 3 - 1.5      # also outside [-1, 1]
+            den = (a.clamp(-1, 1) + 1) / 2 * (hi - lo) + lo
+            o1, r1, d1, i1 = raw.step(den)
+            o2, r2, d2, i2 = fold.step(a)
+            torch.testing.assert_close(i2["action"], i1["action"], atol=2e-6, rtol=0)
+            torch.testing.assert_close(r2, r1, atol=1e-5, rtol=0)
+            torch.testing.assert_close(o2, 2 * (o1 - olo) / (ohi - olo) - 1, atol=1e-5, rtol=1e-4)
+        raw.close(); fold.close()
+
+
 def test_auto_reset_and_episode_limit(torch):
     n = 128
     env, orc = make_pair("walk", "ik", n, np.float32, seed=9, auto_reset=1, max_episode_steps=20)
