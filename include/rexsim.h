@@ -141,6 +141,13 @@ REX_API int rex_obs_dim(const RexConfig* cfg);
 REX_API int rex_create(const RexConfig* cfg, int device, float* d_state, void* stream, RexSim** out);
 REX_API int rex_destroy(RexSim* sim);
 
+/* terrain_type='random' (model/terrain.py:32-54): install a pool of k heightfields. d_heights [k][256*256] float32
+ * raw vertex heights in the reference's layout (data[i + j*256], i along x; 5 cm cells centred on the origin),
+ * d_mids [k] = (min+max)/2 of each field (Bullet centres the shape there).  Caller-owned device buffers that must
+ * outlive the sim.  Each episode of env g uses field (g + 977*episode) mod k; the reset motion is re-run once per
+ * field (one settled snapshot each).  k = 0 returns to the flat plane.  Call before rex_reset. */
+REX_API int rex_set_terrain(RexSim* sim, const float* d_heights, const float* d_mids, int k, void* stream);
+
 /* Reset envs. d_indices == NULL: all envs. Else n int32 env indices (device).  Writes the first
  * observation of each reset env to d_obs[row * obs_dim] where row = position in d_indices (or the
  * env index when d_indices is NULL).  Mirrors RexWalkEnv.reset (walk_env.py:125-154). */

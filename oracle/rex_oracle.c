@@ -519,6 +519,31 @@ static void impulse_response_at(const Aba* A, int kbody, const real fk[6], real 
   }
 }
 
+/* ---- ground: the z = 0 box (plane.urdf) united with an optional random heightfield (model/terrain.py:32-54):
+ * 256 x 256 vertex heights, 5 cm cells, centred on the origin; Bullet centres a heightfield shape on the middle of
+ * its height range, so the field sits at raw - mid and the plane shows wherever that is below 0.
+ * Cell triangulation: Bullet's default (diagonal from vertex (i,j+1) to (i+1,j)). ---- */
+#define HF_N 256
+#define HF_CELL ((real)0.05)
+typedef struct { const float* h; real mid; } Ground;
+
+static void ground_query(const Ground* g, real x, real y, real* height, real n[3]) {
+  n[0] = 0; n[1] = 0; n[2] = 1; *height = 0;
+  if (!g || !g->h) return;
+  real fx = x / HF_CELL + (real)127.5, fy = y / HF_CELL + (real)127.5;
+  fx = clampr(fx, 0, (real)254.999); fy = clampr(fy, 0, (real)254.999);
+  int i = (int)fx, j = (int)fy;
+  real u = fx - i, v = fy - j;
+  real h00 = g->h[j * HF_N + i], h10 = g->h[j * HF_N + i + 1], h01 = g->h[(j + 1) * HF_N + i], h11 = g->h[(j + 1) * HF_N + i + 1];
+  real hh, gx, gy;
+  if (u + v <= 1) { hh = h00 + u * (h10 - h00) + v * (h01 - h00); gx = (h10 - h00) / HF_CELL; gy = (h01 - h00) / HF_CELL; }
+  else { hh = h11 + (1 - u) * (h01 - h11) + (1 - v) * (h10 - h11); gx = (h11 - h01) / HF_CELL; gy = (h11 - h10) / HF_CELL; }
+  hh -= g->mid;
+  if (hh <= 0) return;                      /* the plane is on top here */
+  real inv = 1 / sqrt(gx * gx + gy * gy + 1);
+  *height = hh; n[0] = -gx * inv; n[1] = -gy * inv; n[2] = inv;
+}
+
 /* btPlaneSpace1 */
 static void plane_space(const real n[3], real p[3], real q[3]) {
   if (fabs(n[2]) > (real)0.7071067811865475244) {
@@ -562,7 +587,7 @@ static void contact_jacobian(const Aba* A, int kbody, const real P[3], const rea
 }
 
 /* one 1 ms world step: the restated stepSimulation */
-static void physics_substep(Phys* s, const real tau[NJ], real dt, int iterations, real residual_threshold) {
+static void physics_substep(Phys* s, const real tau[NJ], real dt, int iterations, real residual_threshold, const Ground* ground) {
   static __thread Aba A;
   real qdd[NJ], wdot[3], vdot[3];
   aba_forward(s, tau, &A, qdd, wdot, vdot);
@@ -576,14 +601,15 @@ static void physics_substep(Phys* s, const real tau[NJ], real dt, int iterations
   matTvec3(A.Rw[0], s->linvel, nu + 3);
   for (int j = 0; j < NJ; ++j) nu[6 + j] = s->qd[j];
 
-  /* contact detection at the start-of-step pose: two end points of each toe cylinder vs z = 0 */
+  /* contact detection at the start-of-step pose: the two end points of each toe cylinder against the
+   * ground.  Per end: ground normal n0 under the end centre -> the point of the end circle that is lowest
+   * along n0 -> ground height / normal under THAT point -> signed distance to the local ground plane. */
   Row rows[MAX_ROWS];
   int nrow = 0, npoint = 0;
   int normal_of_point[MAX_POINTS];
-  real PtP[MAX_POINTS][3];
+  real PtP[MAX_POINTS][3], PtN[MAX_POINTS][3];
   int PtBody[MAX_POINTS];
   real PtDist[MAX_POINTS];
-  const real nrm[3] = {0, 0, 1};
   const real rad = (real)REX_TOE_RADIUS + (real)REX_COLLISION_MARGIN;
   for (int l = 0; l < REX_NLEG; ++l) {
     int kb = REX_TOE_BODY[l];
@@ -593,17 +619,22 @@ static void physics_substep(Phys* s, const real tau[NJ], real dt, int iterations
     matvec3(A.Rw[kb], ctr, cw);
     matvec3(A.Rw[kb], axl, aw);
     for (int k = 0; k < 3; ++k) cw[k] += A.pw[kb][k];
-    real na = dot3(nrm, aw);
-    real dv[3] = {nrm[0] - na * aw[0], nrm[1] - na * aw[1], nrm[2] - na * aw[2]};
-    real dn = sqrt(dot3(dv, dv));
-    real inv = dn > (real)1e-9 ? 1 / dn : 0;
     for (int e = 0; e < 2; ++e) {
       real sgn = e == 0 ? (real)-1 : (real)1;
-      real P[3];
-      for (int k = 0; k < 3; ++k) P[k] = cw[k] + sgn * (real)REX_TOE_HALFLEN * aw[k] - rad * inv * dv[k];
-      real dist = P[2];
+      real ce[3], n0[3], h0;
+      for (int k = 0; k < 3; ++k) ce[k] = cw[k] + sgn * (real)REX_TOE_HALFLEN * aw[k];
+      ground_query(ground, ce[0], ce[1], &h0, n0);
+      real na = dot3(n0, aw);
+      real dv[3] = {n0[0] - na * aw[0], n0[1] - na * aw[1], n0[2] - na * aw[2]};
+      real dn = sqrt(dot3(dv, dv));
+      real inv = dn > (real)1e-9 ? 1 / dn : 0;
+      real P[3], n[3], h;
+      for (int k = 0; k < 3; ++k) P[k] = ce[k] - rad * inv * dv[k];
+      ground_query(ground, P[0], P[1], &h, n);
+      real dist = (P[2] - h) * n[2];
       if (dist < CONTACT_BREAKING) {
         memcpy(PtP[npoint], P, sizeof(P));
+        memcpy(PtN[npoint], n, sizeof(n));
         PtBody[npoint] = kb;
         PtDist[npoint] = dist;
         ++npoint;
@@ -611,12 +642,10 @@ static void physics_substep(Phys* s, const real tau[NJ], real dt, int iterations
     }
   }
   /* rows: all normals first, then the friction pairs (Bullet's per-iteration order) */
-  real t1[3], t2[3];
-  plane_space(nrm, t1, t2);
   for (int p = 0; p < npoint; ++p) {
     Row* r = &rows[nrow];
     real fk[6];
-    contact_jacobian(&A, PtBody[p], PtP[p], nrm, r->J, fk);
+    contact_jacobian(&A, PtBody[p], PtP[p], PtN[p], r->J, fk);
     impulse_response_at(&A, PtBody[p], fk, r->resp);
     real diag = 0, vel = 0;
     for (int k = 0; k < NDOF; ++k) { diag += r->J[k] * r->resp[k]; vel += r->J[k] * nu[k]; }
@@ -631,7 +660,8 @@ static void physics_substep(Phys* s, const real tau[NJ], real dt, int iterations
   for (int p = 0; p < npoint; ++p)
     for (int d = 0; d < 2; ++d) {
       Row* r = &rows[nrow];
-      real fk[6];
+      real fk[6], t1[3], t2[3];
+      plane_space(PtN[p], t1, t2);
       contact_jacobian(&A, PtBody[p], PtP[p], d == 0 ? t1 : t2, r->J, fk);
       impulse_response_at(&A, PtBody[p], fk, r->resp);
       real diag = 0, vel = 0;
@@ -734,7 +764,25 @@ typedef struct {
   RexConfig cfg;
   Env* envs;
   Env snapshot; /* settled reset state (rex.py:296-324) */
+  /* terrain pool (terrain_type='random'): K heightfields, one settled snapshot per terrain */
+  int n_terrain;
+  float* heights; /* [K][256*256] */
+  float* mids;    /* [K] */
+  Env* terrain_snapshot;
 } Orc;
+
+/* terrain of (global env index, episode): the reference regenerates the field on every reset
+ * (rex_gym_env.py:347-348); here each episode picks one of the K pool entries */
+static int terrain_index(const Orc* o, int idx, int episode) {
+  if (!o->n_terrain) return -1;
+  return (int)(((uint32_t)(o->cfg.env_index_base + idx) + 977u * (uint32_t)episode) % (uint32_t)o->n_terrain);
+}
+static Ground env_ground(const Orc* o, int idx, int episode) {
+  Ground g = {0, 0};
+  int t = terrain_index(o, idx, episode);
+  if (t >= 0) { g.h = o->heights + (size_t)t * HF_N * HF_N; g.mid = (real)o->mids[t]; }
+  return g;
+}
 
 ORC_API int orc_obs_dim(const RexConfig* c) { return c->task == REX_TASK_GALLOP ? 16 : 4; }
 ORC_API int orc_action_dim(const RexConfig* c) {
@@ -747,7 +795,7 @@ ORC_API int orc_action_dim(const RexConfig* c) {
 static const real* init_pose(const RexConfig* c) { return c->signal == REX_SIGNAL_OL ? POSE_STAND_OL : POSE_STAND; }
 
 /* Rex.ApplyAction + stepSimulation + ReceiveObservation (rex.py:158-163,568-641) */
-static void rex_substep(const RexConfig* c, Env* e, const real cmd[NJ]) {
+static void rex_substep(const RexConfig* c, Env* e, const real cmd[NJ], const Ground* ground) {
   real tau[NJ];
   for (int j = 0; j < NJ; ++j) {
     real act, obs;
@@ -758,11 +806,10 @@ static void rex_substep(const RexConfig* c, Env* e, const real cmd[NJ]) {
     tau[j] = ((e->motor_enabled >> j) & 1u) ? act : 0;
     if (DBG_JOINT_FRICTION > 0 && (j % 3) != 1) tau[j] -= clampr(DBG_JOINT_VISC * e->ph.qd[j], -DBG_JOINT_FRICTION, DBG_JOINT_FRICTION);
   }
-  physics_substep(&e->ph, tau, (real)c->sim_time_step, c->solver_iterations, (real)c->solver_residual_threshold);
+  physics_substep(&e->ph, tau, (real)c->sim_time_step, c->solver_iterations, (real)c->solver_residual_threshold, ground);
 }
 
-static void settle(Orc* o) {
-  Env* e = &o->snapshot;
+static void settle(Orc* o, Env* e, const Ground* ground) {
   memset(e, 0, sizeof(*e));
   e->ph.pos[2] = ROBOT_INIT_Z;
   e->ph.quat[3] = 1;
@@ -771,9 +818,9 @@ static void settle(Orc* o) {
   /* RexPosesEnv.reset() calls the base reset with initial_motor_angles=None: the reset motion is
    * skipped (rex.py:308), the robot starts at the drop height in the 'stand' pose */
   if (o->cfg.task == REX_TASK_POSES) return;
-  for (int k = 0; k < 100; ++k) rex_substep(&o->cfg, e, POSE_STAND);      /* rex.py:315-318 */
+  for (int k = 0; k < 100; ++k) rex_substep(&o->cfg, e, POSE_STAND, ground);      /* rex.py:315-318 */
   int nreset = (int)((real)0.5 / (real)o->cfg.sim_time_step);             /* rex.py:319 */
-  for (int k = 0; k < nreset; ++k) rex_substep(&o->cfg, e, init_pose(&o->cfg));
+  for (int k = 0; k < nreset; ++k) rex_substep(&o->cfg, e, init_pose(&o->cfg), ground);
 }
 
 static void env_observation(const RexConfig* c, const Env* e, real* obs) {
@@ -793,7 +840,10 @@ static void env_reset(Orc* o, int idx) {
   const RexConfig* c = &o->cfg;
   Env* e = &o->envs[idx];
   int32_t episode = e->episode;
-  *e = o->snapshot;
+  {
+    int t = terrain_index(o, idx, episode + 1);
+    *e = t >= 0 ? o->terrain_snapshot[t] : o->snapshot;   /* settled on this episode's terrain */
+  }
   e->episode = episode + 1;
   e->gait.phi = 0; e->gait.last_time = 0; e->gait.alpha = 0;
   uint32_t ctr[4] = {(uint32_t)e->episode, 0, 0, 0};
@@ -1067,7 +1117,8 @@ static void env_step(Orc* o, int idx, const real* action_in, real* obs, real* re
   else if (c->task == REX_TASK_TURN) turn_command(c, e, action, cmd);
   else if (c->task == REX_TASK_POSES) poses_command(c, e, action, cmd);
   else walk_command(c, e, action, cmd);
-  for (int k = 0; k < c->action_repeat; ++k) rex_substep(c, e, cmd);    /* Rex.Step, rex.py:158-163 */
+  Ground ground = env_ground(o, idx, e->episode);
+  for (int k = 0; k < c->action_repeat; ++k) rex_substep(c, e, cmd, &ground);    /* Rex.Step, rex.py:158-163 */
   if (c->task == REX_TASK_TURN) *reward = (real)0.035 - fabs(e->ph.pos[0]) - fabs(e->ph.pos[1]);  /* turn_env.py:362-367 */
   else if (c->task == REX_TASK_POSES) { *reward = 1; for (int j = 0; j < NJ; ++j) (void)e->tau_obs[j]; } /* poses_env.py:267-269 */
   else *reward = base_reward(c, e);
@@ -1092,10 +1143,30 @@ ORC_API void* orc_create(const RexConfig* cfg) {
   Orc* o = (Orc*)calloc(1, sizeof(Orc));
   o->cfg = *cfg;
   o->envs = (Env*)calloc((size_t)cfg->num_envs, sizeof(Env));
-  settle(o);
+  settle(o, &o->snapshot, 0);
   return o;
 }
-ORC_API void orc_destroy(void* h) { Orc* o = (Orc*)h; free(o->envs); free(o); }
+ORC_API void orc_destroy(void* h) { Orc* o = (Orc*)h; free(o->envs); free(o->heights); free(o->mids); free(o->terrain_snapshot); free(o); }
+
+/* terrain pool: heights [k][256*256] raw vertex heights (terrain.py:36-43 layout: data[i + j*rows], i along x),
+ * mids [k] = (min+max)/2 of each field */
+ORC_API void orc_set_terrain(void* h, const float* heights, const float* mids, int k) {
+  Orc* o = (Orc*)h;
+  free(o->heights); free(o->mids); free(o->terrain_snapshot);
+  o->n_terrain = k;
+  o->heights = (float*)malloc(sizeof(float) * (size_t)k * HF_N * HF_N);
+  o->mids = (float*)malloc(sizeof(float) * (size_t)k);
+  o->terrain_snapshot = (Env*)calloc((size_t)k, sizeof(Env));
+  memcpy(o->heights, heights, sizeof(float) * (size_t)k * HF_N * HF_N);
+  memcpy(o->mids, mids, sizeof(float) * (size_t)k);
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic)
+#endif
+  for (int t = 0; t < k; ++t) {
+    Ground g = {o->heights + (size_t)t * HF_N * HF_N, (real)o->mids[t]};
+    settle(o, &o->terrain_snapshot[t], &g);
+  }
+}
 
 ORC_API void orc_reset(void* h, const int32_t* indices, int n, real* obs) {
   Orc* o = (Orc*)h;
@@ -1174,7 +1245,7 @@ ORC_API void orc_physics_substep(real* st, const real* tau, real dt, int iterati
   memcpy(p.pos, st, sizeof(real) * 3); memcpy(p.quat, st + 3, sizeof(real) * 4);
   memcpy(p.linvel, st + 7, sizeof(real) * 3); memcpy(p.angvel, st + 10, sizeof(real) * 3);
   memcpy(p.q, st + 13, sizeof(real) * NJ); memcpy(p.qd, st + 25, sizeof(real) * NJ);
-  for (int k = 0; k < nsteps; ++k) physics_substep(&p, tau, dt, iterations, residual_threshold);
+  for (int k = 0; k < nsteps; ++k) physics_substep(&p, tau, dt, iterations, residual_threshold, 0);
   memcpy(st, p.pos, sizeof(real) * 3); memcpy(st + 3, p.quat, sizeof(real) * 4);
   memcpy(st + 7, p.linvel, sizeof(real) * 3); memcpy(st + 10, p.angvel, sizeof(real) * 3);
   memcpy(st + 13, p.q, sizeof(real) * NJ); memcpy(st + 25, p.qd, sizeof(real) * NJ);

@@ -114,8 +114,42 @@ __device__ __forceinline__ void add(s33& a, const s33& b) {
 struct BaseKin {
   f3 ex, ey, ez;   // columns of the base rotation (body axes in world)
   f3 w, v;         // base angular / linear velocity, world
-  float height;    // base origin z (flat ground at z = 0)
+  float px, py;    // base origin x, y (world): only the heightfield lookup needs them
+  float height;    // base origin z
 };
+
+// Ground = the z = 0 box (plane.urdf) united with an optional random heightfield (model/terrain.py:32-54):
+// 256 x 256 vertex heights, 5 cm cells, centred on the origin, shifted down by `mid` (Bullet centres a
+// heightfield on the middle of its height range) -- the plane shows wherever the field is
+// below 0.  Triangulation: Bullet's default diagonal (i,j+1)-(i+1,j).  h == nullptr: plane only.
+struct Ground { const float* h; float mid; };
+__device__ __forceinline__ void ground_query(const Ground& g, float x, float y, float& height, f3& n) {
+  n = f3{0.f, 0.f, 1.f}; height = 0.0f;
+  float fx = fminf(fmaxf(x / 0.05f + 127.5f, 0.0f), 254.999f), fy = fminf(fmaxf(y / 0.05f + 127.5f, 0.0f), 254.999f);
+  const int i = (int)fx, j = (int)fy;
+  const float u = fx - (float)i, v = fy - (float)j;
+  const float h00 = g.h[j * 256 + i], h10 = g.h[j * 256 + i + 1], h01 = g.h[(j + 1) * 256 + i], h11 = g.h[(j + 1) * 256 + i + 1];
+  float hh, gx, gy;
+  if (u + v <= 1.0f) { hh = h00 + u * (h10 - h00) + v * (h01 - h00); gx = (h10 - h00) / 0.05f; gy = (h01 - h00) / 0.05f; }
+  else { hh = h11 + (1.0f - u) * (h01 - h11) + (1.0f - v) * (h10 - h11); gx = (h11 - h01) / 0.05f; gy = (h11 - h10) / 0.05f; }
+  hh -= g.mid;
+  if (hh > 0.0f) {
+    const float inv = rsqrtf(gx * gx + gy * gy + 1.0f);
+    height = hh; n = f3{-gx * inv, -gy * inv, inv};
+  }
+}
+// btPlaneSpace1
+__device__ __forceinline__ void plane_space(f3 n, f3& p, f3& q) {
+  if (fabsf(n.z) > 0.7071067811865475244f) {
+    const float a = n.y * n.y + n.z * n.z, k = rsqrtf(a);
+    p = f3{0.f, -n.z * k, n.y * k};
+    q = f3{a * k, -n.x * p.z, n.x * p.y};
+  } else {
+    const float a = n.x * n.x + n.y * n.y, k = rsqrtf(a);
+    p = f3{-n.y * k, n.x * k, 0.f};
+    q = f3{-n.z * p.y, n.z * p.x, a * k};
+  }
+}
 
 // what a leg leaves behind for the back-substitution after the constraint solve
 struct LegFactor {
@@ -170,7 +204,7 @@ __device__ __forceinline__ float4& row_chunk(float4* lds, int r, int c, int lane
 // signs of the hip offsets differ between legs.
 __device__ __forceinline__ void leg_pass(int leg, const BaseKin& bk, const float* __restrict__ q, const float* __restrict__ qd,
                                          const float* __restrict__ tau, float dt, LegFactor& L, BaseAccum& acc,
-                                         float4* lds, int lane, unsigned& active_mask) {
+                                         float4* lds, int lane, unsigned& active_mask, const Ground& ground) {
   static_assert(REX_LEG_SX[0] == -1 && REX_LEG_SX[1] == -1 && REX_LEG_SX[2] == 1 && REX_LEG_SX[3] == 1, "leg mirror table");
   static_assert(REX_LEG_SY[0] == -1 && REX_LEG_SY[1] == 1 && REX_LEG_SY[2] == -1 && REX_LEG_SY[3] == 1, "leg mirror table");
   const float SX = leg < 2 ? -1.0f : 1.0f, SY = (leg & 1) ? 1.0f : -1.0f;
@@ -315,18 +349,11 @@ __device__ __forceinline__ void leg_pass(int leg, const BaseKin& bk, const float
   for (int k = 0; k < 6; ++k) { zc1 += L.Bw[0][k] * nu0[k]; zc2 += L.Bw[1][k] * nu0[k]; zc3 += L.Bw[2][k] * nu0[k]; }
   L.z[0] = zc1 + dt * zd1; L.z[1] = zc2 + dt * zd2; L.z[2] = zc3 + dt * zd3;
 
-  // --- toe contact points: both ends of the toe cylinder against z = 0 ---
+  // --- toe contact points: both ends of the toe cylinder against the ground ---
   const f3 tc = o3 + TZ * z3;
   const f3 aw = y1;
-  const f3 dv = mk(-aw.z * aw.x, -aw.z * aw.y, 1.0f - aw.z * aw.z);   // n - (n.a) a, n = +z
-  const float dn2 = dot(dv, dv);
-  const float inv = dn2 > 1e-18f ? rsqrtf(dn2) : 0.0f;
-  const f3 nrm = mk(0.f, 0.f, 1.f), t1 = mk(0.f, -1.f, 0.f), t2 = mk(1.f, 0.f, 0.f);  // btPlaneSpace1(+z)
-#pragma unroll
-  for (int e = 0; e < 2; ++e) {
-    const float sg = e == 0 ? -kToeHalf : kToeHalf;
-    const f3 P = tc + sg * aw - (kToeRad * inv) * dv;
-    const float dist = bk.height + P.z;
+  // rows of one contact point P (relative to the base origin) with signed distance `dist` and frame (n, t1, t2)
+  auto emit_rows = [&](int e, f3 P, float dist, f3 nrm, f3 t1, f3 t2) {
     const bool act = dist < kBreaking;
     const int p = 2 * leg + e;
     if (act) active_mask |= 1u << p;
@@ -351,6 +378,34 @@ __device__ __forceinline__ void leg_pass(int leg, const BaseKin& bk, const float
       row_chunk(lds, r, 0, lane) = make_float4(g[0], g[1], g[2], g[3]);
       row_chunk(lds, r, 1, lane) = make_float4(g[4], g[5], j1, j2);
       row_chunk(lds, r, 2, lane) = make_float4(j3, target, act ? 1.0f : 0.0f, 0.0f);
+    }
+  };
+  if (ground.h == nullptr) {   // flat plane: constant frame, the compiler folds the crosses
+    const f3 dv = mk(-aw.z * aw.x, -aw.z * aw.y, 1.0f - aw.z * aw.z);   // n - (n.a) a, n = +z
+    const float dn2 = dot(dv, dv);
+    const float inv = dn2 > 1e-18f ? rsqrtf(dn2) : 0.0f;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const float sg = e == 0 ? -kToeHalf : kToeHalf;
+      const f3 P = tc + sg * aw - (kToeRad * inv) * dv;
+      emit_rows(e, P, bk.height + P.z, mk(0.f, 0.f, 1.f), mk(0.f, -1.f, 0.f), mk(1.f, 0.f, 0.f));   // btPlaneSpace1(+z)
+    }
+  } else {                     // heightfield: normal under the end centre -> lowest point along it -> local plane
+#pragma unroll 1
+    for (int e = 0; e < 2; ++e) {
+      const float sg = e == 0 ? -kToeHalf : kToeHalf;
+      const f3 ce = tc + sg * aw;
+      f3 n0, nrm, t1, t2;
+      float h0, h;
+      ground_query(ground, bk.px + ce.x, bk.py + ce.y, h0, n0);
+      const float na = dot(n0, aw);
+      const f3 dv = n0 - na * aw;
+      const float dn2 = dot(dv, dv);
+      const float inv = dn2 > 1e-18f ? rsqrtf(dn2) : 0.0f;
+      const f3 P = ce - (kToeRad * inv) * dv;
+      ground_query(ground, bk.px + P.x, bk.py + P.y, h, nrm);
+      plane_space(nrm, t1, t2);
+      emit_rows(e, P, (bk.height + P.z - h) * nrm.z, nrm, t1, t2);
     }
   }
 }
@@ -488,7 +543,7 @@ __device__ __forceinline__ void rotate_leg(T* a) {   // 12-entry per-joint array
 }
 
 __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float dt, int iterations,
-                                                float sqrt_res_thr, float4* lds, int lane) {
+                                                float sqrt_res_thr, float4* lds, int lane, const Ground& ground) {
   // base rotation (btMatrix3x3::setRotation)
   BaseKin bk;
   {
@@ -502,6 +557,7 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
   }
   bk.w = mk(s.ang[0], s.ang[1], s.ang[2]);
   bk.v = mk(s.lin[0], s.lin[1], s.lin[2]);
+  bk.px = s.pos[0]; bk.py = s.pos[1];
   bk.height = s.pos[2];
 
   BaseAccum acc;
@@ -527,7 +583,7 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
     // the current leg always sits in slots 0..2: q / qd / tau are rotated by one leg per iteration,
     // which keeps every register index static inside the rolled loop
     LegFactor L;
-    leg_pass(leg, bk, s.q, s.qd, tau, dt, L, acc, lds, lane, active);
+    leg_pass(leg, bk, s.q, s.qd, tau, dt, L, acc, lds, lane, active, ground);
     leg_park(lds, leg, lane, L);
     rotate_leg(s.q); rotate_leg(s.qd); rotate_leg(tau);
   }

@@ -132,14 +132,33 @@ struct DevCfg {
   int32_t pose_index;
   float pose_value;
   int32_t range_normalize;
+  const float* terrain;      // [n_terrain][256*256] raw vertex heights (nullptr: plane only)
+  const float* terrain_mid;  // [n_terrain]
+  int32_t n_terrain;
   float act_lo, act_hi;      // Box bounds of the env's action space (host: rex_create)
   float obs_hi_ang, obs_hi_rate;
 };
 
 __device__ __forceinline__ float init_pose(const DevCfg& c, int j) { return c.signal == REX_SIGNAL_OL ? pose_stand_ol(j) : pose_stand(j); }
 
+// terrain of (global env index, episode): the reference regenerates the field on every reset
+// (rex_gym_env.py:347-348); here each episode picks one of the pool entries
+__device__ __forceinline__ int terrain_index(const DevCfg& c, int gidx, int episode) {
+  return (int)(((uint32_t)gidx + 977u * (uint32_t)episode) % (uint32_t)c.n_terrain);
+}
+__device__ __forceinline__ Ground env_ground(const DevCfg& c, int gidx, int episode) {
+  Ground g{nullptr, 0.0f};
+  if (c.n_terrain > 0) {
+    const int t = terrain_index(c, gidx, episode);
+    g.h = c.terrain + (size_t)t * 65536;
+    g.mid = c.terrain_mid[t];
+  }
+  return g;
+}
+
 // Rex.ApplyAction + stepSimulation + ReceiveObservation (rex.py:158-163, 568-641)
-__device__ __forceinline__ void rex_substep(const DevCfg& c, EnvState& e, const float* cmd, float* tau_obs, float4* lds, int lane) {
+__device__ __forceinline__ void rex_substep(const DevCfg& c, EnvState& e, const float* cmd, float* tau_obs, float4* lds, int lane,
+                                            const Ground& ground) {
   float tau[12];
   const float limit = 1.0f / c.dt;  // OVERHEAT_SHUTDOWN_TIME / time_step, rex.py:607
 #pragma unroll
@@ -153,7 +172,7 @@ __device__ __forceinline__ void rex_substep(const DevCfg& c, EnvState& e, const 
     tau_obs[j] = obs;
     tau[j] = ((e.motor_en >> j) & 1u) ? act : 0.0f;                             // rex.py:617-623
   }
-  physics_substep(e.ph, tau, c.dt, c.iterations, c.res_thr, lds, lane);
+  physics_substep(e.ph, tau, c.dt, c.iterations, c.res_thr, lds, lane, ground);
 }
 
 // RangeNormalize of the observation (wrappers.py:236-240); bounds are symmetric (rex_gym_env.py:277-278)
@@ -184,7 +203,7 @@ __device__ __forceinline__ void env_observation(const DevCfg& c, const EnvState&
 // RexWalkEnv.reset / RexReactiveEnv.reset draws on top of the settled snapshot
 __device__ __forceinline__ void env_reset(const DevCfg& c, const float* snap, int gidx, EnvState& e) {
   const int32_t episode = e.episode + 1;
-  load_env(snap, 1, 0, e);
+  load_env(snap, c.n_terrain > 0 ? c.n_terrain : 1, c.n_terrain > 0 ? terrain_index(c, gidx, episode) : 0, e);   // settled on this episode's terrain
   e.episode = episode;
   e.gait.phi = 0.0f; e.gait.last_time = 0.0f; e.gait.alpha = 0.0f;
   uint32_t ctr[4] = {(uint32_t)episode, 0u, 0u, 0u};
@@ -403,7 +422,8 @@ __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __r
   else walk_command(c, e, act, cmd);
 
   float tau_obs[12];
-  for (int k = 0; k < c.action_repeat; ++k) rex_substep(c, e, cmd, tau_obs, lds, lane);   // Rex.Step
+  const Ground ground = env_ground(c, c.env_index_base + i, e.episode);
+  for (int k = 0; k < c.action_repeat; ++k) rex_substep(c, e, cmd, tau_obs, lds, lane, ground);   // Rex.Step
 
   // ---- reward (rex_gym_env.py:501-542) ----
   float rpy[3], r20, r21, r22;
@@ -454,10 +474,16 @@ __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __r
   }
 }
 
-// The reset motion of Rex.Reset (rex.py:296-324) for ONE robot; lane 0 writes the snapshot.
+// The reset motion of Rex.Reset (rex.py:296-324).  Plane: ONE robot, lane 0 writes the snapshot.  Terrain pool:
+// lane t settles on terrain t and writes snapshot record t (word-major [53][n_terrain]).
 __global__ __launch_bounds__(REX_WAVE) void rex_settle_kernel(DevCfg c, float* __restrict__ snap) {
   __shared__ float4 lds[REX_LDS_FLOATS / 4];
   const int lane = threadIdx.x;
+  const int nrec = c.n_terrain > 0 ? c.n_terrain : 1;
+  const int rec = blockIdx.x * REX_WAVE + lane;
+  const int t = rec < nrec ? rec : nrec - 1;
+  Ground ground{nullptr, 0.0f};
+  if (c.n_terrain > 0) { ground.h = c.terrain + (size_t)t * 65536; ground.mid = c.terrain_mid[t]; }
   EnvState e;
   memset(&e, 0, sizeof(e));
   e.ph.pos[2] = kInitZ;
@@ -465,19 +491,17 @@ __global__ __launch_bounds__(REX_WAVE) void rex_settle_kernel(DevCfg c, float* _
 #pragma unroll
   for (int j = 0; j < 12; ++j) e.ph.q[j] = pose_stand(j);       // ResetPose: INIT_POSES[pose_id = 'stand']
   e.motor_en = (1u << 12) - 1u;
-  if (c.task == REX_TASK_POSES) {   // base reset() with initial_motor_angles=None skips the reset motion (rex.py:308)
-    if (lane == 0) store_env(snap, 1, 0, e);
-    return;
+  if (c.task != REX_TASK_POSES) {   // RexPosesEnv: base reset() with initial_motor_angles=None skips the motion (rex.py:308)
+    float cmd[12], tau_obs[12];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) cmd[j] = pose_stand(j);
+    for (int k = 0; k < 100; ++k) rex_substep(c, e, cmd, tau_obs, lds, lane, ground);   // rex.py:315-318
+#pragma unroll
+    for (int j = 0; j < 12; ++j) cmd[j] = init_pose(c, j);
+    const int nreset = (int)(0.5f / c.dt);                                               // rex.py:319
+    for (int k = 0; k < nreset; ++k) rex_substep(c, e, cmd, tau_obs, lds, lane, ground);
   }
-  float cmd[12], tau_obs[12];
-#pragma unroll
-  for (int j = 0; j < 12; ++j) cmd[j] = pose_stand(j);
-  for (int k = 0; k < 100; ++k) rex_substep(c, e, cmd, tau_obs, lds, lane);   // rex.py:315-318
-#pragma unroll
-  for (int j = 0; j < 12; ++j) cmd[j] = init_pose(c, j);
-  const int nreset = (int)(0.5f / c.dt);                                       // rex.py:319
-  for (int k = 0; k < nreset; ++k) rex_substep(c, e, cmd, tau_obs, lds, lane);
-  if (lane == 0) store_env(snap, 1, 0, e);
+  if (rec < nrec) store_env(snap, nrec, rec, e);
 }
 
 __global__ void rex_reset_kernel(DevCfg c, float* __restrict__ state, const float* __restrict__ snap,
@@ -540,7 +564,7 @@ struct RexSim {
   rex::DevCfg dev;
   int device;
   float* d_state;   // caller-owned
-  float* d_snap;    // REX_STATE_WORDS floats
+  float* d_snap;    // REX_STATE_WORDS x (n_terrain or 1) floats, word-major
   hipEvent_t ev0, ev1;
   int timing;
   int have_timing;
@@ -637,6 +661,7 @@ int rex_create(const RexConfig* cfg, int device, float* d_state, void* stream, R
   d.action_dim = rex_action_dim(cfg); d.obs_dim = rex_obs_dim(cfg);
   d.pose_index = cfg->pose_index; d.pose_value = cfg->pose_value;
   d.range_normalize = cfg->range_normalize;
+  d.terrain = nullptr; d.terrain_mid = nullptr; d.n_terrain = 0;
   {
     float b;   /* walk_env.py:104-114, gallop_env.py:119-130 (low=+b, high=-b), turn_env.py:100-110, poses_env.py:115-117 */
     if (cfg->task == REX_TASK_WALK) b = cfg->signal == REX_SIGNAL_IK ? 0.4f : 0.01f;
@@ -663,6 +688,25 @@ int rex_create(const RexConfig* cfg, int device, float* d_state, void* stream, R
     return fail(REX_EHIP, "settle kernel: %s", hipGetErrorString(e));
   }
   *out = s;
+  return REX_OK;
+}
+
+int rex_set_terrain(RexSim* s, const float* d_heights, const float* d_mids, int k, void* stream) {
+  if (!s || k < 0 || (k > 0 && (!d_heights || !d_mids))) return fail(REX_EINVAL, "rex_set_terrain: bad arguments%s", "");
+  HIPCHK(hipSetDevice(s->device));
+  hipStream_t st = (hipStream_t)stream;
+  float* snap = nullptr;
+  const int nrec = k > 0 ? k : 1;
+  HIPCHK(hipMalloc(&snap, sizeof(float) * REX_STATE_WORDS * (size_t)nrec));
+  HIPCHK(hipStreamSynchronize(st));
+  (void)hipFree(s->d_snap);
+  s->d_snap = snap;
+  s->dev.terrain = k > 0 ? d_heights : nullptr;
+  s->dev.terrain_mid = k > 0 ? d_mids : nullptr;
+  s->dev.n_terrain = k;
+  hipLaunchKernelGGL(rex::rex_settle_kernel, dim3((nrec + REX_WAVE - 1) / REX_WAVE), dim3(REX_WAVE), 0, st, s->dev, s->d_snap);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(st));
   return REX_OK;
 }
 

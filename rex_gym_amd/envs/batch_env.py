@@ -62,10 +62,11 @@ class RexBatchEnv:
                  base_yaw=None,
                  motor_kp=1.0, motor_kd=0.02, control_time_step=None, action_repeat=None,
                  solver_iterations=None, solver_residual_threshold=None,
-                 range_normalize=False, check_actions=False, terrain_type="plane", mark="base", render=False, stream=None, **unused):
+                 range_normalize=False, check_actions=False, terrain_type="plane", terrain_pool=64, terrain_seed=10,
+                 mark="base", render=False, stream=None, **unused):
         import torch
-        if terrain_type != "plane" or mark != "base" or render:
-            raise NotImplementedError("this round covers terrain_type='plane', mark='base', render=False")
+        if terrain_type not in ("plane", "random") or mark != "base" or render:
+            raise NotImplementedError("this round covers terrain_type in ('plane', 'random'), mark='base', render=False")
         if task not in _lib.TASKS or signal_type not in _lib.SIGNALS:
             raise ValueError(f"unsupported task/signal {task}/{signal_type}")
         self._torch = torch
@@ -126,6 +127,15 @@ class RexBatchEnv:
                                           self._stream_ptr(), ctypes.byref(handle)), "rex_create")
         self._h = handle
         self._needs_reset = True
+        self.terrain_type = terrain_type
+        if terrain_type == "random":   # model/terrain.py:32-54 -- a pool of fields instead of one per env
+            from ..terrain import random_terrain_pool
+            h, m = random_terrain_pool(int(terrain_pool), int(terrain_seed))
+            with torch.cuda.device(self.device):
+                self.terrain_heights = torch.from_numpy(h).to(self.device)
+                self.terrain_mids = torch.from_numpy(m).to(self.device)
+                _lib.check(self._L.rex_set_terrain(self._h, self.terrain_heights.data_ptr(), self.terrain_mids.data_ptr(),
+                                                   int(terrain_pool), self._stream_ptr()), "rex_set_terrain")
 
     # ---- plumbing ----
     def _stream_ptr(self):

@@ -45,10 +45,15 @@ def make_pair(task, signal, n, dtype=np.float32, **kw):
     if "target_position" in okw:
         t = okw.pop("target_position")
         cfg_kw["target_position"] = 0.0 if not t else float(t)
+    terrain = okw.pop("terrain_type", "plane")
+    pool, tseed = okw.pop("terrain_pool", 64), okw.pop("terrain_seed", 10)
     assert not okw, okw
     env = RexBatchEnv(n, task=task, signal_type=signal, **pkw)
     cfg = orclib.default_config(task, signal, n, **cfg_kw)
     orc = orclib.OracleEnv(cfg, dtype)
+    if terrain == "random":
+        from rex_gym_amd.terrain import random_terrain_pool
+        orc.set_terrain(*random_terrain_pool(pool, tseed))
     return env, orc
 
 

@@ -167,6 +167,12 @@ class OracleEnv:
         self.o.lib.orc_step(self.h, self.o._p(a), self.o._p(obs), self.o._p(rew), self.o._p(done), self.o._p(cmd))
         return obs, rew, done.astype(bool), cmd
 
+    def set_terrain(self, heights, mids):
+        heights = np.ascontiguousarray(heights, np.float32)
+        mids = np.ascontiguousarray(mids, np.float32)
+        self.o.lib.orc_set_terrain(self.h, heights.ctypes.data_as(ctypes.c_void_p), mids.ctypes.data_as(ctypes.c_void_p),
+                                   int(heights.shape[0]))
+
     def get_state(self):
         out = np.zeros((STATE_WORDS, self.n), np.float64)
         self.o.lib.orc_get_state(self.h, self.o._p(out))

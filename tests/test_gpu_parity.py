@@ -197,6 +197,36 @@ def test_turn_env_reset_and_goal_logic(torch):
     env.close()
 
 
+def test_random_heightfield_terrain_parity(torch):
+    """terrain_type='random' (model/terrain.py:32-54), BASELINE config 4 shape (turn-IK on a heightfield):
+    per-terrain settled snapshots and lock-step single steps from common states vs the fp32 oracle."""
+    n = 64
+    env, orc = make_pair("turn", "ik", n, np.float32, seed=8, terrain_type="random", terrain_pool=8)
+    env.reset(); orc.reset()
+    ps, os_ = product_state_to_numeric(env.state), orc.get_state()
+    np.testing.assert_allclose(ps[:7], os_[:7], atol=2e-4)
+    np.testing.assert_allclose(ps[orclib.S_Q:orclib.S_Q + 12], os_[orclib.S_Q:orclib.S_Q + 12], atol=3e-4)
+    # different pool entries settle to different joint poses: the terrain is really in the loop
+    assert np.ptp(ps[orclib.S_Q + 1]) > 1e-4
+    rng = np.random.RandomState(1)
+    for k in range(20):
+        orc.step(rng.uniform(-0.01, 0.01, (n, 2)))
+    worst = 0.0
+    for k in range(10):
+        st = orc.get_state()
+        env.state.copy_(numeric_to_product_state(st, torch, env.state.device))
+        a = rng.uniform(-0.01, 0.01, (n, 2)).astype(np.float32)
+        env.step(torch.as_tensor(a, device="cuda")); orc.step(a)
+        ps, os_ = product_state_to_numeric(env.state), orc.get_state()
+        err = np.abs(ps[orclib.S_Q:orclib.S_Q + 12] - os_[orclib.S_Q:orclib.S_Q + 12]).max(axis=0)
+        worst = max(worst, np.median(err))
+        # a toe end sitting exactly on a cell diagonal / plane-field seam may pick the other facet in fp32:
+        # require the bulk of the envs to agree tightly
+        assert np.mean(err < 2e-4) > 0.9, np.sort(err)[-8:]
+    print("heightfield single-step median joint error %.2e rad" % worst)
+    env.close()
+
+
 def test_folded_wrappers_match_explicit_wrappers(torch):
     """ClipAction + RangeNormalize folded into the launch == the same wrappers applied around the raw env
     (agents/tools/wrappers.py:183-265), incl. gallop's inverted Box."""
