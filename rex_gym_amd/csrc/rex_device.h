@@ -26,8 +26,7 @@
 #define REX_NROW (3 * REX_NPOINT)     /* normal + 2 pyramid friction rows per point */
 #define REX_ROW_F4 3                  /* float4 chunks per row in LDS */
 #define REX_LEG_F4 7                  /* float4 chunks per leg parked in LDS (Bw 18 + G 6 + z 3) */
-#define REX_LDS_ROW_F4 (REX_NROW * REX_ROW_F4 * REX_WAVE)
-#define REX_LDS_FLOATS ((REX_NROW * REX_ROW_F4 + REX_NLEG * REX_LEG_F4) * 4 * REX_WAVE)
+#define REX_LDS_F4_PER_ENV (REX_NROW * REX_ROW_F4 + REX_NLEG * REX_LEG_F4)   /* 100 float4 = 1.6 KB per env */
 
 namespace rex {
 
@@ -42,6 +41,16 @@ constexpr float kMu = 0.5f;                // toe 0.5 x plane 1.0
 constexpr float kInitZ = 0.21f;            // terrain.py:14-20
 constexpr float kToeRad = (float)(REX_TOE_RADIUS + REX_COLLISION_MARGIN);
 constexpr float kToeHalf = (float)REX_TOE_HALFLEN;
+
+// LDS view of one workgroup.  EPW = envs per wave (compile-time power of two <= 64): lane l works on env
+// slot l & (EPW-1); lanes beyond EPW mirror a live lane (see rex_step_kernel).  Layout float4[chunk][slot]:
+// lanes of different slots hit consecutive 16 B -> conflict-free ds_read_b128.
+template <int EPW>
+struct Lds {
+  float4* p; int slot;
+  __device__ __forceinline__ float4& row(int r, int c) const { return p[(r * REX_ROW_F4 + c) * EPW + slot]; }
+  __device__ __forceinline__ float4& leg(int l, int c) const { return p[(REX_NROW * REX_ROW_F4 + l * REX_LEG_F4 + c) * EPW + slot]; }
+};
 
 struct f3 { float x, y, z; };
 __device__ __forceinline__ f3 mk(float x, float y, float z) { return f3{x, y, z}; }
@@ -159,21 +168,21 @@ struct LegFactor {
   float z[3];              // whitened predicted velocity of the leg
 };
 // the part of LegFactor that is only needed again after the constraint solve is parked in LDS
-__device__ __forceinline__ float4& leg_chunk(float4* lds, int leg, int c, int lane) {
-  return lds[REX_LDS_ROW_F4 + (leg * REX_LEG_F4 + c) * REX_WAVE + lane];
+
+template <class SM>
+__device__ __forceinline__ void leg_park(const SM& sm, int leg, const LegFactor& L) {
+  sm.leg(leg, 0) = make_float4(L.Bw[0][0], L.Bw[0][1], L.Bw[0][2], L.Bw[0][3]);
+  sm.leg(leg, 1) = make_float4(L.Bw[0][4], L.Bw[0][5], L.Bw[1][0], L.Bw[1][1]);
+  sm.leg(leg, 2) = make_float4(L.Bw[1][2], L.Bw[1][3], L.Bw[1][4], L.Bw[1][5]);
+  sm.leg(leg, 3) = make_float4(L.Bw[2][0], L.Bw[2][1], L.Bw[2][2], L.Bw[2][3]);
+  sm.leg(leg, 4) = make_float4(L.Bw[2][4], L.Bw[2][5], L.gi1, L.gi2);
+  sm.leg(leg, 5) = make_float4(L.gi3, L.g21, L.g31, L.g32);
+  sm.leg(leg, 6) = make_float4(L.z[0], L.z[1], L.z[2], 0.0f);
 }
-__device__ __forceinline__ void leg_park(float4* lds, int leg, int lane, const LegFactor& L) {
-  leg_chunk(lds, leg, 0, lane) = make_float4(L.Bw[0][0], L.Bw[0][1], L.Bw[0][2], L.Bw[0][3]);
-  leg_chunk(lds, leg, 1, lane) = make_float4(L.Bw[0][4], L.Bw[0][5], L.Bw[1][0], L.Bw[1][1]);
-  leg_chunk(lds, leg, 2, lane) = make_float4(L.Bw[1][2], L.Bw[1][3], L.Bw[1][4], L.Bw[1][5]);
-  leg_chunk(lds, leg, 3, lane) = make_float4(L.Bw[2][0], L.Bw[2][1], L.Bw[2][2], L.Bw[2][3]);
-  leg_chunk(lds, leg, 4, lane) = make_float4(L.Bw[2][4], L.Bw[2][5], L.gi1, L.gi2);
-  leg_chunk(lds, leg, 5, lane) = make_float4(L.gi3, L.g21, L.g31, L.g32);
-  leg_chunk(lds, leg, 6, lane) = make_float4(L.z[0], L.z[1], L.z[2], 0.0f);
-}
-__device__ __forceinline__ void leg_unpark(float4* lds, int leg, int lane, LegFactor& L) {
-  const float4 a = leg_chunk(lds, leg, 0, lane), b = leg_chunk(lds, leg, 1, lane), c = leg_chunk(lds, leg, 2, lane);
-  const float4 d = leg_chunk(lds, leg, 3, lane), e = leg_chunk(lds, leg, 4, lane), f = leg_chunk(lds, leg, 5, lane);
+template <class SM>
+__device__ __forceinline__ void leg_unpark(const SM& sm, int leg, LegFactor& L) {
+  const float4 a = sm.leg(leg, 0), b = sm.leg(leg, 1), c = sm.leg(leg, 2);
+  const float4 d = sm.leg(leg, 3), e = sm.leg(leg, 4), f = sm.leg(leg, 5);
   L.Bw[0][0] = a.x; L.Bw[0][1] = a.y; L.Bw[0][2] = a.z; L.Bw[0][3] = a.w; L.Bw[0][4] = b.x; L.Bw[0][5] = b.y;
   L.Bw[1][0] = b.z; L.Bw[1][1] = b.w; L.Bw[1][2] = c.x; L.Bw[1][3] = c.y; L.Bw[1][4] = c.z; L.Bw[1][5] = c.w;
   L.Bw[2][0] = d.x; L.Bw[2][1] = d.y; L.Bw[2][2] = d.z; L.Bw[2][3] = d.w; L.Bw[2][4] = e.x; L.Bw[2][5] = e.y;
@@ -192,19 +201,17 @@ struct BaseAccum {
 
 __device__ __forceinline__ int tri(int i, int j) { return i * (i + 1) / 2 + j; }
 
-// LDS row store: row r, float4 chunk c, lane l  ->  ((r*3 + c)*64 + l) float4
-__device__ __forceinline__ float4& row_chunk(float4* lds, int r, int c, int lane) {
-  return lds[(r * REX_ROW_F4 + c) * REX_WAVE + lane];
-}
+
 
 // One leg: forward kinematics, Newton-Euler bias, composite inertia, leg Cholesky, Schur
 // contributions to the base, and the (unwhitened in the base part) contact rows of its toe.
 // `leg` is a run-time index: the four legs share ONE copy of this code (the caller's leg loop is kept
 // rolled so that a substep's instruction stream stays inside the instruction cache); only the mirror
 // signs of the hip offsets differ between legs.
+template <class SM>
 __device__ __forceinline__ void leg_pass(int leg, const BaseKin& bk, const float* __restrict__ q, const float* __restrict__ qd,
                                          const float* __restrict__ tau, float dt, LegFactor& L, BaseAccum& acc,
-                                         float4* lds, int lane, unsigned& active_mask, const Ground& ground) {
+                                         const SM& sm, unsigned& active_mask, const Ground& ground) {
   static_assert(REX_LEG_SX[0] == -1 && REX_LEG_SX[1] == -1 && REX_LEG_SX[2] == 1 && REX_LEG_SX[3] == 1, "leg mirror table");
   static_assert(REX_LEG_SY[0] == -1 && REX_LEG_SY[1] == 1 && REX_LEG_SY[2] == -1 && REX_LEG_SY[3] == 1, "leg mirror table");
   const float SX = leg < 2 ? -1.0f : 1.0f, SY = (leg & 1) ? 1.0f : -1.0f;
@@ -375,9 +382,9 @@ __device__ __forceinline__ void leg_pass(int leg, const BaseKin& bk, const float
       float target = 0.0f;
       if (d == 0) target = dist > 0.0f ? -dist / dt : -dist * (kErp / dt);
       const int r = d == 0 ? p : (REX_NPOINT + 2 * p + (d - 1));
-      row_chunk(lds, r, 0, lane) = make_float4(g[0], g[1], g[2], g[3]);
-      row_chunk(lds, r, 1, lane) = make_float4(g[4], g[5], j1, j2);
-      row_chunk(lds, r, 2, lane) = make_float4(j3, target, act ? 1.0f : 0.0f, 0.0f);
+      sm.row(r, 0) = make_float4(g[0], g[1], g[2], g[3]);
+      sm.row(r, 1) = make_float4(g[4], g[5], j1, j2);
+      sm.row(r, 2) = make_float4(j3, target, act ? 1.0f : 0.0f, 0.0f);
     }
   };
   if (ground.h == nullptr) {   // flat plane: constant frame, the compiler folds the crosses
@@ -507,17 +514,17 @@ __device__ __forceinline__ void pgs_row(const float4 c0, const float4 c1, const 
   x.z2[LEG] = fmaf(c2.x, dl, x.z2[LEG]);
 }
 
-template <int LEG>
-__device__ __forceinline__ void pgs_leg_normals(float4* lds, int lane, PgsX& x, float* lam, float& worst) {
+template <int LEG, class SM>
+__device__ __forceinline__ void pgs_leg_normals(const SM& sm, PgsX& x, float* lam, float& worst) {
   const int p0 = 2 * LEG, p1 = 2 * LEG + 1;
-  const float4 a0 = row_chunk(lds, p0, 0, lane), a1 = row_chunk(lds, p0, 1, lane), a2 = row_chunk(lds, p0, 2, lane);
-  const float4 b0 = row_chunk(lds, p1, 0, lane), b1 = row_chunk(lds, p1, 1, lane), b2 = row_chunk(lds, p1, 2, lane);
+  const float4 a0 = sm.row(p0, 0), a1 = sm.row(p0, 1), a2 = sm.row(p0, 2);
+  const float4 b0 = sm.row(p1, 0), b1 = sm.row(p1, 1), b2 = sm.row(p1, 2);
   pgs_row<LEG, false>(a0, a1, a2, x, lam[p0], 0.0f, worst);
   pgs_row<LEG, false>(b0, b1, b2, x, lam[p1], 0.0f, worst);
 }
 
-template <int LEG>
-__device__ __forceinline__ void pgs_leg_friction(float4* lds, int lane, PgsX& x, float* lam, float& worst) {
+template <int LEG, class SM>
+__device__ __forceinline__ void pgs_leg_friction(const SM& sm, PgsX& x, float* lam, float& worst) {
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
     const int p = 2 * LEG + e;
@@ -526,8 +533,8 @@ __device__ __forceinline__ void pgs_leg_friction(float4* lds, int lane, PgsX& x,
     // a point that carries no normal impulse (and no friction impulse left from an earlier sweep) in ANY
     // lane can only produce zero friction steps this sweep: skip its two rows for the wavefront (exact)
     if (__builtin_amdgcn_ballot_w64(lim > 0.0f || lam[r0] != 0.0f || lam[r1] != 0.0f) == 0) continue;
-    const float4 a0 = row_chunk(lds, r0, 0, lane), a1 = row_chunk(lds, r0, 1, lane), a2 = row_chunk(lds, r0, 2, lane);
-    const float4 b0 = row_chunk(lds, r1, 0, lane), b1 = row_chunk(lds, r1, 1, lane), b2 = row_chunk(lds, r1, 2, lane);
+    const float4 a0 = sm.row(r0, 0), a1 = sm.row(r0, 1), a2 = sm.row(r0, 2);
+    const float4 b0 = sm.row(r1, 0), b1 = sm.row(r1, 1), b2 = sm.row(r1, 2);
     pgs_row<LEG, true>(a0, a1, a2, x, lam[r0], lim, worst);
     pgs_row<LEG, true>(b0, b1, b2, x, lam[r1], lim, worst);
   }
@@ -542,8 +549,9 @@ __device__ __forceinline__ void rotate_leg(T* a) {   // 12-entry per-joint array
   a[9] = t0; a[10] = t1; a[11] = t2;
 }
 
+template <class SM>
 __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float dt, int iterations,
-                                                float sqrt_res_thr, float4* lds, int lane, const Ground& ground) {
+                                                float sqrt_res_thr, const SM& sm, const Ground& ground) {
   // base rotation (btMatrix3x3::setRotation)
   BaseKin bk;
   {
@@ -583,13 +591,13 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
     // the current leg always sits in slots 0..2: q / qd / tau are rotated by one leg per iteration,
     // which keeps every register index static inside the rolled loop
     LegFactor L;
-    leg_pass(leg, bk, s.q, s.qd, tau, dt, L, acc, lds, lane, active, ground);
-    leg_park(lds, leg, lane, L);
+    leg_pass(leg, bk, s.q, s.qd, tau, dt, L, acc, sm, active, ground);
+    leg_park(sm, leg, L);
     rotate_leg(s.q); rotate_leg(s.qd); rotate_leg(tau);
   }
 #pragma unroll
   for (int k = 0; k < REX_NLEG; ++k) {
-    const float4 zc = leg_chunk(lds, k, 6, lane);
+    const float4 zc = sm.leg(k, 6);
     x.z01[k] = v2{zc.x, zc.y}; x.z2[k] = zc.z;
   }
 
@@ -627,16 +635,16 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
 
   // finish the rows: whiten the base part, inverse diagonal (0 disables an inactive point)
   for (int r = 0; r < REX_NROW; ++r) {
-    float4 c0 = row_chunk(lds, r, 0, lane), c1 = row_chunk(lds, r, 1, lane), c2 = row_chunk(lds, r, 2, lane);
+    float4 c0 = sm.row(r, 0), c1 = sm.row(r, 1), c2 = sm.row(r, 2);
     const float g[6] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y};
     float gw[6];
     fwd6(Lc, g, gw);
     const float diag = gw[0] * gw[0] + gw[1] * gw[1] + gw[2] * gw[2] + gw[3] * gw[3] + gw[4] * gw[4] + gw[5] * gw[5] +
                        c1.z * c1.z + c1.w * c1.w + c2.x * c2.x;
     const float invd = c2.z != 0.0f ? __builtin_amdgcn_rcpf(diag) : 0.0f;
-    row_chunk(lds, r, 0, lane) = make_float4(gw[0], gw[1], gw[2], gw[3]);
-    row_chunk(lds, r, 1, lane) = make_float4(gw[4], gw[5], c1.z, c1.w);
-    row_chunk(lds, r, 2, lane) = make_float4(c2.x, c2.y * invd, invd, diag);
+    sm.row(r, 0) = make_float4(gw[0], gw[1], gw[2], gw[3]);
+    sm.row(r, 1) = make_float4(gw[4], gw[5], c1.z, c1.w);
+    sm.row(r, 2) = make_float4(c2.x, c2.y * invd, invd, diag);
   }
 
   // projected Gauss-Seidel in Bullet's order: all normals, then all friction rows; a point that no
@@ -657,14 +665,14 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
   for (int it = 0; it < iterations; ++it) {
     if (running) {
       float worst = 0.0f;
-      if (any0) pgs_leg_normals<0>(lds, lane, x, lam, worst);
-      if (any1) pgs_leg_normals<1>(lds, lane, x, lam, worst);
-      if (any2) pgs_leg_normals<2>(lds, lane, x, lam, worst);
-      if (any3) pgs_leg_normals<3>(lds, lane, x, lam, worst);
-      if (any0) pgs_leg_friction<0>(lds, lane, x, lam, worst);
-      if (any1) pgs_leg_friction<1>(lds, lane, x, lam, worst);
-      if (any2) pgs_leg_friction<2>(lds, lane, x, lam, worst);
-      if (any3) pgs_leg_friction<3>(lds, lane, x, lam, worst);
+      if (any0) pgs_leg_normals<0>(sm, x, lam, worst);
+      if (any1) pgs_leg_normals<1>(sm, x, lam, worst);
+      if (any2) pgs_leg_normals<2>(sm, x, lam, worst);
+      if (any3) pgs_leg_normals<3>(sm, x, lam, worst);
+      if (any0) pgs_leg_friction<0>(sm, x, lam, worst);
+      if (any1) pgs_leg_friction<1>(sm, x, lam, worst);
+      if (any2) pgs_leg_friction<2>(sm, x, lam, worst);
+      if (any3) pgs_leg_friction<3>(sm, x, lam, worst);
       running = worst > sqrt_res_thr;
     }
     if (__builtin_amdgcn_ballot_w64(running) == 0) break;
@@ -680,7 +688,7 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
 #pragma unroll 1
   for (int leg = 0; leg < REX_NLEG; ++leg) {
     LegFactor L;
-    leg_unpark(lds, leg, lane, L);
+    leg_unpark(sm, leg, L);
     float t1 = zt[0], t2 = zt[1], t3 = zt[2];
 #pragma unroll
     for (int k = 0; k < 6; ++k) { t1 -= L.Bw[0][k] * nu[k]; t2 -= L.Bw[1][k] * nu[k]; t3 -= L.Bw[2][k] * nu[k]; }

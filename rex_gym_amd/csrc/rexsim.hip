@@ -14,6 +14,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <math.h>
+#include <stdlib.h>
 
 #include "rex_device.h"
 #include "rex_controller.h"
@@ -157,7 +158,8 @@ __device__ __forceinline__ Ground env_ground(const DevCfg& c, int gidx, int epis
 }
 
 // Rex.ApplyAction + stepSimulation + ReceiveObservation (rex.py:158-163, 568-641)
-__device__ __forceinline__ void rex_substep(const DevCfg& c, EnvState& e, const float* cmd, float* tau_obs, float4* lds, int lane,
+template <class SM>
+__device__ __forceinline__ void rex_substep(const DevCfg& c, EnvState& e, const float* cmd, float* tau_obs, const SM& sm,
                                             const Ground& ground) {
   float tau[12];
   const float limit = 1.0f / c.dt;  // OVERHEAT_SHUTDOWN_TIME / time_step, rex.py:607
@@ -172,7 +174,7 @@ __device__ __forceinline__ void rex_substep(const DevCfg& c, EnvState& e, const 
     tau_obs[j] = obs;
     tau[j] = ((e.motor_en >> j) & 1u) ? act : 0.0f;                             // rex.py:617-623
   }
-  physics_substep(e.ph, tau, c.dt, c.iterations, c.res_thr, lds, lane, ground);
+  physics_substep(e.ph, tau, c.dt, c.iterations, c.res_thr, sm, ground);
 }
 
 // RangeNormalize of the observation (wrappers.py:236-240); bounds are symmetric (rex_gym_env.py:277-278)
@@ -392,15 +394,22 @@ __device__ __forceinline__ void turn_command(const DevCfg& c, EnvState& e, const
 }
 
 // ------------------------------------------------------------------------------------------
+template <int EPW>
 __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __restrict__ state, const float* __restrict__ snap,
                                                             const float* __restrict__ action, float* __restrict__ obs_out,
                                                             float* __restrict__ reward_out, uint8_t* __restrict__ done_out,
                                                             float* __restrict__ cmd_out) {
-  __shared__ float4 lds[REX_LDS_FLOATS / 4];
+  // EPW envs share this wave (host picks it, rex_step): a small batch is spread over MORE, emptier waves because
+  // idle SIMDs are free and a wave leaves the PGS sweep loop only when its slowest env has converged (and skips
+  // only the legs no env of the wave has in contact), so fewer envs per wave means fewer sweeps and rows per
+  // wave.  Lanes >= EPW mirror lane (lane mod EPW): same env, same arithmetic, no stores.
+  __shared__ float4 lds[REX_LDS_F4_PER_ENV * EPW];
   const int lane = threadIdx.x;
-  const int gi = blockIdx.x * REX_WAVE + lane;
-  const bool live = gi < c.n;
-  const int i = live ? gi : c.n - 1;   // tail lanes shadow the last env (keeps the wave convergent)
+  const int slot = lane & (EPW - 1);
+  const int gi = blockIdx.x * EPW + slot;
+  const bool live = lane < EPW && gi < c.n;
+  const int i = gi < c.n ? gi : c.n - 1;   // tail slots shadow the last env (keeps the wave convergent)
+  const Lds<EPW> sm{lds, slot};
 
   EnvState e;
   load_env(state, c.n, i, e);
@@ -423,7 +432,7 @@ __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __r
 
   float tau_obs[12];
   const Ground ground = env_ground(c, c.env_index_base + i, e.episode);
-  for (int k = 0; k < c.action_repeat; ++k) rex_substep(c, e, cmd, tau_obs, lds, lane, ground);   // Rex.Step
+  for (int k = 0; k < c.action_repeat; ++k) rex_substep(c, e, cmd, tau_obs, sm, ground);   // Rex.Step
 
   // ---- reward (rex_gym_env.py:501-542) ----
   float rpy[3], r20, r21, r22;
@@ -477,8 +486,9 @@ __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __r
 // The reset motion of Rex.Reset (rex.py:296-324).  Plane: ONE robot, lane 0 writes the snapshot.  Terrain pool:
 // lane t settles on terrain t and writes snapshot record t (word-major [53][n_terrain]).
 __global__ __launch_bounds__(REX_WAVE) void rex_settle_kernel(DevCfg c, float* __restrict__ snap) {
-  __shared__ float4 lds[REX_LDS_FLOATS / 4];
+  __shared__ float4 lds[REX_LDS_F4_PER_ENV * REX_WAVE];
   const int lane = threadIdx.x;
+  const Lds<REX_WAVE> sm{lds, lane};
   const int nrec = c.n_terrain > 0 ? c.n_terrain : 1;
   const int rec = blockIdx.x * REX_WAVE + lane;
   const int t = rec < nrec ? rec : nrec - 1;
@@ -495,11 +505,11 @@ __global__ __launch_bounds__(REX_WAVE) void rex_settle_kernel(DevCfg c, float* _
     float cmd[12], tau_obs[12];
 #pragma unroll
     for (int j = 0; j < 12; ++j) cmd[j] = pose_stand(j);
-    for (int k = 0; k < 100; ++k) rex_substep(c, e, cmd, tau_obs, lds, lane, ground);   // rex.py:315-318
+    for (int k = 0; k < 100; ++k) rex_substep(c, e, cmd, tau_obs, sm, ground);   // rex.py:315-318
 #pragma unroll
     for (int j = 0; j < 12; ++j) cmd[j] = init_pose(c, j);
     const int nreset = (int)(0.5f / c.dt);                                               // rex.py:319
-    for (int k = 0; k < nreset; ++k) rex_substep(c, e, cmd, tau_obs, lds, lane, ground);
+    for (int k = 0; k < nreset; ++k) rex_substep(c, e, cmd, tau_obs, sm, ground);
   }
   if (rec < nrec) store_env(snap, nrec, rec, e);
 }
@@ -562,6 +572,7 @@ __global__ void rex_gait_kernel(int n, int mode, float* __restrict__ planner, co
 struct RexSim {
   RexConfig cfg;
   rex::DevCfg dev;
+  int epw;          // envs per wave of rex_step_kernel
   int device;
   float* d_state;   // caller-owned
   float* d_snap;    // REX_STATE_WORDS x (n_terrain or 1) floats, word-major
@@ -627,6 +638,17 @@ int rex_obs_dim(const RexConfig* c) {
   return c->task == REX_TASK_GALLOP ? 16 : 4;                                    /* gallop_env.py:349-356 */
 }
 
+// Envs per wave.  Up to 16 384 envs the launch is latency-bound with idle SIMDs (256 CUs x 4 SIMDs = 1 024), so the
+// batch is spread over up to 1 024 waves (one per SIMD) of 4 / 16 envs; beyond that, full 64-env waves give the best
+// throughput per issued instruction.  REX_ENVS_PER_WAVE overrides (4, 16 or 64).
+static int pick_envs_per_wave(int n) {
+  const char* ov = getenv("REX_ENVS_PER_WAVE");
+  if (ov) { int v = atoi(ov); if (v == 4 || v == 16 || v == 64) return v; }
+  if (n <= 4096) return 4;
+  if (n <= 16384) return 16;
+  return 64;
+}
+
 static int validate(const RexConfig* c) {
   if (!c) return fail(REX_EINVAL, "null config%s", "");
   if (c->abi_version != REX_ABI_VERSION) return fail(REX_EINVAL, "RexConfig.abi_version mismatch%s", "");
@@ -659,6 +681,7 @@ int rex_create(const RexConfig* cfg, int device, float* d_state, void* stream, R
   d.auto_reset = cfg->auto_reset; d.max_steps = cfg->max_episode_steps;
   d.w_dist = cfg->distance_weight; d.w_energy = cfg->energy_weight; d.w_drift = cfg->drift_weight; d.w_shake = cfg->shake_weight;
   d.action_dim = rex_action_dim(cfg); d.obs_dim = rex_obs_dim(cfg);
+  s->epw = pick_envs_per_wave(cfg->num_envs);
   d.pose_index = cfg->pose_index; d.pose_value = cfg->pose_value;
   d.range_normalize = cfg->range_normalize;
   d.terrain = nullptr; d.terrain_mid = nullptr; d.n_terrain = 0;
@@ -736,10 +759,17 @@ int rex_step(RexSim* s, const float* d_action, float* d_obs, float* d_reward, ui
   if (!s || !d_action || !d_obs || !d_reward || !d_done) return fail(REX_EINVAL, "rex_step: null pointer%s", "");
   HIPCHK(hipSetDevice(s->device));
   hipStream_t st = (hipStream_t)stream;
-  const int blocks = (s->cfg.num_envs + REX_WAVE - 1) / REX_WAVE;
+  const int blocks = (s->cfg.num_envs + s->epw - 1) / s->epw;
   if (s->timing) HIPCHK(hipEventRecord(s->ev0, st));
-  hipLaunchKernelGGL(rex::rex_step_kernel, dim3(blocks), dim3(REX_WAVE), 0, st, s->dev, s->d_state, s->d_snap, d_action, d_obs,
-                     d_reward, d_done, d_motor_cmd);
+  if (s->epw == 4)
+    hipLaunchKernelGGL(rex::rex_step_kernel<4>, dim3(blocks), dim3(REX_WAVE), 0, st, s->dev, s->d_state, s->d_snap, d_action, d_obs,
+                       d_reward, d_done, d_motor_cmd);
+  else if (s->epw == 16)
+    hipLaunchKernelGGL(rex::rex_step_kernel<16>, dim3(blocks), dim3(REX_WAVE), 0, st, s->dev, s->d_state, s->d_snap, d_action, d_obs,
+                       d_reward, d_done, d_motor_cmd);
+  else
+    hipLaunchKernelGGL(rex::rex_step_kernel<64>, dim3(blocks), dim3(REX_WAVE), 0, st, s->dev, s->d_state, s->d_snap, d_action, d_obs,
+                       d_reward, d_done, d_motor_cmd);
   HIPCHK(hipGetLastError());
   if (s->timing) { HIPCHK(hipEventRecord(s->ev1, st)); s->have_timing = 1; }
   return REX_OK;
