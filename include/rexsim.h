@@ -148,6 +148,13 @@ REX_API int rex_destroy(RexSim* sim);
  * field (one settled snapshot each).  k = 0 returns to the flat plane.  Call before rex_reset. */
 REX_API int rex_set_terrain(RexSim* sim, const float* d_heights, const float* d_mids, int k, void* stream);
 
+/* Domain randomisation hooks (the knobs an env_randomizer turns: Rex.SetBaseMasses / SetLegMasses, model/rex.py:659-692;
+ * the reference has no friction setter).  d_params: caller-owned device array [3][num_envs], word-major:
+ * base-link mass scale, leg-link mass scale, foot friction coefficient; read on every step (so the caller may rewrite
+ * entries when it resets envs).  As in Bullet's changeDynamics(mass=...), only masses change: the inertia tensors stay
+ * the ones computed at load.  NULL restores (1, 1, 0.5). */
+REX_API int rex_set_body_params(RexSim* sim, const float* d_params);
+
 /* Reset envs. d_indices == NULL: all envs. Else n int32 env indices (device).  Writes the first
  * observation of each reset env to d_obs[row * obs_dim] where row = position in d_indices (or the
  * env index when d_indices is NULL).  Mirrors RexWalkEnv.reset (walk_env.py:125-154). */

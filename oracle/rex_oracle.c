@@ -327,9 +327,13 @@ static void matTvec3(const real R[3][3], const real v[3], real o[3]) {
   for (int i = 0; i < 3; ++i) o[i] = R[0][i] * v[0] + R[1][i] * v[1] + R[2][i] * v[2];
 }
 
+/* domain randomisation of the current substep (Rex.SetBaseMasses / SetLegMasses change masses only) */
+static __thread real MASS_SCALE_BASE = 1, MASS_SCALE_LEG = 1;
+static real body_mass(int i) { return (real)REX_MASS[i] * (i == 0 ? MASS_SCALE_BASE : MASS_SCALE_LEG); }
+
 /* spatial inertia of body i about its own origin, body axes */
 static void body_inertia6(int i, real I[6][6]) {
-  real m = (real)REX_MASS[i];
+  real m = body_mass(i);
   real c[3] = {(real)REX_COM[i][0], (real)REX_COM[i][1], (real)REX_COM[i][2]};
   real Ic[3][3] = {{(real)REX_INERTIA[i][0], (real)REX_INERTIA[i][3], (real)REX_INERTIA[i][4]},
                    {(real)REX_INERTIA[i][3], (real)REX_INERTIA[i][1], (real)REX_INERTIA[i][5]},
@@ -367,7 +371,7 @@ static void mat6Tvec(const real M[6][6], const real v[6], real o[6]) {
 
 /* Bullet's per-link damping, expressed as a bias force (force needed for zero acceleration) */
 static void add_damping(int i, const real v[6], real pA[6]) {
-  real m = (real)REX_MASS[i];
+  real m = body_mass(i);
   real c[3] = {(real)REX_COM[i][0], (real)REX_COM[i][1], (real)REX_COM[i][2]};
   real wxc[3], vc[3];
   cross3(v, c, wxc);
@@ -525,7 +529,7 @@ static void impulse_response_at(const Aba* A, int kbody, const real fk[6], real 
  * Cell triangulation: Bullet's default (diagonal from vertex (i,j+1) to (i+1,j)). ---- */
 #define HF_N 256
 #define HF_CELL ((real)0.05)
-typedef struct { const float* h; real mid; } Ground;
+typedef struct { const float* h; real mid; real base_mass_scale, leg_mass_scale, mu; int has_params; } Ground;
 
 static void ground_query(const Ground* g, real x, real y, real* height, real n[3]) {
   n[0] = 0; n[1] = 0; n[2] = 1; *height = 0;
@@ -590,6 +594,9 @@ static void contact_jacobian(const Aba* A, int kbody, const real P[3], const rea
 static void physics_substep(Phys* s, const real tau[NJ], real dt, int iterations, real residual_threshold, const Ground* ground) {
   static __thread Aba A;
   real qdd[NJ], wdot[3], vdot[3];
+  real mu = FRICTION_MU;
+  MASS_SCALE_BASE = 1; MASS_SCALE_LEG = 1;
+  if (ground && ground->has_params) { MASS_SCALE_BASE = ground->base_mass_scale; MASS_SCALE_LEG = ground->leg_mass_scale; mu = ground->mu; }
   aba_forward(s, tau, &A, qdd, wdot, vdot);
   /* v <- v + dt a  (btMultiBodyDynamicsWorld::solveConstraints, before the constraint solve) */
   for (int k = 0; k < 3; ++k) { s->angvel[k] += dt * wdot[k]; s->linvel[k] += dt * vdot[k]; }
@@ -679,7 +686,7 @@ static void physics_substep(Phys* s, const real tau[NJ], real dt, int iterations
     for (int i = 0; i < nrow; ++i) {
       Row* r = &rows[i];
       real lo = r->lo, hi = r->hi;
-      if (r->normal_row >= 0) { hi = FRICTION_MU * rows[r->normal_row].lambda; lo = -hi; }
+      if (r->normal_row >= 0) { hi = mu * rows[r->normal_row].lambda; lo = -hi; }
       real dvel = 0;
       for (int k = 0; k < NDOF; ++k) dvel += r->J[k] * dv[k];
       real dl = r->rhs - dvel * r->invdiag;
@@ -769,6 +776,7 @@ typedef struct {
   float* heights; /* [K][256*256] */
   float* mids;    /* [K] */
   Env* terrain_snapshot;
+  float* body_params; /* [3][N] or NULL */
 } Orc;
 
 /* terrain of (global env index, episode): the reference regenerates the field on every reset
@@ -778,7 +786,12 @@ static int terrain_index(const Orc* o, int idx, int episode) {
   return (int)(((uint32_t)(o->cfg.env_index_base + idx) + 977u * (uint32_t)episode) % (uint32_t)o->n_terrain);
 }
 static Ground env_ground(const Orc* o, int idx, int episode) {
-  Ground g = {0, 0};
+  Ground g = {0, 0, 1, 1, FRICTION_MU, 0};
+  if (o->body_params) {
+    int n = o->cfg.num_envs;
+    g.has_params = 1; g.base_mass_scale = (real)o->body_params[idx]; g.leg_mass_scale = (real)o->body_params[n + idx];
+    g.mu = (real)o->body_params[2 * n + idx];
+  }
   int t = terrain_index(o, idx, episode);
   if (t >= 0) { g.h = o->heights + (size_t)t * HF_N * HF_N; g.mid = (real)o->mids[t]; }
   return g;
@@ -1146,7 +1159,15 @@ ORC_API void* orc_create(const RexConfig* cfg) {
   settle(o, &o->snapshot, 0);
   return o;
 }
-ORC_API void orc_destroy(void* h) { Orc* o = (Orc*)h; free(o->envs); free(o->heights); free(o->mids); free(o->terrain_snapshot); free(o); }
+ORC_API void orc_set_body_params(void* h, const float* params) {
+  Orc* o = (Orc*)h;
+  free(o->body_params); o->body_params = 0;
+  if (params) {
+    o->body_params = (float*)malloc(sizeof(float) * 3 * (size_t)o->cfg.num_envs);
+    memcpy(o->body_params, params, sizeof(float) * 3 * (size_t)o->cfg.num_envs);
+  }
+}
+ORC_API void orc_destroy(void* h) { Orc* o = (Orc*)h; free(o->body_params); free(o->envs); free(o->heights); free(o->mids); free(o->terrain_snapshot); free(o); }
 
 /* terrain pool: heights [k][256*256] raw vertex heights (terrain.py:36-43 layout: data[i + j*rows], i along x),
  * mids [k] = (min+max)/2 of each field */
@@ -1163,7 +1184,7 @@ ORC_API void orc_set_terrain(void* h, const float* heights, const float* mids, i
 #pragma omp parallel for schedule(dynamic)
 #endif
   for (int t = 0; t < k; ++t) {
-    Ground g = {o->heights + (size_t)t * HF_N * HF_N, (real)o->mids[t]};
+    Ground g = {o->heights + (size_t)t * HF_N * HF_N, (real)o->mids[t], 1, 1, FRICTION_MU, 0};
     settle(o, &o->terrain_snapshot[t], &g);
   }
 }

@@ -42,6 +42,7 @@ _SIGS = {
     "rex_create": ([ctypes.POINTER(RexConfig), ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                     ctypes.POINTER(ctypes.c_void_p)], ctypes.c_int),
     "rex_destroy": ([ctypes.c_void_p], ctypes.c_int),
+    "rex_set_body_params": ([ctypes.c_void_p, ctypes.c_void_p], ctypes.c_int),
     "rex_set_terrain": ([ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
     "rex_reset": ([ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p], ctypes.c_int),
     "rex_step": ([ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,

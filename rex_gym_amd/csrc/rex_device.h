@@ -131,7 +131,12 @@ struct BaseKin {
 // 256 x 256 vertex heights, 5 cm cells, centred on the origin, shifted down by `mid` (Bullet centres a
 // heightfield on the middle of its height range) -- the plane shows wherever the field is
 // below 0.  Triangulation: Bullet's default diagonal (i,j+1)-(i+1,j).  h == nullptr: plane only.
-struct Ground { const float* h; float mid; };
+struct Ground {
+  const float* h; float mid;
+  // per-env domain randomisation (Rex.SetBaseMasses / SetLegMasses, rex.py:659-692: masses only -- Bullet keeps the
+  // inertia tensors computed at load time; plus the foot friction coefficient)
+  float base_mass_scale, leg_mass_scale, mu;
+};
 __device__ __forceinline__ void ground_query(const Ground& g, float x, float y, float& height, f3& n) {
   n = f3{0.f, 0.f, 1.f}; height = 0.0f;
   float fx = fminf(fmaxf(x / 0.05f + 127.5f, 0.0f), 254.999f), fy = fminf(fmaxf(y / 0.05f + 127.5f, 0.0f), 254.999f);
@@ -217,7 +222,8 @@ __device__ __forceinline__ void leg_pass(int leg, const BaseKin& bk, const float
   const float SX = leg < 2 ? -1.0f : 1.0f, SY = (leg & 1) ? 1.0f : -1.0f;
   const float HX = SX * (float)REX_HIP_X, HY = SY * (float)REX_HIP_Y, UY = SY * (float)REX_UPPER_Y;
   constexpr float KX = (float)REX_KNEE_X, KZ = (float)REX_KNEE_Z, CZ = (float)REX_LOWER_COM_Z, TZ = (float)REX_TOE_Z;
-  constexpr float M1 = (float)REX_SHOULDER_MASS, M2 = (float)REX_UPPER_MASS, M3 = (float)REX_LOWER_MASS;
+  const float M1 = (float)REX_SHOULDER_MASS * ground.leg_mass_scale, M2 = (float)REX_UPPER_MASS * ground.leg_mass_scale,
+              M3 = (float)REX_LOWER_MASS * ground.leg_mass_scale;
 
   const float q1 = q[0], q2 = q[1], q3 = q[2];
   const float qd1 = qd[0], qd2 = qd[1], qd3 = qd[2];
@@ -295,7 +301,7 @@ __device__ __forceinline__ void leg_pass(int leg, const BaseKin& bk, const float
   const f3 h2 = h3 + M2 * o2;
   s33 Io1 = I1; add_point(Io1, M1, o1); add(Io1, Io2);
   const f3 h1 = h2 + M1 * o1;
-  constexpr float m3c = M3, m2c = M3 + M2, m1c = M3 + M2 + M1;
+  const float m3c = M3, m2c = M3 + M2, m1c = M3 + M2 + M1;
   add(acc.Io, Io1);
   acc.h = acc.h + h1;
   acc.m += m1c;
@@ -524,11 +530,11 @@ __device__ __forceinline__ void pgs_leg_normals(const SM& sm, PgsX& x, float* la
 }
 
 template <int LEG, class SM>
-__device__ __forceinline__ void pgs_leg_friction(const SM& sm, PgsX& x, float* lam, float& worst) {
+__device__ __forceinline__ void pgs_leg_friction(const SM& sm, PgsX& x, float* lam, float& worst, float mu) {
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
     const int p = 2 * LEG + e;
-    const float lim = kMu * lam[p];
+    const float lim = mu * lam[p];
     const int r0 = REX_NPOINT + 2 * p, r1 = r0 + 1;
     // a point that carries no normal impulse (and no friction impulse left from an earlier sweep) in ANY
     // lane can only produce zero friction steps this sweep: skip its two rows for the wavefront (exact)
@@ -571,7 +577,8 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
   BaseAccum acc;
   acc.Io = rot_inertia(bk.ex, bk.ey, bk.ez, (float)REX_BASE_IXX, (float)REX_BASE_IYY, (float)REX_BASE_IZZ);
   acc.h = mk(0.f, 0.f, 0.f);
-  acc.m = (float)REX_BASE_MASS;
+  const float mbase = (float)REX_BASE_MASS * ground.base_mass_scale;
+  acc.m = mbase;
 #pragma unroll
   for (int k = 0; k < 21; ++k) acc.S[k] = 0.0f;
 #pragma unroll
@@ -581,7 +588,7 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
     const float dl = kLinDamp + kLinDamp * sqrtf(dot(bk.v, bk.v));
     const float da = kAngDamp + kAngDamp * sqrtf(dot(bk.w, bk.w));
     acc.N = cross(bk.w, Iw) + da * Iw;
-    acc.F = mk(0.f, 0.f, (float)REX_BASE_MASS * kGravity) + ((float)REX_BASE_MASS * dl) * bk.v;
+    acc.F = mk(0.f, 0.f, mbase * kGravity) + (mbase * dl) * bk.v;
   }
 
   unsigned active = 0;
@@ -669,10 +676,10 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
       if (any1) pgs_leg_normals<1>(sm, x, lam, worst);
       if (any2) pgs_leg_normals<2>(sm, x, lam, worst);
       if (any3) pgs_leg_normals<3>(sm, x, lam, worst);
-      if (any0) pgs_leg_friction<0>(sm, x, lam, worst);
-      if (any1) pgs_leg_friction<1>(sm, x, lam, worst);
-      if (any2) pgs_leg_friction<2>(sm, x, lam, worst);
-      if (any3) pgs_leg_friction<3>(sm, x, lam, worst);
+      if (any0) pgs_leg_friction<0>(sm, x, lam, worst, ground.mu);
+      if (any1) pgs_leg_friction<1>(sm, x, lam, worst, ground.mu);
+      if (any2) pgs_leg_friction<2>(sm, x, lam, worst, ground.mu);
+      if (any3) pgs_leg_friction<3>(sm, x, lam, worst, ground.mu);
       running = worst > sqrt_res_thr;
     }
     if (__builtin_amdgcn_ballot_w64(running) == 0) break;

@@ -136,6 +136,7 @@ struct DevCfg {
   const float* terrain;      // [n_terrain][256*256] raw vertex heights (nullptr: plane only)
   const float* terrain_mid;  // [n_terrain]
   int32_t n_terrain;
+  const float* body_params;  // [3][n] word-major: base mass scale, leg mass scale, foot friction (nullptr: 1, 1, 0.5)
   float act_lo, act_hi;      // Box bounds of the env's action space (host: rex_create)
   float obs_hi_ang, obs_hi_rate;
 };
@@ -147,8 +148,11 @@ __device__ __forceinline__ float init_pose(const DevCfg& c, int j) { return c.si
 __device__ __forceinline__ int terrain_index(const DevCfg& c, int gidx, int episode) {
   return (int)(((uint32_t)gidx + 977u * (uint32_t)episode) % (uint32_t)c.n_terrain);
 }
-__device__ __forceinline__ Ground env_ground(const DevCfg& c, int gidx, int episode) {
-  Ground g{nullptr, 0.0f};
+__device__ __forceinline__ Ground env_ground(const DevCfg& c, int i, int gidx, int episode) {
+  Ground g{nullptr, 0.0f, 1.0f, 1.0f, kMu};
+  if (c.body_params) {
+    g.base_mass_scale = c.body_params[i]; g.leg_mass_scale = c.body_params[(size_t)c.n + i]; g.mu = c.body_params[2 * (size_t)c.n + i];
+  }
   if (c.n_terrain > 0) {
     const int t = terrain_index(c, gidx, episode);
     g.h = c.terrain + (size_t)t * 65536;
@@ -431,7 +435,7 @@ __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __r
   else walk_command(c, e, act, cmd);
 
   float tau_obs[12];
-  const Ground ground = env_ground(c, c.env_index_base + i, e.episode);
+  const Ground ground = env_ground(c, i, c.env_index_base + i, e.episode);
   for (int k = 0; k < c.action_repeat; ++k) rex_substep(c, e, cmd, tau_obs, sm, ground);   // Rex.Step
 
   // ---- reward (rex_gym_env.py:501-542) ----
@@ -492,7 +496,7 @@ __global__ __launch_bounds__(REX_WAVE) void rex_settle_kernel(DevCfg c, float* _
   const int nrec = c.n_terrain > 0 ? c.n_terrain : 1;
   const int rec = blockIdx.x * REX_WAVE + lane;
   const int t = rec < nrec ? rec : nrec - 1;
-  Ground ground{nullptr, 0.0f};
+  Ground ground{nullptr, 0.0f, 1.0f, 1.0f, kMu};
   if (c.n_terrain > 0) { ground.h = c.terrain + (size_t)t * 65536; ground.mid = c.terrain_mid[t]; }
   EnvState e;
   memset(&e, 0, sizeof(e));
@@ -684,7 +688,7 @@ int rex_create(const RexConfig* cfg, int device, float* d_state, void* stream, R
   s->epw = pick_envs_per_wave(cfg->num_envs);
   d.pose_index = cfg->pose_index; d.pose_value = cfg->pose_value;
   d.range_normalize = cfg->range_normalize;
-  d.terrain = nullptr; d.terrain_mid = nullptr; d.n_terrain = 0;
+  d.terrain = nullptr; d.terrain_mid = nullptr; d.n_terrain = 0; d.body_params = nullptr;
   {
     float b;   /* walk_env.py:104-114, gallop_env.py:119-130 (low=+b, high=-b), turn_env.py:100-110, poses_env.py:115-117 */
     if (cfg->task == REX_TASK_WALK) b = cfg->signal == REX_SIGNAL_IK ? 0.4f : 0.01f;
@@ -730,6 +734,12 @@ int rex_set_terrain(RexSim* s, const float* d_heights, const float* d_mids, int 
   hipLaunchKernelGGL(rex::rex_settle_kernel, dim3((nrec + REX_WAVE - 1) / REX_WAVE), dim3(REX_WAVE), 0, st, s->dev, s->d_snap);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(st));
+  return REX_OK;
+}
+
+int rex_set_body_params(RexSim* s, const float* d_params) {
+  if (!s) return fail(REX_EINVAL, "rex_set_body_params: null sim%s", "");
+  s->dev.body_params = d_params;
   return REX_OK;
 }
 

@@ -171,6 +171,19 @@ class RexBatchEnv:
         _lib.check(self._L.rex_last_step_ms(self._h, ctypes.byref(ms)), "rex_last_step_ms")
         return ms.value
 
+    def set_body_params(self, base_mass_scale=None, leg_mass_scale=None, foot_friction=None):
+        """Per-env domain randomisation (the knobs of Rex.SetBaseMasses / SetLegMasses, rex.py:659-692, plus the foot
+        friction). Each argument: None (keep), a float, or an [N] tensor/array. The values live in `self.body_params`
+        ([3, N] device tensor) and may be edited in place between steps."""
+        torch = self._torch
+        if getattr(self, "body_params", None) is None:
+            self.body_params = torch.tensor([[1.0], [1.0], [0.5]], device=self.device).repeat(1, self.num_envs).contiguous()
+            _lib.check(self._L.rex_set_body_params(self._h, self.body_params.data_ptr()), "rex_set_body_params")
+        for row, v in enumerate((base_mass_scale, leg_mass_scale, foot_friction)):
+            if v is not None:
+                self.body_params[row] = torch.as_tensor(v, dtype=torch.float32, device=self.device)
+        return self.body_params
+
     # ---- Gym / BatchEnv surface ----
     def reset(self, indices=None):
         """Reset all envs (indices=None) or the given ones; returns their first observations."""

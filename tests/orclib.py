@@ -167,6 +167,11 @@ class OracleEnv:
         self.o.lib.orc_step(self.h, self.o._p(a), self.o._p(obs), self.o._p(rew), self.o._p(done), self.o._p(cmd))
         return obs, rew, done.astype(bool), cmd
 
+    def set_body_params(self, params):
+        params = np.ascontiguousarray(params, np.float32)
+        assert params.shape == (3, self.n)
+        self.o.lib.orc_set_body_params(self.h, params.ctypes.data_as(ctypes.c_void_p))
+
     def set_terrain(self, heights, mids):
         heights = np.ascontiguousarray(heights, np.float32)
         mids = np.ascontiguousarray(mids, np.float32)

@@ -227,6 +227,36 @@ def test_random_heightfield_terrain_parity(torch):
     env.close()
 
 
+def test_domain_randomisation_params(torch):
+    """Per-env mass scales and foot friction (rex_set_body_params): parity with the oracle, and the knobs act."""
+    n = 64
+    env, orc = make_pair("walk", "ik", n, np.float32, seed=2)
+    rng = np.random.RandomState(9)
+    params = np.stack([rng.uniform(0.8, 1.2, n), rng.uniform(0.8, 1.2, n), rng.uniform(0.25, 0.625, n)]).astype(np.float32)
+    env.set_body_params(*[torch.as_tensor(p) for p in params])
+    orc.set_body_params(params)
+    env.reset(); orc.reset()
+    for k in range(25):
+        orc.step(rng.uniform(-0.4, 0.4, (n, 2)))
+    for k in range(5):
+        st = orc.get_state()
+        env.state.copy_(numeric_to_product_state(st, torch, env.state.device))
+        a = rng.uniform(-0.4, 0.4, (n, 2)).astype(np.float32)
+        env.step(torch.as_tensor(a, device="cuda")); orc.step(a)
+        ps, os_ = product_state_to_numeric(env.state), orc.get_state()
+        np.testing.assert_allclose(ps[orclib.S_Q:orclib.S_Q + 12], os_[orclib.S_Q:orclib.S_Q + 12], atol=1e-4)
+        np.testing.assert_allclose(ps[:7], os_[:7], atol=1e-4)
+    # heavier base -> the stand sags more: compare two envs stepped from the same snapshot
+    e2, _ = make_pair("walk", "ik", 2, np.float32, seed=2)
+    e2.set_body_params(torch.tensor([0.8, 1.2]), None, None)
+    e2.reset()
+    for k in range(40):
+        e2.step(torch.zeros((2, 2), device="cuda"))
+    z = e2.state[2].cpu().numpy()
+    assert z[1] < z[0] - 1e-4
+    env.close(); e2.close()
+
+
 def test_folded_wrappers_match_explicit_wrappers(torch):
     """ClipAction + RangeNormalize folded into the launch == the same wrappers applied around the raw env
     (agents/tools/wrappers.py:183-265), incl. gallop's inverted Box."""
