@@ -496,6 +496,32 @@ static void aba_forward(const Phys* s, const real tau[NJ], Aba* A, real qdd[NJ],
   vdot_w[2] += GRAVITY_Z;
 }
 
+/* unit torque impulse on joint jbody-1 (between body jbody and its parent) -> generalized velocity change */
+static void impulse_response_joint(const Aba* A, int jbody, real out[NDOF]) {
+  real pA[NB][6], u[NB], da[NB][6];
+  memset(pA, 0, sizeof(pA));
+  for (int i = NB - 1; i >= 1; --i) {
+    int p = REX_PARENT[i], ax = REX_JOINT_AXIS[i - 1];
+    u[i] = (i == jbody ? (real)1 : (real)0) - pA[i][ax];
+    real pa[6], pp[6];
+    for (int k = 0; k < 6; ++k) pa[k] = pA[i][k] + A->U[i][k] * (u[i] * A->Dinv[i]);
+    mat6Tvec(A->X[i], pa, pp);
+    for (int k = 0; k < 6; ++k) pA[p][k] += pp[k];
+  }
+  real nb[6];
+  for (int k = 0; k < 6; ++k) nb[k] = -pA[0][k];
+  chol6_solve(A->L0, nb, da[0]);
+  for (int k = 0; k < 6; ++k) out[k] = da[0][k];
+  for (int i = 1; i < NB; ++i) {
+    int p = REX_PARENT[i], ax = REX_JOINT_AXIS[i - 1];
+    mat6vec(A->X[i], da[p], da[i]);
+    real Ua = 0; for (int k = 0; k < 6; ++k) Ua += A->U[i][k] * da[i][k];
+    real dq = A->Dinv[i] * (u[i] - Ua);
+    out[6 + i - 1] = dq;
+    da[i][ax] += dq;
+  }
+}
+
 /* impulse f_k (6, body-k coords) applied to body k -> generalized velocity change */
 static void impulse_response_at(const Aba* A, int kbody, const real fk[6], real out[NDOF]) {
   real pA[NB][6], u[NB], da[NB][6];
@@ -562,7 +588,8 @@ static void plane_space(const real n[3], real p[3], real q[3]) {
 }
 
 #define MAX_POINTS 8
-#define MAX_ROWS (3 * MAX_POINTS)
+#define MAX_ROWS (3 * MAX_POINTS + NJ)
+#define LIMIT_ACTIVATION ((real)0.15)  /* a limit row further away than this cannot act: |qd| dt <= 100 * 1e-3 */
 typedef struct {
   real J[NDOF], resp[NDOF];
   real rhs, invdiag, lo, hi, lambda;
@@ -648,7 +675,29 @@ static void physics_substep(Phys* s, const real tau[NJ], real dt, int iterations
       }
     }
   }
-  /* rows: all normals first, then the friction pairs (Bullet's per-iteration order) */
+  /* non-contact rows come first in every sweep (btMultiBodyConstraintSolver::solveSingleIteration): the URDF joint
+   * limits (btMultiBodyJointLimitConstraint, one unilateral row per bound).  Bullet creates both rows for every joint;
+   * a row whose bound is more than LIMIT_ACTIVATION away can never receive an impulse (|qd| <= 100 rad/s, dt = 1 ms),
+   * so only the near bound of a joint is instantiated. */
+  for (int j = 0; j < NJ; ++j) {
+    real lo_gap = s->q[j] - (real)REX_JOINT_LOWER[j], hi_gap = (real)REX_JOINT_UPPER[j] - s->q[j];
+    int lower = lo_gap < hi_gap;
+    real gap = lower ? lo_gap : hi_gap;
+    if (gap >= LIMIT_ACTIVATION) continue;
+    Row* r = &rows[nrow++];
+    real sgn = lower ? (real)1 : (real)-1;
+    for (int k = 0; k < NDOF; ++k) r->J[k] = 0;
+    r->J[6 + j] = sgn;
+    impulse_response_joint(&A, j + 1, r->resp);
+    for (int k = 0; k < NDOF; ++k) r->resp[k] *= sgn;
+    real diag = r->resp[6 + j] * sgn, vel = sgn * nu[6 + j];
+    r->invdiag = 1 / diag;
+    real poserr = 0, velerr = -vel;
+    if (gap > 0) velerr -= gap / dt; else poserr = -gap * CONTACT_ERP / dt;
+    r->rhs = (poserr + velerr) * r->invdiag;
+    r->lo = 0; r->hi = (real)1e10; r->lambda = 0; r->normal_row = -1;
+  }
+  /* then all contact normals, then the friction pairs (Bullet's per-iteration order) */
   for (int p = 0; p < npoint; ++p) {
     Row* r = &rows[nrow];
     real fk[6];

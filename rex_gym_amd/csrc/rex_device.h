@@ -23,10 +23,12 @@
 
 #define REX_WAVE 64
 #define REX_NPOINT 8                  /* 2 toe-cylinder end points per foot */
-#define REX_NROW (3 * REX_NPOINT)     /* normal + 2 pyramid friction rows per point */
+#define REX_NCROW (3 * REX_NPOINT)    /* contact rows: normal + 2 pyramid friction rows per point */
+#define REX_NLROW (3 * REX_NLEG)      /* joint-limit rows: the near bound of each of the 12 joints */
+#define REX_NROW (REX_NCROW + REX_NLROW)
 #define REX_ROW_F4 3                  /* float4 chunks per row in LDS */
 #define REX_LEG_F4 7                  /* float4 chunks per leg parked in LDS (Bw 18 + G 6 + z 3) */
-#define REX_LDS_F4_PER_ENV (REX_NROW * REX_ROW_F4 + REX_NLEG * REX_LEG_F4)   /* 100 float4 = 1.6 KB per env */
+#define REX_LDS_F4_PER_ENV (REX_NROW * REX_ROW_F4 + REX_NLEG * REX_LEG_F4)   /* 136 float4 = 2.2 KB per env */
 
 namespace rex {
 
@@ -37,6 +39,7 @@ constexpr float kAngDamp = 0.04f;
 constexpr float kMaxCoordVel = 100.0f;     // btMultiBody::m_maxCoordinateVelocity
 constexpr float kErp = 0.2f;               // btContactSolverInfo::m_erp2
 constexpr float kBreaking = 0.02f;         // contact breaking threshold
+constexpr float kLimitActivation = 0.15f;  // a joint bound further away cannot act within one step (|qd| dt <= 0.1)
 constexpr float kMu = 0.5f;                // toe 0.5 x plane 1.0
 constexpr float kInitZ = 0.21f;            // terrain.py:14-20
 constexpr float kToeRad = (float)(REX_TOE_RADIUS + REX_COLLISION_MARGIN);
@@ -421,6 +424,30 @@ __device__ __forceinline__ void leg_pass(int leg, const BaseKin& bk, const float
       emit_rows(e, P, (bk.height + P.z - h) * nrm.z, nrm, t1, t2);
     }
   }
+
+  // --- joint-limit rows (btMultiBodyJointLimitConstraint): the near bound of each joint, active within
+  //     kLimitActivation; J = +-e_k on the leg's joints, so the whitened row is a column of G^-1 ---
+  const float qv[3] = {q1, q2, q3};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float lo_gap = qv[k] - (float)REX_LEG_LIMIT_LO[k], hi_gap = (float)REX_LEG_LIMIT_HI[k] - qv[k];
+    const bool lower = lo_gap < hi_gap;
+    const float gap = lower ? lo_gap : hi_gap;
+    const bool act = gap < kLimitActivation;
+    if (act) active_mask |= 1u << (REX_NPOINT + 3 * leg + k);
+    const float sgn = lower ? 1.0f : -1.0f;
+    const float j1 = k == 0 ? sgn * gi1 : 0.0f;
+    const float j2 = k == 0 ? (-g21 * j1) * gi2 : (k == 1 ? sgn * gi2 : 0.0f);
+    const float j3 = k == 2 ? sgn * gi3 : (-g31 * j1 - g32 * j2) * gi3;
+    float g[6];
+#pragma unroll
+    for (int m = 0; m < 6; ++m) g[m] = -(L.Bw[0][m] * j1 + L.Bw[1][m] * j2 + L.Bw[2][m] * j3);
+    const float target = gap > 0.0f ? -gap / dt : -gap * (kErp / dt);
+    const int r = REX_NCROW + 3 * leg + k;
+    sm.row(r, 0) = make_float4(g[0], g[1], g[2], g[3]);
+    sm.row(r, 1) = make_float4(g[4], g[5], j1, j2);
+    sm.row(r, 2) = make_float4(j3, target, act ? 1.0f : 0.0f, 0.0f);
+  }
 }
 
 // Lower-triangular 6x6 Cholesky factor, packed: off-diagonals + inverse diagonal
@@ -527,6 +554,16 @@ __device__ __forceinline__ void pgs_leg_normals(const SM& sm, PgsX& x, float* la
   const float4 b0 = sm.row(p1, 0), b1 = sm.row(p1, 1), b2 = sm.row(p1, 2);
   pgs_row<LEG, false>(a0, a1, a2, x, lam[p0], 0.0f, worst);
   pgs_row<LEG, false>(b0, b1, b2, x, lam[p1], 0.0f, worst);
+}
+
+template <int LEG, class SM>
+__device__ __forceinline__ void pgs_leg_limits(const SM& sm, PgsX& x, float* lam, float& worst) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int r = REX_NCROW + 3 * LEG + k;
+    const float4 a0 = sm.row(r, 0), a1 = sm.row(r, 1), a2 = sm.row(r, 2);
+    pgs_row<LEG, false>(a0, a1, a2, x, lam[r], 0.0f, worst);
+  }
 }
 
 template <int LEG, class SM>
@@ -641,7 +678,8 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
   }
 
   // finish the rows: whiten the base part, inverse diagonal (0 disables an inactive point)
-  for (int r = 0; r < REX_NROW; ++r) {
+  const bool any_limit = __builtin_amdgcn_ballot_w64((active >> REX_NPOINT) != 0) != 0;
+  for (int r = 0; r < (any_limit ? REX_NROW : REX_NCROW); ++r) {
     float4 c0 = sm.row(r, 0), c1 = sm.row(r, 1), c2 = sm.row(r, 2);
     const float g[6] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y};
     float gw[6];
@@ -664,6 +702,10 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
   const bool any1 = __builtin_amdgcn_ballot_w64((active & 0x0Cu) != 0) != 0;
   const bool any2 = __builtin_amdgcn_ballot_w64((active & 0x30u) != 0) != 0;
   const bool any3 = __builtin_amdgcn_ballot_w64((active & 0xC0u) != 0) != 0;
+  const bool lim0 = __builtin_amdgcn_ballot_w64((active & (7u << (REX_NPOINT + 0))) != 0) != 0;
+  const bool lim1 = __builtin_amdgcn_ballot_w64((active & (7u << (REX_NPOINT + 3))) != 0) != 0;
+  const bool lim2 = __builtin_amdgcn_ballot_w64((active & (7u << (REX_NPOINT + 6))) != 0) != 0;
+  const bool lim3 = __builtin_amdgcn_ballot_w64((active & (7u << (REX_NPOINT + 9))) != 0) != 0;
   x.y01 = v2{y[0], y[1]}; x.y23 = v2{y[2], y[3]}; x.y45 = v2{y[4], y[5]};
   // Bullet leaves the sweep loop as soon as the largest velocity residual of a sweep is below
   // m_leastSquaresResidualThreshold; each lane (env) stops on its own sweep, the wavefront leaves the
@@ -672,6 +714,10 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
   for (int it = 0; it < iterations; ++it) {
     if (running) {
       float worst = 0.0f;
+      if (lim0) pgs_leg_limits<0>(sm, x, lam, worst);   // non-contact rows first (Bullet's sweep order)
+      if (lim1) pgs_leg_limits<1>(sm, x, lam, worst);
+      if (lim2) pgs_leg_limits<2>(sm, x, lam, worst);
+      if (lim3) pgs_leg_limits<3>(sm, x, lam, worst);
       if (any0) pgs_leg_normals<0>(sm, x, lam, worst);
       if (any1) pgs_leg_normals<1>(sm, x, lam, worst);
       if (any2) pgs_leg_normals<2>(sm, x, lam, worst);

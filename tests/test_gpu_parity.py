@@ -227,6 +227,33 @@ def test_random_heightfield_terrain_parity(torch):
     env.close()
 
 
+def test_joint_limit_rows_parity(torch):
+    """URDF joint limits as unilateral solver rows (btMultiBodyJointLimitConstraint): states at / beyond the bounds,
+    moving into them, must be stopped identically by kernel and oracle."""
+    n = 64
+    env, orc = make_pair("walk", "ol", n, np.float32, seed=13)
+    env.reset(); orc.reset()
+    rng = np.random.RandomState(3)
+    st = orc.get_state()
+    st[orclib.S_POS + 2] += 0.5                                   # lift the robots: limits act without ground contact too
+    st[orclib.S_Q + 0] = rng.uniform(0.9, 1.03, n)                # FL shoulder at its upper bound (1.0)
+    st[orclib.S_QD + 0] = rng.uniform(0.0, 5.0, n)
+    st[orclib.S_Q + 5] = rng.uniform(2.5, 2.62, n)                # FR foot at its upper bound (2.59)
+    st[orclib.S_QD + 5] = rng.uniform(0.0, 8.0, n)
+    st[orclib.S_Q + 7] = rng.uniform(-2.2, -2.1, n)               # RL leg at its lower bound (-2.17)
+    st[orclib.S_QD + 7] = rng.uniform(-6.0, 0.0, n)
+    orc.set_state(st)
+    env.state.copy_(numeric_to_product_state(st, torch, env.state.device))
+    for k in range(4):
+        a = np.zeros((n, 8), np.float32)
+        env.step(torch.as_tensor(a, device="cuda")); orc.step(a)
+        ps, os_ = product_state_to_numeric(env.state), orc.get_state()
+        np.testing.assert_allclose(ps[orclib.S_Q:orclib.S_Q + 12], os_[orclib.S_Q:orclib.S_Q + 12], atol=2e-4)
+        np.testing.assert_allclose(ps[orclib.S_QD:orclib.S_QD + 12], os_[orclib.S_QD:orclib.S_QD + 12], atol=5e-2)
+    assert ps[orclib.S_Q + 0].max() < 1.0 + 0.03 and ps[orclib.S_Q + 5].max() < 2.59 + 0.03 and ps[orclib.S_Q + 7].min() > -2.17 - 0.03
+    env.close()
+
+
 def test_domain_randomisation_params(torch):
     """Per-env mass scales and foot friction (rex_set_body_params): parity with the oracle, and the knobs act."""
     n = 64

@@ -370,6 +370,13 @@ def main():
         w(f"#define REX_{nm}_IYY {fmt(b['I'][1, 1])}")
         w(f"#define REX_{nm}_IZZ {fmt(b['I'][2, 2])}")
     w(f"#define REX_LOWER_COM_Z {fmt(f0['com'][2])}")
+    for l in range(4):
+        for k in range(3):
+            assert bodies[1 + 3 * l + k]["joint"]["lower"] == bodies[1 + k]["joint"]["lower"]
+            assert bodies[1 + 3 * l + k]["joint"]["upper"] == bodies[1 + k]["joint"]["upper"]
+    w("/* joint limits, identical on the four legs: shoulder, leg, foot */")
+    w("REX_CONST double REX_LEG_LIMIT_LO[3] = {" + ", ".join(fmt(bodies[1 + k]["joint"]["lower"]) for k in range(3)) + "};")
+    w("REX_CONST double REX_LEG_LIMIT_HI[3] = {" + ", ".join(fmt(bodies[1 + k]["joint"]["upper"]) for k in range(3)) + "};")
     w("")
     w("#endif /* REX_MODEL_GEN_H */")
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
