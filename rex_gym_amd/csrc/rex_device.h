@@ -428,6 +428,11 @@ __device__ __forceinline__ void leg_pass(int leg, const BaseKin& bk, const float
   // --- joint-limit rows (btMultiBodyJointLimitConstraint): the near bound of each joint, active within
   //     kLimitActivation; J = +-e_k on the leg's joints, so the whitened row is a column of G^-1 ---
   const float qv[3] = {q1, q2, q3};
+  bool near_any = false;
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+    near_any |= fminf(qv[k] - (float)REX_LEG_LIMIT_LO[k], (float)REX_LEG_LIMIT_HI[k] - qv[k]) < kLimitActivation;
+  if (__builtin_amdgcn_ballot_w64(near_any) == 0) return;   // no env of this wave has this leg near a bound
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     const float lo_gap = qv[k] - (float)REX_LEG_LIMIT_LO[k], hi_gap = (float)REX_LEG_LIMIT_HI[k] - qv[k];
