@@ -74,7 +74,8 @@ enum RexStateWord {
   REX_S_EPISODE  = 45,  /* int: episodes started (RNG counter)                                           */
   REX_S_MOTOR_EN = 46,  /* int: bit i = motor i enabled (Rex._motor_enabled_list, rex.py:302)            */
   REX_S_OVERHEAT = 47,  /* 6 ints: 12 x u16 overheat counters, motor 2k in low half (rex.py:301,601-608) */
-  REX_STATE_WORDS = 53
+  REX_S_HIST     = 53,  /* int: observation-history ring, bits 0-7 newest slot, bits 8-15 fill (1..100)      */
+  REX_STATE_WORDS = 54
 };
 
 #define REX_F_GOAL_REACHED   1u   /* walk_env.py:211 */
@@ -122,7 +123,9 @@ typedef struct RexConfig {
      ((a+1)/2 (high-low)+low with the env's Box) and of the returned observation (2(o-low)/(high-low)-1).
      d_motor_cmd is unaffected. */
   int32_t range_normalize;
-  int32_t reserved[1];
+  /* seconds; Rex(pd_latency=, control_latency=) (model/rex.py:59-60,735-763). Non-zero values need
+     rex_set_history() before the first reset. */
+  float   pd_latency, control_latency;
 } RexConfig;
 
 typedef struct RexSim RexSim;
@@ -154,6 +157,14 @@ REX_API int rex_set_terrain(RexSim* sim, const float* d_heights, const float* d_
  * entries when it resets envs).  As in Bullet's changeDynamics(mass=...), only masses change: the inertia tensors stay
  * the ones computed at load.  NULL restores (1, 1, 0.5). */
 REX_API int rex_set_body_params(RexSim* sim, const float* d_params);
+
+/* Observation-history ring for the latency model (Rex._observation_history, deque(maxlen=100) of 43-vectors:
+ * q, qd, observed torque, base quaternion, base angular velocity; model/rex.py:122,717-763).  d_history: caller-owned
+ * device buffer of REX_HISTORY_LEN * REX_HISTORY_WORDS * num_envs float32, laid out [slot][word][env].  Required only
+ * when pd_latency or control_latency is non-zero. */
+#define REX_HISTORY_LEN 100
+#define REX_HISTORY_WORDS 43
+REX_API int rex_set_history(RexSim* sim, float* d_history);
 
 /* Reset envs. d_indices == NULL: all envs. Else n int32 env indices (device).  Writes the first
  * observation of each reset env to d_obs[row * obs_dim] where row = position in d_indices (or the

@@ -814,6 +814,10 @@ typedef struct {
   uint32_t motor_enabled;
   uint16_t overheat[NJ];
   real tau_obs[NJ]; /* Rex._observed_motor_torques (transient; not part of the persistent state) */
+  /* Rex._observation_history (deque(maxlen=100) of 43-vectors, rex.py:122): ring, hist_head = newest slot */
+  int hist_head, hist_len;
+  real (*hist)[REX_HISTORY_WORDS];   /* [REX_HISTORY_LEN][43], allocated only when a latency is configured */
+  real ctrl_obs[REX_HISTORY_WORDS];  /* Rex._control_observation */
 } Env;
 
 typedef struct {
@@ -856,12 +860,41 @@ ORC_API int orc_action_dim(const RexConfig* c) {
 
 static const real* init_pose(const RexConfig* c) { return c->signal == REX_SIGNAL_OL ? POSE_STAND_OL : POSE_STAND; }
 
+/* Rex.GetTrueObservation (rex.py:717-724) */
+static void true_observation(const Env* e, real o[REX_HISTORY_WORDS]) {
+  for (int j = 0; j < NJ; ++j) { o[j] = e->ph.q[j]; o[NJ + j] = e->ph.qd[j]; o[2 * NJ + j] = e->tau_obs[j]; }
+  for (int k = 0; k < 4; ++k) o[3 * NJ + k] = e->ph.quat[k];
+  for (int k = 0; k < 3; ++k) o[3 * NJ + 4 + k] = e->ph.angvel[k];
+}
+/* Rex._GetDelayedObservation (rex.py:735-753) */
+static void delayed_observation(const RexConfig* c, const Env* e, real latency, real o[REX_HISTORY_WORDS]) {
+  if (!e->hist) { true_observation(e, o); return; }
+#define SLOT(k) e->hist[(e->hist_head - (k) + 2 * REX_HISTORY_LEN) % REX_HISTORY_LEN]
+  if (latency <= 0 || e->hist_len == 1) { memcpy(o, SLOT(0), sizeof(real) * REX_HISTORY_WORDS); return; }
+  real dt = (real)c->sim_time_step;
+  int n = (int)(latency / dt);
+  if (n + 1 >= e->hist_len) { memcpy(o, SLOT(e->hist_len - 1), sizeof(real) * REX_HISTORY_WORDS); return; }
+  real alpha = (latency - n * dt) / dt;
+  for (int k = 0; k < REX_HISTORY_WORDS; ++k) o[k] = (1 - alpha) * SLOT(n)[k] + alpha * SLOT(n + 1)[k];
+#undef SLOT
+}
+/* Rex.ReceiveObservation (rex.py:726-733) */
+static void receive_observation(const RexConfig* c, Env* e) {
+  if (!e->hist) return;
+  e->hist_head = (e->hist_head + 1) % REX_HISTORY_LEN;
+  if (e->hist_len < REX_HISTORY_LEN) e->hist_len++;
+  true_observation(e, e->hist[e->hist_head]);
+  delayed_observation(c, e, (real)c->control_latency, e->ctrl_obs);
+}
+
 /* Rex.ApplyAction + stepSimulation + ReceiveObservation (rex.py:158-163,568-641) */
 static void rex_substep(const RexConfig* c, Env* e, const real cmd[NJ], const Ground* ground) {
   real tau[NJ];
+  real pd[REX_HISTORY_WORDS];
+  delayed_observation(c, e, (real)c->pd_latency, pd);                  /* _GetPDObservation, rex.py:755-759 */
   for (int j = 0; j < NJ; ++j) {
     real act, obs;
-    motor_torque(cmd[j], e->ph.q[j], e->ph.qd[j], e->ph.qd[j], (real)c->motor_kp, (real)c->motor_kd, &act, &obs);
+    motor_torque(cmd[j], pd[j], pd[NJ + j], e->ph.qd[j], (real)c->motor_kp, (real)c->motor_kd, &act, &obs);
     if (fabs(act) > OVERHEAT_TORQUE) { if (e->overheat[j] < 65535) e->overheat[j]++; } else e->overheat[j] = 0;
     if ((real)e->overheat[j] > OVERHEAT_TIME / (real)c->sim_time_step) e->motor_enabled &= ~(1u << j);
     e->tau_obs[j] = obs;
@@ -869,6 +902,7 @@ static void rex_substep(const RexConfig* c, Env* e, const real cmd[NJ], const Gr
     if (DBG_JOINT_FRICTION > 0 && (j % 3) != 1) tau[j] -= clampr(DBG_JOINT_VISC * e->ph.qd[j], -DBG_JOINT_FRICTION, DBG_JOINT_FRICTION);
   }
   physics_substep(&e->ph, tau, (real)c->sim_time_step, c->solver_iterations, (real)c->solver_residual_threshold, ground);
+  receive_observation(c, e);
 }
 
 static void settle(Orc* o, Env* e, const Ground* ground) {
@@ -885,13 +919,20 @@ static void settle(Orc* o, Env* e, const Ground* ground) {
   for (int k = 0; k < nreset; ++k) rex_substep(&o->cfg, e, init_pose(&o->cfg), ground);
 }
 
+/* the observation the controller-facing getters read (Rex._control_observation): delayed when a latency is set */
+static void control_observation(const Env* e, real o[REX_HISTORY_WORDS]) {
+  if (e->hist) memcpy(o, e->ctrl_obs, sizeof(real) * REX_HISTORY_WORDS);
+  else true_observation(e, o);
+}
+
 static void env_observation(const RexConfig* c, const Env* e, real* obs) {
-  real rpy[3];
-  quat_to_euler(e->ph.quat, rpy);
-  obs[0] = rpy[0]; obs[1] = rpy[1]; obs[2] = e->ph.angvel[0]; obs[3] = e->ph.angvel[1];
+  real co[REX_HISTORY_WORDS], rpy[3];
+  control_observation(e, co);
+  quat_to_euler(co + 3 * NJ, rpy);
+  obs[0] = rpy[0]; obs[1] = rpy[1]; obs[2] = co[3 * NJ + 4]; obs[3] = co[3 * NJ + 5];
   if (c->task == REX_TASK_GALLOP) {
     for (int j = 0; j < NJ; ++j) { /* MapToMinusPiToPi, rex.py:26-41 */
-      real a = fmod(e->ph.q[j], (real)(2 * M_PI));
+      real a = fmod(co[j], (real)(2 * M_PI));
       if (a >= (real)M_PI) a -= (real)(2 * M_PI); else if (a < -(real)M_PI) a += (real)(2 * M_PI);
       obs[4 + j] = a;
     }
@@ -902,11 +943,13 @@ static void env_reset(Orc* o, int idx) {
   const RexConfig* c = &o->cfg;
   Env* e = &o->envs[idx];
   int32_t episode = e->episode;
+  real (*hist)[REX_HISTORY_WORDS] = e->hist;
   {
     int t = terrain_index(o, idx, episode + 1);
     *e = t >= 0 ? o->terrain_snapshot[t] : o->snapshot;   /* settled on this episode's terrain */
   }
   e->episode = episode + 1;
+  e->hist = hist;
   e->gait.phi = 0; e->gait.last_time = 0; e->gait.alpha = 0;
   uint32_t ctr[4] = {(uint32_t)e->episode, 0, 0, 0};
   philox4x32(ctr, (uint32_t)c->seed ^ (uint32_t)(c->env_index_base + idx), (uint32_t)(c->seed >> 32));
@@ -942,6 +985,16 @@ static void env_reset(Orc* o, int idx) {
     real rpy[3] = {0, 0, (real)ini};
     euler_to_quat(rpy, e->ph.quat);                                             /* resetBasePositionAndOrientation */
     e->ph.pos[0] = 0; e->ph.pos[1] = 0; e->ph.pos[2] = ROBOT_INIT_Z;
+  }
+  /* history restarts with the settled observation (the reference's deque holds the last 100 settle substeps,
+   * all within 1e-4 of it; the turn env's teleport does not touch the history either, turn_env.py:158-159) */
+  if (e->hist) {
+    Env snap = o->n_terrain ? o->terrain_snapshot[terrain_index(o, idx, e->episode)] : o->snapshot;
+    e->hist_head = 0; e->hist_len = 1;
+    memset(snap.tau_obs, 0, sizeof(snap.tau_obs));   /* the snapshot record does not carry the observed torques */
+    for (int k = 0; k < 4; ++k) snap.ph.quat[k] = e->ph.quat[k] * 0 + snap.ph.quat[k];
+    true_observation(&snap, e->hist[0]);
+    memcpy(e->ctrl_obs, e->hist[0], sizeof(real) * REX_HISTORY_WORDS);
   }
 }
 
@@ -1059,8 +1112,9 @@ static void turn_command(const RexConfig* c, Env* e, const real* action, real cm
     return;
   }
   {                                                                                 /* _check_target_position */
-    real rpy[3];
-    quat_to_euler(e->ph.quat, rpy);
+    real rpy[3], co[REX_HISTORY_WORDS];
+    control_observation(e, co);
+    quat_to_euler(co + 3 * NJ, rpy);
     real cz = rpy[2];
     if (cz < 0) cz += (real)6.28;
     if (fabs(e->target - cz) <= (real)0.01) {
@@ -1119,13 +1173,14 @@ static real base_reward(const RexConfig* c, Env* e) {
   else if (x <= (real)0.05) fwd = 0;
   else fwd = x / T;
   real drift = -fabs(e->ph.pos[1]);
-  real rpy[3], qq[4], R[3][3];
-  quat_to_euler(e->ph.quat, rpy);  /* GetBaseOrientation: quat -> RPY -> quat (rex.py:530-537) */
+  real co[REX_HISTORY_WORDS], rpy[3], qq[4], R[3][3];
+  control_observation(e, co);
+  quat_to_euler(co + 3 * NJ, rpy);  /* GetBaseOrientation: delayed quat -> RPY -> quat (rex.py:530-537) */
   euler_to_quat(rpy, qq);
   quat_to_mat(qq, R);
   real shake = -fabs(R[2][0] + R[2][1]);
   real dotp = 0;
-  for (int j = 0; j < NJ; ++j) dotp += e->tau_obs[j] * e->ph.qd[j];
+  for (int j = 0; j < NJ; ++j) dotp += co[2 * NJ + j] * co[NJ + j];   /* GetMotorTorques . GetMotorVelocities */
   real energy = -fabs(dotp) * (real)c->sim_time_step;
   return (real)c->distance_weight * fwd + (real)c->energy_weight * energy + (real)c->drift_weight * drift + (real)c->shake_weight * shake;
 }
@@ -1135,6 +1190,9 @@ static int env_fallen(const RexConfig* c, const Env* e) {
   quat_to_euler(e->ph.quat, rpy);
   if (c->task == REX_TASK_GALLOP)                                       /* gallop_env.py:319-329 (true RPY) */
     return fabs(rpy[0]) > (real)0.3 || fabs(rpy[1]) > (real)0.5;
+  real co[REX_HISTORY_WORDS];
+  control_observation(e, co);
+  quat_to_euler(co + 3 * NJ, rpy);                                      /* GetBaseOrientation (delayed) */
   real qq[4], R[3][3];                                                  /* walk_env.py:326-338 */
   euler_to_quat(rpy, qq);
   quat_to_mat(qq, R);
@@ -1205,6 +1263,8 @@ ORC_API void* orc_create(const RexConfig* cfg) {
   Orc* o = (Orc*)calloc(1, sizeof(Orc));
   o->cfg = *cfg;
   o->envs = (Env*)calloc((size_t)cfg->num_envs, sizeof(Env));
+  if (cfg->pd_latency > 0 || cfg->control_latency > 0)
+    for (int i = 0; i < cfg->num_envs; ++i) o->envs[i].hist = calloc(REX_HISTORY_LEN, sizeof(real[REX_HISTORY_WORDS]));
   settle(o, &o->snapshot, 0);
   return o;
 }
@@ -1216,7 +1276,7 @@ ORC_API void orc_set_body_params(void* h, const float* params) {
     memcpy(o->body_params, params, sizeof(float) * 3 * (size_t)o->cfg.num_envs);
   }
 }
-ORC_API void orc_destroy(void* h) { Orc* o = (Orc*)h; free(o->body_params); free(o->envs); free(o->heights); free(o->mids); free(o->terrain_snapshot); free(o); }
+ORC_API void orc_destroy(void* h) { Orc* o = (Orc*)h; for (int i = 0; i < o->cfg.num_envs; ++i) free(o->envs[i].hist); free(o->body_params); free(o->envs); free(o->heights); free(o->mids); free(o->terrain_snapshot); free(o); }
 
 /* terrain pool: heights [k][256*256] raw vertex heights (terrain.py:36-43 layout: data[i + j*rows], i along x),
  * mids [k] = (min+max)/2 of each field */
@@ -1276,6 +1336,7 @@ ORC_API void orc_get_state(void* h, double* out) {
     W(REX_S_TARGET) = e->target; W(REX_S_ENDTIME) = e->end_time; W(REX_S_AUX) = e->aux;
     W(REX_S_FLAGS) = e->flags; W(REX_S_STEPS) = e->steps; W(REX_S_EPISODE) = e->episode;
     W(REX_S_MOTOR_EN) = e->motor_enabled;
+    W(REX_S_HIST) = e->hist ? (double)(e->hist_head + 256 * e->hist_len) : 0.0;
     for (int k = 0; k < NJ / 2; ++k) W(REX_S_OVERHEAT + k) = (double)e->overheat[2 * k] + 65536.0 * (double)e->overheat[2 * k + 1];
 #undef W
   }

@@ -9,7 +9,7 @@ from . import build as _build
 
 TASKS = {"walk": 0, "gallop": 1, "turn": 2, "poses": 3}
 SIGNALS = {"ik": 0, "ol": 1}
-STATE_WORDS = 53
+STATE_WORDS = 54
 NUM_MOTORS = 12
 
 
@@ -25,7 +25,7 @@ class RexConfig(ctypes.Structure):
         ("energy_weight", ctypes.c_float), ("drift_weight", ctypes.c_float), ("shake_weight", ctypes.c_float),
         ("solver_residual_threshold", ctypes.c_float), ("target_orient", ctypes.c_float),
         ("init_orient", ctypes.c_float), ("orient_fixed", ctypes.c_int32), ("pose_index", ctypes.c_int32),
-        ("pose_value", ctypes.c_float), ("range_normalize", ctypes.c_int32), ("reserved", ctypes.c_int32 * 1),
+        ("pose_value", ctypes.c_float), ("range_normalize", ctypes.c_int32), ("pd_latency", ctypes.c_float), ("control_latency", ctypes.c_float),
     ]
 
 
@@ -43,6 +43,7 @@ _SIGS = {
                     ctypes.POINTER(ctypes.c_void_p)], ctypes.c_int),
     "rex_destroy": ([ctypes.c_void_p], ctypes.c_int),
     "rex_set_body_params": ([ctypes.c_void_p, ctypes.c_void_p], ctypes.c_int),
+    "rex_set_history": ([ctypes.c_void_p, ctypes.c_void_p], ctypes.c_int),
     "rex_set_terrain": ([ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
     "rex_reset": ([ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p], ctypes.c_int),
     "rex_step": ([ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,

@@ -39,6 +39,7 @@ struct EnvState {
   int32_t steps, episode;
   uint32_t motor_en;
   uint32_t overheat[12]; // one counter per motor in registers; packed 2 x u16 per state word in HBM
+  uint32_t hist;         // observation-history ring: bits 0-7 newest slot, bits 8-15 fill
 };
 
 __device__ __forceinline__ float ldw(const float* st, int n, int w, int i) { return st[(size_t)w * n + i]; }
@@ -57,6 +58,7 @@ __device__ __forceinline__ void load_env(const float* st, int n, int i, EnvState
   e.target = ldw(st, n, REX_S_TARGET, i); e.end_time = ldw(st, n, REX_S_ENDTIME, i); e.aux = ldw(st, n, REX_S_AUX, i);
   e.flags = ldi(st, n, REX_S_FLAGS, i); e.steps = (int32_t)ldi(st, n, REX_S_STEPS, i); e.episode = (int32_t)ldi(st, n, REX_S_EPISODE, i);
   e.motor_en = ldi(st, n, REX_S_MOTOR_EN, i);
+  e.hist = ldi(st, n, REX_S_HIST, i);
 #pragma unroll
   for (int k = 0; k < 6; ++k) {
     const uint32_t w = ldi(st, n, REX_S_OVERHEAT + k, i);
@@ -75,6 +77,7 @@ __device__ __forceinline__ void store_env(float* st, int n, int i, const EnvStat
   stw(st, n, REX_S_TARGET, i, e.target); stw(st, n, REX_S_ENDTIME, i, e.end_time); stw(st, n, REX_S_AUX, i, e.aux);
   sti(st, n, REX_S_FLAGS, i, e.flags); sti(st, n, REX_S_STEPS, i, (uint32_t)e.steps); sti(st, n, REX_S_EPISODE, i, (uint32_t)e.episode);
   sti(st, n, REX_S_MOTOR_EN, i, e.motor_en);
+  sti(st, n, REX_S_HIST, i, e.hist);
 #pragma unroll
   for (int k = 0; k < 6; ++k) sti(st, n, REX_S_OVERHEAT + k, i, e.overheat[2 * k] | (e.overheat[2 * k + 1] << 16));
 }
@@ -136,12 +139,37 @@ struct DevCfg {
   const float* terrain;      // [n_terrain][256*256] raw vertex heights (nullptr: plane only)
   const float* terrain_mid;  // [n_terrain]
   int32_t n_terrain;
+  float* hist;               // [100][43][n] observation history (nullptr: no latency model)
+  float pd_latency, control_latency;
   const float* body_params;  // [3][n] word-major: base mass scale, leg mass scale, foot friction (nullptr: 1, 1, 0.5)
   float act_lo, act_hi;      // Box bounds of the env's action space (host: rex_create)
   float obs_hi_ang, obs_hi_rate;
 };
 
 __device__ __forceinline__ float init_pose(const DevCfg& c, int j) { return c.signal == REX_SIGNAL_OL ? pose_stand_ol(j) : pose_stand(j); }
+
+// ---- latency model: Rex._observation_history / _GetDelayedObservation (model/rex.py:122,717-763) ----
+__device__ __forceinline__ float& hist_at(const DevCfg& c, int i, int slot, int w) {
+  return c.hist[((size_t)slot * REX_HISTORY_WORDS + w) * c.n + i];
+}
+// which two ring slots to blend, and with which weight, for an observation `latency` seconds old
+__device__ __forceinline__ void delay_slots(const DevCfg& c, uint32_t hist, float latency, int& s0, int& s1, float& alpha) {
+  const int head = (int)(hist & 0xFFu), len = (int)((hist >> 8) & 0xFFu);
+  int k0 = 0, k1 = 0;
+  alpha = 0.0f;
+  if (latency > 0.0f && len != 1) {
+    const int n = (int)(latency / c.dt);
+    if (n + 1 >= len) { k0 = k1 = len - 1; }
+    else { k0 = n; k1 = n + 1; alpha = (latency - (float)n * c.dt) / c.dt; }
+  }
+  s0 = (head - k0 + 2 * REX_HISTORY_LEN) % REX_HISTORY_LEN;
+  s1 = (head - k1 + 2 * REX_HISTORY_LEN) % REX_HISTORY_LEN;
+}
+__device__ __forceinline__ float delayed_word(const DevCfg& c, int i, int s0, int s1, float alpha, int w) {
+  return (1.0f - alpha) * hist_at(c, i, s0, w) + alpha * hist_at(c, i, s1, w);
+}
+// the controller-facing observation (Rex._control_observation): q, qd, tau_obs, quat, angular velocity
+struct CtrlObs { float q[12], qd[12], tau[12], quat[4], w[3]; };
 
 // terrain of (global env index, episode): the reference regenerates the field on every reset
 // (rex_gym_env.py:347-348); here each episode picks one of the pool entries
@@ -163,14 +191,19 @@ __device__ __forceinline__ Ground env_ground(const DevCfg& c, int i, int gidx, i
 
 // Rex.ApplyAction + stepSimulation + ReceiveObservation (rex.py:158-163, 568-641)
 template <class SM>
-__device__ __forceinline__ void rex_substep(const DevCfg& c, EnvState& e, const float* cmd, float* tau_obs, const SM& sm,
-                                            const Ground& ground) {
+__device__ __forceinline__ void rex_substep(const DevCfg& c, EnvState& e, int i, bool live, const float* cmd, float* tau_obs,
+                                            const SM& sm, const Ground& ground) {
   float tau[12];
   const float limit = 1.0f / c.dt;  // OVERHEAT_SHUTDOWN_TIME / time_step, rex.py:607
+  int s0 = 0, s1 = 0;
+  float alpha = 0.0f;
+  if (c.hist) delay_slots(c, e.hist, c.pd_latency, s0, s1, alpha);               // _GetPDObservation, rex.py:755-759
 #pragma unroll
   for (int j = 0; j < 12; ++j) {
     float act, obs;
-    motor_torque(cmd[j], e.ph.q[j], e.ph.qd[j], e.ph.qd[j], c.kp, c.kd, act, obs);
+    const float qo = c.hist ? delayed_word(c, i, s0, s1, alpha, j) : e.ph.q[j];
+    const float qdo = c.hist ? delayed_word(c, i, s0, s1, alpha, 12 + j) : e.ph.qd[j];
+    motor_torque(cmd[j], qo, qdo, e.ph.qd[j], c.kp, c.kd, act, obs);
     uint32_t cnt = e.overheat[j];
     cnt = fabsf(act) > 2.45f ? min(cnt + 1u, 65535u) : 0u;                      // rex.py:603-606
     if ((float)cnt > limit) e.motor_en &= ~(1u << j);                           // rex.py:607-608
@@ -179,6 +212,43 @@ __device__ __forceinline__ void rex_substep(const DevCfg& c, EnvState& e, const 
     tau[j] = ((e.motor_en >> j) & 1u) ? act : 0.0f;                             // rex.py:617-623
   }
   physics_substep(e.ph, tau, c.dt, c.iterations, c.res_thr, sm, ground);
+  if (c.hist) {                                                                  // ReceiveObservation, rex.py:726-733
+    const int head = ((int)(e.hist & 0xFFu) + 1) % REX_HISTORY_LEN;
+    const int len = min((int)((e.hist >> 8) & 0xFFu) + 1, REX_HISTORY_LEN);
+    e.hist = (uint32_t)head | ((uint32_t)len << 8);
+    if (live) {
+#pragma unroll
+      for (int j = 0; j < 12; ++j) { hist_at(c, i, head, j) = e.ph.q[j]; hist_at(c, i, head, 12 + j) = e.ph.qd[j]; hist_at(c, i, head, 24 + j) = tau_obs[j]; }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) hist_at(c, i, head, 36 + k) = e.ph.quat[k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) hist_at(c, i, head, 40 + k) = e.ph.ang[k];
+    }
+  }
+}
+
+// Rex._control_observation as the env-level getters see it (delayed by control_latency when the model is on)
+__device__ __forceinline__ void control_observation(const DevCfg& c, const EnvState& e, int i, const float* tau_obs, CtrlObs& o) {
+  if (c.hist) {
+    int s0, s1; float alpha;
+    delay_slots(c, e.hist, c.control_latency, s0, s1, alpha);
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+      o.q[j] = delayed_word(c, i, s0, s1, alpha, j); o.qd[j] = delayed_word(c, i, s0, s1, alpha, 12 + j);
+      o.tau[j] = delayed_word(c, i, s0, s1, alpha, 24 + j);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o.quat[k] = delayed_word(c, i, s0, s1, alpha, 36 + k);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) o.w[k] = delayed_word(c, i, s0, s1, alpha, 40 + k);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 12; ++j) { o.q[j] = e.ph.q[j]; o.qd[j] = e.ph.qd[j]; o.tau[j] = tau_obs[j]; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o.quat[k] = e.ph.quat[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) o.w[k] = e.ph.ang[k];
+  }
 }
 
 // RangeNormalize of the observation (wrappers.py:236-240); bounds are symmetric (rex_gym_env.py:277-278)
@@ -192,14 +262,14 @@ __device__ __forceinline__ void normalize_obs(const DevCfg& c, float* obs) {
   }
 }
 
-__device__ __forceinline__ void env_observation(const DevCfg& c, const EnvState& e, float* obs) {
+__device__ __forceinline__ void env_observation(const DevCfg& c, const CtrlObs& co, float* obs) {
   float rpy[3];
-  quat_to_euler(e.ph.quat, rpy);
-  obs[0] = rpy[0]; obs[1] = rpy[1]; obs[2] = e.ph.ang[0]; obs[3] = e.ph.ang[1];   // walk_env.py:356-362
+  quat_to_euler(co.quat, rpy);
+  obs[0] = rpy[0]; obs[1] = rpy[1]; obs[2] = co.w[0]; obs[3] = co.w[1];           // walk_env.py:356-362
   if (c.task == REX_TASK_GALLOP) {
 #pragma unroll
     for (int j = 0; j < 12; ++j) {                                                // MapToMinusPiToPi, rex.py:26-41
-      float a = fmodf(e.ph.q[j], 2.0f * kPi);
+      float a = fmodf(co.q[j], 2.0f * kPi);
       if (a >= kPi) a -= 2.0f * kPi; else if (a < -kPi) a += 2.0f * kPi;
       obs[4 + j] = a;
     }
@@ -207,9 +277,20 @@ __device__ __forceinline__ void env_observation(const DevCfg& c, const EnvState&
 }
 
 // RexWalkEnv.reset / RexReactiveEnv.reset draws on top of the settled snapshot
-__device__ __forceinline__ void env_reset(const DevCfg& c, const float* snap, int gidx, EnvState& e) {
+__device__ __forceinline__ void env_reset(const DevCfg& c, const float* snap, int i, bool live, int gidx, EnvState& e) {
   const int32_t episode = e.episode + 1;
   load_env(snap, c.n_terrain > 0 ? c.n_terrain : 1, c.n_terrain > 0 ? terrain_index(c, gidx, episode) : 0, e);   // settled on this episode's terrain
+  if (c.hist) {   // the history restarts with the settled observation (observed torques are not part of the snapshot: 0)
+    e.hist = 0u | (1u << 8);
+    if (live) {
+#pragma unroll
+      for (int j = 0; j < 12; ++j) { hist_at(c, i, 0, j) = e.ph.q[j]; hist_at(c, i, 0, 12 + j) = e.ph.qd[j]; hist_at(c, i, 0, 24 + j) = 0.0f; }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) hist_at(c, i, 0, 36 + k) = e.ph.quat[k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) hist_at(c, i, 0, 40 + k) = e.ph.ang[k];
+    }
+  } else e.hist = 0u;
   e.episode = episode;
   e.gait.phi = 0.0f; e.gait.last_time = 0.0f; e.gait.alpha = 0.0f;
   uint32_t ctr[4] = {(uint32_t)episode, 0u, 0u, 0u};
@@ -356,7 +437,7 @@ __device__ __forceinline__ void poses_command(const DevCfg& c, EnvState& e, cons
 }
 
 // RexTurnEnv._transform_action_to_motor_command (turn_env.py:239-347)
-__device__ __forceinline__ void turn_command(const DevCfg& c, EnvState& e, const float* action, float* cmd) {
+__device__ __forceinline__ void turn_command(const DevCfg& c, EnvState& e, const float* ctrl_quat, const float* action, float* cmd) {
   const float t = (float)(e.steps * c.action_repeat) * c.dt;
   if (e.flags & REX_F_STAY_STILL) {
     if (t - e.end_time >= 1.0f) e.flags |= REX_F_ENV_GOAL;                       // _terminate_with_delay
@@ -366,7 +447,7 @@ __device__ __forceinline__ void turn_command(const DevCfg& c, EnvState& e, const
   }
   {                                                                              // _check_target_position
     float rpy[3];
-    quat_to_euler(e.ph.quat, rpy);
+    quat_to_euler(ctrl_quat, rpy);                                               // GetBaseOrientation (delayed when latency is on)
     float cz = rpy[2];
     if (cz < 0.0f) cz += 6.28f;
     if (fabsf(e.target - cz) <= 0.01f) {
@@ -430,17 +511,28 @@ __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __r
 
   float cmd[12];
   if (c.task == REX_TASK_GALLOP) gallop_command(c, e, act, cmd);
-  else if (c.task == REX_TASK_TURN) turn_command(c, e, act, cmd);
+  else if (c.task == REX_TASK_TURN) {
+    float cq[4] = {e.ph.quat[0], e.ph.quat[1], e.ph.quat[2], e.ph.quat[3]};
+    if (c.hist) {
+      int s0, s1; float alpha;
+      delay_slots(c, e.hist, c.control_latency, s0, s1, alpha);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) cq[k] = delayed_word(c, i, s0, s1, alpha, 36 + k);
+    }
+    turn_command(c, e, cq, act, cmd);
+  }
   else if (c.task == REX_TASK_POSES) poses_command(c, e, act, cmd);
   else walk_command(c, e, act, cmd);
 
   float tau_obs[12];
   const Ground ground = env_ground(c, i, c.env_index_base + i, e.episode);
-  for (int k = 0; k < c.action_repeat; ++k) rex_substep(c, e, cmd, tau_obs, sm, ground);   // Rex.Step
+  for (int k = 0; k < c.action_repeat; ++k) rex_substep(c, e, i, live, cmd, tau_obs, sm, ground);   // Rex.Step
 
   // ---- reward (rex_gym_env.py:501-542) ----
+  CtrlObs co;
+  control_observation(c, e, i, tau_obs, co);
   float rpy[3], r20, r21, r22;
-  quat_to_euler(e.ph.quat, rpy);
+  quat_to_euler(co.quat, rpy);       // GetBaseOrientation: (delayed) quat -> RPY -> quat, rex.py:530-537
   euler_to_row2(rpy, r20, r21, r22);
   float x = -e.ph.pos[0];
   if (c.backwards > 0) x = -x;      // `if self._backwards:` is the constructor argument, not the draw
@@ -455,7 +547,7 @@ __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __r
   const float shake = -fabsf(r20 + r21);
   float dp = 0.0f;
 #pragma unroll
-  for (int j = 0; j < 12; ++j) dp += tau_obs[j] * e.ph.qd[j];
+  for (int j = 0; j < 12; ++j) dp += co.tau[j] * co.qd[j];   // GetMotorTorques . GetMotorVelocities
   const float energy = -fabsf(dp) * c.dt;
   float reward = c.w_dist * fwd + c.w_energy * energy + c.w_drift * drift + c.w_shake * shake;
   if (c.task == REX_TASK_TURN) reward = 0.035f - fabsf(e.ph.pos[0]) - fabsf(e.ph.pos[1]);   // turn_env.py:362-367
@@ -463,17 +555,25 @@ __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __r
 
   // ---- termination (rex_gym_env.py:490-499, walk_env.py:326-338, gallop_env.py:315-329) ----
   bool done;
-  if (c.task == REX_TASK_GALLOP) done = fabsf(rpy[0]) > 0.3f || fabsf(rpy[1]) > 0.5f || e.ph.pos[1] > 0.3f;
-  else done = r22 < 0.85f;
+  if (c.task == REX_TASK_GALLOP) {   // GetTrueBaseRollPitchYaw: never delayed (gallop_env.py:319-329)
+    float trpy[3];
+    quat_to_euler(e.ph.quat, trpy);
+    done = fabsf(trpy[0]) > 0.3f || fabsf(trpy[1]) > 0.5f || e.ph.pos[1] > 0.3f;
+  } else done = r22 < 0.85f;
   if (e.flags & REX_F_ENV_GOAL) done = true;                                     // rex_gym_env.py:495
   if (c.task == REX_TASK_POSES) done = false;                                    // is_fallen() returns False, poses_env.py:265
   e.steps += 1;
   if (c.max_steps > 0 && e.steps >= c.max_steps) done = true;
   if (done) e.flags |= REX_F_DONE;
-  if (done && c.auto_reset) env_reset(c, snap, c.env_index_base + i, e);
+  if (done && c.auto_reset) {
+    env_reset(c, snap, i, live, c.env_index_base + i, e);
+#pragma unroll
+    for (int j = 0; j < 12; ++j) tau_obs[j] = 0.0f;
+    control_observation(c, e, i, tau_obs, co);
+  }
 
   float obs[16];
-  env_observation(c, e, obs);
+  env_observation(c, co, obs);
   if (c.range_normalize) normalize_obs(c, obs);
   if (live) {
     store_env(state, c.n, i, e);
@@ -506,14 +606,16 @@ __global__ __launch_bounds__(REX_WAVE) void rex_settle_kernel(DevCfg c, float* _
   for (int j = 0; j < 12; ++j) e.ph.q[j] = pose_stand(j);       // ResetPose: INIT_POSES[pose_id = 'stand']
   e.motor_en = (1u << 12) - 1u;
   if (c.task != REX_TASK_POSES) {   // RexPosesEnv: base reset() with initial_motor_angles=None skips the motion (rex.py:308)
+    DevCfg cs = c;
+    cs.hist = nullptr;              // the reset motion runs without the latency model (the snapshot carries no history)
     float cmd[12], tau_obs[12];
 #pragma unroll
     for (int j = 0; j < 12; ++j) cmd[j] = pose_stand(j);
-    for (int k = 0; k < 100; ++k) rex_substep(c, e, cmd, tau_obs, sm, ground);   // rex.py:315-318
+    for (int k = 0; k < 100; ++k) rex_substep(cs, e, 0, false, cmd, tau_obs, sm, ground);   // rex.py:315-318
 #pragma unroll
     for (int j = 0; j < 12; ++j) cmd[j] = init_pose(c, j);
     const int nreset = (int)(0.5f / c.dt);                                               // rex.py:319
-    for (int k = 0; k < nreset; ++k) rex_substep(c, e, cmd, tau_obs, sm, ground);
+    for (int k = 0; k < nreset; ++k) rex_substep(cs, e, 0, false, cmd, tau_obs, sm, ground);
   }
   if (rec < nrec) store_env(snap, nrec, rec, e);
 }
@@ -526,10 +628,12 @@ __global__ void rex_reset_kernel(DevCfg c, float* __restrict__ state, const floa
   if (i < 0 || i >= c.n) return;
   EnvState e;
   e.episode = (int32_t)ldi(state, c.n, REX_S_EPISODE, i);
-  env_reset(c, snap, c.env_index_base + i, e);
+  env_reset(c, snap, i, true, c.env_index_base + i, e);
   store_env(state, c.n, i, e);
-  float obs[16];
-  env_observation(c, e, obs);
+  float obs[16], tz[12] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  CtrlObs co;
+  control_observation(c, e, i, tz, co);
+  env_observation(c, co, obs);
   if (c.range_normalize) normalize_obs(c, obs);
   if (obs_out) for (int k = 0; k < c.obs_dim; ++k) obs_out[(size_t)r * c.obs_dim + k] = obs[k];
 }
@@ -689,6 +793,7 @@ int rex_create(const RexConfig* cfg, int device, float* d_state, void* stream, R
   d.pose_index = cfg->pose_index; d.pose_value = cfg->pose_value;
   d.range_normalize = cfg->range_normalize;
   d.terrain = nullptr; d.terrain_mid = nullptr; d.n_terrain = 0; d.body_params = nullptr;
+  d.hist = nullptr; d.pd_latency = cfg->pd_latency; d.control_latency = cfg->control_latency;
   {
     float b;   /* walk_env.py:104-114, gallop_env.py:119-130 (low=+b, high=-b), turn_env.py:100-110, poses_env.py:115-117 */
     if (cfg->task == REX_TASK_WALK) b = cfg->signal == REX_SIGNAL_IK ? 0.4f : 0.01f;
@@ -737,6 +842,12 @@ int rex_set_terrain(RexSim* s, const float* d_heights, const float* d_mids, int 
   return REX_OK;
 }
 
+int rex_set_history(RexSim* s, float* d_history) {
+  if (!s) return fail(REX_EINVAL, "rex_set_history: null sim%s", "");
+  s->dev.hist = d_history;
+  return REX_OK;
+}
+
 int rex_set_body_params(RexSim* s, const float* d_params) {
   if (!s) return fail(REX_EINVAL, "rex_set_body_params: null sim%s", "");
   s->dev.body_params = d_params;
@@ -755,6 +866,8 @@ int rex_destroy(RexSim* s) {
 
 int rex_reset(RexSim* s, const int32_t* d_indices, int n, float* d_obs, void* stream) {
   if (!s) return fail(REX_EINVAL, "rex_reset: null sim%s", "");
+  if ((s->cfg.pd_latency > 0.0f || s->cfg.control_latency > 0.0f) && !s->dev.hist)
+    return fail(REX_EINVAL, "rex_reset: pd_latency/control_latency are set but rex_set_history() was not called%s", "");
   const int count = d_indices ? n : s->cfg.num_envs;
   if (count <= 0) return d_indices ? REX_OK : fail(REX_EINVAL, "rex_reset: empty%s", "");
   HIPCHK(hipSetDevice(s->device));

@@ -60,7 +60,8 @@ class RexBatchEnv:
                  auto_reset=False, max_episode_steps=0, backwards=None, target_position=None,
                  target_orient=None, init_orient=None, base_y=None, base_z=None, base_roll=None, base_pitch=None,
                  base_yaw=None,
-                 motor_kp=1.0, motor_kd=0.02, control_time_step=None, action_repeat=None,
+                 motor_kp=1.0, motor_kd=0.02, control_time_step=None, action_repeat=None, control_latency=0.0,
+                 pd_latency=0.0,
                  solver_iterations=None, solver_residual_threshold=None,
                  range_normalize=False, check_actions=False, terrain_type="plane", terrain_pool=64, terrain_seed=10,
                  mark="base", render=False, stream=None, **unused):
@@ -100,6 +101,7 @@ class RexBatchEnv:
             vals = [0.0 if v is None else float(v) for v in pose_kw]
             k = next((i for i, v in enumerate(vals[:4]) if v != 0.0), 4)
             cfg.pose_index, cfg.pose_value = k, vals[k]
+        cfg.pd_latency, cfg.control_latency = float(pd_latency or 0.0), float(control_latency or 0.0)
         cfg.range_normalize = int(bool(range_normalize))
         cfg.seed = int(seed) & (2 ** 64 - 1)
         cfg.env_index_base = int(env_index_base)
@@ -127,6 +129,10 @@ class RexBatchEnv:
                                           self._stream_ptr(), ctypes.byref(handle)), "rex_create")
         self._h = handle
         self._needs_reset = True
+        if cfg.pd_latency > 0 or cfg.control_latency > 0:   # observation-history ring of the latency model (rex.py:122)
+            with torch.cuda.device(self.device):
+                self.history = torch.zeros((100 * 43, self.num_envs), dtype=torch.float32, device=self.device)
+            _lib.check(self._L.rex_set_history(self._h, self.history.data_ptr()), "rex_set_history")
         self.terrain_type = terrain_type
         if terrain_type == "random":   # model/terrain.py:32-54 -- a pool of fields instead of one per env
             from ..terrain import random_terrain_pool

@@ -44,8 +44,9 @@ class RexWalkEnv(_SingleEnv):
                  pd_latency=0, on_rack=False, motor_kp=1.0, motor_kd=0.02, render=False, num_steps_to_log=2000,
                  env_randomizer=None, log_path=None, target_position=None, backwards=None, signal_type="ik",
                  terrain_type="plane", terrain_id=None, mark="base", **kw):
-        if control_latency or pd_latency or on_rack or env_randomizer:
-            raise NotImplementedError("latency / on_rack / env_randomizer are not covered by this round")
+        if on_rack or env_randomizer:
+            raise NotImplementedError("on_rack / env_randomizer are not covered by this round")
         super().__init__(signal_type=signal_type, control_time_step=control_time_step, action_repeat=action_repeat,
-                         motor_kp=motor_kp, motor_kd=motor_kd, render=render, target_position=target_position,
+                         motor_kp=motor_kp, motor_kd=motor_kd, control_latency=control_latency, pd_latency=pd_latency,
+                         render=render, target_position=target_position,
                          backwards=backwards, terrain_type=terrain_type, mark=mark, **kw)

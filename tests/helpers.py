@@ -30,7 +30,8 @@ def make_pair(task, signal, n, dtype=np.float32, **kw):
     okw = dict(kw)
     pkw = dict(kw)
     cfg_kw = {}
-    for k in ("seed", "auto_reset", "max_episode_steps", "env_index_base", "motor_kp", "motor_kd", "range_normalize"):
+    for k in ("seed", "auto_reset", "max_episode_steps", "env_index_base", "motor_kp", "motor_kd", "range_normalize", "pd_latency",
+              "control_latency"):
         if k in okw:
             cfg_kw[k] = okw.pop(k)
     if "backwards" in okw:

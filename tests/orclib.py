@@ -11,10 +11,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 
-STATE_WORDS = 53
+STATE_WORDS = 54
 S_POS, S_QUAT, S_LINVEL, S_ANGVEL, S_Q, S_QD = 0, 3, 7, 10, 13, 25
 S_PHI, S_LASTT, S_ALPHA, S_TARGET, S_ENDTIME, S_AUX = 37, 38, 39, 40, 41, 42
-S_FLAGS, S_STEPS, S_EPISODE, S_MOTOR_EN, S_OVERHEAT = 43, 44, 45, 46, 47
+S_FLAGS, S_STEPS, S_EPISODE, S_MOTOR_EN, S_OVERHEAT, S_HIST = 43, 44, 45, 46, 47, 53
 INT_WORDS = list(range(S_FLAGS, STATE_WORDS))
 
 
@@ -30,7 +30,7 @@ class RexConfig(ctypes.Structure):
         ("energy_weight", ctypes.c_float), ("drift_weight", ctypes.c_float), ("shake_weight", ctypes.c_float),
         ("solver_residual_threshold", ctypes.c_float), ("target_orient", ctypes.c_float),
         ("init_orient", ctypes.c_float), ("orient_fixed", ctypes.c_int32), ("pose_index", ctypes.c_int32),
-        ("pose_value", ctypes.c_float), ("range_normalize", ctypes.c_int32), ("reserved", ctypes.c_int32 * 1),
+        ("pose_value", ctypes.c_float), ("range_normalize", ctypes.c_int32), ("pd_latency", ctypes.c_float), ("control_latency", ctypes.c_float),
     ]
 
 

@@ -227,6 +227,33 @@ def test_random_heightfield_terrain_parity(torch):
     env.close()
 
 
+def test_latency_model_parity(torch):
+    """pd_latency / control_latency (Rex._GetDelayedObservation, rex.py:735-763): history ring + interpolation.
+    Lock-step rollout from reset vs the fp32 oracle; also checks that the delayed observation really lags."""
+    n = 64
+    env, orc = make_pair("walk", "ik", n, np.float32, seed=6, pd_latency=0.0025, control_latency=0.0125)
+    obs, oobs = env.reset().cpu().numpy(), orc.reset()
+    np.testing.assert_allclose(obs, oobs, atol=2e-3)
+    rng = np.random.RandomState(8)
+    worst = np.zeros(n)
+    # a PD loop fed with 2.5 ms old velocities is lightly damped: rounding differences grow ~10x per 5 control
+    # steps once the gait starts, so the lock-step window is the first 25 steps (5e-7 rad agreement there)
+    for k in range(25):
+        a = rng.uniform(-0.4, 0.4, (n, 2)).astype(np.float32)
+        o, r, d, _ = env.step(torch.as_tensor(a, device="cuda"))
+        oo, orr, od, _ = orc.step(a)
+        ps, os_ = product_state_to_numeric(env.state), orc.get_state()
+        worst = np.maximum(worst, joint_rmse(ps, os_))
+        np.testing.assert_array_equal(ps[orclib.S_HIST], os_[orclib.S_HIST])
+        np.testing.assert_allclose(o.cpu().numpy(), oo, atol=5e-3)
+        np.testing.assert_allclose(r.cpu().numpy(), orr, atol=1e-4)
+    assert np.median(worst) < 1e-4
+    # the returned angular rates are the 12.5 ms old ones, not the current ones
+    cur = env.state[orclib.S_ANGVEL:orclib.S_ANGVEL + 2].cpu().numpy().T
+    assert np.abs(o.cpu().numpy()[:, 2:4] - cur).max() > 1e-3
+    env.close()
+
+
 def test_joint_limit_rows_parity(torch):
     """URDF joint limits as unilateral solver rows (btMultiBodyJointLimitConstraint): states at / beyond the bounds,
     moving into them, must be stopped identically by kernel and oracle."""
