@@ -66,6 +66,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    # the default line is BASELINE.json configs[1]; the other supported configs can be timed with these
+    ap.add_argument("--task", default="walk", choices=["walk", "gallop", "turn", "poses"])
+    ap.add_argument("--signal", default="ik", choices=["ik", "ol"])
+    ap.add_argument("--terrain", default="plane", choices=["plane", "random"])
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to smoke-test the "
                                                       "multi-rank path on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
@@ -95,11 +99,13 @@ def main():
 
     from rex_gym_amd import RexBatchEnv
     n = args.envs_per_gpu
-    env = RexBatchEnv(n, task="walk", signal_type="ik", device=local_rank, seed=0, env_index_base=rank * n,
-                      auto_reset=True, max_episode_steps=2000)
+    env = RexBatchEnv(n, task=args.task, signal_type=args.signal, device=local_rank, seed=0, env_index_base=rank * n,
+                      auto_reset=True, max_episode_steps=2000, terrain_type=args.terrain)
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
-    pool = [(torch.rand((n, 2), device=dev, generator=gen) * 0.8 - 0.4).contiguous() for _ in range(16)]
+    lo = torch.as_tensor(env.action_space.low, device=dev).minimum(torch.as_tensor(env.action_space.high, device=dev))
+    hi = torch.as_tensor(env.action_space.low, device=dev).maximum(torch.as_tensor(env.action_space.high, device=dev))
+    pool = [(torch.rand((n, env.action_dim), device=dev, generator=gen) * (hi - lo) + lo).contiguous() for _ in range(16)]
     env.reset()
 
     def barrier():
@@ -143,12 +149,15 @@ def main():
         value = total_envs * args.steps / elapsed
         achieved_gbs = ALGO_BYTES_PER_ENV_STEP * n / (kernel_ms * 1e-3) / 1e9
         out = {
-            "metric": "env-steps/sec (all envs) Rex walk-IK",
+            "metric": f"env-steps/sec (all envs) Rex {args.task}-{args.signal.upper()}",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{n} Rex envs per GPU, walk-IK, flat plane, base mark, dt 1 ms x 5 substeps, "
-                                   "60 PGS iterations, auto-reset, random actions U(-0.4,0.4)",
+            "config": {"workload": f"{n} Rex envs per GPU, {args.task}-{args.signal.upper()}, "
+                                   f"{'flat plane' if args.terrain == 'plane' else 'random heightfield pool'}, base mark, "
+                                   f"dt 1 ms x {env.config.action_repeat} substeps, <= {env.config.solver_iterations} PGS sweeps "
+                                   "(Bullet residual threshold 1e-7), auto-reset, episode cap 2000, uniform random actions "
+                                   "over the env's action Box",
                        "envs_total": total_envs, "parallelism": f"env-shards x{world} (no data-path collective)"},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
