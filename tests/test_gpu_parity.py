@@ -375,6 +375,37 @@ def test_reset_indices_and_sharding_invariance(torch):
         e.close()
 
 
+@pytest.mark.parametrize("n", [1, 3, 63, 65, 1000, 4097])
+def test_ragged_batch_sizes(torch, n):
+    """Batch sizes that are not multiples of the wave / envs-per-wave: tail lanes must not corrupt neighbours."""
+    from rex_gym_amd import RexBatchEnv
+    env = RexBatchEnv(n, seed=2, auto_reset=True, max_episode_steps=7)
+    ref = RexBatchEnv(4100, seed=2, auto_reset=True, max_episode_steps=7)
+    o, o_ref = env.reset(), ref.reset()
+    assert o.shape == (n, 4) and torch.equal(o, o_ref[:n])
+    g = torch.Generator(device="cuda"); g.manual_seed(1)
+    for k in range(9):
+        a = torch.rand((4100, 2), device="cuda", generator=g) * 0.8 - 0.4
+        on, rn, dn, _ = env.step(a[:n].contiguous())
+        orf, rr, dr, _ = ref.step(a)
+        assert torch.equal(on, orf[:n]) and torch.equal(rn, rr[:n]) and torch.equal(dn, dr[:n])
+    assert torch.equal(env.state, ref.state[:, :n])
+    assert torch.isfinite(env.state[:37]).all()
+    env.close(); ref.close()
+
+
+def test_reset_with_empty_and_duplicate_indices(torch):
+    from rex_gym_amd import RexBatchEnv
+    env = RexBatchEnv(16, seed=1)
+    env.reset()
+    assert env.reset(torch.zeros(0, dtype=torch.int32)).shape == (0, 4)
+    before = product_state_to_numeric(env.state)[orclib.S_EPISODE].copy()
+    o = env.reset([5, 5, 9])
+    after = product_state_to_numeric(env.state)[orclib.S_EPISODE]
+    assert o.shape == (3, 4) and after[9] == before[9] + 1 and after[5] >= before[5] + 1 and after[0] == before[0]
+    env.close()
+
+
 def test_gym_surface_single_env(torch):
     from rex_gym_amd.envs.gym import RexWalkEnv
     env = RexWalkEnv(render=False, signal_type="ik", terrain_type="plane", mark="base")
