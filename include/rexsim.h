@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define REX_ABI_VERSION 1
+#define REX_ABI_VERSION 2
 #define REX_API __attribute__((visibility("default")))
 
 /* tasks (reference env classes) */
@@ -42,7 +42,13 @@ extern "C" {
 #define REX_SIGNAL_IK 0
 #define REX_SIGNAL_OL 1
 
-#define REX_NUM_MOTORS 12
+/* `mark` kwarg of the reference envs (model/mark_constants.py:1-120): the robot variant.  'arm' adds the
+ * 6-joint arm of rex_arm.urdf, its 6 motors held at ARM_POSES['rest'] (rex_gym_env.py:347-353). */
+#define REX_MARK_BASE 0
+#define REX_MARK_ARM  1
+
+#define REX_NUM_MOTORS 12       /* mark 'base' */
+#define REX_NUM_MOTORS_ARM 18   /* mark 'arm'  */
 
 /* error codes */
 #define REX_OK          0
@@ -126,6 +132,10 @@ typedef struct RexConfig {
   /* seconds; Rex(pd_latency=, control_latency=) (model/rex.py:59-60,735-763). Non-zero values need
      rex_set_history() before the first reset. */
   float   pd_latency, control_latency;
+  /* REX_MARK_BASE / REX_MARK_ARM.  With REX_MARK_ARM the per-env state has rex_state_words() = 69 words (the q, qd
+     and overheat blocks grow to 18 motors, every other word keeps its order), d_motor_cmd rows are 18 wide and the
+     gallop observation is 4 + 18; the latency model (43-word history records) is not offered. */
+  int32_t mark;
 } RexConfig;
 
 typedef struct RexSim RexSim;
@@ -136,9 +146,12 @@ REX_API int rex_default_config(int task, int signal, int num_envs, RexConfig* cf
 /* Dimensions implied by a config (action/observation vector lengths of the reference env). */
 REX_API int rex_action_dim(const RexConfig* cfg);
 REX_API int rex_obs_dim(const RexConfig* cfg);
+/* Motors (12 / 18) and per-env state words (REX_STATE_WORDS / 69) of the config's mark. */
+REX_API int rex_num_motors(const RexConfig* cfg);
+REX_API int rex_state_words(const RexConfig* cfg);
 
 /* Create a simulator on HIP device `device`. `d_state` is a caller-owned device buffer of
- * REX_STATE_WORDS * num_envs float32 words; the library never allocates per-env memory.
+ * rex_state_words(cfg) * num_envs float32 words; the library never allocates per-env memory.
  * Computes the settled reset snapshot (rex.py:314-323: 100 + 500 substeps holding the init
  * pose) once, on the device, with the same kernels. */
 REX_API int rex_create(const RexConfig* cfg, int device, float* d_state, void* stream, RexSim** out);

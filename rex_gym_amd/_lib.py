@@ -9,8 +9,10 @@ from . import build as _build
 
 TASKS = {"walk": 0, "gallop": 1, "turn": 2, "poses": 3}
 SIGNALS = {"ik": 0, "ol": 1}
-STATE_WORDS = 54
-NUM_MOTORS = 12
+MARKS = {"base": 0, "arm": 1}
+STATE_WORDS = 54      # mark 'base'; rex_state_words(cfg) for the others
+NUM_MOTORS = 12       # mark 'base'; rex_num_motors(cfg) for the others
+ABI_VERSION = 2
 
 
 class RexConfig(ctypes.Structure):
@@ -26,6 +28,7 @@ class RexConfig(ctypes.Structure):
         ("solver_residual_threshold", ctypes.c_float), ("target_orient", ctypes.c_float),
         ("init_orient", ctypes.c_float), ("orient_fixed", ctypes.c_int32), ("pose_index", ctypes.c_int32),
         ("pose_value", ctypes.c_float), ("range_normalize", ctypes.c_int32), ("pd_latency", ctypes.c_float), ("control_latency", ctypes.c_float),
+        ("mark", ctypes.c_int32),
     ]
 
 
@@ -39,6 +42,8 @@ _SIGS = {
     "rex_default_config": ([ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(RexConfig)], ctypes.c_int),
     "rex_action_dim": ([ctypes.POINTER(RexConfig)], ctypes.c_int),
     "rex_obs_dim": ([ctypes.POINTER(RexConfig)], ctypes.c_int),
+    "rex_num_motors": ([ctypes.POINTER(RexConfig)], ctypes.c_int),
+    "rex_state_words": ([ctypes.POINTER(RexConfig)], ctypes.c_int),
     "rex_create": ([ctypes.POINTER(RexConfig), ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                     ctypes.POINTER(ctypes.c_void_p)], ctypes.c_int),
     "rex_destroy": ([ctypes.c_void_p], ctypes.c_int),
@@ -77,7 +82,7 @@ def lib():
             fn = getattr(l, name)  # AttributeError if the ABI header and the library disagree
             fn.argtypes = argtypes
             fn.restype = restype
-        if l.rex_abi_version() != 1:
+        if l.rex_abi_version() != ABI_VERSION:
             raise RexSimError("librexsim_hip.so ABI version mismatch")
         _lib = l
     return _lib

@@ -1,0 +1,316 @@
+// rex_arm_device.h -- the 6-joint arm chain of mark='arm' (rex_arm.urdf:610-791) in the same world-aligned,
+// Cholesky-whitened formulation as the legs (rex_device.h): a fifth branch on the base with
+//     H_a = G_a G_a^T (6x6),  Bw_a = G_a^-1 B_a^T (6x6),  A -= Bw_a^T Bw_a,  z_a = G_a^T qd_a + Bw_a nu_base.
+// The arm never touches the ground; its only constraint rows are the URDF joint limits (the rest pose the envs
+// command, ARM_POSES['rest'] = (-1.6, -1.6, 0, 0, 1.6, 0), sits beyond the +-1.5 rad bounds of m1, m2, m5, so three
+// limit rows are permanently active).  A limit row is a 12-vector (6 whitened base + 6 whitened arm entries).
+#pragma once
+#include "rex_arm_model_gen.h"
+#include "rex_device.h"
+
+#define REX_ARM_NJ 6
+#define REX_ARM_PARK_F4 16   /* Bw 36 + G 21 + z 6 = 63 floats */
+#define REX_ARM_ROW_F4 4     /* g' 6 + j' 6 + (invd*target, invd, diag, active) */
+#define REX_LDS_F4_PER_ENV_ARM (REX_LDS_F4_PER_ENV + REX_ARM_PARK_F4 + REX_ARM_NJ * REX_ARM_ROW_F4)
+
+namespace rex {
+
+struct m33 { f3 x, y, z; };   // columns
+
+template <int EPW>
+struct LdsArm {
+  float4* p; int slot;
+  __device__ __forceinline__ float4& park(int c) const { return p[(REX_LDS_F4_PER_ENV + c) * EPW + slot]; }
+  __device__ __forceinline__ float4& row(int k, int c) const {
+    return p[(REX_LDS_F4_PER_ENV + REX_ARM_PARK_F4 + k * REX_ARM_ROW_F4 + c) * EPW + slot];
+  }
+};
+
+struct ArmFactor {
+  Chol6 G;          // Cholesky factor of the arm joint-space inertia
+  float Bw[6][6];   // G^-1 B^T: row m = whitened arm coordinate, column k = base coordinate
+  float z[6];       // whitened predicted arm velocity
+};
+
+// forward kinematics, Newton-Euler bias, composite inertias, arm Cholesky, Schur contributions to the base and the
+// limit rows.  q/qd/tau: the 6 arm joints.  Returns bits 0..5: limit row k active.
+template <class SMA>
+__device__ __forceinline__ unsigned arm_pass(const BaseKin& bk, const float* __restrict__ q, const float* __restrict__ qd,
+                                             const float* __restrict__ tau, float dt, ArmFactor& L, BaseAccum& acc,
+                                             const SMA& sma, const Ground& ground) {
+  f3 a[6], o[6], c[6], w[6], al[6], fo[6], no[6];   // axis, joint origin, COM (rel. base origin), ang. vel, ang. acc, force, moment
+  s33 Ib[6];
+  float m[6];
+  {
+    m33 Rp{bk.ex, bk.ey, bk.ez};
+    f3 op = mk(0.f, 0.f, 0.f), wp = bk.w, alp = mk(0.f, 0.f, 0.f);
+    f3 vop = bk.v;                                    // velocity of the parent origin
+    f3 aop = mk(0.f, 0.f, kGravity);                  // acceleration of the parent origin (zero gen. acc., gravity as +g)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      // joint frame in parent coordinates (signed permutation, constants fold), then the turn about +-z
+      const float e00 = (float)REXA_E0[k][0], e01 = (float)REXA_E0[k][1], e02 = (float)REXA_E0[k][2];
+      const float e10 = (float)REXA_E0[k][3], e11 = (float)REXA_E0[k][4], e12 = (float)REXA_E0[k][5];
+      const float e20 = (float)REXA_E0[k][6], e21 = (float)REXA_E0[k][7], e22 = (float)REXA_E0[k][8];
+      const f3 jx = e00 * Rp.x + e10 * Rp.y + e20 * Rp.z;
+      const f3 jy = e01 * Rp.x + e11 * Rp.y + e21 * Rp.z;
+      const f3 jz = e02 * Rp.x + e12 * Rp.y + e22 * Rp.z;
+      float sq, cq;
+      sincos_fast((float)REXA_AXIS_SIGN[k] * q[k], sq, cq);
+      m33 R;
+      R.x = cq * jx + sq * jy;
+      R.y = cq * jy - sq * jx;
+      R.z = jz;
+      a[k] = (float)REXA_AXIS_SIGN[k] * jz;
+      const f3 d = (float)REXA_POS[k][0] * Rp.x + (float)REXA_POS[k][1] * Rp.y + (float)REXA_POS[k][2] * Rp.z;
+      o[k] = op + d;
+      const f3 e = (float)REXA_COM[k][0] * R.x + (float)REXA_COM[k][1] * R.y + (float)REXA_COM[k][2] * R.z;
+      c[k] = o[k] + e;
+      // kinematics (same recursion as the legs)
+      const f3 vo = vop + cross(wp, d);
+      const f3 ao = aop + cross(alp, d) + cross(wp, cross(wp, d));
+      w[k] = wp + qd[k] * a[k];
+      al[k] = alp + cross(wp, qd[k] * a[k]);
+      const f3 vc = vo + cross(w[k], e);
+      const f3 ac = ao + cross(al[k], e) + cross(w[k], cross(w[k], e));
+      m[k] = (float)REXA_MASS[k] * ground.leg_mass_scale;
+      Ib[k] = rot_inertia(R.x, R.y, R.z, (float)REXA_INERTIA[k][0], (float)REXA_INERTIA[k][1], (float)REXA_INERTIA[k][2]);
+      const f3 Iw = mul(Ib[k], w[k]);
+      const float dl = kLinDamp + kLinDamp * sqrtf(dot(vc, vc));
+      const float da = kAngDamp + kAngDamp * sqrtf(dot(w[k], w[k]));
+      fo[k] = m[k] * ac + (m[k] * dl) * vc;
+      no[k] = mul(Ib[k], al[k]) + cross(w[k], Iw) + da * Iw + cross(c[k], fo[k]);   // moment about the base origin
+      Rp = R; op = o[k]; wp = w[k]; alp = al[k]; vop = vo; aop = ao;
+    }
+  }
+  // inward: subtree wrenches, joint bias, composite inertias, joint columns
+  float C[6];
+  f3 Fl[6], Fa[6], v[6];
+  {
+    f3 F = mk(0.f, 0.f, 0.f), N = F, h = F;
+    s33 Io{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float mc = 0.0f;
+#pragma unroll
+    for (int k = 5; k >= 0; --k) {
+      F = F + fo[k]; N = N + no[k];
+      C[k] = dot(a[k], N - cross(o[k], F));
+      add(Io, Ib[k]); add_point(Io, m[k], c[k]);
+      h = h + m[k] * c[k];
+      mc += m[k];
+      v[k] = cross(o[k], a[k]);
+      Fl[k] = mc * v[k] + cross(a[k], h);
+      Fa[k] = mul(Io, a[k]) + cross(h, v[k]);
+    }
+    acc.N = acc.N + N; acc.F = acc.F + F;
+    add(acc.Io, Io); acc.h = acc.h + h; acc.m += mc;
+  }
+  // H (lower triangle): H[j][i] (j >= i) = S_i . F_j
+  float H[21];
+#pragma unroll
+  for (int j = 0; j < 6; ++j)
+#pragma unroll
+    for (int i = 0; i <= j; ++i) H[tri(j, i)] = dot(a[i], Fa[j]) + dot(v[i], Fl[j]);
+  chol6(H, L.G);
+  // Bw columns: solve G u = B^T[:, k] where B^T[j][k] = component k of (Fa_j, Fl_j)
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    float b[6], u[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const f3 src = k < 3 ? Fa[j] : Fl[j];
+      b[j] = (k % 3) == 0 ? src.x : ((k % 3) == 1 ? src.y : src.z);
+    }
+    fwd6(L.G, b, u);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) L.Bw[j][k] = u[j];
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j <= i; ++j) {
+      float t = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) t += L.Bw[r][i] * L.Bw[r][j];
+      acc.S[tri(i, j)] += t;
+    }
+  // free whitened acceleration and predicted whitened velocity
+  float rhs[6], zd[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) rhs[k] = tau[k] - C[k];
+  fwd6(L.G, rhs, zd);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    float t = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) t += L.Bw[r][k] * zd[r];
+    acc.bz[k] += t;
+  }
+  {
+    const float nu0[6] = {bk.w.x, bk.w.y, bk.w.z, bk.v.x, bk.v.y, bk.v.z};
+    float zc[6];
+    mulT6(L.G, qd, zc);     // G^T qd
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      float t = zc[r];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) t += L.Bw[r][k] * nu0[k];
+      L.z[r] = t + dt * zd[r];
+    }
+  }
+  // limit rows: near bound of each arm joint
+  unsigned active = 0;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const float lo_gap = q[k] - (float)REXA_LOWER[k], hi_gap = (float)REXA_UPPER[k] - q[k];
+    const bool lower = lo_gap < hi_gap;
+    const float gap = lower ? lo_gap : hi_gap;
+    const bool act = gap < kLimitActivation;
+    if (act) active |= 1u << k;
+    float e[6], j[6], g[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) e[r] = r == k ? (lower ? 1.0f : -1.0f) : 0.0f;
+    fwd6(L.G, e, j);
+#pragma unroll
+    for (int c2 = 0; c2 < 6; ++c2) {
+      float t = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) t += L.Bw[r][c2] * j[r];
+      g[c2] = -t;
+    }
+    const float target = gap > 0.0f ? -gap / dt : -gap * (kErp / dt);
+    sma.row(k, 0) = make_float4(g[0], g[1], g[2], g[3]);
+    sma.row(k, 1) = make_float4(g[4], g[5], j[0], j[1]);
+    sma.row(k, 2) = make_float4(j[2], j[3], j[4], j[5]);
+    sma.row(k, 3) = make_float4(target, act ? 1.0f : 0.0f, 0.0f, 0.0f);
+  }
+  return active;
+}
+
+template <class SMA>
+__device__ __forceinline__ void arm_park(const SMA& sma, const ArmFactor& L) {
+  float buf[64];
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) buf[6 * r + k] = L.Bw[r][k];
+#pragma unroll
+  for (int k = 0; k < 15; ++k) buf[36 + k] = L.G.l[k];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { buf[51 + k] = L.G.di[k]; buf[57 + k] = L.z[k]; }
+  buf[63] = 0.0f;
+#pragma unroll
+  for (int c = 0; c < REX_ARM_PARK_F4; ++c) sma.park(c) = make_float4(buf[4 * c], buf[4 * c + 1], buf[4 * c + 2], buf[4 * c + 3]);
+}
+template <class SMA>
+__device__ __forceinline__ void arm_unpark(const SMA& sma, ArmFactor& L) {
+  float buf[64];
+#pragma unroll
+  for (int c = 0; c < REX_ARM_PARK_F4; ++c) {
+    const float4 t = sma.park(c);
+    buf[4 * c] = t.x; buf[4 * c + 1] = t.y; buf[4 * c + 2] = t.z; buf[4 * c + 3] = t.w;
+  }
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) L.Bw[r][k] = buf[6 * r + k];
+#pragma unroll
+  for (int k = 0; k < 15; ++k) L.G.l[k] = buf[36 + k];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { L.G.di[k] = buf[51 + k]; L.z[k] = buf[57 + k]; }
+}
+
+// whiten the base part of the arm limit rows and finish them (after the base Cholesky)
+template <class SMA>
+__device__ __forceinline__ void arm_rows_finish(const SMA& sma, const Chol6& Lc) {
+#pragma unroll 1
+  for (int k = 0; k < 6; ++k) {
+    const float4 c0 = sma.row(k, 0), c1 = sma.row(k, 1), c2 = sma.row(k, 2), c3 = sma.row(k, 3);
+    const float g[6] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y};
+    float gw[6];
+    fwd6(Lc, g, gw);
+    const float diag = gw[0] * gw[0] + gw[1] * gw[1] + gw[2] * gw[2] + gw[3] * gw[3] + gw[4] * gw[4] + gw[5] * gw[5] +
+                       c1.z * c1.z + c1.w * c1.w + c2.x * c2.x + c2.y * c2.y + c2.z * c2.z + c2.w * c2.w;
+    const float invd = c3.y != 0.0f ? __builtin_amdgcn_rcpf(diag) : 0.0f;
+    sma.row(k, 0) = make_float4(gw[0], gw[1], gw[2], gw[3]);
+    sma.row(k, 1) = make_float4(gw[4], gw[5], c1.z, c1.w);
+    sma.row(k, 3) = make_float4(c3.x * invd, invd, diag, 0.0f);
+  }
+}
+
+// one sweep over the arm limit rows (they are non-contact rows: first in Bullet's sweep order)
+template <class SMA>
+__device__ __forceinline__ void pgs_arm_limits(const SMA& sma, PgsX& x, float* za, float* lam_a, unsigned active_any, float& worst) {
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    if (!((active_any >> k) & 1u)) continue;   // wave-uniform: no env of the wave has this bound in reach
+    const float4 c0 = sma.row(k, 0), c1 = sma.row(k, 1), c2 = sma.row(k, 2), c3 = sma.row(k, 3);
+    const float vel = c0.x * x.y01.x + c0.y * x.y01.y + c0.z * x.y23.x + c0.w * x.y23.y + c1.x * x.y45.x + c1.y * x.y45.y +
+                      c1.z * za[0] + c1.w * za[1] + c2.x * za[2] + c2.y * za[3] + c2.z * za[4] + c2.w * za[5];
+    const float nl = fmaxf(fmaf(-c3.y, vel, lam_a[k] + c3.x), 0.0f);
+    const float dl = nl - lam_a[k];
+    lam_a[k] = nl;
+    worst = fmaxf(worst, fabsf(dl * c3.z));
+    x.y01.x += c0.x * dl; x.y01.y += c0.y * dl; x.y23.x += c0.z * dl; x.y23.y += c0.w * dl; x.y45.x += c1.x * dl; x.y45.y += c1.y * dl;
+    za[0] += c1.z * dl; za[1] += c1.w * dl; za[2] += c2.x * dl; za[3] += c2.y * dl; za[4] += c2.z * dl; za[5] += c2.w * dl;
+  }
+}
+
+// qd_a = G^-T (z_a - Bw nu)
+template <class SMA>
+__device__ __forceinline__ void arm_back(const SMA& sma, const float* za, const float* nu, float* qd) {
+  ArmFactor L;
+  arm_unpark(sma, L);
+  float t[6], u[6];
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    float s = za[r];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) s -= L.Bw[r][k] * nu[k];
+    t[r] = s;
+  }
+  bwd6(L.G, t, u);
+#pragma unroll
+  for (int r = 0; r < 6; ++r) qd[r] = clampf(u[r], -kMaxCoordVel, kMaxCoordVel);
+}
+
+// the ARMP hook of physics_substep for mark='arm'
+template <int EPW>
+struct ArmChain {
+  static constexpr int NM = 18;
+  LdsArm<EPW> sma;
+  float za[6], lam_a[6];
+  unsigned active_any;   // bit k: some env of the wave has arm limit row k in reach
+
+  __device__ __forceinline__ void pass(const BaseKin& bk, PhysState& s, const float* tau, float dt, BaseAccum& acc, const Ground& ground) {
+    ArmFactor L;
+    const unsigned act = arm_pass(bk, s.q + 12, s.qd + 12, tau + 12, dt, L, acc, sma, ground);
+    arm_park(sma, L);
+    active_any = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      za[k] = L.z[k]; lam_a[k] = 0.0f;
+      if (__builtin_amdgcn_ballot_w64((act >> k) & 1u) != 0) active_any |= 1u << k;
+    }
+  }
+  __device__ __forceinline__ void finish(const Chol6& Lc) { arm_rows_finish(sma, Lc); }
+  __device__ __forceinline__ void sweep(PgsX& x, float& worst) { pgs_arm_limits(sma, x, za, lam_a, active_any, worst); }
+  __device__ __forceinline__ void back(const float* nu, PhysState& s) { arm_back(sma, za, nu, s.qd + 12); }
+};
+
+// picks the physics_substep hook of a kernel instantiation
+template <int EPW, bool ARM> struct ArmHook;
+template <int EPW> struct ArmHook<EPW, false> {
+  using type = NoArm;
+  __device__ __forceinline__ static NoArm make(float4*, int) { return NoArm{}; }
+};
+template <int EPW> struct ArmHook<EPW, true> {
+  using type = ArmChain<EPW>;
+  __device__ __forceinline__ static ArmChain<EPW> make(float4* lds, int slot) {
+    ArmChain<EPW> a;
+    a.sma = LdsArm<EPW>{lds, slot};
+    a.active_any = 0;
+    return a;
+  }
+};
+
+}  // namespace rex

@@ -516,7 +516,19 @@ __device__ __forceinline__ void mulT6(const Chol6& C, const float* b, float* x) 
 
 struct PhysState {
   float pos[3], quat[4], lin[3], ang[3];
-  float q[12], qd[12];
+  float q[18], qd[18];   // 12 leg motors (+ 6 arm motors for mark='arm'; untouched and optimised away otherwise)
+};
+
+struct BaseAccum;
+struct Chol6;
+struct PgsX;
+// Hook for an extra branch on the base (the arm of mark='arm', rex_arm_device.h).  NoArm = mark 'base'.
+struct NoArm {
+  static constexpr int NM = 12;
+  __device__ __forceinline__ void pass(const BaseKin&, PhysState&, const float*, float, BaseAccum&, const Ground&) {}
+  __device__ __forceinline__ void finish(const Chol6&) {}
+  __device__ __forceinline__ void sweep(PgsX&, float&) {}
+  __device__ __forceinline__ void back(const float*, PhysState&) {}
 };
 
 // whitened solver state: y = 3 packed pairs, per leg z = (pair, scalar)
@@ -597,9 +609,9 @@ __device__ __forceinline__ void rotate_leg(T* a) {   // 12-entry per-joint array
   a[9] = t0; a[10] = t1; a[11] = t2;
 }
 
-template <class SM>
+template <class SM, class ARMP>
 __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float dt, int iterations,
-                                                float sqrt_res_thr, const SM& sm, const Ground& ground) {
+                                                float sqrt_res_thr, const SM& sm, const Ground& ground, ARMP& armp) {
   // base rotation (btMatrix3x3::setRotation)
   BaseKin bk;
   {
@@ -649,6 +661,7 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
     const float4 zc = sm.leg(k, 6);
     x.z01[k] = v2{zc.x, zc.y}; x.z2[k] = zc.z;
   }
+  armp.pass(bk, s, tau, dt, acc, ground);   // extra branch on the base (mark='arm'), no-op otherwise
 
   // base articulated inertia A = [[Io, hx],[hx^T, m]] - S, then A = Lc Lc^T
   float A[21];
@@ -683,6 +696,7 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
   }
 
   // finish the rows: whiten the base part, inverse diagonal (0 disables an inactive point)
+  armp.finish(Lc);
   const bool any_limit = __builtin_amdgcn_ballot_w64((active >> REX_NPOINT) != 0) != 0;
   for (int r = 0; r < (any_limit ? REX_NROW : REX_NCROW); ++r) {
     float4 c0 = sm.row(r, 0), c1 = sm.row(r, 1), c2 = sm.row(r, 2);
@@ -723,6 +737,7 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
       if (lim1) pgs_leg_limits<1>(sm, x, lam, worst);
       if (lim2) pgs_leg_limits<2>(sm, x, lam, worst);
       if (lim3) pgs_leg_limits<3>(sm, x, lam, worst);
+      armp.sweep(x, worst);
       if (any0) pgs_leg_normals<0>(sm, x, lam, worst);
       if (any1) pgs_leg_normals<1>(sm, x, lam, worst);
       if (any2) pgs_leg_normals<2>(sm, x, lam, worst);
@@ -758,6 +773,7 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
     s.qd[2] = clampf(u3, -kMaxCoordVel, kMaxCoordVel);
     rotate_leg(s.qd); rotate_leg(zt);
   }
+  armp.back(nu, s);
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     s.ang[k] = clampf(nu[k], -kMaxCoordVel, kMaxCoordVel);
@@ -767,7 +783,7 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
 #pragma unroll
   for (int k = 0; k < 3; ++k) s.pos[k] += dt * s.lin[k];
 #pragma unroll
-  for (int j = 0; j < 12; ++j) s.q[j] += dt * s.qd[j];
+  for (int j = 0; j < ARMP::NM; ++j) s.q[j] += dt * s.qd[j];
   {
     const float wn = sqrtf(s.ang[0] * s.ang[0] + s.ang[1] * s.ang[1] + s.ang[2] * s.ang[2]);
     const float angle = wn * dt;

@@ -17,6 +17,7 @@
 #include <stdlib.h>
 
 #include "rex_device.h"
+#include "rex_arm_device.h"
 #include "rex_controller.h"
 
 namespace rex {
@@ -38,48 +39,63 @@ struct EnvState {
   uint32_t flags;
   int32_t steps, episode;
   uint32_t motor_en;
-  uint32_t overheat[12]; // one counter per motor in registers; packed 2 x u16 per state word in HBM
+  uint32_t overheat[18]; // one counter per motor in registers; packed 2 x u16 per state word in HBM
   uint32_t hist;         // observation-history ring: bits 0-7 newest slot, bits 8-15 fill
 };
+
+// Persistent-state word layout for NM motors (include/rexsim.h spells out NM = 12 as enum RexStateWord; mark='arm'
+// has NM = 18: the q / qd blocks and the overheat block grow, everything else keeps its order)
+template <int NM>
+struct Lay {
+  static constexpr int Q = 13, QD = 13 + NM, PHI = 13 + 2 * NM, LASTT = PHI + 1, ALPHA = PHI + 2, TARGET = PHI + 3,
+                       ENDTIME = PHI + 4, AUX = PHI + 5, FLAGS = PHI + 6, STEPS = PHI + 7, EPISODE = PHI + 8, MOTOR_EN = PHI + 9,
+                       OVERHEAT = PHI + 10, HIST = OVERHEAT + NM / 2, WORDS = HIST + 1;
+};
+static_assert(Lay<12>::PHI == REX_S_PHI && Lay<12>::FLAGS == REX_S_FLAGS && Lay<12>::OVERHEAT == REX_S_OVERHEAT &&
+              Lay<12>::HIST == REX_S_HIST && Lay<12>::WORDS == REX_STATE_WORDS, "layout must match include/rexsim.h");
 
 __device__ __forceinline__ float ldw(const float* st, int n, int w, int i) { return st[(size_t)w * n + i]; }
 __device__ __forceinline__ uint32_t ldi(const float* st, int n, int w, int i) { return __float_as_uint(st[(size_t)w * n + i]); }
 __device__ __forceinline__ void stw(float* st, int n, int w, int i, float v) { st[(size_t)w * n + i] = v; }
 __device__ __forceinline__ void sti(float* st, int n, int w, int i, uint32_t v) { st[(size_t)w * n + i] = __uint_as_float(v); }
 
+template <int NM>
 __device__ __forceinline__ void load_env(const float* st, int n, int i, EnvState& e) {
+  using Y = Lay<NM>;
 #pragma unroll
   for (int k = 0; k < 3; ++k) { e.ph.pos[k] = ldw(st, n, REX_S_POS + k, i); e.ph.lin[k] = ldw(st, n, REX_S_LINVEL + k, i); e.ph.ang[k] = ldw(st, n, REX_S_ANGVEL + k, i); }
 #pragma unroll
   for (int k = 0; k < 4; ++k) e.ph.quat[k] = ldw(st, n, REX_S_QUAT + k, i);
 #pragma unroll
-  for (int j = 0; j < 12; ++j) { e.ph.q[j] = ldw(st, n, REX_S_Q + j, i); e.ph.qd[j] = ldw(st, n, REX_S_QD + j, i); }
-  e.gait.phi = ldw(st, n, REX_S_PHI, i); e.gait.last_time = ldw(st, n, REX_S_LASTT, i); e.gait.alpha = ldw(st, n, REX_S_ALPHA, i);
-  e.target = ldw(st, n, REX_S_TARGET, i); e.end_time = ldw(st, n, REX_S_ENDTIME, i); e.aux = ldw(st, n, REX_S_AUX, i);
-  e.flags = ldi(st, n, REX_S_FLAGS, i); e.steps = (int32_t)ldi(st, n, REX_S_STEPS, i); e.episode = (int32_t)ldi(st, n, REX_S_EPISODE, i);
-  e.motor_en = ldi(st, n, REX_S_MOTOR_EN, i);
-  e.hist = ldi(st, n, REX_S_HIST, i);
+  for (int j = 0; j < NM; ++j) { e.ph.q[j] = ldw(st, n, Y::Q + j, i); e.ph.qd[j] = ldw(st, n, Y::QD + j, i); }
+  e.gait.phi = ldw(st, n, Y::PHI, i); e.gait.last_time = ldw(st, n, Y::LASTT, i); e.gait.alpha = ldw(st, n, Y::ALPHA, i);
+  e.target = ldw(st, n, Y::TARGET, i); e.end_time = ldw(st, n, Y::ENDTIME, i); e.aux = ldw(st, n, Y::AUX, i);
+  e.flags = ldi(st, n, Y::FLAGS, i); e.steps = (int32_t)ldi(st, n, Y::STEPS, i); e.episode = (int32_t)ldi(st, n, Y::EPISODE, i);
+  e.motor_en = ldi(st, n, Y::MOTOR_EN, i);
+  e.hist = ldi(st, n, Y::HIST, i);
 #pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    const uint32_t w = ldi(st, n, REX_S_OVERHEAT + k, i);
+  for (int k = 0; k < NM / 2; ++k) {
+    const uint32_t w = ldi(st, n, Y::OVERHEAT + k, i);
     e.overheat[2 * k] = w & 0xFFFFu; e.overheat[2 * k + 1] = w >> 16;
   }
 }
 
+template <int NM>
 __device__ __forceinline__ void store_env(float* st, int n, int i, const EnvState& e) {
+  using Y = Lay<NM>;
 #pragma unroll
   for (int k = 0; k < 3; ++k) { stw(st, n, REX_S_POS + k, i, e.ph.pos[k]); stw(st, n, REX_S_LINVEL + k, i, e.ph.lin[k]); stw(st, n, REX_S_ANGVEL + k, i, e.ph.ang[k]); }
 #pragma unroll
   for (int k = 0; k < 4; ++k) stw(st, n, REX_S_QUAT + k, i, e.ph.quat[k]);
 #pragma unroll
-  for (int j = 0; j < 12; ++j) { stw(st, n, REX_S_Q + j, i, e.ph.q[j]); stw(st, n, REX_S_QD + j, i, e.ph.qd[j]); }
-  stw(st, n, REX_S_PHI, i, e.gait.phi); stw(st, n, REX_S_LASTT, i, e.gait.last_time); stw(st, n, REX_S_ALPHA, i, e.gait.alpha);
-  stw(st, n, REX_S_TARGET, i, e.target); stw(st, n, REX_S_ENDTIME, i, e.end_time); stw(st, n, REX_S_AUX, i, e.aux);
-  sti(st, n, REX_S_FLAGS, i, e.flags); sti(st, n, REX_S_STEPS, i, (uint32_t)e.steps); sti(st, n, REX_S_EPISODE, i, (uint32_t)e.episode);
-  sti(st, n, REX_S_MOTOR_EN, i, e.motor_en);
-  sti(st, n, REX_S_HIST, i, e.hist);
+  for (int j = 0; j < NM; ++j) { stw(st, n, Y::Q + j, i, e.ph.q[j]); stw(st, n, Y::QD + j, i, e.ph.qd[j]); }
+  stw(st, n, Y::PHI, i, e.gait.phi); stw(st, n, Y::LASTT, i, e.gait.last_time); stw(st, n, Y::ALPHA, i, e.gait.alpha);
+  stw(st, n, Y::TARGET, i, e.target); stw(st, n, Y::ENDTIME, i, e.end_time); stw(st, n, Y::AUX, i, e.aux);
+  sti(st, n, Y::FLAGS, i, e.flags); sti(st, n, Y::STEPS, i, (uint32_t)e.steps); sti(st, n, Y::EPISODE, i, (uint32_t)e.episode);
+  sti(st, n, Y::MOTOR_EN, i, e.motor_en);
+  sti(st, n, Y::HIST, i, e.hist);
 #pragma unroll
-  for (int k = 0; k < 6; ++k) sti(st, n, REX_S_OVERHEAT + k, i, e.overheat[2 * k] | (e.overheat[2 * k + 1] << 16));
+  for (int k = 0; k < NM / 2; ++k) sti(st, n, Y::OVERHEAT + k, i, e.overheat[2 * k] | (e.overheat[2 * k + 1] << 16));
 }
 
 // ---- PyBullet quaternion conventions ----
@@ -169,7 +185,7 @@ __device__ __forceinline__ float delayed_word(const DevCfg& c, int i, int s0, in
   return (1.0f - alpha) * hist_at(c, i, s0, w) + alpha * hist_at(c, i, s1, w);
 }
 // the controller-facing observation (Rex._control_observation): q, qd, tau_obs, quat, angular velocity
-struct CtrlObs { float q[12], qd[12], tau[12], quat[4], w[3]; };
+struct CtrlObs { float q[18], qd[18], tau[18], quat[4], w[3]; };
 
 // terrain of (global env index, episode): the reference regenerates the field on every reset
 // (rex_gym_env.py:347-348); here each episode picks one of the pool entries
@@ -189,20 +205,22 @@ __device__ __forceinline__ Ground env_ground(const DevCfg& c, int i, int gidx, i
   return g;
 }
 
-// Rex.ApplyAction + stepSimulation + ReceiveObservation (rex.py:158-163, 568-641)
-template <class SM>
+// Rex.ApplyAction + stepSimulation + ReceiveObservation (rex.py:158-163, 568-641).  The latency model (c.hist) is
+// only offered for mark 'base' (43-word history records); rex_create rejects it for mark 'arm'.
+template <class SM, class ARMP>
 __device__ __forceinline__ void rex_substep(const DevCfg& c, EnvState& e, int i, bool live, const float* cmd, float* tau_obs,
-                                            const SM& sm, const Ground& ground) {
-  float tau[12];
+                                            const SM& sm, const Ground& ground, ARMP& armp) {
+  constexpr int NM = ARMP::NM;
+  float tau[18];
   const float limit = 1.0f / c.dt;  // OVERHEAT_SHUTDOWN_TIME / time_step, rex.py:607
   int s0 = 0, s1 = 0;
   float alpha = 0.0f;
   if (c.hist) delay_slots(c, e.hist, c.pd_latency, s0, s1, alpha);               // _GetPDObservation, rex.py:755-759
 #pragma unroll
-  for (int j = 0; j < 12; ++j) {
+  for (int j = 0; j < NM; ++j) {
     float act, obs;
-    const float qo = c.hist ? delayed_word(c, i, s0, s1, alpha, j) : e.ph.q[j];
-    const float qdo = c.hist ? delayed_word(c, i, s0, s1, alpha, 12 + j) : e.ph.qd[j];
+    const float qo = (c.hist && j < 12) ? delayed_word(c, i, s0, s1, alpha, j) : e.ph.q[j];
+    const float qdo = (c.hist && j < 12) ? delayed_word(c, i, s0, s1, alpha, 12 + j) : e.ph.qd[j];
     motor_torque(cmd[j], qo, qdo, e.ph.qd[j], c.kp, c.kd, act, obs);
     uint32_t cnt = e.overheat[j];
     cnt = fabsf(act) > 2.45f ? min(cnt + 1u, 65535u) : 0u;                      // rex.py:603-606
@@ -211,7 +229,7 @@ __device__ __forceinline__ void rex_substep(const DevCfg& c, EnvState& e, int i,
     tau_obs[j] = obs;
     tau[j] = ((e.motor_en >> j) & 1u) ? act : 0.0f;                             // rex.py:617-623
   }
-  physics_substep(e.ph, tau, c.dt, c.iterations, c.res_thr, sm, ground);
+  physics_substep(e.ph, tau, c.dt, c.iterations, c.res_thr, sm, ground, armp);
   if (c.hist) {                                                                  // ReceiveObservation, rex.py:726-733
     const int head = ((int)(e.hist & 0xFFu) + 1) % REX_HISTORY_LEN;
     const int len = min((int)((e.hist >> 8) & 0xFFu) + 1, REX_HISTORY_LEN);
@@ -228,6 +246,7 @@ __device__ __forceinline__ void rex_substep(const DevCfg& c, EnvState& e, int i,
 }
 
 // Rex._control_observation as the env-level getters see it (delayed by control_latency when the model is on)
+template <int NM>
 __device__ __forceinline__ void control_observation(const DevCfg& c, const EnvState& e, int i, const float* tau_obs, CtrlObs& o) {
   if (c.hist) {
     int s0, s1; float alpha;
@@ -243,7 +262,7 @@ __device__ __forceinline__ void control_observation(const DevCfg& c, const EnvSt
     for (int k = 0; k < 3; ++k) o.w[k] = delayed_word(c, i, s0, s1, alpha, 40 + k);
   } else {
 #pragma unroll
-    for (int j = 0; j < 12; ++j) { o.q[j] = e.ph.q[j]; o.qd[j] = e.ph.qd[j]; o.tau[j] = tau_obs[j]; }
+    for (int j = 0; j < NM; ++j) { o.q[j] = e.ph.q[j]; o.qd[j] = e.ph.qd[j]; o.tau[j] = tau_obs[j]; }
 #pragma unroll
     for (int k = 0; k < 4; ++k) o.quat[k] = e.ph.quat[k];
 #pragma unroll
@@ -254,7 +273,7 @@ __device__ __forceinline__ void control_observation(const DevCfg& c, const EnvSt
 // RangeNormalize of the observation (wrappers.py:236-240); bounds are symmetric (rex_gym_env.py:277-278)
 __device__ __forceinline__ void normalize_obs(const DevCfg& c, float* obs) {
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
+  for (int k = 0; k < 22; ++k) {
     if (k < c.obs_dim) {
       const float hi = (k == 2 || k == 3) ? c.obs_hi_rate : c.obs_hi_ang, lo = -hi;
       obs[k] = 2.0f * (obs[k] - lo) / (hi - lo) - 1.0f;
@@ -262,13 +281,14 @@ __device__ __forceinline__ void normalize_obs(const DevCfg& c, float* obs) {
   }
 }
 
+template <int NM>
 __device__ __forceinline__ void env_observation(const DevCfg& c, const CtrlObs& co, float* obs) {
   float rpy[3];
   quat_to_euler(co.quat, rpy);
   obs[0] = rpy[0]; obs[1] = rpy[1]; obs[2] = co.w[0]; obs[3] = co.w[1];           // walk_env.py:356-362
   if (c.task == REX_TASK_GALLOP) {
 #pragma unroll
-    for (int j = 0; j < 12; ++j) {                                                // MapToMinusPiToPi, rex.py:26-41
+    for (int j = 0; j < NM; ++j) {                                                // MapToMinusPiToPi, rex.py:26-41
       float a = fmodf(co.q[j], 2.0f * kPi);
       if (a >= kPi) a -= 2.0f * kPi; else if (a < -kPi) a += 2.0f * kPi;
       obs[4 + j] = a;
@@ -277,9 +297,10 @@ __device__ __forceinline__ void env_observation(const DevCfg& c, const CtrlObs& 
 }
 
 // RexWalkEnv.reset / RexReactiveEnv.reset draws on top of the settled snapshot
+template <int NM>
 __device__ __forceinline__ void env_reset(const DevCfg& c, const float* snap, int i, bool live, int gidx, EnvState& e) {
   const int32_t episode = e.episode + 1;
-  load_env(snap, c.n_terrain > 0 ? c.n_terrain : 1, c.n_terrain > 0 ? terrain_index(c, gidx, episode) : 0, e);   // settled on this episode's terrain
+  load_env<NM>(snap, c.n_terrain > 0 ? c.n_terrain : 1, c.n_terrain > 0 ? terrain_index(c, gidx, episode) : 0, e);   // settled on this episode's terrain
   if (c.hist) {   // the history restarts with the settled observation (observed torques are not part of the snapshot: 0)
     e.hist = 0u | (1u << 8);
     if (live) {
@@ -479,7 +500,7 @@ __device__ __forceinline__ void turn_command(const DevCfg& c, EnvState& e, const
 }
 
 // ------------------------------------------------------------------------------------------
-template <int EPW>
+template <int EPW, bool ARM>
 __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __restrict__ state, const float* __restrict__ snap,
                                                             const float* __restrict__ action, float* __restrict__ obs_out,
                                                             float* __restrict__ reward_out, uint8_t* __restrict__ done_out,
@@ -488,16 +509,18 @@ __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __r
   // idle SIMDs are free and a wave leaves the PGS sweep loop only when its slowest env has converged (and skips
   // only the legs no env of the wave has in contact), so fewer envs per wave means fewer sweeps and rows per
   // wave.  Lanes >= EPW mirror lane (lane mod EPW): same env, same arithmetic, no stores.
-  __shared__ float4 lds[REX_LDS_F4_PER_ENV * EPW];
+  constexpr int NM = ARM ? 18 : 12;   // mark='arm': 6 more motors held at ARM_POSES['rest'] (rex_gym_env.py:347-353)
+  __shared__ float4 lds[(ARM ? REX_LDS_F4_PER_ENV_ARM : REX_LDS_F4_PER_ENV) * EPW];
   const int lane = threadIdx.x;
   const int slot = lane & (EPW - 1);
   const int gi = blockIdx.x * EPW + slot;
   const bool live = lane < EPW && gi < c.n;
   const int i = gi < c.n ? gi : c.n - 1;   // tail slots shadow the last env (keeps the wave convergent)
   const Lds<EPW> sm{lds, slot};
+  typename ArmHook<EPW, ARM>::type armp = ArmHook<EPW, ARM>::make(lds, slot);
 
   EnvState e;
-  load_env(state, c.n, i, e);
+  load_env<NM>(state, c.n, i, e);
   float act[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
@@ -509,7 +532,11 @@ __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __r
     act[k] = a;
   }
 
-  float cmd[12];
+  float cmd[NM];
+  if (ARM) {
+#pragma unroll
+    for (int j = 12; j < NM; ++j) cmd[j] = (float)REXA_REST[j - 12];
+  }
   if (c.task == REX_TASK_GALLOP) gallop_command(c, e, act, cmd);
   else if (c.task == REX_TASK_TURN) {
     float cq[4] = {e.ph.quat[0], e.ph.quat[1], e.ph.quat[2], e.ph.quat[3]};
@@ -524,13 +551,13 @@ __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __r
   else if (c.task == REX_TASK_POSES) poses_command(c, e, act, cmd);
   else walk_command(c, e, act, cmd);
 
-  float tau_obs[12];
+  float tau_obs[NM];
   const Ground ground = env_ground(c, i, c.env_index_base + i, e.episode);
-  for (int k = 0; k < c.action_repeat; ++k) rex_substep(c, e, i, live, cmd, tau_obs, sm, ground);   // Rex.Step
+  for (int k = 0; k < c.action_repeat; ++k) rex_substep(c, e, i, live, cmd, tau_obs, sm, ground, armp);   // Rex.Step
 
   // ---- reward (rex_gym_env.py:501-542) ----
   CtrlObs co;
-  control_observation(c, e, i, tau_obs, co);
+  control_observation<NM>(c, e, i, tau_obs, co);
   float rpy[3], r20, r21, r22;
   quat_to_euler(co.quat, rpy);       // GetBaseOrientation: (delayed) quat -> RPY -> quat, rex.py:530-537
   euler_to_row2(rpy, r20, r21, r22);
@@ -547,7 +574,7 @@ __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __r
   const float shake = -fabsf(r20 + r21);
   float dp = 0.0f;
 #pragma unroll
-  for (int j = 0; j < 12; ++j) dp += co.tau[j] * co.qd[j];   // GetMotorTorques . GetMotorVelocities
+  for (int j = 0; j < NM; ++j) dp += co.tau[j] * co.qd[j];   // GetMotorTorques . GetMotorVelocities
   const float energy = -fabsf(dp) * c.dt;
   float reward = c.w_dist * fwd + c.w_energy * energy + c.w_drift * drift + c.w_shake * shake;
   if (c.task == REX_TASK_TURN) reward = 0.035f - fabsf(e.ph.pos[0]) - fabsf(e.ph.pos[1]);   // turn_env.py:362-367
@@ -566,36 +593,40 @@ __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __r
   if (c.max_steps > 0 && e.steps >= c.max_steps) done = true;
   if (done) e.flags |= REX_F_DONE;
   if (done && c.auto_reset) {
-    env_reset(c, snap, i, live, c.env_index_base + i, e);
+    env_reset<NM>(c, snap, i, live, c.env_index_base + i, e);
 #pragma unroll
-    for (int j = 0; j < 12; ++j) tau_obs[j] = 0.0f;
-    control_observation(c, e, i, tau_obs, co);
+    for (int j = 0; j < NM; ++j) tau_obs[j] = 0.0f;
+    control_observation<NM>(c, e, i, tau_obs, co);
   }
 
-  float obs[16];
-  env_observation(c, co, obs);
+  float obs[22];
+  env_observation<NM>(c, co, obs);
   if (c.range_normalize) normalize_obs(c, obs);
   if (live) {
-    store_env(state, c.n, i, e);
+    store_env<NM>(state, c.n, i, e);
     for (int k = 0; k < c.obs_dim; ++k) obs_out[(size_t)i * c.obs_dim + k] = obs[k];
     reward_out[i] = reward;
     done_out[i] = done ? 1 : 0;
     if (cmd_out) {
 #pragma unroll
-      for (int j = 0; j < 12; ++j) cmd_out[(size_t)i * 12 + j] = cmd[j];
+      for (int j = 0; j < NM; ++j) cmd_out[(size_t)i * NM + j] = cmd[j];
     }
   }
 }
 
 // The reset motion of Rex.Reset (rex.py:296-324).  Plane: ONE robot, lane 0 writes the snapshot.  Terrain pool:
 // lane t settles on terrain t and writes snapshot record t (word-major [53][n_terrain]).
+template <bool ARM>
 __global__ __launch_bounds__(REX_WAVE) void rex_settle_kernel(DevCfg c, float* __restrict__ snap) {
-  __shared__ float4 lds[REX_LDS_F4_PER_ENV * REX_WAVE];
-  const int lane = threadIdx.x;
-  const Lds<REX_WAVE> sm{lds, lane};
+  constexpr int NM = ARM ? 18 : 12;
+  constexpr int EPW = ARM ? 16 : REX_WAVE;   // the arm rows do not fit 64 envs per workgroup in LDS
+  __shared__ float4 lds[(ARM ? REX_LDS_F4_PER_ENV_ARM : REX_LDS_F4_PER_ENV) * EPW];
+  const int lane = threadIdx.x & (EPW - 1);
+  const Lds<EPW> sm{lds, lane};
+  typename ArmHook<EPW, ARM>::type armp = ArmHook<EPW, ARM>::make(lds, lane);
   const int nrec = c.n_terrain > 0 ? c.n_terrain : 1;
-  const int rec = blockIdx.x * REX_WAVE + lane;
-  const int t = rec < nrec ? rec : nrec - 1;
+  const int rec = threadIdx.x < EPW ? blockIdx.x * EPW + lane : nrec;
+  const int t = blockIdx.x * EPW + lane < nrec ? blockIdx.x * EPW + lane : nrec - 1;
   Ground ground{nullptr, 0.0f, 1.0f, 1.0f, kMu};
   if (c.n_terrain > 0) { ground.h = c.terrain + (size_t)t * 65536; ground.mid = c.terrain_mid[t]; }
   EnvState e;
@@ -604,22 +635,31 @@ __global__ __launch_bounds__(REX_WAVE) void rex_settle_kernel(DevCfg c, float* _
   e.ph.quat[3] = 1.0f;
 #pragma unroll
   for (int j = 0; j < 12; ++j) e.ph.q[j] = pose_stand(j);       // ResetPose: INIT_POSES[pose_id = 'stand']
-  e.motor_en = (1u << 12) - 1u;
+  if (ARM) {                                                     // ResetPose: arm motors at ARM_POSES['rest'] (rex.py:371-373)
+#pragma unroll
+    for (int j = 12; j < NM; ++j) e.ph.q[j] = (float)REXA_REST[j - 12];
+  }
+  e.motor_en = (1u << NM) - 1u;
   if (c.task != REX_TASK_POSES) {   // RexPosesEnv: base reset() with initial_motor_angles=None skips the motion (rex.py:308)
     DevCfg cs = c;
     cs.hist = nullptr;              // the reset motion runs without the latency model (the snapshot carries no history)
-    float cmd[12], tau_obs[12];
+    float cmd[NM], tau_obs[NM];
+    if (ARM) {
+#pragma unroll
+      for (int j = 12; j < NM; ++j) cmd[j] = (float)REXA_REST[j - 12];
+    }
 #pragma unroll
     for (int j = 0; j < 12; ++j) cmd[j] = pose_stand(j);
-    for (int k = 0; k < 100; ++k) rex_substep(cs, e, 0, false, cmd, tau_obs, sm, ground);   // rex.py:315-318
+    for (int k = 0; k < 100; ++k) rex_substep(cs, e, 0, false, cmd, tau_obs, sm, ground, armp);   // rex.py:315-318
 #pragma unroll
     for (int j = 0; j < 12; ++j) cmd[j] = init_pose(c, j);
     const int nreset = (int)(0.5f / c.dt);                                               // rex.py:319
-    for (int k = 0; k < nreset; ++k) rex_substep(cs, e, 0, false, cmd, tau_obs, sm, ground);
+    for (int k = 0; k < nreset; ++k) rex_substep(cs, e, 0, false, cmd, tau_obs, sm, ground, armp);
   }
-  if (rec < nrec) store_env(snap, nrec, rec, e);
+  if (rec < nrec) store_env<NM>(snap, nrec, rec, e);
 }
 
+template <int NM>
 __global__ void rex_reset_kernel(DevCfg c, float* __restrict__ state, const float* __restrict__ snap,
                                  const int32_t* __restrict__ indices, int count, float* __restrict__ obs_out) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -627,13 +667,15 @@ __global__ void rex_reset_kernel(DevCfg c, float* __restrict__ state, const floa
   const int i = indices ? indices[r] : r;
   if (i < 0 || i >= c.n) return;
   EnvState e;
-  e.episode = (int32_t)ldi(state, c.n, REX_S_EPISODE, i);
-  env_reset(c, snap, i, true, c.env_index_base + i, e);
-  store_env(state, c.n, i, e);
-  float obs[16], tz[12] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  e.episode = (int32_t)ldi(state, c.n, Lay<NM>::EPISODE, i);
+  env_reset<NM>(c, snap, i, true, c.env_index_base + i, e);
+  store_env<NM>(state, c.n, i, e);
+  float obs[22], tz[NM];
+#pragma unroll
+  for (int j = 0; j < NM; ++j) tz[j] = 0.0f;
   CtrlObs co;
-  control_observation(c, e, i, tz, co);
-  env_observation(c, co, obs);
+  control_observation<NM>(c, e, i, tz, co);
+  env_observation<NM>(c, co, obs);
   if (c.range_normalize) normalize_obs(c, obs);
   if (obs_out) for (int k = 0; k < c.obs_dim; ++k) obs_out[(size_t)r * c.obs_dim + k] = obs[k];
 }
@@ -687,6 +729,7 @@ struct RexSim {
   hipEvent_t ev0, ev1;
   int timing;
   int have_timing;
+  int words;   // per-env state words of the config's mark
 };
 
 static thread_local char g_err[512] = "";
@@ -741,9 +784,17 @@ int rex_action_dim(const RexConfig* c) {
   if (c->task == REX_TASK_POSES) return 1;                                      /* poses_env.py:115-117 */
   return REX_EINVAL;
 }
+int rex_num_motors(const RexConfig* c) {
+  if (!c) return REX_EINVAL;
+  return c->mark == REX_MARK_ARM ? REX_NUM_MOTORS_ARM : REX_NUM_MOTORS;         /* mark_constants.py MARK_DETAILS['motors_num'] */
+}
+int rex_state_words(const RexConfig* c) {
+  if (!c) return REX_EINVAL;
+  return c->mark == REX_MARK_ARM ? rex::Lay<REX_NUM_MOTORS_ARM>::WORDS : REX_STATE_WORDS;
+}
 int rex_obs_dim(const RexConfig* c) {
   if (!c) return REX_EINVAL;
-  return c->task == REX_TASK_GALLOP ? 16 : 4;                                    /* gallop_env.py:349-356 */
+  return c->task == REX_TASK_GALLOP ? 4 + rex_num_motors(c) : 4;                 /* gallop_env.py:349-356 */
 }
 
 // Envs per wave.  Up to 16 384 envs the launch is latency-bound with idle SIMDs (256 CUs x 4 SIMDs = 1 024), so the
@@ -757,6 +808,10 @@ static int pick_envs_per_wave(int n) {
   return 64;
 }
 
+// kernel instantiations by (envs per wave, mark); the arm rows fit 4 or 16 envs per workgroup in LDS
+static void launch_step(RexSim* s, int blocks, hipStream_t st, const float* a, float* o, float* r, uint8_t* d, float* m);
+static void launch_settle(RexSim* s, int nrec, hipStream_t st, float* snap);
+
 static int validate(const RexConfig* c) {
   if (!c) return fail(REX_EINVAL, "null config%s", "");
   if (c->abi_version != REX_ABI_VERSION) return fail(REX_EINVAL, "RexConfig.abi_version mismatch%s", "");
@@ -764,6 +819,9 @@ static int validate(const RexConfig* c) {
   if (rex_action_dim(c) < 0) return fail(REX_EINVAL, "unsupported task/signal%s", "");
   if (c->action_repeat <= 0 || c->solver_iterations <= 0 || !(c->sim_time_step > 0.0f))
     return fail(REX_EINVAL, "action_repeat, solver_iterations and sim_time_step must be positive%s", "");
+  if (c->mark != REX_MARK_BASE && c->mark != REX_MARK_ARM) return fail(REX_EINVAL, "unknown mark%s", "");
+  if (c->mark == REX_MARK_ARM && (c->pd_latency > 0.0f || c->control_latency > 0.0f))
+    return fail(REX_EINVAL, "the latency model is not available with mark 'arm'%s", "");
   return REX_OK;
 }
 
@@ -790,6 +848,8 @@ int rex_create(const RexConfig* cfg, int device, float* d_state, void* stream, R
   d.w_dist = cfg->distance_weight; d.w_energy = cfg->energy_weight; d.w_drift = cfg->drift_weight; d.w_shake = cfg->shake_weight;
   d.action_dim = rex_action_dim(cfg); d.obs_dim = rex_obs_dim(cfg);
   s->epw = pick_envs_per_wave(cfg->num_envs);
+  if (cfg->mark == REX_MARK_ARM && s->epw > 16) s->epw = 16;
+  s->words = rex_state_words(cfg);
   d.pose_index = cfg->pose_index; d.pose_value = cfg->pose_value;
   d.range_normalize = cfg->range_normalize;
   d.terrain = nullptr; d.terrain_mid = nullptr; d.n_terrain = 0; d.body_params = nullptr;
@@ -805,14 +865,14 @@ int rex_create(const RexConfig* cfg, int device, float* d_state, void* stream, R
     d.obs_hi_rate = (float)(2.0 * M_PI) / cfg->sim_time_step + 0.01f;
   }
   d.target_orient = cfg->target_orient; d.init_orient = cfg->init_orient; d.orient_fixed = cfg->orient_fixed;
-  hipError_t e = hipMalloc(&s->d_snap, sizeof(float) * REX_STATE_WORDS);
+  hipError_t e = hipMalloc(&s->d_snap, sizeof(float) * s->words);
   if (e != hipSuccess) { delete s; return fail(REX_ENOMEM, "hipMalloc(snapshot): %s", hipGetErrorString(e)); }
   (void)hipEventCreate(&s->ev0);
   (void)hipEventCreate(&s->ev1);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(rex::rex_settle_kernel, dim3(1), dim3(REX_WAVE), 0, st, s->dev, s->d_snap);
+  launch_settle(s, 1, st, s->d_snap);
   e = hipGetLastError();
-  if (e == hipSuccess) e = hipMemsetAsync(d_state, 0, sizeof(float) * (size_t)REX_STATE_WORDS * cfg->num_envs, st);
+  if (e == hipSuccess) e = hipMemsetAsync(d_state, 0, sizeof(float) * (size_t)s->words * cfg->num_envs, st);
   if (e == hipSuccess) e = hipStreamSynchronize(st);
   if (e != hipSuccess) {
     (void)hipFree(s->d_snap);
@@ -829,14 +889,14 @@ int rex_set_terrain(RexSim* s, const float* d_heights, const float* d_mids, int 
   hipStream_t st = (hipStream_t)stream;
   float* snap = nullptr;
   const int nrec = k > 0 ? k : 1;
-  HIPCHK(hipMalloc(&snap, sizeof(float) * REX_STATE_WORDS * (size_t)nrec));
+  HIPCHK(hipMalloc(&snap, sizeof(float) * s->words * (size_t)nrec));
   HIPCHK(hipStreamSynchronize(st));
   (void)hipFree(s->d_snap);
   s->d_snap = snap;
   s->dev.terrain = k > 0 ? d_heights : nullptr;
   s->dev.terrain_mid = k > 0 ? d_mids : nullptr;
   s->dev.n_terrain = k;
-  hipLaunchKernelGGL(rex::rex_settle_kernel, dim3((nrec + REX_WAVE - 1) / REX_WAVE), dim3(REX_WAVE), 0, st, s->dev, s->d_snap);
+  launch_settle(s, nrec, st, s->d_snap);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(st));
   return REX_OK;
@@ -844,6 +904,7 @@ int rex_set_terrain(RexSim* s, const float* d_heights, const float* d_mids, int 
 
 int rex_set_history(RexSim* s, float* d_history) {
   if (!s) return fail(REX_EINVAL, "rex_set_history: null sim%s", "");
+  if (s->cfg.mark == REX_MARK_ARM && d_history) return fail(REX_EINVAL, "rex_set_history: not available with mark 'arm'%s", "");
   s->dev.hist = d_history;
   return REX_OK;
 }
@@ -872,8 +933,12 @@ int rex_reset(RexSim* s, const int32_t* d_indices, int n, float* d_obs, void* st
   if (count <= 0) return d_indices ? REX_OK : fail(REX_EINVAL, "rex_reset: empty%s", "");
   HIPCHK(hipSetDevice(s->device));
   const int block = 256;
-  hipLaunchKernelGGL(rex::rex_reset_kernel, dim3((count + block - 1) / block), dim3(block), 0, (hipStream_t)stream, s->dev,
-                     s->d_state, s->d_snap, d_indices, count, d_obs);
+  if (s->cfg.mark == REX_MARK_ARM)
+    hipLaunchKernelGGL(rex::rex_reset_kernel<18>, dim3((count + block - 1) / block), dim3(block), 0, (hipStream_t)stream, s->dev,
+                       s->d_state, s->d_snap, d_indices, count, d_obs);
+  else
+    hipLaunchKernelGGL(rex::rex_reset_kernel<12>, dim3((count + block - 1) / block), dim3(block), 0, (hipStream_t)stream, s->dev,
+                       s->d_state, s->d_snap, d_indices, count, d_obs);
   HIPCHK(hipGetLastError());
   return REX_OK;
 }
@@ -884,15 +949,7 @@ int rex_step(RexSim* s, const float* d_action, float* d_obs, float* d_reward, ui
   hipStream_t st = (hipStream_t)stream;
   const int blocks = (s->cfg.num_envs + s->epw - 1) / s->epw;
   if (s->timing) HIPCHK(hipEventRecord(s->ev0, st));
-  if (s->epw == 4)
-    hipLaunchKernelGGL(rex::rex_step_kernel<4>, dim3(blocks), dim3(REX_WAVE), 0, st, s->dev, s->d_state, s->d_snap, d_action, d_obs,
-                       d_reward, d_done, d_motor_cmd);
-  else if (s->epw == 16)
-    hipLaunchKernelGGL(rex::rex_step_kernel<16>, dim3(blocks), dim3(REX_WAVE), 0, st, s->dev, s->d_state, s->d_snap, d_action, d_obs,
-                       d_reward, d_done, d_motor_cmd);
-  else
-    hipLaunchKernelGGL(rex::rex_step_kernel<64>, dim3(blocks), dim3(REX_WAVE), 0, st, s->dev, s->d_state, s->d_snap, d_action, d_obs,
-                       d_reward, d_done, d_motor_cmd);
+  launch_step(s, blocks, st, d_action, d_obs, d_reward, d_done, d_motor_cmd);
   HIPCHK(hipGetLastError());
   if (s->timing) { HIPCHK(hipEventRecord(s->ev1, st)); s->have_timing = 1; }
   return REX_OK;
@@ -937,3 +994,23 @@ int rex_gait_loop(int n, int mode, float* d_planner, const float* d_params, floa
 }
 
 }  // extern "C"
+
+#define REX_LAUNCH_STEP(EPW, ARM)                                                                                        \
+  hipLaunchKernelGGL((rex::rex_step_kernel<EPW, ARM>), dim3(blocks), dim3(REX_WAVE), 0, st, s->dev, s->d_state, s->d_snap, a, o, \
+                     r, d, m)
+static void launch_step(RexSim* s, int blocks, hipStream_t st, const float* a, float* o, float* r, uint8_t* d, float* m) {
+  if (s->cfg.mark == REX_MARK_ARM) {
+    if (s->epw == 4) REX_LAUNCH_STEP(4, true);
+    else REX_LAUNCH_STEP(16, true);
+  } else {
+    if (s->epw == 4) REX_LAUNCH_STEP(4, false);
+    else if (s->epw == 16) REX_LAUNCH_STEP(16, false);
+    else REX_LAUNCH_STEP(64, false);
+  }
+}
+static void launch_settle(RexSim* s, int nrec, hipStream_t st, float* snap) {
+  if (s->cfg.mark == REX_MARK_ARM)
+    hipLaunchKernelGGL(rex::rex_settle_kernel<true>, dim3((nrec + 15) / 16), dim3(REX_WAVE), 0, st, s->dev, snap);
+  else
+    hipLaunchKernelGGL(rex::rex_settle_kernel<false>, dim3((nrec + REX_WAVE - 1) / REX_WAVE), dim3(REX_WAVE), 0, st, s->dev, snap);
+}

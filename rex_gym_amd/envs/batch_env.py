@@ -18,7 +18,7 @@ from .spaces import Box
 OBSERVATION_EPS = 0.01  # rex_gym_env.py:20
 
 
-def _spaces(task, signal, sim_dt):
+def _spaces(task, signal, sim_dt, num_motors=12):
     """Box bounds of the reference envs (part of the drop-in contract)."""
     if task == "walk":      # walk_env.py:104-114
         hi = {"ik": 0.4, "ol": 0.01}[signal]
@@ -29,7 +29,7 @@ def _spaces(task, signal, sim_dt):
         hi = {"ik": 0.4, "ol": 0.3}[signal]
         dim = {"ik": 2, "ol": 4}[signal]
         action = Box(np.full(dim, hi), -np.full(dim, hi))
-        ub = np.array([2 * math.pi, 2 * math.pi, 2 * math.pi / sim_dt, 2 * math.pi / sim_dt] + [2 * math.pi] * 12)
+        ub = np.array([2 * math.pi, 2 * math.pi, 2 * math.pi / sim_dt, 2 * math.pi / sim_dt] + [2 * math.pi] * num_motors)
     elif task == "turn":    # turn_env.py:100-110
         action = Box(-np.full(2, 0.01), np.full(2, 0.01))
         ub = np.array([2 * math.pi, 2 * math.pi, 2 * math.pi / sim_dt, 2 * math.pi / sim_dt])
@@ -66,8 +66,9 @@ class RexBatchEnv:
                  range_normalize=False, check_actions=False, terrain_type="plane", terrain_pool=64, terrain_seed=10,
                  mark="base", render=False, stream=None, **unused):
         import torch
-        if terrain_type not in ("plane", "random") or mark != "base" or render:
-            raise NotImplementedError("this round covers terrain_type in ('plane', 'random'), mark='base', render=False")
+        if terrain_type not in ("plane", "random") or mark not in _lib.MARKS or render:
+            raise NotImplementedError("this round covers terrain_type in ('plane', 'random'), mark in ('base', 'arm'), "
+                                      "render=False")
         if task not in _lib.TASKS or signal_type not in _lib.SIGNALS:
             raise ValueError(f"unsupported task/signal {task}/{signal_type}")
         self._torch = torch
@@ -107,10 +108,14 @@ class RexBatchEnv:
         cfg.env_index_base = int(env_index_base)
         cfg.auto_reset = int(bool(auto_reset))
         cfg.max_episode_steps = int(max_episode_steps)
+        cfg.mark = _lib.MARKS[mark]
+        self.mark = mark
         self.config = cfg
+        self.num_motors = self._L.rex_num_motors(ctypes.byref(cfg))    # mark_constants.MARK_DETAILS['motors_num']
+        self.state_words = self._L.rex_state_words(ctypes.byref(cfg))
         self.action_dim = self._L.rex_action_dim(ctypes.byref(cfg))
         self.obs_dim = self._L.rex_obs_dim(ctypes.byref(cfg))
-        self.action_space, self.observation_space = _spaces(task, signal_type, cfg.sim_time_step)
+        self.action_space, self.observation_space = _spaces(task, signal_type, cfg.sim_time_step, self.num_motors)
         if range_normalize:   # RangeNormalize / ClipAction expose [-1, 1] boxes (wrappers.py:205-219)
             self.inner_action_space, self.inner_observation_space = self.action_space, self.observation_space
             self.action_space = Box(-np.ones(self.action_space.shape), np.ones(self.action_space.shape))
@@ -119,11 +124,11 @@ class RexBatchEnv:
         self.check_actions = bool(check_actions)
         self._stream = stream
         with torch.cuda.device(self.device):
-            self.state = torch.zeros((_lib.STATE_WORDS, self.num_envs), dtype=torch.float32, device=self.device)
+            self.state = torch.zeros((self.state_words, self.num_envs), dtype=torch.float32, device=self.device)
             self._obs = torch.zeros((self.num_envs, self.obs_dim), dtype=torch.float32, device=self.device)
             self._reward = torch.zeros(self.num_envs, dtype=torch.float32, device=self.device)
             self._done = torch.zeros(self.num_envs, dtype=torch.uint8, device=self.device)
-            self._cmd = torch.zeros((self.num_envs, _lib.NUM_MOTORS), dtype=torch.float32, device=self.device)
+            self._cmd = torch.zeros((self.num_envs, self.num_motors), dtype=torch.float32, device=self.device)
             handle = ctypes.c_void_p()
             _lib.check(self._L.rex_create(ctypes.byref(cfg), self.device.index, self.state.data_ptr(),
                                           self._stream_ptr(), ctypes.byref(handle)), "rex_create")

@@ -11,7 +11,7 @@ def product_state_to_numeric(state_tensor):
     raw = state_tensor.detach().cpu().numpy()
     out = raw.astype(np.float64)
     ints = raw.view(np.int32)
-    for w in INT_WORDS:
+    for w in orclib.int_words(raw.shape[0]):
         out[w] = ints[w].astype(np.uint32).astype(np.float64)
     return out
 
@@ -19,7 +19,7 @@ def product_state_to_numeric(state_tensor):
 def numeric_to_product_state(num, torch, device):
     raw = np.ascontiguousarray(num, dtype=np.float32).copy()
     ints = raw.view(np.uint32)
-    for w in INT_WORDS:
+    for w in orclib.int_words(raw.shape[0]):
         ints[w] = np.asarray(num[w], dtype=np.uint32)
     return torch.from_numpy(raw).to(device)
 
@@ -48,10 +48,12 @@ def make_pair(task, signal, n, dtype=np.float32, **kw):
         cfg_kw["target_position"] = 0.0 if not t else float(t)
     terrain = okw.pop("terrain_type", "plane")
     pool, tseed = okw.pop("terrain_pool", 64), okw.pop("terrain_seed", 10)
+    mark = okw.pop("mark", "base")
+    cfg_kw["mark"] = {"base": 0, "arm": 1}[mark]
     assert not okw, okw
     env = RexBatchEnv(n, task=task, signal_type=signal, **pkw)
     cfg = orclib.default_config(task, signal, n, **cfg_kw)
-    orc = orclib.OracleEnv(cfg, dtype)
+    orc = orclib.OracleEnv(cfg, dtype, mark)
     if terrain == "random":
         from rex_gym_amd.terrain import random_terrain_pool
         orc.set_terrain(*random_terrain_pool(pool, tseed))
@@ -60,5 +62,6 @@ def make_pair(task, signal, n, dtype=np.float32, **kw):
 
 def joint_rmse(a, b):
     """RMSE over the 12 joint angles, per env: a, b numeric states [53, N]."""
-    d = a[orclib.S_Q:orclib.S_Q + 12] - b[orclib.S_Q:orclib.S_Q + 12]
+    nm = {54: 12, 69: 18}[a.shape[0]]
+    d = a[orclib.S_Q:orclib.S_Q + nm] - b[orclib.S_Q:orclib.S_Q + nm]
     return np.sqrt(np.mean(d * d, axis=0))

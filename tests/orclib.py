@@ -18,6 +18,13 @@ S_FLAGS, S_STEPS, S_EPISODE, S_MOTOR_EN, S_OVERHEAT, S_HIST = 43, 44, 45, 46, 47
 INT_WORDS = list(range(S_FLAGS, STATE_WORDS))
 
 
+def int_words(state_words):
+    """Integer-valued words of a [state_words, N] state block: mark 'base' has 54 words / 12 motors, mark 'arm'
+    69 words / 18 motors (the q, qd and overheat blocks grow; FLAGS sits at 13 + 2 nm + 6)."""
+    nm = {54: 12, 69: 18}[state_words]
+    return list(range(13 + 2 * nm + 6, state_words))
+
+
 class RexConfig(ctypes.Structure):
     """Mirror of `struct RexConfig` in include/rexsim.h."""
     _fields_ = [
@@ -31,6 +38,7 @@ class RexConfig(ctypes.Structure):
         ("solver_residual_threshold", ctypes.c_float), ("target_orient", ctypes.c_float),
         ("init_orient", ctypes.c_float), ("orient_fixed", ctypes.c_int32), ("pose_index", ctypes.c_int32),
         ("pose_value", ctypes.c_float), ("range_normalize", ctypes.c_int32), ("pd_latency", ctypes.c_float), ("control_latency", ctypes.c_float),
+        ("mark", ctypes.c_int32),
     ]
 
 
@@ -41,7 +49,7 @@ SIGNALS = {"ik": 0, "ol": 1}
 def default_config(task="walk", signal="ik", num_envs=1, **kw):
     """Reference defaults."""
     repeat = 6 if task in ("gallop", "poses") else 5
-    c = RexConfig(abi_version=1, num_envs=num_envs, env_index_base=0, task=TASKS[task], signal=SIGNALS[signal],
+    c = RexConfig(abi_version=2, num_envs=num_envs, env_index_base=0, task=TASKS[task], signal=SIGNALS[signal],
                   action_repeat=repeat, solver_iterations=300 // repeat, sim_time_step=0.001,
                   motor_kp=1.0, motor_kd=0.02, backwards=-1, target_position=0.0, seed=0, auto_reset=0,
                   max_episode_steps=0, distance_weight=1.0, energy_weight=0.005 if task == "gallop" else 0.0005, drift_weight=2.0,
@@ -64,11 +72,14 @@ def _build():
 class Oracle:
     """One precision of the oracle library (np.float64 or np.float32)."""
 
-    def __init__(self, dtype=np.float64):
+    def __init__(self, dtype=np.float64, mark="base"):
         _build()
         self.dtype = np.dtype(dtype)
-        suffix = "f64" if self.dtype == np.float64 else "f32"
+        self.mark = mark
+        suffix = ("arm_" if mark == "arm" else "") + ("f64" if self.dtype == np.float64 else "f32")
         self.lib = ctypes.CDLL(os.path.join(ORACLE_DIR, "_build", f"librex_oracle_{suffix}.so"))
+        self.num_motors = self.lib.orc_num_motors()
+        self.state_words = self.lib.orc_state_words()
         assert self.lib.orc_sizeof_real() == self.dtype.itemsize
         self.lib.orc_create.restype = ctypes.c_void_p
         self.creal = ctypes.c_double if self.dtype == np.float64 else ctypes.c_float
@@ -112,7 +123,7 @@ class Oracle:
 
     def forward_dynamics(self, st, tau):
         st, tau = self._arr(st).ravel(), self._arr(tau).ravel()
-        out = np.zeros(18, self.dtype)
+        out = np.zeros(6 + self.num_motors, self.dtype)
         self.lib.orc_forward_dynamics(self._p(st), self._p(tau), self._p(out))
         return out
 
@@ -129,8 +140,8 @@ class Oracle:
 class OracleEnv:
     """Batched env on the oracle; same call shapes as the product's RexSim."""
 
-    def __init__(self, cfg, dtype=np.float64):
-        self.o = Oracle(dtype)
+    def __init__(self, cfg, dtype=np.float64, mark="base"):
+        self.o = Oracle(dtype, mark)
         self.cfg = cfg
         self.n = cfg.num_envs
         self.h = ctypes.c_void_p(self.o.lib.orc_create(ctypes.byref(cfg)))
@@ -163,7 +174,7 @@ class OracleEnv:
         obs = np.zeros((self.n, self.obs_dim), self.o.dtype)
         rew = np.zeros(self.n, self.o.dtype)
         done = np.zeros(self.n, np.uint8)
-        cmd = np.zeros((self.n, 12), self.o.dtype)
+        cmd = np.zeros((self.n, self.o.num_motors), self.o.dtype)
         self.o.lib.orc_step(self.h, self.o._p(a), self.o._p(obs), self.o._p(rew), self.o._p(done), self.o._p(cmd))
         return obs, rew, done.astype(bool), cmd
 
@@ -179,11 +190,11 @@ class OracleEnv:
                                    int(heights.shape[0]))
 
     def get_state(self):
-        out = np.zeros((STATE_WORDS, self.n), np.float64)
+        out = np.zeros((self.o.state_words, self.n), np.float64)
         self.o.lib.orc_get_state(self.h, self.o._p(out))
         return out
 
     def set_state(self, st):
         st = np.ascontiguousarray(st, np.float64)
-        assert st.shape == (STATE_WORDS, self.n)
+        assert st.shape == (self.o.state_words, self.n)
         self.o.lib.orc_set_state(self.h, self.o._p(st))

@@ -171,6 +171,100 @@ def test_walk_ik_trajectory_rmse(torch):
     env.close()
 
 
+# ------------------------------------------------------------------ mark='arm' (18 motors, rex_arm.urdf)
+def _arm_words(nm=18):
+    q, qd = 13, 13 + nm
+    return q, qd, 13 + 2 * nm + 6    # Q, QD, FLAGS
+
+
+def test_arm_mark_settled_snapshot_and_shapes(torch):
+    """mark='arm': 69 state words, 18-wide motor command, gallop observation 4 + 18; the settled reset state
+    (arm held at ARM_POSES['rest'] against its +-1.5 rad bounds) matches the fp32 arm oracle."""
+    n = 8
+    env, orc = make_pair("gallop", "ol", n, np.float32, seed=2, mark="arm")
+    assert env.num_motors == 18 and env.state_words == 69 and env.obs_dim == 22
+    assert env.observation_space.shape == (22,)
+    obs, oobs = env.reset().cpu().numpy(), orc.reset()
+    ps, os_ = product_state_to_numeric(env.state), orc.get_state()
+    Q, QD, FL = _arm_words()
+    np.testing.assert_allclose(ps[Q:Q + 18], os_[Q:Q + 18], atol=2e-4)
+    np.testing.assert_allclose(ps[:7], os_[:7], atol=1e-4)
+    np.testing.assert_allclose(ps[7:13], os_[7:13], atol=2e-3)
+    np.testing.assert_allclose(ps[QD:QD + 18], os_[QD:QD + 18], atol=2e-3)
+    np.testing.assert_array_equal(ps[FL:], os_[FL:])
+    np.testing.assert_allclose(obs, oobs, atol=2e-3)
+    # the three out-of-range rest targets sit on their limits
+    assert np.all(np.abs(ps[Q + 12:Q + 14]) < 1.52) and np.all(np.abs(ps[Q + 16]) < 1.52)
+    env.close()
+
+
+@pytest.mark.parametrize("task,signal", [("walk", "ik"), ("gallop", "ol"), ("turn", "ik")])
+def test_arm_mark_single_step_parity(torch, task, signal):
+    """One env.step() from identical states, mark='arm', against the fp32 arm oracle (same tolerances as the base
+    mark: 1e-4 rad / 1e-4 m / 2e-2 rad/s)."""
+    n = 32
+    env, orc = make_pair(task, signal, n, np.float32, seed=13, mark="arm")
+    env.reset(); orc.reset()
+    rng = np.random.RandomState(8)
+    lo, hi = np.minimum(env.action_space.low, env.action_space.high), np.maximum(env.action_space.low, env.action_space.high)
+    Q, QD, FL = _arm_words()
+    for k in range(20):
+        orc.step(rng.uniform(lo, hi, (n, env.action_dim)))
+    for k in range(8):
+        st = orc.get_state()
+        env.state.copy_(numeric_to_product_state(st, torch, env.state.device))
+        a = rng.uniform(lo, hi, (n, env.action_dim)).astype(np.float32)
+        obs, rew, done, info = env.step(torch.as_tensor(a, device="cuda"))
+        oobs, orew, odone, ocmd = orc.step(a.astype(np.float64))
+        ps, os_ = product_state_to_numeric(env.state), orc.get_state()
+        np.testing.assert_allclose(info["action"].cpu().numpy(), ocmd, atol=3e-5)
+        np.testing.assert_allclose(ps[Q:Q + 18], os_[Q:Q + 18], atol=1e-4)
+        np.testing.assert_allclose(ps[:7], os_[:7], atol=1e-4)
+        np.testing.assert_allclose(ps[7:13], os_[7:13], atol=5e-3)
+        np.testing.assert_allclose(ps[QD:QD + 18], os_[QD:QD + 18], atol=2e-2)
+        np.testing.assert_allclose(rew.cpu().numpy(), orew, atol=1e-4)
+        np.testing.assert_array_equal(done.cpu().numpy(), odone)
+        np.testing.assert_allclose(obs.cpu().numpy(), oobs, atol=5e-3)
+    env.close()
+
+
+def test_arm_mark_trajectory_and_auto_reset(torch):
+    """100 lock-step control steps from reset (median joint RMSE < 1e-3 rad over all 18 joints), then a long
+    auto-reset rollout at a ragged batch size stays finite and keeps the arm inside its limits."""
+    n = 64
+    env, orc = make_pair("walk", "ik", n, np.float32, seed=3, mark="arm")
+    env.reset(); orc.reset()
+    rng = np.random.RandomState(1)
+    worst = np.zeros(n)
+    for k in range(100):
+        a = rng.uniform(-0.4, 0.4, (n, 2)).astype(np.float32)
+        env.step(torch.as_tensor(a, device="cuda"))
+        orc.step(a)
+        worst = np.maximum(worst, joint_rmse(product_state_to_numeric(env.state), orc.get_state()))
+    print("arm walk-ik 100-step joint RMSE vs f32 oracle: median %.3e max %.3e" % (np.median(worst), worst.max()))
+    assert np.median(worst) < 1e-3
+    env.close()
+    from rex_gym_amd import RexBatchEnv
+    env = RexBatchEnv(4099, task="walk", signal_type="ik", mark="arm", seed=5, auto_reset=True, max_episode_steps=150)
+    env.reset()
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    ndone = 0
+    for k in range(400):
+        a = torch.rand((4099, 2), device="cuda", generator=g) * 0.8 - 0.4
+        obs, rew, done, _ = env.step(a)
+        ndone += int(done.sum())
+    assert bool(torch.isfinite(env.state[:67]).all()) and bool(torch.isfinite(obs).all()) and ndone >= 4099
+    Q = 13
+    assert float(env.state[Q + 12:Q + 18].abs().max()) < 3.2
+    env.close()
+
+
+def test_arm_mark_rejects_latency_model(torch):
+    from rex_gym_amd import RexBatchEnv, _lib
+    with pytest.raises(_lib.RexSimError):
+        RexBatchEnv(4, task="walk", signal_type="ik", mark="arm", pd_latency=0.003)
+
+
 def test_turn_env_reset_and_goal_logic(torch):
     """RexTurnEnv: yaw draws, teleport to the start heading, goal detection -> hold pose -> done 1 s later
     (turn_env.py:129-160,324-347). Discrete outcomes must match the fp32 oracle exactly."""

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol(L):
     lib = L.lib()
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.rex_abi_version() == 1
+    assert lib.rex_abi_version() == L.ABI_VERSION == 2
 
 
 def test_default_config_matches_reference_constants(L):
@@ -44,6 +44,10 @@ def test_default_config_matches_reference_constants(L):
     assert (c.action_repeat, c.solver_iterations) == (6, 50)          # gallop_env.py:47-48
     assert abs(c.energy_weight - 0.005) < 1e-9                         # gallop_env.py:45
     assert lib.rex_action_dim(ctypes.byref(c)) == 4 and lib.rex_obs_dim(ctypes.byref(c)) == 16
+    assert lib.rex_num_motors(ctypes.byref(c)) == 12 and lib.rex_state_words(ctypes.byref(c)) == 54
+    c.mark = L.MARKS["arm"]                                           # mark_constants.py MARK_DETAILS['motors_num']
+    assert lib.rex_num_motors(ctypes.byref(c)) == 18 and lib.rex_state_words(ctypes.byref(c)) == 69
+    assert lib.rex_obs_dim(ctypes.byref(c)) == 22
     assert lib.rex_default_config(L.TASKS["walk"], L.SIGNALS["ol"], 3, ctypes.byref(c)) == 0
     assert lib.rex_action_dim(ctypes.byref(c)) == 8
 

@@ -204,6 +204,105 @@ def fmt(x):
     return repr(float(f"{x:.13g}"))
 
 
+ARM_MOTOR_NAMES = ["motor_arm_m1", "motor_arm_m2", "motor_arm_m3", "motor_arm_m4", "motor_arm_m5", "motor_arm_m6"]
+DEFAULT_ARM_URDF = "/root/reference/rex_gym/util/pybullet_data/assets/urdf/rex_arm.urdf"
+DEFAULT_ARM_OUT = os.path.join(os.path.dirname(DEFAULT_OUT), "rex_arm_model_gen.h")
+
+
+def load_bodies(urdf, motor_names):
+    urdf_dir = os.path.dirname(urdf)
+    root = ET.parse(urdf).getroot()
+    links = {l.get("name"): Link(l, urdf_dir) for l in root.findall("link")}
+    joints = []
+    for j in root.findall("joint"):
+        xyz, rpy = parse_origin(j)
+        ax = j.find("axis")
+        lim = j.find("limit")
+        joints.append(dict(
+            name=j.get("name"), type=j.get("type"), parent=j.find("parent").get("link"),
+            child=j.find("child").get("link"), xyz=xyz, rpy=rpy,
+            axis=np.array([float(v) for v in ax.get("xyz").split()]) if ax is not None else np.array([1.0, 0, 0]),
+            lower=float(lim.get("lower")) if lim is not None else 0.0,
+            upper=float(lim.get("upper")) if lim is not None else 0.0))
+    child_links = {j["child"] for j in joints}
+    root_link = [n for n in links if n not in child_links]
+    assert len(root_link) == 1
+    bodies = merge_bodies(links, joints, root_link[0])
+    by_joint = {b["joint"]["name"]: i for i, b in enumerate(bodies) if b["joint"] is not None}
+    order = [0] + [by_joint[n] for n in motor_names]
+    assert sorted(order) == list(range(len(bodies))), "unexpected set of movable joints"
+    remap = {old: new for new, old in enumerate(order)}
+    bodies = [bodies[i] for i in order]
+    for b in bodies:
+        b["parent"] = remap[b["parent"]] if b["parent"] >= 0 else -1
+    return bodies, links
+
+
+def emit_arm(base_bodies):
+    """rex_arm.urdf (mark='arm'): the 13 base-mark bodies must be identical; emit the 6 arm bodies as a general
+    serial chain (joint frames carry fixed rotations, axes are +-z)."""
+    bodies, _ = load_bodies(DEFAULT_ARM_URDF, BASE_MOTOR_NAMES + ARM_MOTOR_NAMES)
+    assert len(bodies) == 19
+    for a, b in zip(bodies[:13], base_bodies):
+        assert abs(a["mass"] - b["mass"]) < 1e-12 and np.allclose(a["I"], b["I"]) and np.allclose(a["com"], b["com"]), a["name"]
+    arm = bodies[13:]
+    out = []
+    w = out.append
+    w("// GENERATED by tools/compile_model.py from the reference's rex_arm.urdf -- do not edit.")
+    w("// The 6 arm bodies of mark='arm' (rex_gym/util/pybullet_data/assets/urdf/rex_arm.urdf:610-791); bodies 0..12 are")
+    w("// identical to rex.urdf (asserted) and come from rex_model_gen.h.  Same Bullet-style inertias (compound AABB),")
+    w("// fixed tips merged.  Body 13+k hangs off REXA_PARENT[k] through joint 12+k: the joint frame sits at REXA_POS[k]")
+    w("// in the parent body frame with fixed rotation REXA_E0[k] (joint-frame axes in parent coordinates, row-major),")
+    w("// and turns about REXA_AXIS[k] (unit vector in the joint = child frame).")
+    w("#ifndef REX_ARM_MODEL_GEN_H")
+    w("#define REX_ARM_MODEL_GEN_H")
+    w('#include "rex_model_gen.h"')
+    w("#define REXA_NJ 6")
+    w("REX_CONST int REXA_PARENT[REXA_NJ] = {" + ", ".join(str(b["parent"]) for b in arm) + "};")
+    w("REX_CONST double REXA_POS[REXA_NJ][3] = {")
+    for b in arm:
+        w("  {" + ", ".join(fmt(v) for v in b["joint"]["xyz_in_body"]) + "},  /* " + b["joint"]["name"] + " */")
+    w("};")
+    w("REX_CONST double REXA_E0[REXA_NJ][9] = {")
+    for b in arm:
+        w("  {" + ", ".join(fmt(v) for v in b["joint"]["R_in_body"].ravel()) + "},")
+    w("};")
+    w("REX_CONST double REXA_AXIS[REXA_NJ][3] = {")
+    for b in arm:
+        a = b["joint"]["axis"] / np.linalg.norm(b["joint"]["axis"])
+        w("  {" + ", ".join(fmt(v) for v in a) + "},")
+    w("};")
+    w("REX_CONST double REXA_LOWER[REXA_NJ] = {" + ", ".join(fmt(b["joint"]["lower"]) for b in arm) + "};")
+    w("REX_CONST double REXA_UPPER[REXA_NJ] = {" + ", ".join(fmt(b["joint"]["upper"]) for b in arm) + "};")
+    w("REX_CONST double REXA_MASS[REXA_NJ] = {" + ", ".join(fmt(b["mass"]) for b in arm) + "};")
+    w("REX_CONST double REXA_COM[REXA_NJ][3] = {")
+    for b in arm:
+        w("  {" + ", ".join(fmt(v) for v in b["com"]) + "},  /* " + b["name"] + " */")
+    w("};")
+    w("/* rotational inertia about the COM, body axes: xx, yy, zz, xy, xz, yz */")
+    w("REX_CONST double REXA_INERTIA[REXA_NJ][6] = {")
+    for b in arm:
+        I = b["I"]
+        w("  {" + ", ".join(fmt(v) for v in (I[0, 0], I[1, 1], I[2, 2], I[0, 1], I[0, 2], I[1, 2])) + "},")
+    w("};")
+    for b in arm:
+        a = b["joint"]["axis"]
+        assert abs(a[0]) < 1e-12 and abs(a[1]) < 1e-12 and abs(abs(a[2]) - 1) < 1e-12, "arm axes are +-z in rex_arm.urdf"
+        assert np.allclose(b["I"], np.diag(np.diag(b["I"]))), "arm inertias are diagonal"
+        E = b["joint"]["R_in_body"]
+        assert np.allclose(np.abs(E), np.round(np.abs(E))), "arm joint frames are signed permutations"
+    w("/* all arm axes are +-z of the joint frame: sign per joint (used by the HIP arm chain) */")
+    w("REX_CONST double REXA_AXIS_SIGN[REXA_NJ] = {" + ", ".join(fmt(b["joint"]["axis"][2]) for b in arm) + "};")
+    w("/* ARM_POSES['rest'] (rex_gym/model/rex_constants.py:3-8): the command the envs append for the arm motors */")
+    w("REX_CONST double REXA_REST[REXA_NJ] = {-1.6, -1.6, 0.0, 0.0, 1.6, 0.0};")
+    w("#endif /* REX_ARM_MODEL_GEN_H */")
+    with open(DEFAULT_ARM_OUT, "w") as f:
+        f.write("\n".join(out) + "\n")
+    print(f"wrote {DEFAULT_ARM_OUT}: arm mass {sum(b['mass'] for b in arm):.4f} kg")
+    for i, b in enumerate(arm):
+        print(13 + i, b["name"], "parent", b["parent"], "m=%.3f" % b["mass"], "com", np.round(b["com"], 5), "I", np.round(b["I"], 7).tolist())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--urdf", default=DEFAULT_URDF)
@@ -390,3 +489,5 @@ def main():
 
 if __name__ == "__main__":
     main()
+    if os.path.exists(DEFAULT_ARM_URDF):
+        emit_arm(load_bodies(DEFAULT_URDF, BASE_MOTOR_NAMES)[0])
