@@ -146,14 +146,11 @@ __device__ __forceinline__ void motor_torque(float cmd, float q, float qd, float
   const float vnet = __builtin_amdgcn_fmed3f(pwm * V - (KT + 0.0f) * qd_true, -50.0f, 50.0f);
   const float cur = vnet * RINV;
   const float mag = fabsf(cur);
-  // np.interp(|I|, [0,10,...,60], [0,1,1.9,2.45,3.0,3.25,3.5]), clamped at the ends: segment k = floor(|I|/10)
-  const float kf = fminf(floorf(mag * 0.1f), 5.0f);
-  const int k = (int)kf;
-  const float t0 = k == 0 ? 0.0f : (k == 1 ? 1.0f : (k == 2 ? 1.9f : (k == 3 ? 2.45f : (k == 4 ? 3.0f : 3.25f))));
-  const float sl = k == 0 ? 0.1f : (k == 1 ? 0.09f : (k == 2 ? 0.055f : (k == 3 ? 0.055f : 0.025f)));
-  float t = fmaf(sl, mag - 10.0f * kf, t0);
-  t = fminf(t, 3.5f);
-  actual = cur > 0.0f ? t : (cur < 0.0f ? -t : 0.0f);
+  // np.interp(|I|, [0,10,...,60], [0,1,1.9,2.45,3.0,3.25,3.5]), clamped at the ends.  The table is concave (slopes
+  // 0.1, 0.09, 0.055, 0.055, 0.025, 0.025), so the interpolant is the minimum of its segment lines and the end
+  // clamp: branch-free, where a per-segment select compiles to a switch tree per motor.
+  const float t = fminf(fminf(fminf(0.1f * mag, fmaf(0.09f, mag, 0.1f)), fminf(fmaf(0.055f, mag, 0.8f), fmaf(0.025f, mag, 2.0f))), 3.5f);
+  actual = copysignf(t, cur);
 }
 
 }  // namespace rex

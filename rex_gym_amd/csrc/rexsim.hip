@@ -213,15 +213,20 @@ __device__ __forceinline__ void rex_substep(const DevCfg& c, EnvState& e, int i,
   constexpr int NM = ARMP::NM;
   float tau[18];
   const float limit = 1.0f / c.dt;  // OVERHEAT_SHUTDOWN_TIME / time_step, rex.py:607
-  int s0 = 0, s1 = 0;
-  float alpha = 0.0f;
-  if (c.hist) delay_slots(c, e.hist, c.pd_latency, s0, s1, alpha);               // _GetPDObservation, rex.py:755-759
+  float qo[NM], qdo[NM];                        // what the PD loop sees: _GetPDObservation, rex.py:755-759
+#pragma unroll
+  for (int j = 0; j < NM; ++j) { qo[j] = e.ph.q[j]; qdo[j] = e.ph.qd[j]; }
+  if (c.hist) {
+    int s0, s1;
+    float alpha;
+    delay_slots(c, e.hist, c.pd_latency, s0, s1, alpha);
+#pragma unroll
+    for (int j = 0; j < 12; ++j) { qo[j] = delayed_word(c, i, s0, s1, alpha, j); qdo[j] = delayed_word(c, i, s0, s1, alpha, 12 + j); }
+  }
 #pragma unroll
   for (int j = 0; j < NM; ++j) {
     float act, obs;
-    const float qo = (c.hist && j < 12) ? delayed_word(c, i, s0, s1, alpha, j) : e.ph.q[j];
-    const float qdo = (c.hist && j < 12) ? delayed_word(c, i, s0, s1, alpha, 12 + j) : e.ph.qd[j];
-    motor_torque(cmd[j], qo, qdo, e.ph.qd[j], c.kp, c.kd, act, obs);
+    motor_torque(cmd[j], qo[j], qdo[j], e.ph.qd[j], c.kp, c.kd, act, obs);
     uint32_t cnt = e.overheat[j];
     cnt = fabsf(act) > 2.45f ? min(cnt + 1u, 65535u) : 0u;                      // rex.py:603-606
     if ((float)cnt > limit) e.motor_en &= ~(1u << j);                           // rex.py:607-608

@@ -92,3 +92,59 @@ def test_walk_reward_terms_and_termination_flags():
     assert done_at == 6                                # LimitDuration semantics (wrappers.py:268-291)
     # standing start: forward term 0 (x <= 0.05), small negative drift/shake/energy terms
     assert -0.05 < rew[0] <= 0.0
+
+
+# ---- mark='arm' (rex_arm.urdf: 19 bodies, 18 motors; model/mark_constants.py:14-27) ----
+ARM_REST = np.array([-1.6, -1.6, 0.0, 0.0, 1.6, 0.0])     # mark_constants.py ARM_POSES['rest']
+
+
+def _arm_state(rng=None, pos=(0, 0, 5.0)):
+    q = np.concatenate([STAND, 0.5 * ARM_REST])
+    q[17] = -0.5                                      # keep the last joint (bounds -1.3 .. 0.2) away from its limit rows
+    qd = np.zeros(18)
+    quat = np.array([0, 0, 0, 1.0])
+    if rng is not None:
+        q = q + 0.15 * rng.randn(18)
+        qd = rng.randn(18)
+        quat = rng.randn(4)
+        quat /= np.linalg.norm(quat)
+    return np.concatenate([pos, quat, np.zeros(6), q, qd]).astype(np.float64)
+
+
+def test_arm_mark_free_fall_and_momentum():
+    o = Oracle(np.float64, "arm")
+    assert o.num_motors == 18 and o.state_words == 69
+    a = o.forward_dynamics(_arm_state(), np.zeros(18))
+    np.testing.assert_allclose(a[:3], 0, atol=1e-12)
+    np.testing.assert_allclose(a[3:6], [0, 0, -10.0], atol=1e-12)
+    np.testing.assert_allclose(a[6:], 0, atol=1e-10)
+    o.set_damping(0, 0)
+    try:
+        rng = np.random.RandomState(5)
+        st = _arm_state(rng)
+        p0 = o.energy_momentum(st)[1:]
+        st2 = o.physics_substep(st, rng.uniform(-0.02, 0.02, 18), dt=1e-4, nsteps=500)
+        p1 = o.energy_momentum(st2)[1:]
+        mass = 4.52 + 2.1                                                  # rex.urdf + the arm links of rex_arm.urdf
+        np.testing.assert_allclose(p1[:2], p0[:2], atol=3e-4)
+        np.testing.assert_allclose(p1[2], p0[2] - mass * 10.0 * 0.05, atol=3e-4)
+    finally:
+        o.set_damping(0.04, 0.04)
+
+
+def test_arm_mark_reset_holds_the_arm_on_its_limits():
+    """ARM_POSES['rest'] asks m1, m2, m5 for +-1.6 rad, beyond the +-1.5 rad URDF bounds: after the reset motion
+    the three joints rest on their limit rows, the robot stands, and the env API is 18 / 22 wide."""
+    env = OracleEnv(default_config("gallop", "ol", 2, mark=1), np.float64, "arm")
+    assert env.obs_dim == 22
+    obs = env.reset()
+    st = env.get_state()
+    q = st[13:31, 0]
+    np.testing.assert_allclose(q[[12, 13, 16]], [-1.5, -1.5, 1.5], atol=5e-3)
+    np.testing.assert_allclose(q[[14, 15, 17]], 0.0, atol=2e-2)
+    assert 0.12 < st[2, 0] < 0.25 and np.abs(st[7:13, 0]).max() < 0.1     # standing, nearly at rest
+    o, r, d, cmd = env.step(np.zeros((2, 4)))
+    assert cmd.shape == (2, 18)
+    np.testing.assert_allclose(cmd[:, 12:], np.tile(ARM_REST, (2, 1)))
+    np.testing.assert_allclose(o[:, 4:], env.get_state()[13:31].T, atol=1e-12)   # gallop obs = rpy rates + 18 angles
+    env.close()
