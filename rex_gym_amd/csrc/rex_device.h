@@ -50,6 +50,7 @@ constexpr float kToeHalf = (float)REX_TOE_HALFLEN;
 // lanes of different slots hit consecutive 16 B -> conflict-free ds_read_b128.
 template <int EPW>
 struct Lds {
+  static constexpr int kEpw = EPW;
   float4* p; int slot;
   __device__ __forceinline__ float4& row(int r, int c) const { return p[(r * REX_ROW_F4 + c) * EPW + slot]; }
   __device__ __forceinline__ float4& leg(int l, int c) const { return p[(REX_NROW * REX_ROW_F4 + l * REX_LEG_F4 + c) * EPW + slot]; }
@@ -600,6 +601,31 @@ __device__ __forceinline__ void pgs_leg_friction(const SM& sm, PgsX& x, float* l
   }
 }
 
+// ---- leg-per-mirror-lane helpers (EPW < 64) ----
+// A wave that carries EPW < 64 envs has 64 / EPW lanes per env that run the same arithmetic ("mirrors", see
+// rex_step_kernel).  The four legs of an env are independent until the base Cholesky, so mirror lane m = (lane / EPW) & 3
+// factorises leg m only, and the per-leg partial sums meet in an xor butterfly over the mirror lanes; the row
+// finishing and the back-substitution are split the same way.  The additions of a butterfly step commute, so all
+// mirrors of an env stay bit-identical.
+template <int EPW>
+__device__ __forceinline__ float mirror_sum(float v) {
+  v += __shfl_xor(v, EPW, REX_WAVE);
+  v += __shfl_xor(v, 2 * EPW, REX_WAVE);
+  return v;
+}
+template <int EPW>
+__device__ __forceinline__ unsigned mirror_or(unsigned v) {
+  v |= (unsigned)__shfl_xor((int)v, EPW, REX_WAVE);
+  v |= (unsigned)__shfl_xor((int)v, 2 * EPW, REX_WAVE);
+  return v;
+}
+__device__ __forceinline__ float pick_leg(const float* a, int m, int j) {   // a[3 m + j] with a per-lane m, no scratch
+  const float lo = m & 1 ? a[3 + j] : a[j], hi = m & 1 ? a[9 + j] : a[6 + j];
+  return m & 2 ? hi : lo;
+}
+// LDS rows / parked factors written by one mirror lane are read by the others: order the accesses of the wave
+__device__ __forceinline__ void mirror_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+
 // The restated pybullet.stepSimulation for one env (one lane): tau is held for this substep.
 template <class T>
 __device__ __forceinline__ void rotate_leg(T* a) {   // 12-entry per-joint array: leg k+1 moves into leg k's slots
@@ -647,14 +673,46 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
 
   unsigned active = 0;
   PgsX x;
-#pragma unroll 1
-  for (int leg = 0; leg < REX_NLEG; ++leg) {
-    // the current leg always sits in slots 0..2: q / qd / tau are rotated by one leg per iteration,
-    // which keeps every register index static inside the rolled loop
+  constexpr int EPW = SM::kEpw;
+  constexpr bool kSplitLegs = EPW <= 16;          // at least 4 mirror lanes per env
+  const int mleg = kSplitLegs ? (int)((threadIdx.x / EPW) & 3u) : 0;
+  if constexpr (kSplitLegs) {
+    const float ql[3] = {pick_leg(s.q, mleg, 0), pick_leg(s.q, mleg, 1), pick_leg(s.q, mleg, 2)};
+    const float qdl[3] = {pick_leg(s.qd, mleg, 0), pick_leg(s.qd, mleg, 1), pick_leg(s.qd, mleg, 2)};
+    const float tl[3] = {pick_leg(tau, mleg, 0), pick_leg(tau, mleg, 1), pick_leg(tau, mleg, 2)};
+    BaseAccum part;
+    part.Io = s33{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    part.h = part.N = part.F = mk(0.f, 0.f, 0.f);
+    part.m = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 21; ++k) part.S[k] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) part.bz[k] = 0.0f;
     LegFactor L;
-    leg_pass(leg, bk, s.q, s.qd, tau, dt, L, acc, sm, active, ground);
-    leg_park(sm, leg, L);
-    rotate_leg(s.q); rotate_leg(s.qd); rotate_leg(tau);
+    leg_pass(mleg, bk, ql, qdl, tl, dt, L, part, sm, active, ground);
+    leg_park(sm, mleg, L);
+    active = mirror_or<EPW>(active);
+    acc.Io.xx += mirror_sum<EPW>(part.Io.xx); acc.Io.yy += mirror_sum<EPW>(part.Io.yy); acc.Io.zz += mirror_sum<EPW>(part.Io.zz);
+    acc.Io.xy += mirror_sum<EPW>(part.Io.xy); acc.Io.xz += mirror_sum<EPW>(part.Io.xz); acc.Io.yz += mirror_sum<EPW>(part.Io.yz);
+    acc.h = acc.h + mk(mirror_sum<EPW>(part.h.x), mirror_sum<EPW>(part.h.y), mirror_sum<EPW>(part.h.z));
+    acc.N = acc.N + mk(mirror_sum<EPW>(part.N.x), mirror_sum<EPW>(part.N.y), mirror_sum<EPW>(part.N.z));
+    acc.F = acc.F + mk(mirror_sum<EPW>(part.F.x), mirror_sum<EPW>(part.F.y), mirror_sum<EPW>(part.F.z));
+    acc.m += mirror_sum<EPW>(part.m);
+#pragma unroll
+    for (int k = 0; k < 21; ++k) acc.S[k] += mirror_sum<EPW>(part.S[k]);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) acc.bz[k] += mirror_sum<EPW>(part.bz[k]);
+    mirror_sync();
+  } else {
+#pragma unroll 1
+    for (int leg = 0; leg < REX_NLEG; ++leg) {
+      // the current leg always sits in slots 0..2: q / qd / tau are rotated by one leg per iteration,
+      // which keeps every register index static inside the rolled loop
+      LegFactor L;
+      leg_pass(leg, bk, s.q, s.qd, tau, dt, L, acc, sm, active, ground);
+      leg_park(sm, leg, L);
+      rotate_leg(s.q); rotate_leg(s.qd); rotate_leg(tau);
+    }
   }
 #pragma unroll
   for (int k = 0; k < REX_NLEG; ++k) {
@@ -698,7 +756,7 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
   // finish the rows: whiten the base part, inverse diagonal (0 disables an inactive point)
   armp.finish(Lc);
   const bool any_limit = __builtin_amdgcn_ballot_w64((active >> REX_NPOINT) != 0) != 0;
-  for (int r = 0; r < (any_limit ? REX_NROW : REX_NCROW); ++r) {
+  for (int r = mleg; r < (any_limit ? REX_NROW : REX_NCROW); r += kSplitLegs ? 4 : 1) {   // mirror lane m: rows m, m+4, ...
     float4 c0 = sm.row(r, 0), c1 = sm.row(r, 1), c2 = sm.row(r, 2);
     const float g[6] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y};
     float gw[6];
@@ -711,6 +769,7 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
     sm.row(r, 2) = make_float4(c2.x, c2.y * invd, invd, diag);
   }
 
+  if constexpr (kSplitLegs) mirror_sync();
   // projected Gauss-Seidel in Bullet's order: all normals, then all friction rows; a point that no
   // lane of the wavefront has within the breaking distance is skipped for the whole wavefront
   // (its rows could only ever produce zero impulses).
@@ -758,20 +817,40 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
   float zt[12];
 #pragma unroll
   for (int k = 0; k < REX_NLEG; ++k) { zt[3 * k] = x.z01[k].x; zt[3 * k + 1] = x.z01[k].y; zt[3 * k + 2] = x.z2[k]; }
-#pragma unroll 1
-  for (int leg = 0; leg < REX_NLEG; ++leg) {
+  if constexpr (kSplitLegs) {
     LegFactor L;
-    leg_unpark(sm, leg, L);
-    float t1 = zt[0], t2 = zt[1], t3 = zt[2];
+    leg_unpark(sm, mleg, L);
+    float t1 = pick_leg(zt, mleg, 0), t2 = pick_leg(zt, mleg, 1), t3 = pick_leg(zt, mleg, 2);
 #pragma unroll
     for (int k = 0; k < 6; ++k) { t1 -= L.Bw[0][k] * nu[k]; t2 -= L.Bw[1][k] * nu[k]; t3 -= L.Bw[2][k] * nu[k]; }
     const float u3 = t3 * L.gi3;
     const float u2 = (t2 - L.g32 * u3) * L.gi2;
     const float u1 = (t1 - L.g21 * u2 - L.g31 * u3) * L.gi1;
-    s.qd[0] = clampf(u1, -kMaxCoordVel, kMaxCoordVel);
-    s.qd[1] = clampf(u2, -kMaxCoordVel, kMaxCoordVel);
-    s.qd[2] = clampf(u3, -kMaxCoordVel, kMaxCoordVel);
-    rotate_leg(s.qd); rotate_leg(zt);
+    sm.leg(mleg, 6) = make_float4(clampf(u1, -kMaxCoordVel, kMaxCoordVel), clampf(u2, -kMaxCoordVel, kMaxCoordVel),
+                                  clampf(u3, -kMaxCoordVel, kMaxCoordVel), 0.0f);
+    mirror_sync();
+#pragma unroll
+    for (int k = 0; k < REX_NLEG; ++k) {
+      const float4 u = sm.leg(k, 6);
+      s.qd[3 * k] = u.x; s.qd[3 * k + 1] = u.y; s.qd[3 * k + 2] = u.z;
+    }
+    mirror_sync();   // the next substep's leg_park overwrites these chunks
+  } else {
+#pragma unroll 1
+    for (int leg = 0; leg < REX_NLEG; ++leg) {
+      LegFactor L;
+      leg_unpark(sm, leg, L);
+      float t1 = zt[0], t2 = zt[1], t3 = zt[2];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { t1 -= L.Bw[0][k] * nu[k]; t2 -= L.Bw[1][k] * nu[k]; t3 -= L.Bw[2][k] * nu[k]; }
+      const float u3 = t3 * L.gi3;
+      const float u2 = (t2 - L.g32 * u3) * L.gi2;
+      const float u1 = (t1 - L.g21 * u2 - L.g31 * u3) * L.gi1;
+      s.qd[0] = clampf(u1, -kMaxCoordVel, kMaxCoordVel);
+      s.qd[1] = clampf(u2, -kMaxCoordVel, kMaxCoordVel);
+      s.qd[2] = clampf(u3, -kMaxCoordVel, kMaxCoordVel);
+      rotate_leg(s.qd); rotate_leg(zt);
+    }
   }
   armp.back(nu, s);
 #pragma unroll
