@@ -601,29 +601,35 @@ __device__ __forceinline__ void pgs_leg_friction(const SM& sm, PgsX& x, float* l
   }
 }
 
-// ---- leg-per-mirror-lane helpers (EPW < 64) ----
-// A wave that carries EPW < 64 envs has 64 / EPW lanes per env that run the same arithmetic ("mirrors", see
-// rex_step_kernel).  The four legs of an env are independent until the base Cholesky, so mirror lane m = (lane / EPW) & 3
-// factorises leg m only, and the per-leg partial sums meet in an xor butterfly over the mirror lanes; the row
-// finishing and the back-substitution are split the same way.  The additions of a butterfly step commute, so all
-// mirrors of an env stay bit-identical.
-template <int EPW>
-__device__ __forceinline__ float mirror_sum(float v) {
-  v += __shfl_xor(v, EPW, REX_WAVE);
-  v += __shfl_xor(v, 2 * EPW, REX_WAVE);
+// ---- leg-per-lane helpers (EPW < 64) ----
+// A wave that carries EPW <= 16 envs gives every env a QUAD of adjacent lanes (lane = 4 * slot + m; for EPW = 4 the
+// upper 48 lanes repeat the lower 16) that run the same arithmetic on the same state (see rex_step_kernel).  The four
+// legs of an env are independent until the base Cholesky, so lane m of the quad factorises leg m only and the
+// per-leg partial sums meet in an xor butterfly inside the quad (DPP quad_perm, no LDS); the row finishing and the
+// back-substitution are split the same way.  Each butterfly step adds the same two numbers in both lanes, so the
+// four lanes of a quad stay bit-identical.
+__device__ __forceinline__ int quad_slot(int lane, int epw) { return (lane >> 2) & (epw - 1); }
+__device__ __forceinline__ float quad_xor1(float v) {   // value of lane ^ 1: quad_perm [1,0,3,2]
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float quad_xor2(float v) {   // value of lane ^ 2: quad_perm [2,3,0,1]
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float quad_sum(float v) {
+  v += quad_xor1(v);
+  v += quad_xor2(v);
   return v;
 }
-template <int EPW>
-__device__ __forceinline__ unsigned mirror_or(unsigned v) {
-  v |= (unsigned)__shfl_xor((int)v, EPW, REX_WAVE);
-  v |= (unsigned)__shfl_xor((int)v, 2 * EPW, REX_WAVE);
+__device__ __forceinline__ unsigned quad_or(unsigned v) {
+  v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
+  v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);
   return v;
 }
 __device__ __forceinline__ float pick_leg(const float* a, int m, int j) {   // a[3 m + j] with a per-lane m, no scratch
   const float lo = m & 1 ? a[3 + j] : a[j], hi = m & 1 ? a[9 + j] : a[6 + j];
   return m & 2 ? hi : lo;
 }
-// LDS rows / parked factors written by one mirror lane are read by the others: order the accesses of the wave
+// LDS rows / parked factors written by one lane of a quad are read by the others: order the accesses of the wave
 __device__ __forceinline__ void mirror_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
 
 // The restated pybullet.stepSimulation for one env (one lane): tau is held for this substep.
@@ -635,9 +641,16 @@ __device__ __forceinline__ void rotate_leg(T* a) {   // 12-entry per-joint array
   a[9] = t0; a[10] = t1; a[11] = t2;
 }
 
+#ifdef REX_PROF
+__device__ long long g_prof[8 * 1024];   // per block: cycle counters of the sections of physics_substep
+#define REX_STAMP(var) const long long var = clock64()
+#else
+#define REX_STAMP(var)
+#endif
 template <class SM, class ARMP>
 __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float dt, int iterations,
                                                 float sqrt_res_thr, const SM& sm, const Ground& ground, ARMP& armp) {
+  REX_STAMP(t_begin);
   // base rotation (btMatrix3x3::setRotation)
   BaseKin bk;
   {
@@ -674,8 +687,8 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
   unsigned active = 0;
   PgsX x;
   constexpr int EPW = SM::kEpw;
-  constexpr bool kSplitLegs = EPW <= 16;          // at least 4 mirror lanes per env
-  const int mleg = kSplitLegs ? (int)((threadIdx.x / EPW) & 3u) : 0;
+  constexpr bool kSplitLegs = EPW <= 16;          // quad layout: 4 lanes per env
+  const int mleg = kSplitLegs ? (int)(threadIdx.x & 3u) : 0;
   if constexpr (kSplitLegs) {
     const float ql[3] = {pick_leg(s.q, mleg, 0), pick_leg(s.q, mleg, 1), pick_leg(s.q, mleg, 2)};
     const float qdl[3] = {pick_leg(s.qd, mleg, 0), pick_leg(s.qd, mleg, 1), pick_leg(s.qd, mleg, 2)};
@@ -691,17 +704,17 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
     LegFactor L;
     leg_pass(mleg, bk, ql, qdl, tl, dt, L, part, sm, active, ground);
     leg_park(sm, mleg, L);
-    active = mirror_or<EPW>(active);
-    acc.Io.xx += mirror_sum<EPW>(part.Io.xx); acc.Io.yy += mirror_sum<EPW>(part.Io.yy); acc.Io.zz += mirror_sum<EPW>(part.Io.zz);
-    acc.Io.xy += mirror_sum<EPW>(part.Io.xy); acc.Io.xz += mirror_sum<EPW>(part.Io.xz); acc.Io.yz += mirror_sum<EPW>(part.Io.yz);
-    acc.h = acc.h + mk(mirror_sum<EPW>(part.h.x), mirror_sum<EPW>(part.h.y), mirror_sum<EPW>(part.h.z));
-    acc.N = acc.N + mk(mirror_sum<EPW>(part.N.x), mirror_sum<EPW>(part.N.y), mirror_sum<EPW>(part.N.z));
-    acc.F = acc.F + mk(mirror_sum<EPW>(part.F.x), mirror_sum<EPW>(part.F.y), mirror_sum<EPW>(part.F.z));
-    acc.m += mirror_sum<EPW>(part.m);
+    active = quad_or(active);
+    acc.Io.xx += quad_sum(part.Io.xx); acc.Io.yy += quad_sum(part.Io.yy); acc.Io.zz += quad_sum(part.Io.zz);
+    acc.Io.xy += quad_sum(part.Io.xy); acc.Io.xz += quad_sum(part.Io.xz); acc.Io.yz += quad_sum(part.Io.yz);
+    acc.h = acc.h + mk(quad_sum(part.h.x), quad_sum(part.h.y), quad_sum(part.h.z));
+    acc.N = acc.N + mk(quad_sum(part.N.x), quad_sum(part.N.y), quad_sum(part.N.z));
+    acc.F = acc.F + mk(quad_sum(part.F.x), quad_sum(part.F.y), quad_sum(part.F.z));
+    acc.m += quad_sum(part.m);
 #pragma unroll
-    for (int k = 0; k < 21; ++k) acc.S[k] += mirror_sum<EPW>(part.S[k]);
+    for (int k = 0; k < 21; ++k) acc.S[k] += quad_sum(part.S[k]);
 #pragma unroll
-    for (int k = 0; k < 6; ++k) acc.bz[k] += mirror_sum<EPW>(part.bz[k]);
+    for (int k = 0; k < 6; ++k) acc.bz[k] += quad_sum(part.bz[k]);
     mirror_sync();
   } else {
 #pragma unroll 1
@@ -719,6 +732,7 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
     const float4 zc = sm.leg(k, 6);
     x.z01[k] = v2{zc.x, zc.y}; x.z2[k] = zc.z;
   }
+  REX_STAMP(t_legs);
   armp.pass(bk, s, tau, dt, acc, ground);   // extra branch on the base (mark='arm'), no-op otherwise
 
   // base articulated inertia A = [[Io, hx],[hx^T, m]] - S, then A = Lc Lc^T
@@ -753,6 +767,7 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
     for (int k = 0; k < 6; ++k) y[k] += dt * yd[k];
   }
 
+  REX_STAMP(t_chol);
   // finish the rows: whiten the base part, inverse diagonal (0 disables an inactive point)
   armp.finish(Lc);
   const bool any_limit = __builtin_amdgcn_ballot_w64((active >> REX_NPOINT) != 0) != 0;
@@ -788,8 +803,11 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
   // Bullet leaves the sweep loop as soon as the largest velocity residual of a sweep is below
   // m_leastSquaresResidualThreshold; each lane (env) stops on its own sweep, the wavefront leaves the
   // loop when its last lane has stopped.
+  REX_STAMP(t_pgs0);
+  int nsweeps = 0;
   bool running = true;
   for (int it = 0; it < iterations; ++it) {
+    ++nsweeps;
     if (running) {
       float worst = 0.0f;
       if (lim0) pgs_leg_limits<0>(sm, x, lam, worst);   // non-contact rows first (Bullet's sweep order)
@@ -809,6 +827,7 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
     }
     if (__builtin_amdgcn_ballot_w64(running) == 0) break;
   }
+  REX_STAMP(t_pgs1);
   y[0] = x.y01.x; y[1] = x.y01.y; y[2] = x.y23.x; y[3] = x.y23.y; y[4] = x.y45.x; y[5] = x.y45.y;
 
   // back to generalized velocities: nu0 = Lc^-T y ;  qd_f = G^-T (z_f - Bw_f nu0)
@@ -877,6 +896,13 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
     const float nw = dw * qw - dx * qx - dy * qy - dz * qz;
     const float nn = rsqrtf(nx * nx + ny * ny + nz * nz + nw * nw);
     s.quat[0] = nx * nn; s.quat[1] = ny * nn; s.quat[2] = nz * nn; s.quat[3] = nw * nn;
+#ifdef REX_PROF
+    if (threadIdx.x == 0 && blockIdx.x < 1024) {
+      long long* p = g_prof + 8 * blockIdx.x;
+      p[0] += t_pgs1 - t_pgs0; p[1] += nsweeps; p[2] += clock64() - t_begin; p[4] += 1;
+      p[3] += t_pgs0 - t_chol; p[6] += t_legs - t_begin; p[7] += t_chol - t_legs;
+    }
+#endif
   }
 }
 

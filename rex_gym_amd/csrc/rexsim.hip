@@ -513,13 +513,15 @@ __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __r
   // EPW envs share this wave (host picks it, rex_step): a small batch is spread over MORE, emptier waves because
   // idle SIMDs are free and a wave leaves the PGS sweep loop only when its slowest env has converged (and skips
   // only the legs no env of the wave has in contact), so fewer envs per wave means fewer sweeps and rows per
-  // wave.  Lanes >= EPW mirror lane (lane mod EPW): same env, same arithmetic, no stores.
+  // wave.  With EPW <= 16 every env owns a quad of adjacent lanes (lane = 4 * slot + m; for EPW = 4 the upper 48 lanes
+  // repeat the lower 16): the four lanes run the same arithmetic on the same state, split the per-leg work of a substep
+  // between them (rex_device.h) and only lane m = 0 stores.
   constexpr int NM = ARM ? 18 : 12;   // mark='arm': 6 more motors held at ARM_POSES['rest'] (rex_gym_env.py:347-353)
   __shared__ float4 lds[(ARM ? REX_LDS_F4_PER_ENV_ARM : REX_LDS_F4_PER_ENV) * EPW];
   const int lane = threadIdx.x;
-  const int slot = lane & (EPW - 1);
+  const int slot = EPW < 64 ? quad_slot(lane, EPW) : lane;   // EPW <= 16: lane = 4 * slot + leg (rex_device.h, quad layout)
   const int gi = blockIdx.x * EPW + slot;
-  const bool live = lane < EPW && gi < c.n;
+  const bool live = (EPW == 64 || (lane < 4 * EPW && (lane & 3) == 0)) && gi < c.n;
   const int i = gi < c.n ? gi : c.n - 1;   // tail slots shadow the last env (keeps the wave convergent)
   const Lds<EPW> sm{lds, slot};
   typename ArmHook<EPW, ARM>::type armp = ArmHook<EPW, ARM>::make(lds, slot);
@@ -626,11 +628,11 @@ __global__ __launch_bounds__(REX_WAVE) void rex_settle_kernel(DevCfg c, float* _
   constexpr int NM = ARM ? 18 : 12;
   constexpr int EPW = ARM ? 16 : REX_WAVE;   // the arm rows do not fit 64 envs per workgroup in LDS
   __shared__ float4 lds[(ARM ? REX_LDS_F4_PER_ENV_ARM : REX_LDS_F4_PER_ENV) * EPW];
-  const int lane = threadIdx.x & (EPW - 1);
+  const int lane = EPW < 64 ? quad_slot(threadIdx.x, EPW) : (int)threadIdx.x;
   const Lds<EPW> sm{lds, lane};
   typename ArmHook<EPW, ARM>::type armp = ArmHook<EPW, ARM>::make(lds, lane);
   const int nrec = c.n_terrain > 0 ? c.n_terrain : 1;
-  const int rec = threadIdx.x < EPW ? blockIdx.x * EPW + lane : nrec;
+  const int rec = (EPW == 64 || (threadIdx.x & 3) == 0) ? blockIdx.x * EPW + lane : nrec;
   const int t = blockIdx.x * EPW + lane < nrec ? blockIdx.x * EPW + lane : nrec - 1;
   Ground ground{nullptr, 0.0f, 1.0f, 1.0f, kMu};
   if (c.n_terrain > 0) { ground.h = c.terrain + (size_t)t * 65536; ground.mid = c.terrain_mid[t]; }
@@ -998,6 +1000,13 @@ int rex_gait_loop(int n, int mode, float* d_planner, const float* d_params, floa
   return REX_OK;
 }
 
+#ifdef REX_PROF   /* developer build only (tools/prof_sections.py): cycle counters of the sections of a substep */
+REX_API int rex_debug_prof(long long* out, int reset) {
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(rex::g_prof), sizeof(long long) * 8 * 1024) != hipSuccess) return REX_EHIP;
+  if (reset) { static long long z[8 * 1024]; if (hipMemcpyToSymbol(HIP_SYMBOL(rex::g_prof), z, sizeof(z)) != hipSuccess) return REX_EHIP; }
+  return REX_OK;
+}
+#endif
 }  // extern "C"
 
 #define REX_LAUNCH_STEP(EPW, ARM)                                                                                        \
