@@ -277,6 +277,7 @@ __device__ __forceinline__ void arm_back(const SMA& sma, const float* za, const 
 template <int EPW>
 struct ArmChain {
   static constexpr int NM = 18;
+  static constexpr bool kHasRows = true;   // its joint-limit rows are always in the sweep
   LdsArm<EPW> sma;
   float za[6], lam_a[6];
   unsigned active_any;   // bit k: some env of the wave has arm limit row k in reach

@@ -526,6 +526,7 @@ struct PgsX;
 // Hook for an extra branch on the base (the arm of mark='arm', rex_arm_device.h).  NoArm = mark 'base'.
 struct NoArm {
   static constexpr int NM = 12;
+  static constexpr bool kHasRows = false;
   __device__ __forceinline__ void pass(const BaseKin&, PhysState&, const float*, float, BaseAccum&, const Ground&) {}
   __device__ __forceinline__ void finish(const Chol6&) {}
   __device__ __forceinline__ void sweep(PgsX&, float&) {}
@@ -601,36 +602,159 @@ __device__ __forceinline__ void pgs_leg_friction(const SM& sm, PgsX& x, float* l
   }
 }
 
-// ---- leg-per-lane helpers (EPW < 64) ----
-// A wave that carries EPW <= 16 envs gives every env a QUAD of adjacent lanes (lane = 4 * slot + m; for EPW = 4 the
-// upper 48 lanes repeat the lower 16) that run the same arithmetic on the same state (see rex_step_kernel).  The four
-// legs of an env are independent until the base Cholesky, so lane m of the quad factorises leg m only and the
-// per-leg partial sums meet in an xor butterfly inside the quad (DPP quad_perm, no LDS); the row finishing and the
-// back-substitution are split the same way.  Each butterfly step adds the same two numbers in both lanes, so the
-// four lanes of a quad stay bit-identical.
-__device__ __forceinline__ int quad_slot(int lane, int epw) { return (lane >> 2) & (epw - 1); }
-__device__ __forceinline__ float quad_xor1(float v) {   // value of lane ^ 1: quad_perm [1,0,3,2]
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+// ---- lanes-per-env helpers (EPW < 64) ----
+// A wave that carries EPW <= 16 envs gives every env a GROUP of LPE adjacent lanes (LPE = 8 for EPW <= 8, 4 for
+// EPW = 16; lane = LPE * slot + p; for EPW = 4 the upper 32 lanes repeat the lower 32) that run the same arithmetic on
+// the same state (see rex_step_kernel).  The four legs of an env are independent until the base Cholesky, so a lane
+// factorises ONE leg (leg p for LPE = 4, leg p / 2 for LPE = 8) and the per-leg partial sums meet in an xor butterfly
+// inside the group (DPP, no LDS); the row finishing, the sweep loop (pgs_lanes) and the back-substitution are split
+// over the lanes as well.  Each butterfly step adds the same two numbers in both lanes, so the lanes of a group stay
+// bit-identical.
+__device__ __forceinline__ constexpr int lanes_per_env(int epw) { return epw <= 8 ? 8 : 4; }
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
-__device__ __forceinline__ float quad_xor2(float v) {   // value of lane ^ 2: quad_perm [2,3,0,1]
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float quad_sum(float v) {
-  v += quad_xor1(v);
-  v += quad_xor2(v);
+constexpr int kDppXor1 = 0xB1;         // quad_perm [1,0,3,2]
+constexpr int kDppXor2 = 0x4E;         // quad_perm [2,3,0,1]
+constexpr int kDppHalfMirror = 0x141;  // row_half_mirror: lane i of 8 reads lane 7 - i (the other quad)
+// sum over the lanes of a group, every lane holding a distinct addend
+template <int LPE>
+__device__ __forceinline__ float group_sum(float v) {
+  v += dpp_f<kDppXor1>(v);
+  v += dpp_f<kDppXor2>(v);
+  if (LPE == 8) v += dpp_f<kDppHalfMirror>(v);   // all lanes of a quad hold its total: any lane of the other quad will do
   return v;
 }
-__device__ __forceinline__ unsigned quad_or(unsigned v) {
-  v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
-  v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);
+// sum over the four LEGS of a group: with LPE = 8 lanes 2L and 2L+1 both hold leg L's addend
+template <int LPE>
+__device__ __forceinline__ float leg_sum(float v) {
+  if (LPE == 4) v += dpp_f<kDppXor1>(v);
+  v += dpp_f<kDppXor2>(v);
+  if (LPE == 8) v += dpp_f<kDppHalfMirror>(v);
+  return v;
+}
+template <int LPE>
+__device__ __forceinline__ unsigned leg_or(unsigned v) {
+  if (LPE == 4) v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, kDppXor1, 0xF, 0xF, true);
+  v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, kDppXor2, 0xF, 0xF, true);
+  if (LPE == 8) v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, kDppHalfMirror, 0xF, 0xF, true);
   return v;
 }
 __device__ __forceinline__ float pick_leg(const float* a, int m, int j) {   // a[3 m + j] with a per-lane m, no scratch
   const float lo = m & 1 ? a[3 + j] : a[j], hi = m & 1 ? a[9 + j] : a[6 + j];
   return m & 2 ? hi : lo;
 }
-// LDS rows / parked factors written by one lane of a quad are read by the others: order the accesses of the wave
+// LDS rows / parked factors written by one lane of a group are read by the others: order the accesses of the wave
 __device__ __forceinline__ void mirror_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+
+// ---- the sweep loop of a lane group (EPW <= 16), contact rows only, in impulse space ----
+// The same Gauss-Seidel iterates as the row-by-row velocity form below (same row order, same clamps, same residual
+// test), written on the Delassus matrix A = J~ J~^T of the 24 contact rows: vel_r = b_r + sum_s A_rs lam_s.  A lane
+// keeps the columns of A that belong to ITS rows (LPE = 8: the normal and the two friction rows of contact point p,
+// 24 x 3 registers; LPE = 4: the six rows of leg p) and the impulses of those rows; the partial sums of a row meet
+// in a DPP sum over the group.  The sweep is software-pipelined: the group sum of row r+1 is taken over the impulses
+// as they stand BEFORE row r is solved and corrected by A(r+1,r) dl_r afterwards, so the dependent chain of a row is
+// fma - fma - clamp - subtract (the velocity form has 9 dependent operations per row, 21 instructions and three LDS
+// reads; this has about 15 instructions and none).  A lone wave issues one VALU instruction per 4 cycles, which is
+// what bounds a small batch.  Rows no env of the group has within reach have invd = 0: they produce zero impulses
+// and are not skipped (a wave rarely has a whole leg out of reach, and a static row sequence is what lets the
+// pipeline run across rows and sweeps).
+__device__ __forceinline__ constexpr int crow_point(int r) { return r < REX_NPOINT ? r : (r - REX_NPOINT) / 2; }
+template <int LPE> __device__ __forceinline__ constexpr int crow_owner(int r) { return LPE == 8 ? crow_point(r) : crow_point(r) / 2; }
+template <int LPE> __device__ __forceinline__ constexpr int crow_own(int r) {   // index of row r among its owner's rows
+  return LPE == 8 ? (r < REX_NPOINT ? 0 : 1 + (r - REX_NPOINT) % 2) : (r < REX_NPOINT ? r % 2 : 2 + (r - REX_NPOINT) % 4);
+}
+
+template <int LPE, class SM>
+__device__ __forceinline__ void pgs_lanes(const SM& sm, PgsX& x, int p, float mu, int iterations, float thr, int& nsweeps) {
+  constexpr int NO = REX_NCROW / LPE;   // rows owned by a lane: 3 or 6
+  constexpr int kN = REX_NCROW;
+  float Jo[NO][9];
+#pragma unroll
+  for (int j = 0; j < NO; ++j) {
+    int r;
+    if (LPE == 8) r = j == 0 ? p : REX_NPOINT + 2 * p + (j - 1);
+    else r = j < 2 ? 2 * p + j : REX_NPOINT + 4 * p + (j - 2);
+    const float4 c0 = sm.row(r, 0), c1 = sm.row(r, 1), c2 = sm.row(r, 2);
+    Jo[j][0] = c0.x; Jo[j][1] = c0.y; Jo[j][2] = c0.z; Jo[j][3] = c0.w; Jo[j][4] = c1.x; Jo[j][5] = c1.y;
+    Jo[j][6] = c1.z; Jo[j][7] = c1.w; Jo[j][8] = c2.x;
+  }
+  const int myleg = LPE == 8 ? p >> 1 : p;
+  const float y[6] = {x.y01.x, x.y01.y, x.y23.x, x.y23.y, x.y45.x, x.y45.y};
+  float A[kN][NO], invd[kN], kk[kN], cpl[kN];   // cpl[r] = A(r, r-1), needed by every lane
+#pragma unroll
+  for (int r = 0; r < kN; ++r) {
+    const int Lr = crow_point(r) / 2;
+    const float4 c0 = sm.row(r, 0), c1 = sm.row(r, 1), c2 = sm.row(r, 2);
+    const float g[6] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y};
+    const float jr[3] = {c1.z, c1.w, c2.x};
+    float b = jr[0] * x.z01[Lr].x + jr[1] * x.z01[Lr].y + jr[2] * x.z2[Lr];   // free velocity of the row
+#pragma unroll
+    for (int k = 0; k < 6; ++k) b = fmaf(g[k], y[k], b);
+    invd[r] = c2.z;
+    kk[r] = fmaf(-c2.z, b, c2.y);                 // invd * (target - b)
+    const bool same = myleg == Lr;                // rows of other legs couple through the base part only
+    const float j0 = same ? jr[0] : 0.0f, j1 = same ? jr[1] : 0.0f, j2 = same ? jr[2] : 0.0f;
+#pragma unroll
+    for (int j = 0; j < NO; ++j) {
+      float t0 = j0 * Jo[j][6] + g[0] * Jo[j][0], t1 = j1 * Jo[j][7] + g[1] * Jo[j][1], t2 = j2 * Jo[j][8] + g[2] * Jo[j][2];
+      t0 = fmaf(g[3], Jo[j][3], t0); t1 = fmaf(g[4], Jo[j][4], t1); t2 = fmaf(g[5], Jo[j][5], t2);
+      A[r][j] = (t0 + t1) + t2;
+    }
+    const int rp = (r + kN - 1) % kN;
+    const int src = (int)((threadIdx.x & ~(unsigned)(LPE - 1)) + crow_owner<LPE>(rp));
+    cpl[r] = __shfl(A[r][crow_own<LPE>(rp)], src, REX_WAVE);
+  }
+  float lam[kN], lo[NO];
+#pragma unroll
+  for (int r = 0; r < kN; ++r) lam[r] = 0.0f;
+#pragma unroll
+  for (int j = 0; j < NO; ++j) lo[j] = 0.0f;
+  float S = 0.0f, dlp = 0.0f;   // group sum of the row about to be solved (without its predecessor's step), that step
+  bool running = true;
+  for (int it = 0; it < iterations; ++it) {
+    ++nsweeps;
+    if (running) {
+      float worst = 0.0f;
+#pragma unroll
+      for (int r = 0; r < kN; ++r) {
+        const int rn = (r + 1) % kN;
+        const float sum = fmaf(cpl[r], dlp, S);
+        float nl = fmaf(-invd[r], sum, lam[r] + kk[r]);
+        if (r < REX_NPOINT) nl = fmaxf(nl, 0.0f);
+        else {
+          const float lim = mu * lam[(r - REX_NPOINT) / 2];
+          nl = __builtin_amdgcn_fmed3f(nl, -lim, lim);
+        }
+        const float dl = nl - lam[r];
+        // group sum of the next row over the impulses through row r-1
+        float part = A[rn][0] * lo[0];
+#pragma unroll
+        for (int j = 1; j < NO; ++j) part = fmaf(A[rn][j], lo[j], part);
+        S = group_sum<LPE>(part);
+        worst = fmaxf(worst, fmaf(-thr, invd[r], fabsf(dl)));   // |dl| / invd > thr: Bullet's velocity residual
+        lam[r] = nl;
+        dlp = dl;
+        if (p == crow_owner<LPE>(r)) lo[crow_own<LPE>(r)] = nl;
+      }
+      running = worst > 0.0f;
+    }
+    if (__builtin_amdgcn_ballot_w64(running) == 0) break;
+  }
+  // x = x0 + sum_r J~_r lam_r
+  float yn[6] = {y[0], y[1], y[2], y[3], y[4], y[5]};
+#pragma unroll
+  for (int r = 0; r < kN; ++r) {
+    const int Lr = crow_point(r) / 2;
+    const float4 c0 = sm.row(r, 0), c1 = sm.row(r, 1), c2 = sm.row(r, 2);
+    const float l = lam[r];
+    yn[0] = fmaf(c0.x, l, yn[0]); yn[1] = fmaf(c0.y, l, yn[1]); yn[2] = fmaf(c0.z, l, yn[2]);
+    yn[3] = fmaf(c0.w, l, yn[3]); yn[4] = fmaf(c1.x, l, yn[4]); yn[5] = fmaf(c1.y, l, yn[5]);
+    x.z01[Lr].x = fmaf(c1.z, l, x.z01[Lr].x); x.z01[Lr].y = fmaf(c1.w, l, x.z01[Lr].y); x.z2[Lr] = fmaf(c2.x, l, x.z2[Lr]);
+  }
+  x.y01 = v2{yn[0], yn[1]}; x.y23 = v2{yn[2], yn[3]}; x.y45 = v2{yn[4], yn[5]};
+}
 
 // The restated pybullet.stepSimulation for one env (one lane): tau is held for this substep.
 template <class T>
@@ -687,8 +811,10 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
   unsigned active = 0;
   PgsX x;
   constexpr int EPW = SM::kEpw;
-  constexpr bool kSplitLegs = EPW <= 16;          // quad layout: 4 lanes per env
-  const int mleg = kSplitLegs ? (int)(threadIdx.x & 3u) : 0;
+  constexpr bool kSplitLegs = EPW <= 16;          // group layout: LPE lanes per env
+  constexpr int LPE = lanes_per_env(EPW);
+  const int pl = kSplitLegs ? (int)(threadIdx.x & (unsigned)(LPE - 1)) : 0;   // lane of the group
+  const int mleg = LPE == 8 ? pl >> 1 : pl;                                   // the leg this lane factorises
   if constexpr (kSplitLegs) {
     const float ql[3] = {pick_leg(s.q, mleg, 0), pick_leg(s.q, mleg, 1), pick_leg(s.q, mleg, 2)};
     const float qdl[3] = {pick_leg(s.qd, mleg, 0), pick_leg(s.qd, mleg, 1), pick_leg(s.qd, mleg, 2)};
@@ -704,17 +830,17 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
     LegFactor L;
     leg_pass(mleg, bk, ql, qdl, tl, dt, L, part, sm, active, ground);
     leg_park(sm, mleg, L);
-    active = quad_or(active);
-    acc.Io.xx += quad_sum(part.Io.xx); acc.Io.yy += quad_sum(part.Io.yy); acc.Io.zz += quad_sum(part.Io.zz);
-    acc.Io.xy += quad_sum(part.Io.xy); acc.Io.xz += quad_sum(part.Io.xz); acc.Io.yz += quad_sum(part.Io.yz);
-    acc.h = acc.h + mk(quad_sum(part.h.x), quad_sum(part.h.y), quad_sum(part.h.z));
-    acc.N = acc.N + mk(quad_sum(part.N.x), quad_sum(part.N.y), quad_sum(part.N.z));
-    acc.F = acc.F + mk(quad_sum(part.F.x), quad_sum(part.F.y), quad_sum(part.F.z));
-    acc.m += quad_sum(part.m);
+    active = leg_or<LPE>(active);
+    acc.Io.xx += leg_sum<LPE>(part.Io.xx); acc.Io.yy += leg_sum<LPE>(part.Io.yy); acc.Io.zz += leg_sum<LPE>(part.Io.zz);
+    acc.Io.xy += leg_sum<LPE>(part.Io.xy); acc.Io.xz += leg_sum<LPE>(part.Io.xz); acc.Io.yz += leg_sum<LPE>(part.Io.yz);
+    acc.h = acc.h + mk(leg_sum<LPE>(part.h.x), leg_sum<LPE>(part.h.y), leg_sum<LPE>(part.h.z));
+    acc.N = acc.N + mk(leg_sum<LPE>(part.N.x), leg_sum<LPE>(part.N.y), leg_sum<LPE>(part.N.z));
+    acc.F = acc.F + mk(leg_sum<LPE>(part.F.x), leg_sum<LPE>(part.F.y), leg_sum<LPE>(part.F.z));
+    acc.m += leg_sum<LPE>(part.m);
 #pragma unroll
-    for (int k = 0; k < 21; ++k) acc.S[k] += quad_sum(part.S[k]);
+    for (int k = 0; k < 21; ++k) acc.S[k] += leg_sum<LPE>(part.S[k]);
 #pragma unroll
-    for (int k = 0; k < 6; ++k) acc.bz[k] += quad_sum(part.bz[k]);
+    for (int k = 0; k < 6; ++k) acc.bz[k] += leg_sum<LPE>(part.bz[k]);
     mirror_sync();
   } else {
 #pragma unroll 1
@@ -771,7 +897,7 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
   // finish the rows: whiten the base part, inverse diagonal (0 disables an inactive point)
   armp.finish(Lc);
   const bool any_limit = __builtin_amdgcn_ballot_w64((active >> REX_NPOINT) != 0) != 0;
-  for (int r = mleg; r < (any_limit ? REX_NROW : REX_NCROW); r += kSplitLegs ? 4 : 1) {   // mirror lane m: rows m, m+4, ...
+  for (int r = pl; r < (any_limit ? REX_NROW : REX_NCROW); r += kSplitLegs ? LPE : 1) {   // lane p: rows p, p + LPE, ...
     float4 c0 = sm.row(r, 0), c1 = sm.row(r, 1), c2 = sm.row(r, 2);
     const float g[6] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y};
     float gw[6];
@@ -805,8 +931,15 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
   // loop when its last lane has stopped.
   REX_STAMP(t_pgs0);
   int nsweeps = 0;
-  bool running = true;
-  for (int it = 0; it < iterations; ++it) {
+  bool lanes_solved = false;
+  if constexpr (kSplitLegs && !ARMP::kHasRows) {
+    if (!any_limit) {                                  // wave-uniform; joint-limit rows are rare (pgs_lanes)
+      pgs_lanes<LPE>(sm, x, pl, ground.mu, iterations, sqrt_res_thr, nsweeps);
+      lanes_solved = true;
+    }
+  }
+  bool running = !lanes_solved;
+  for (int it = 0; it < (lanes_solved ? 0 : iterations); ++it) {
     ++nsweeps;
     if (running) {
       float worst = 0.0f;

@@ -513,15 +513,16 @@ __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __r
   // EPW envs share this wave (host picks it, rex_step): a small batch is spread over MORE, emptier waves because
   // idle SIMDs are free and a wave leaves the PGS sweep loop only when its slowest env has converged (and skips
   // only the legs no env of the wave has in contact), so fewer envs per wave means fewer sweeps and rows per
-  // wave.  With EPW <= 16 every env owns a quad of adjacent lanes (lane = 4 * slot + m; for EPW = 4 the upper 48 lanes
-  // repeat the lower 16): the four lanes run the same arithmetic on the same state, split the per-leg work of a substep
-  // between them (rex_device.h) and only lane m = 0 stores.
+  // wave.  With EPW <= 16 every env owns a group of LPE = 8 (EPW <= 8) or 4 (EPW = 16) adjacent lanes (for EPW = 4 the
+  // upper 32 lanes repeat the lower 32): the lanes of a group run the same arithmetic on the same state, split the
+  // per-leg and per-row work of a substep between them (rex_device.h) and only lane 0 of the group stores.
   constexpr int NM = ARM ? 18 : 12;   // mark='arm': 6 more motors held at ARM_POSES['rest'] (rex_gym_env.py:347-353)
   __shared__ float4 lds[(ARM ? REX_LDS_F4_PER_ENV_ARM : REX_LDS_F4_PER_ENV) * EPW];
   const int lane = threadIdx.x;
-  const int slot = EPW < 64 ? quad_slot(lane, EPW) : lane;   // EPW <= 16: lane = 4 * slot + leg (rex_device.h, quad layout)
+  constexpr int LPE = EPW < 64 ? lanes_per_env(EPW) : 1;     // EPW <= 16: lane = LPE * slot + p (rex_device.h, group layout)
+  const int slot = (lane / LPE) & (EPW - 1);
   const int gi = blockIdx.x * EPW + slot;
-  const bool live = (EPW == 64 || (lane < 4 * EPW && (lane & 3) == 0)) && gi < c.n;
+  const bool live = lane < LPE * EPW && (lane & (LPE - 1)) == 0 && gi < c.n;
   const int i = gi < c.n ? gi : c.n - 1;   // tail slots shadow the last env (keeps the wave convergent)
   const Lds<EPW> sm{lds, slot};
   typename ArmHook<EPW, ARM>::type armp = ArmHook<EPW, ARM>::make(lds, slot);
@@ -628,11 +629,12 @@ __global__ __launch_bounds__(REX_WAVE) void rex_settle_kernel(DevCfg c, float* _
   constexpr int NM = ARM ? 18 : 12;
   constexpr int EPW = ARM ? 16 : REX_WAVE;   // the arm rows do not fit 64 envs per workgroup in LDS
   __shared__ float4 lds[(ARM ? REX_LDS_F4_PER_ENV_ARM : REX_LDS_F4_PER_ENV) * EPW];
-  const int lane = EPW < 64 ? quad_slot(threadIdx.x, EPW) : (int)threadIdx.x;
+  constexpr int LPE = EPW < 64 ? lanes_per_env(EPW) : 1;
+  const int lane = (int)(threadIdx.x / LPE) & (EPW - 1);
   const Lds<EPW> sm{lds, lane};
   typename ArmHook<EPW, ARM>::type armp = ArmHook<EPW, ARM>::make(lds, lane);
   const int nrec = c.n_terrain > 0 ? c.n_terrain : 1;
-  const int rec = (EPW == 64 || (threadIdx.x & 3) == 0) ? blockIdx.x * EPW + lane : nrec;
+  const int rec = (threadIdx.x & (LPE - 1)) == 0 ? blockIdx.x * EPW + lane : nrec;
   const int t = blockIdx.x * EPW + lane < nrec ? blockIdx.x * EPW + lane : nrec - 1;
   Ground ground{nullptr, 0.0f, 1.0f, 1.0f, kMu};
   if (c.n_terrain > 0) { ground.h = c.terrain + (size_t)t * 65536; ground.mid = c.terrain_mid[t]; }
@@ -809,8 +811,9 @@ int rex_obs_dim(const RexConfig* c) {
 // throughput per issued instruction.  REX_ENVS_PER_WAVE overrides (4, 16 or 64).
 static int pick_envs_per_wave(int n) {
   const char* ov = getenv("REX_ENVS_PER_WAVE");
-  if (ov) { int v = atoi(ov); if (v == 4 || v == 16 || v == 64) return v; }
+  if (ov) { int v = atoi(ov); if (v == 4 || v == 8 || v == 16 || v == 64) return v; }
   if (n <= 4096) return 4;
+  if (n <= 8192) return 8;
   if (n <= 16384) return 16;
   return 64;
 }
@@ -1015,9 +1018,11 @@ REX_API int rex_debug_prof(long long* out, int reset) {
 static void launch_step(RexSim* s, int blocks, hipStream_t st, const float* a, float* o, float* r, uint8_t* d, float* m) {
   if (s->cfg.mark == REX_MARK_ARM) {
     if (s->epw == 4) REX_LAUNCH_STEP(4, true);
+    else if (s->epw == 8) REX_LAUNCH_STEP(8, true);
     else REX_LAUNCH_STEP(16, true);
   } else {
     if (s->epw == 4) REX_LAUNCH_STEP(4, false);
+    else if (s->epw == 8) REX_LAUNCH_STEP(8, false);
     else if (s->epw == 16) REX_LAUNCH_STEP(16, false);
     else REX_LAUNCH_STEP(64, false);
   }

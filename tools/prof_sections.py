@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Cycle breakdown of one physics substep inside rex_step_kernel (developer tool, needs a GPU).
+
+Builds rexsim.hip with -DREX_PROF (clock64() stamps around the sections of physics_substep, accumulated per
+workgroup by lane 0) into scratch/librexsim_prof.so, runs walk-IK at N envs and prints cycles per substep for:
+leg factorisation, base Cholesky, row finishing, PGS sweeps, back-substitution + integration.
+  python tools/prof_sections.py [N=4096]
+"""
+import ctypes
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+so = os.path.join(ROOT, "scratch", "librexsim_prof.so")
+os.makedirs(os.path.dirname(so), exist_ok=True)
+if not os.path.exists(so) or "--rebuild" in sys.argv:
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-fvisibility=hidden",
+                           "-DREX_PROF", os.path.join(ROOT, "rex_gym_amd", "csrc", "rexsim.hip"), "-o", so])
+import rex_gym_amd.build as b
+b.LIB_PATH = so
+import torch
+from rex_gym_amd import RexBatchEnv, _lib
+
+L = _lib.lib()
+L.rex_debug_prof.argtypes = [ctypes.c_void_p, ctypes.c_int]
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+n = int(args[0]) if args else 4096
+env = RexBatchEnv(n, seed=0, auto_reset=True, max_episode_steps=2000)
+env.reset()
+acts = [torch.rand((n, 2), device="cuda") * 0.8 - 0.4 for _ in range(8)]
+
+
+def window(steps, label):
+    torch.cuda.synchronize()
+    L.rex_debug_prof(None, 1)
+    for k in range(steps):
+        env.step(acts[k % 8])
+    torch.cuda.synchronize()
+    out = np.zeros((1024, 8), np.int64)
+    L.rex_debug_prof(out.ctypes.data, 0)
+    out = out[out[:, 4] > 0].astype(float)
+    pgs, sw, tot, fin, sub, legs, chol = (out[:, i] for i in (0, 1, 2, 3, 4, 6, 7))
+    rest = tot - pgs - fin - legs - chol
+    print(f"{label}: {len(out)} workgroups sampled, sweeps/substep mean {np.mean(sw / sub):.1f} (slowest workgroup "
+          f"{np.max(sw / sub):.1f}), cycles/sweep {pgs.sum() / sw.sum():.0f}")
+    print("  cycles/substep: total %.0f (slowest workgroup %.0f) = legs %.0f + base chol %.0f + finish rows %.0f + pgs %.0f "
+          "+ back-subst/integrate %.0f" % (np.mean(tot / sub), np.max(tot / sub), np.mean(legs / sub), np.mean(chol / sub),
+                                           np.mean(fin / sub), np.mean(pgs / sub), np.mean(rest / sub)))
+
+
+window(20, "first 20 steps after reset")
+for k in range(1500):
+    env.step(acts[k % 8])
+window(100, "steady state (after 1500 steps)")
