@@ -29,6 +29,7 @@
 #define REX_ROW_F4 3                  /* float4 chunks per row in LDS */
 #define REX_LEG_F4 7                  /* float4 chunks per leg parked in LDS (Bw 18 + G 6 + z 3) */
 #define REX_LDS_F4_PER_ENV (REX_NROW * REX_ROW_F4 + REX_NLEG * REX_LEG_F4)   /* 136 float4 = 2.2 KB per env */
+#define REX_PARK_F4 18                /* small-batch waves only: env state parked while the solver owns the registers */
 
 namespace rex {
 
@@ -52,6 +53,8 @@ template <int EPW>
 struct Lds {
   static constexpr int kEpw = EPW;
   float4* p; int slot;
+  float4* pk;   // park region (REX_PARK_F4 chunks per env, behind the rows of all marks); null when EPW = 64
+  __device__ __forceinline__ float4& park(int c) const { return pk[c * EPW + slot]; }
   __device__ __forceinline__ float4& row(int r, int c) const { return p[(r * REX_ROW_F4 + c) * EPW + slot]; }
   __device__ __forceinline__ float4& leg(int l, int c) const { return p[(REX_NROW * REX_ROW_F4 + l * REX_LEG_F4 + c) * EPW + slot]; }
 };
@@ -683,17 +686,29 @@ __device__ __forceinline__ void pgs_lanes(const SM& sm, PgsX& x, int p, float mu
   const int myleg = LPE == 8 ? p >> 1 : p;
   const float y[6] = {x.y01.x, x.y01.y, x.y23.x, x.y23.y, x.y45.x, x.y45.y};
   float A[kN][NO], invd[kN], kk[kN], cpl[kN];   // cpl[r] = A(r, r-1), needed by every lane
+  // one row at a time (hoisting all 72 row reads costs more registers than it hides), the next row's reads in flight;
+  // `pg`, `pj` walk one row behind for the coupling A(r, r-1)
+  float pg[6], pj[3];
+  {
+    const float4 c0 = sm.row(kN - 1, 0), c1 = sm.row(kN - 1, 1), c2 = sm.row(kN - 1, 2);
+    pg[0] = c0.x; pg[1] = c0.y; pg[2] = c0.z; pg[3] = c0.w; pg[4] = c1.x; pg[5] = c1.y; pj[0] = c1.z; pj[1] = c1.w; pj[2] = c2.x;
+  }
+  float4 n0 = sm.row(0, 0), n1 = sm.row(0, 1), n2 = sm.row(0, 2);
 #pragma unroll
   for (int r = 0; r < kN; ++r) {
-    const int Lr = crow_point(r) / 2;
-    const float4 c0 = sm.row(r, 0), c1 = sm.row(r, 1), c2 = sm.row(r, 2);
+    const int Lr = crow_point(r) / 2, Lp = crow_point((r + kN - 1) % kN) / 2;
+    const float4 c0 = n0, c1 = n1, c2 = n2;
+    if (r + 1 < kN) { n0 = sm.row(r + 1, 0); n1 = sm.row(r + 1, 1); n2 = sm.row(r + 1, 2); }
+    __builtin_amdgcn_sched_barrier(0);
     const float g[6] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y};
     const float jr[3] = {c1.z, c1.w, c2.x};
     float b = jr[0] * x.z01[Lr].x + jr[1] * x.z01[Lr].y + jr[2] * x.z2[Lr];   // free velocity of the row
+    float cp = Lr == Lp ? jr[0] * pj[0] + jr[1] * pj[1] + jr[2] * pj[2] : 0.0f;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) b = fmaf(g[k], y[k], b);
+    for (int k = 0; k < 6; ++k) { b = fmaf(g[k], y[k], b); cp = fmaf(g[k], pg[k], cp); }
     invd[r] = c2.z;
     kk[r] = fmaf(-c2.z, b, c2.y);                 // invd * (target - b)
+    cpl[r] = cp;
     const bool same = myleg == Lr;                // rows of other legs couple through the base part only
     const float j0 = same ? jr[0] : 0.0f, j1 = same ? jr[1] : 0.0f, j2 = same ? jr[2] : 0.0f;
 #pragma unroll
@@ -702,9 +717,9 @@ __device__ __forceinline__ void pgs_lanes(const SM& sm, PgsX& x, int p, float mu
       t0 = fmaf(g[3], Jo[j][3], t0); t1 = fmaf(g[4], Jo[j][4], t1); t2 = fmaf(g[5], Jo[j][5], t2);
       A[r][j] = (t0 + t1) + t2;
     }
-    const int rp = (r + kN - 1) % kN;
-    const int src = (int)((threadIdx.x & ~(unsigned)(LPE - 1)) + crow_owner<LPE>(rp));
-    cpl[r] = __shfl(A[r][crow_own<LPE>(rp)], src, REX_WAVE);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) pg[k] = g[k];
+    pj[0] = jr[0]; pj[1] = jr[1]; pj[2] = jr[2];
   }
   float lam[kN], lo[NO];
 #pragma unroll
