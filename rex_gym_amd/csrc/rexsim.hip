@@ -847,16 +847,18 @@ int rex_obs_dim(const RexConfig* c) {
   return c->task == REX_TASK_GALLOP ? 4 + rex_num_motors(c) : 4;                 /* gallop_env.py:349-356 */
 }
 
-// Envs per wave.  Up to 16 384 envs the launch is latency-bound with idle SIMDs (256 CUs x 4 SIMDs = 1 024), so the
-// batch is spread over up to 1 024 waves (one per SIMD) of 4 / 16 envs; beyond that, full 64-env waves give the best
-// throughput per issued instruction.  REX_ENVS_PER_WAVE overrides (4, 16 or 64).
+// Envs per wave (measured on MI355X, walk-IK, steady state; REX_ENVS_PER_WAVE = 4, 8, 16 or 64 overrides).  A wave with
+// EPW <= 16 envs spends its other lanes on the per-leg / per-row parallelism inside an env (rex_device.h: 8 lanes per
+// env for EPW <= 8, 4 for EPW = 16), which cuts the instructions a lone wave has to issue per env.  Up to 4 096 envs the
+// launch is one wave per SIMD and bound by its slowest wave: 4 envs per wave.  From 16 384 envs on, 16 envs per wave
+// (4 workgroups per CU fit in LDS) also has the best throughput: 57 M env-steps/s at 131 072 envs against 33 M for the
+// one-env-per-lane kernel (EPW = 64), whose 139 KB of LDS rows leave one wave per CU.
 static int pick_envs_per_wave(int n) {
   const char* ov = getenv("REX_ENVS_PER_WAVE");
   if (ov) { int v = atoi(ov); if (v == 4 || v == 8 || v == 16 || v == 64) return v; }
   if (n <= 4096) return 4;
   if (n <= 8192) return 8;
-  if (n <= 16384) return 16;
-  return 64;
+  return 16;
 }
 
 // kernel instantiations by (envs per wave, mark); the arm rows fit 4 or 16 envs per workgroup in LDS
