@@ -54,10 +54,13 @@ struct Lay {
 static_assert(Lay<12>::PHI == REX_S_PHI && Lay<12>::FLAGS == REX_S_FLAGS && Lay<12>::OVERHEAT == REX_S_OVERHEAT &&
               Lay<12>::HIST == REX_S_HIST && Lay<12>::WORDS == REX_STATE_WORDS, "layout must match include/rexsim.h");
 
-__device__ __forceinline__ float ldw(const float* st, int n, int w, int i) { return st[(size_t)w * n + i]; }
-__device__ __forceinline__ uint32_t ldi(const float* st, int n, int w, int i) { return __float_as_uint(st[(size_t)w * n + i]); }
-__device__ __forceinline__ void stw(float* st, int n, int w, int i, float v) { st[(size_t)w * n + i] = v; }
-__device__ __forceinline__ void sti(float* st, int n, int w, int i, uint32_t v) { st[(size_t)w * n + i] = __uint_as_float(v); }
+// word w of env i at a 32-bit element offset from the block's base (rex_create checks words * n < 2^30): the loads
+// and stores use the saddr + 32-bit voffset form, and no per-word 64-bit address has to stay in vector registers
+// between load_env and store_env
+__device__ __forceinline__ float ldw(const float* st, int n, int w, int i) { return st[(unsigned)(w * n + i)]; }
+__device__ __forceinline__ uint32_t ldi(const float* st, int n, int w, int i) { return __float_as_uint(ldw(st, n, w, i)); }
+__device__ __forceinline__ void stw(float* st, int n, int w, int i, float v) { st[(unsigned)(w * n + i)] = v; }
+__device__ __forceinline__ void sti(float* st, int n, int w, int i, uint32_t v) { stw(st, n, w, i, __uint_as_float(v)); }
 
 template <int NM>
 __device__ __forceinline__ void load_env(const float* st, int n, int i, EnvState& e) {
@@ -651,13 +654,17 @@ __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __r
   env_observation<NM>(c, co, obs);
   if (c.range_normalize) normalize_obs(c, obs);
   if (live) {
-    store_env<NM>(state, c.n, i, e);
-    for (int k = 0; k < c.obs_dim; ++k) obs_out[(size_t)i * c.obs_dim + k] = obs[k];
-    reward_out[i] = reward;
-    done_out[i] = done ? 1 : 0;
+    // an opaque copy of the env index: the store addresses are rebuilt here instead of 54 address pairs being carried
+    // (in AGPRs and scratch) from load_env across the whole kernel
+    int is = i;
+    asm volatile("" : "+v"(is));
+    store_env<NM>(state, c.n, is, e);
+    for (int k = 0; k < c.obs_dim; ++k) obs_out[(size_t)is * c.obs_dim + k] = obs[k];
+    reward_out[is] = reward;
+    done_out[is] = done ? 1 : 0;
     if (cmd_out) {
 #pragma unroll
-      for (int j = 0; j < NM; ++j) cmd_out[(size_t)i * NM + j] = cmd[j];
+      for (int j = 0; j < NM; ++j) cmd_out[(size_t)is * NM + j] = cmd[j];
     }
   }
 }
@@ -873,6 +880,7 @@ static int validate(const RexConfig* c) {
   if (c->action_repeat <= 0 || c->solver_iterations <= 0 || !(c->sim_time_step > 0.0f))
     return fail(REX_EINVAL, "action_repeat, solver_iterations and sim_time_step must be positive%s", "");
   if (c->mark != REX_MARK_BASE && c->mark != REX_MARK_ARM) return fail(REX_EINVAL, "unknown mark%s", "");
+  if ((long long)c->num_envs * 128 >= (1ll << 30)) return fail(REX_EINVAL, "num_envs too large for 32-bit state offsets%s", "");
   if (c->mark == REX_MARK_ARM && (c->pd_latency > 0.0f || c->control_latency > 0.0f))
     return fail(REX_EINVAL, "the latency model is not available with mark 'arm'%s", "");
   return REX_OK;
