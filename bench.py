@@ -24,8 +24,8 @@ sys.path.insert(0, ROOT)
 ENVS_PER_GPU = 4096
 # algorithmic bytes per env-step, walk-IK base mark (state r+w, action, obs, reward, done)
 ALGO_BYTES_PER_ENV_STEP = 541
-# this implementation's own layout: 53 state words read + written, action 8 B, obs 16 B, reward 4 B, done 1 B
-LAYOUT_BYTES_PER_ENV_STEP = 2 * 53 * 4 + 8 + 16 + 4 + 1
+# this implementation's own layout: 54 state words read + written, action 8 B, obs 16 B, reward 4 B, done 1 B
+LAYOUT_BYTES_PER_ENV_STEP = 2 * 54 * 4 + 8 + 16 + 4 + 1
 ALGO_FLOP_PER_ENV_STEP = 3.0e5   # SURVEY.md 8(d) estimate
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
 FP32_PEAK_TFLOPS = 157.3
@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--task", default="walk", choices=["walk", "gallop", "turn", "poses"])
     ap.add_argument("--signal", default="ik", choices=["ik", "ol"])
     ap.add_argument("--terrain", default="plane", choices=["plane", "random"])
+    ap.add_argument("--mark", default="base", choices=["base", "arm"])
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to smoke-test the "
                                                       "multi-rank path on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
@@ -100,7 +101,7 @@ def main():
     from rex_gym_amd import RexBatchEnv
     n = args.envs_per_gpu
     env = RexBatchEnv(n, task=args.task, signal_type=args.signal, device=local_rank, seed=0, env_index_base=rank * n,
-                      auto_reset=True, max_episode_steps=2000, terrain_type=args.terrain)
+                      auto_reset=True, max_episode_steps=2000, terrain_type=args.terrain, mark=args.mark)
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
     lo = torch.as_tensor(env.action_space.low, device=dev).minimum(torch.as_tensor(env.action_space.high, device=dev))
@@ -139,6 +140,16 @@ def main():
     kms.sort()
     kernel_ms = sum(kms) / len(kms)
 
+    # HBM bytes per launch as measured with rocprofv3 PMC passes of this same command (cannot be collected from inside
+    # the process); null when no measurement of this workload is committed
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            t = json.load(f).get(f"{args.task}-{args.signal}/{args.terrain}/{args.mark}/{n}")
+        traffic = t and t["bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
+
     # sanity: the rollout must be alive (finite observations, some episodes running)
     obs = env._obs
     finite = bool(torch.isfinite(obs).all().item())
@@ -154,13 +165,13 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{n} Rex envs per GPU, {args.task}-{args.signal.upper()}, "
-                                   f"{'flat plane' if args.terrain == 'plane' else 'random heightfield pool'}, base mark, "
+                                   f"{'flat plane' if args.terrain == 'plane' else 'random heightfield pool'}, {args.mark} mark, "
                                    f"dt 1 ms x {env.config.action_repeat} substeps, <= {env.config.solver_iterations} PGS sweeps "
                                    "(Bullet residual threshold 1e-7), auto-reset, episode cap 2000, uniform random actions "
                                    "over the env's action Box",
                        "envs_total": total_envs, "parallelism": f"env-shards x{world} (no data-path collective)"},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "rex_step_kernel", "kernel_ms": kernel_ms, "kernel_ms_min": kms[0],
                          "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP,
                          "layout_bytes_per_env_step": LAYOUT_BYTES_PER_ENV_STEP,
