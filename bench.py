@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--signal", default="ik", choices=["ik", "ol"])
     ap.add_argument("--terrain", default="plane", choices=["plane", "random"])
     ap.add_argument("--mark", default="base", choices=["base", "arm"])
+    ap.add_argument("--mixed", action="store_true", help="BASELINE configs[4] shape: env task split over {walk, gallop, turn}-IK "
+                                                         "+ per-env mass x U(0.8,1.2) / foot friction 0.5 x U(0.5,1.25)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to smoke-test the "
                                                       "multi-rank path on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
@@ -98,10 +100,15 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    from rex_gym_amd import RexBatchEnv
+    from rex_gym_amd import RexBatchEnv, RexMixedBatchEnv
     n = args.envs_per_gpu
-    env = RexBatchEnv(n, task=args.task, signal_type=args.signal, device=local_rank, seed=0, env_index_base=rank * n,
-                      auto_reset=True, max_episode_steps=2000, terrain_type=args.terrain, mark=args.mark)
+    if args.mixed:
+        env = RexMixedBatchEnv(n, device=local_rank, seed=0, env_index_base=rank * n, auto_reset=True, max_episode_steps=2000,
+                               terrain_type=args.terrain, mark=args.mark, mass_scale_range=(0.8, 1.2), friction_range=(0.25, 0.625))
+        env.action_space, env.config = env.envs[2].action_space, env.envs[0].config   # +-0.01: inside every task's Box
+    else:
+        env = RexBatchEnv(n, task=args.task, signal_type=args.signal, device=local_rank, seed=0, env_index_base=rank * n,
+                          auto_reset=True, max_episode_steps=2000, terrain_type=args.terrain, mark=args.mark)
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
     lo = torch.as_tensor(env.action_space.low, device=dev).minimum(torch.as_tensor(env.action_space.high, device=dev))
@@ -130,13 +137,14 @@ def main():
         elapsed = float(t.item())
 
     # per-launch duration of the dominant kernel: HIP events recorded around each launch on the launch stream
-    env.set_timing(True)
+    timed = env.envs[0] if args.mixed else env    # mixed: the kernel of the first sub-batch
+    timed.set_timing(True)
     m = min(200, max(20, args.steps // 10))
     kms = []
     for k in range(m):
         env.step(pool[k % 16])
-        kms.append(env.last_step_ms())
-    env.set_timing(False)
+        kms.append(timed.last_step_ms())
+    timed.set_timing(False)
     kms.sort()
     kernel_ms = sum(kms) / len(kms)
 
@@ -160,11 +168,12 @@ def main():
         value = total_envs * args.steps / elapsed
         achieved_gbs = ALGO_BYTES_PER_ENV_STEP * n / (kernel_ms * 1e-3) / 1e9
         out = {
-            "metric": f"env-steps/sec (all envs) Rex {args.task}-{args.signal.upper()}",
+            "metric": "env-steps/sec (all envs) Rex " + ("mixed walk/gallop/turn-IK" if args.mixed else f"{args.task}-{args.signal.upper()}"),
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{n} Rex envs per GPU, {args.task}-{args.signal.upper()}, "
+            "config": {"workload": f"{n} Rex envs per GPU, " + ("walk/gallop/turn-IK in equal parts with per-env mass and friction "
+                                   "draws, " if args.mixed else f"{args.task}-{args.signal.upper()}, ") + f""
                                    f"{'flat plane' if args.terrain == 'plane' else 'random heightfield pool'}, {args.mark} mark, "
                                    f"dt 1 ms x {env.config.action_repeat} substeps, <= {env.config.solver_iterations} PGS sweeps "
                                    "(Bullet residual threshold 1e-7), auto-reset, episode cap 2000, uniform random actions "

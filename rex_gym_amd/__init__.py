@@ -7,4 +7,5 @@ gfx950 HIP kernels behind the C ABI of include/rexsim.h.  See DESIGN.md.
 __version__ = "0.1.0"
 
 from .envs.batch_env import RexBatchEnv  # noqa: F401
+from .envs.mixed_env import RexMixedBatchEnv  # noqa: F401
 from .envs.spaces import Box  # noqa: F401
