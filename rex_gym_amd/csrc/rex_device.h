@@ -220,10 +220,12 @@ __device__ __forceinline__ int tri(int i, int j) { return i * (i + 1) / 2 + j; }
 // `leg` is a run-time index: the four legs share ONE copy of this code (the caller's leg loop is kept
 // rolled so that a substep's instruction stream stays inside the instruction cache); only the mirror
 // signs of the hip offsets differ between legs.
+// `esel` >= 0 (8 lanes per env: two lanes share a leg): emit the rows of toe end point `esel` only, the lane's
+// partner emits the other one; -1: both.
 template <class SM>
 __device__ __forceinline__ void leg_pass(int leg, const BaseKin& bk, const float* __restrict__ q, const float* __restrict__ qd,
                                          const float* __restrict__ tau, float dt, LegFactor& L, BaseAccum& acc,
-                                         const SM& sm, unsigned& active_mask, const Ground& ground) {
+                                         const SM& sm, unsigned& active_mask, const Ground& ground, int esel = -1) {
   static_assert(REX_LEG_SX[0] == -1 && REX_LEG_SX[1] == -1 && REX_LEG_SX[2] == 1 && REX_LEG_SX[3] == 1, "leg mirror table");
   static_assert(REX_LEG_SY[0] == -1 && REX_LEG_SY[1] == 1 && REX_LEG_SY[2] == -1 && REX_LEG_SY[3] == 1, "leg mirror table");
   const float SX = leg < 2 ? -1.0f : 1.0f, SY = (leg & 1) ? 1.0f : -1.0f;
@@ -404,15 +406,22 @@ __device__ __forceinline__ void leg_pass(int leg, const BaseKin& bk, const float
     const f3 dv = mk(-aw.z * aw.x, -aw.z * aw.y, 1.0f - aw.z * aw.z);   // n - (n.a) a, n = +z
     const float dn2 = dot(dv, dv);
     const float inv = dn2 > 1e-18f ? rsqrtf(dn2) : 0.0f;
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const float sg = e == 0 ? -kToeHalf : kToeHalf;
+    if (esel >= 0) {           // wave-uniform: all lanes of a wave run the same lanes-per-env mode
+      const float sg = esel == 0 ? -kToeHalf : kToeHalf;
       const f3 P = tc + sg * aw - (kToeRad * inv) * dv;
-      emit_rows(e, P, bk.height + P.z, mk(0.f, 0.f, 1.f), mk(0.f, -1.f, 0.f), mk(1.f, 0.f, 0.f));   // btPlaneSpace1(+z)
+      emit_rows(esel, P, bk.height + P.z, mk(0.f, 0.f, 1.f), mk(0.f, -1.f, 0.f), mk(1.f, 0.f, 0.f));
+    } else {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const float sg = e == 0 ? -kToeHalf : kToeHalf;
+        const f3 P = tc + sg * aw - (kToeRad * inv) * dv;
+        emit_rows(e, P, bk.height + P.z, mk(0.f, 0.f, 1.f), mk(0.f, -1.f, 0.f), mk(1.f, 0.f, 0.f));   // btPlaneSpace1(+z)
+      }
     }
   } else {                     // heightfield: normal under the end centre -> lowest point along it -> local plane
 #pragma unroll 1
-    for (int e = 0; e < 2; ++e) {
+    for (int t = 0; t < (esel >= 0 ? 1 : 2); ++t) {
+      const int e = esel >= 0 ? esel : t;    // esel >= 0: one trip, every lane with its own end point
       const float sg = e == 0 ? -kToeHalf : kToeHalf;
       const f3 ce = tc + sg * aw;
       f3 n0, nrm, t1, t2;
@@ -638,8 +647,8 @@ __device__ __forceinline__ float leg_sum(float v) {
   return v;
 }
 template <int LPE>
-__device__ __forceinline__ unsigned leg_or(unsigned v) {
-  if (LPE == 4) v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, kDppXor1, 0xF, 0xF, true);
+__device__ __forceinline__ unsigned leg_or(unsigned v) {   // over ALL lanes of the group (with LPE = 8 each lane of a leg sets its own point)
+  v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, kDppXor1, 0xF, 0xF, true);
   v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, kDppXor2, 0xF, 0xF, true);
   if (LPE == 8) v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, kDppHalfMirror, 0xF, 0xF, true);
   return v;
@@ -685,7 +694,9 @@ __device__ __forceinline__ void pgs_lanes(const SM& sm, PgsX& x, int p, float mu
   }
   const int myleg = LPE == 8 ? p >> 1 : p;
   const float y[6] = {x.y01.x, x.y01.y, x.y23.x, x.y23.y, x.y45.x, x.y45.y};
-  float A[kN][NO], invd[kN], kk[kN], cpl[kN];   // cpl[r] = A(r, r-1), needed by every lane
+  // cpl[r] = A(r, r-1), needed by every lane; cv[r] = b_r - target_r (free velocity minus the row's target) in lane 0 of
+  // the group and 0 elsewhere: it enters the group sum as the addend of the row's first product
+  float A[kN][NO], invd[kN], cv[kN], cpl[kN], S0 = 0.0f;
   // one row at a time (hoisting all 72 row reads costs more registers than it hides), the next row's reads in flight;
   // `pg`, `pj` walk one row behind for the coupling A(r, r-1)
   float pg[6], pj[3];
@@ -707,7 +718,9 @@ __device__ __forceinline__ void pgs_lanes(const SM& sm, PgsX& x, int p, float mu
 #pragma unroll
     for (int k = 0; k < 6; ++k) { b = fmaf(g[k], y[k], b); cp = fmaf(g[k], pg[k], cp); }
     invd[r] = c2.z;
-    kk[r] = fmaf(-c2.z, b, c2.y);                 // invd * (target - b)
+    const float bt = fmaf(-c2.y, c2.w, b);        // c2.y = target * invd, c2.w = 1 / invd
+    cv[r] = p == 0 ? bt : 0.0f;
+    if (r == 0) S0 = bt;
     cpl[r] = cp;
     const bool same = myleg == Lr;                // rows of other legs couple through the base part only
     const float j0 = same ? jr[0] : 0.0f, j1 = same ? jr[1] : 0.0f, j2 = same ? jr[2] : 0.0f;
@@ -726,7 +739,7 @@ __device__ __forceinline__ void pgs_lanes(const SM& sm, PgsX& x, int p, float mu
   for (int r = 0; r < kN; ++r) lam[r] = 0.0f;
 #pragma unroll
   for (int j = 0; j < NO; ++j) lo[j] = 0.0f;
-  float S = 0.0f, dlp = 0.0f;   // group sum of the row about to be solved (without its predecessor's step), that step
+  float S = S0, dlp = 0.0f;     // group sum of the row about to be solved (without its predecessor's step), that step
   bool running = true;
   for (int it = 0; it < iterations; ++it) {
     ++nsweeps;
@@ -736,7 +749,7 @@ __device__ __forceinline__ void pgs_lanes(const SM& sm, PgsX& x, int p, float mu
       for (int r = 0; r < kN; ++r) {
         const int rn = (r + 1) % kN;
         const float sum = fmaf(cpl[r], dlp, S);
-        float nl = fmaf(-invd[r], sum, lam[r] + kk[r]);
+        float nl = fmaf(-invd[r], sum, lam[r]);
         if (r < REX_NPOINT) nl = fmaxf(nl, 0.0f);
         else {
           const float lim = mu * lam[(r - REX_NPOINT) / 2];
@@ -744,7 +757,7 @@ __device__ __forceinline__ void pgs_lanes(const SM& sm, PgsX& x, int p, float mu
         }
         const float dl = nl - lam[r];
         // group sum of the next row over the impulses through row r-1
-        float part = A[rn][0] * lo[0];
+        float part = fmaf(A[rn][0], lo[0], cv[rn]);
 #pragma unroll
         for (int j = 1; j < NO; ++j) part = fmaf(A[rn][j], lo[j], part);
         S = group_sum<LPE>(part);
@@ -843,7 +856,7 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
 #pragma unroll
     for (int k = 0; k < 6; ++k) part.bz[k] = 0.0f;
     LegFactor L;
-    leg_pass(mleg, bk, ql, qdl, tl, dt, L, part, sm, active, ground);
+    leg_pass(mleg, bk, ql, qdl, tl, dt, L, part, sm, active, ground, LPE == 8 ? (pl & 1) : -1);
     leg_park(sm, mleg, L);
     active = leg_or<LPE>(active);
     acc.Io.xx += leg_sum<LPE>(part.Io.xx); acc.Io.yy += leg_sum<LPE>(part.Io.yy); acc.Io.zz += leg_sum<LPE>(part.Io.zz);
@@ -1049,6 +1062,7 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
       long long* p = g_prof + 8 * blockIdx.x;
       p[0] += t_pgs1 - t_pgs0; p[1] += nsweeps; p[2] += clock64() - t_begin; p[4] += 1;
       p[3] += t_pgs0 - t_chol; p[6] += t_legs - t_begin; p[7] += t_chol - t_legs;
+      p[5] += lanes_solved ? 0 : 1;   // substeps solved by the velocity-form fallback (joint-limit rows in reach)
     }
 #endif
   }

@@ -45,8 +45,10 @@ def window(steps, label):
     out = out[out[:, 4] > 0].astype(float)
     pgs, sw, tot, fin, sub, legs, chol = (out[:, i] for i in (0, 1, 2, 3, 4, 6, 7))
     rest = tot - pgs - fin - legs - chol
+    fb = out[:, 5]
     print(f"{label}: {len(out)} workgroups sampled, sweeps/substep mean {np.mean(sw / sub):.1f} (slowest workgroup "
-          f"{np.max(sw / sub):.1f}), cycles/sweep {pgs.sum() / sw.sum():.0f}")
+          f"{np.max(sw / sub):.1f}), cycles/sweep {pgs.sum() / sw.sum():.0f}, velocity-form fallback in "
+          f"{100 * fb.sum() / sub.sum():.2f} % of the substeps")
     print("  cycles/substep: total %.0f (slowest workgroup %.0f) = legs %.0f + base chol %.0f + finish rows %.0f + pgs %.0f "
           "+ back-subst/integrate %.0f" % (np.mean(tot / sub), np.max(tot / sub), np.mean(legs / sub), np.mean(chol / sub),
                                            np.mean(fin / sub), np.mean(pgs / sub), np.mean(rest / sub)))
