@@ -67,7 +67,7 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     # the default line is BASELINE.json configs[1]; the other supported configs can be timed with these
-    ap.add_argument("--task", default="walk", choices=["walk", "gallop", "turn", "poses"])
+    ap.add_argument("--task", default="walk", choices=["walk", "gallop", "turn", "poses", "standup"])
     ap.add_argument("--signal", default="ik", choices=["ik", "ol"])
     ap.add_argument("--terrain", default="plane", choices=["plane", "random"])
     ap.add_argument("--mark", default="base", choices=["base", "arm"])

@@ -38,6 +38,7 @@ extern "C" {
 #define REX_TASK_GALLOP 1   /* envs/gym/gallop_env.py RexReactiveEnv  */
 #define REX_TASK_TURN   2   /* envs/gym/turn_env.py   RexTurnEnv      */
 #define REX_TASK_POSES  3   /* envs/gym/poses_env.py  RexPosesEnv     */
+#define REX_TASK_STANDUP 4  /* envs/gym/standup_env.py RexStandupEnv  (the signal kwarg is unused by the env) */
 /* signal_type kwarg of the reference envs */
 #define REX_SIGNAL_IK 0
 #define REX_SIGNAL_OL 1

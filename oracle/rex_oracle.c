@@ -943,11 +943,16 @@ ORC_API int orc_state_words(void) { return SW_WORDS; }
 ORC_API int orc_action_dim(const RexConfig* c) {
   if (c->task == REX_TASK_WALK) return c->signal == REX_SIGNAL_IK ? 2 : 8;
   if (c->task == REX_TASK_GALLOP) return c->signal == REX_SIGNAL_IK ? 2 : 4;
-  if (c->task == REX_TASK_POSES) return 1;
+  if (c->task == REX_TASK_POSES || c->task == REX_TASK_STANDUP) return 1;         /* standup_env.py:99-101 */
   return 2;
 }
 
-static const real* init_pose(const RexConfig* c) { return c->signal == REX_SIGNAL_OL ? POSE_STAND_OL : POSE_STAND; }
+/* INIT_POSES['rest_position'] (rex_constants.py:41-46); the foot target 6 rad lies beyond the URDF bound 2.59 */
+static const real POSE_REST[12] = {-0.4, -1.5, 6, 0.4, -1.5, 6, -0.4, -1.5, 6, 0.4, -1.5, 6};
+static const real* init_pose(const RexConfig* c) {
+  if (c->task == REX_TASK_STANDUP) return POSE_REST;                   /* standup_env.py:108-110 */
+  return c->signal == REX_SIGNAL_OL ? POSE_STAND_OL : POSE_STAND;
+}
 /* RexGymEnv._transform_action_to_motor_command (rex_gym_env.py:363-367): the 12 leg targets, then ARM_POSES['rest'] */
 static void full_command(const real leg12[12], real cmd[NJ]) {
   memcpy(cmd, leg12, sizeof(real) * 12);
@@ -1287,7 +1292,7 @@ static real base_reward(const RexConfig* c, Env* e) {
 static int env_fallen(const RexConfig* c, const Env* e) {
   real rpy[3];
   quat_to_euler(e->ph.quat, rpy);
-  if (c->task == REX_TASK_GALLOP)                                       /* gallop_env.py:319-329 (true RPY) */
+  if (c->task == REX_TASK_GALLOP || c->task == REX_TASK_STANDUP)        /* gallop_env.py:319-329, standup_env.py:138-148 (true RPY) */
     return fabs(rpy[0]) > (real)0.3 || fabs(rpy[1]) > (real)0.5;
   real co[HIST_WORDS];
   control_observation(e, co);
@@ -1335,16 +1340,27 @@ static void env_step(Orc* o, int idx, const real* action_in, real* obs, real* re
   if (c->task == REX_TASK_GALLOP) gallop_command(c, e, action, leg_cmd);
   else if (c->task == REX_TASK_TURN) turn_command(c, e, action, leg_cmd);
   else if (c->task == REX_TASK_POSES) poses_command(c, e, action, leg_cmd);
+  else if (c->task == REX_TASK_STANDUP) {                                           /* RexStandupEnv._signal, standup_env.py:113-120 */
+    real t = (real)(e->steps * c->action_repeat) * (real)c->sim_time_step;         /* GetTimeSinceReset, rex.py:155-156 */
+    real f = t > (real)0.1 ? 1 : ((real)0.1 + action[0]) / (t + 1) + (real)1.5;    /* the 'brake' function */
+    for (int j = 0; j < 12; ++j) leg_cmd[j] = POSE_STAND[j] * f;
+  }
   else walk_command(c, e, action, leg_cmd);
   full_command(leg_cmd, cmd);
   Ground ground = env_ground(o, idx, e->episode);
   for (int k = 0; k < c->action_repeat; ++k) rex_substep(c, e, cmd, &ground);    /* Rex.Step, rex.py:158-163 */
   if (c->task == REX_TASK_TURN) *reward = (real)0.035 - fabs(e->ph.pos[0]) - fabs(e->ph.pos[1]);  /* turn_env.py:362-367 */
   else if (c->task == REX_TASK_POSES) { *reward = 1; for (int j = 0; j < NJ; ++j) (void)e->tau_obs[j]; } /* poses_env.py:267-269 */
+  else if (c->task == REX_TASK_STANDUP) {                                /* standup_env.py:150-166, target (0, 0, 0.21) */
+    real pr = fabs(e->ph.pos[0]) + fabs(e->ph.pos[1]) + fabs((real)0.21 - e->ph.pos[2]);
+    pr = pr < (real)0.1 ? 1 - pr : -pr;
+    if (e->ph.pos[2] > (real)0.21) pr = -1 - pr;
+    *reward = pr;
+  }
   else *reward = base_reward(c, e);
   int d = env_fallen(c, e);
   if (c->task == REX_TASK_POSES) d = 0;                                 /* is_fallen() returns False, poses_env.py:265 */
-  if (e->flags & REX_F_ENV_GOAL) d = 1;                                 /* rex_gym_env.py:495 */
+  if ((e->flags & REX_F_ENV_GOAL) && c->task != REX_TASK_STANDUP) d = 1; /* rex_gym_env.py:495; standup overrides _termination */
   if (c->task == REX_TASK_GALLOP && e->ph.pos[1] > (real)0.3) d = 1;    /* gallop_env.py:315-317 */
   e->steps += 1;
   if (c->max_episode_steps > 0 && e->steps >= c->max_episode_steps) d = 1;

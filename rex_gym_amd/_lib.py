@@ -7,7 +7,7 @@ import os
 
 from . import build as _build
 
-TASKS = {"walk": 0, "gallop": 1, "turn": 2, "poses": 3}
+TASKS = {"walk": 0, "gallop": 1, "turn": 2, "poses": 3, "standup": 4}
 SIGNALS = {"ik": 0, "ol": 1}
 MARKS = {"base": 0, "arm": 1}
 STATE_WORDS = 54      # mark 'base'; rex_state_words(cfg) for the others

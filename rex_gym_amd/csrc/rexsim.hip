@@ -165,7 +165,15 @@ struct DevCfg {
   float obs_hi_ang, obs_hi_rate;
 };
 
-__device__ __forceinline__ float init_pose(const DevCfg& c, int j) { return c.signal == REX_SIGNAL_OL ? pose_stand_ol(j) : pose_stand(j); }
+// INIT_POSES['rest_position'] (rex_constants.py:41-46): the foot target 6 rad lies beyond the URDF bound 2.59
+__device__ __forceinline__ float pose_rest(int j) {
+  const int k = j % 3;
+  return k == 0 ? (((j / 3) & 1) ? 0.4f : -0.4f) : (k == 1 ? -1.5f : 6.0f);
+}
+__device__ __forceinline__ float init_pose(const DevCfg& c, int j) {
+  if (c.task == REX_TASK_STANDUP) return pose_rest(j);                          // standup_env.py:108-110
+  return c.signal == REX_SIGNAL_OL ? pose_stand_ol(j) : pose_stand(j);
+}
 
 // ---- latency model: Rex._observation_history / _GetDelayedObservation (model/rex.py:122,717-763) ----
 __device__ __forceinline__ float& hist_at(const DevCfg& c, int i, int slot, int w) {
@@ -600,6 +608,12 @@ __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __r
     turn_command(c, e, cq, act, cmd);
   }
   else if (c.task == REX_TASK_POSES) poses_command(c, e, act, cmd);
+  else if (c.task == REX_TASK_STANDUP) {                                     // RexStandupEnv._signal, standup_env.py:113-120
+    const float t = (float)(e.steps * c.action_repeat) * c.dt;               // GetTimeSinceReset, rex.py:155-156
+    const float f = t > 0.1f ? 1.0f : (0.1f + act[0]) / (t + 1.0f) + 1.5f;   // the 'brake' function
+#pragma unroll
+    for (int j = 0; j < 12; ++j) cmd[j] = pose_stand(j) * f;
+  }
   else walk_command(c, e, act, cmd);
 
   float tau_obs[NM];
@@ -630,15 +644,21 @@ __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __r
   float reward = c.w_dist * fwd + c.w_energy * energy + c.w_drift * drift + c.w_shake * shake;
   if (c.task == REX_TASK_TURN) reward = 0.035f - fabsf(e.ph.pos[0]) - fabsf(e.ph.pos[1]);   // turn_env.py:362-367
   if (c.task == REX_TASK_POSES) reward = 1.0f;                                                // poses_env.py:267-269
+  if (c.task == REX_TASK_STANDUP) {                                                           // standup_env.py:150-166
+    float pr = fabsf(e.ph.pos[0]) + fabsf(e.ph.pos[1]) + fabsf(0.21f - e.ph.pos[2]);
+    pr = pr < 0.1f ? 1.0f - pr : -pr;
+    if (e.ph.pos[2] > 0.21f) pr = -1.0f - pr;
+    reward = pr;
+  }
 
   // ---- termination (rex_gym_env.py:490-499, walk_env.py:326-338, gallop_env.py:315-329) ----
   bool done;
-  if (c.task == REX_TASK_GALLOP) {   // GetTrueBaseRollPitchYaw: never delayed (gallop_env.py:319-329)
+  if (c.task == REX_TASK_GALLOP || c.task == REX_TASK_STANDUP) {   // GetTrueBaseRollPitchYaw: never delayed (gallop_env.py:319-329)
     float trpy[3];
     quat_to_euler(e.ph.quat, trpy);
-    done = fabsf(trpy[0]) > 0.3f || fabsf(trpy[1]) > 0.5f || e.ph.pos[1] > 0.3f;
+    done = fabsf(trpy[0]) > 0.3f || fabsf(trpy[1]) > 0.5f || (c.task == REX_TASK_GALLOP && e.ph.pos[1] > 0.3f);
   } else done = r22 < 0.85f;
-  if (e.flags & REX_F_ENV_GOAL) done = true;                                     // rex_gym_env.py:495
+  if ((e.flags & REX_F_ENV_GOAL) && c.task != REX_TASK_STANDUP) done = true;     // rex_gym_env.py:495; standup overrides _termination
   if (c.task == REX_TASK_POSES) done = false;                                    // is_fallen() returns False, poses_env.py:265
   e.steps += 1;
   if (c.max_steps > 0 && e.steps >= c.max_steps) done = true;
@@ -807,7 +827,7 @@ int rex_abi_version(void) { return REX_ABI_VERSION; }
 
 int rex_default_config(int task, int signal, int num_envs, RexConfig* cfg) {
   if (!cfg || num_envs <= 0) return fail(REX_EINVAL, "rex_default_config: bad arguments%s", "");
-  if (task != REX_TASK_WALK && task != REX_TASK_GALLOP && task != REX_TASK_TURN && task != REX_TASK_POSES) return fail(REX_EINVAL, "rex_default_config: unsupported task%s", "");
+  if (task != REX_TASK_WALK && task != REX_TASK_GALLOP && task != REX_TASK_TURN && task != REX_TASK_POSES && task != REX_TASK_STANDUP) return fail(REX_EINVAL, "rex_default_config: unsupported task%s", "");
   if (signal != REX_SIGNAL_IK && signal != REX_SIGNAL_OL) return fail(REX_EINVAL, "rex_default_config: unsupported signal%s", "");
   memset(cfg, 0, sizeof(*cfg));
   cfg->abi_version = REX_ABI_VERSION;
@@ -838,7 +858,7 @@ int rex_action_dim(const RexConfig* c) {
   if (c->task == REX_TASK_WALK) return c->signal == REX_SIGNAL_IK ? 2 : 8;      /* walk_env.py:104-112 */
   if (c->task == REX_TASK_GALLOP) return c->signal == REX_SIGNAL_IK ? 2 : 4;    /* gallop_env.py:119-130 */
   if (c->task == REX_TASK_TURN) return 2;                                       /* turn_env.py:100-110 */
-  if (c->task == REX_TASK_POSES) return 1;                                      /* poses_env.py:115-117 */
+  if (c->task == REX_TASK_POSES || c->task == REX_TASK_STANDUP) return 1;       /* poses_env.py:115-117, standup_env.py:99-101 */
   return REX_EINVAL;
 }
 int rex_num_motors(const RexConfig* c) {

@@ -33,6 +33,9 @@ def _spaces(task, signal, sim_dt, num_motors=12):
     elif task == "turn":    # turn_env.py:100-110
         action = Box(-np.full(2, 0.01), np.full(2, 0.01))
         ub = np.array([2 * math.pi, 2 * math.pi, 2 * math.pi / sim_dt, 2 * math.pi / sim_dt])
+    elif task == "standup":  # standup_env.py:99-101,200-204 (signal_type is unused by the env)
+        action = Box(-np.full(1, 0.1), np.full(1, 0.1))
+        ub = np.array([2 * math.pi, 2 * math.pi, 2 * math.pi / sim_dt, 2 * math.pi / sim_dt])
     elif task == "poses":   # poses_env.py:115-117
         action = Box(-np.full(1, 0.1), np.full(1, 0.1))
         ub = np.array([2 * math.pi, 2 * math.pi, 2 * math.pi / sim_dt, 2 * math.pi / sim_dt])

@@ -42,7 +42,7 @@ class RexConfig(ctypes.Structure):
     ]
 
 
-TASKS = {"walk": 0, "gallop": 1, "turn": 2, "poses": 3}
+TASKS = {"walk": 0, "gallop": 1, "turn": 2, "poses": 3, "standup": 4}
 SIGNALS = {"ik": 0, "ol": 1}
 
 

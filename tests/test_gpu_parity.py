@@ -98,7 +98,7 @@ def test_settled_snapshot_matches_oracle(torch):
 
 
 @pytest.mark.parametrize("task,signal", [("walk", "ik"), ("walk", "ol"), ("gallop", "ol"), ("gallop", "ik"),
-                                         ("turn", "ik"), ("turn", "ol"), ("poses", "ik")])
+                                         ("turn", "ik"), ("turn", "ol"), ("poses", "ik"), ("standup", "ol")])
 def test_single_step_parity_from_common_states(torch, task, signal):
     """One env.step() from identical states: isolates per-step error from chaotic divergence.
     Tolerance: 1e-4 rad / 1e-4 m / 2e-2 rad/s over 5-6 substeps x 50-60 PGS iterations.
@@ -602,3 +602,32 @@ def test_kernel_variants_agree_at_benchmark_sizes(torch, task, signal, n, monkey
             assert ((r - rr).abs() <= 1e-4).float().mean() > 0.999
             assert (d == rd).float().mean() > 0.999
     np.testing.assert_array_equal(finals[(4, "first")][0], finals[(4, "rerun")][0])   # determinism
+
+
+def test_standup_env_crouch_and_rise(torch):
+    """RexStandupEnv (standup_env.py:108-166): reset ends crouched on the foot joint limits (2.59 rad), the first
+    steps push the base up towards 0.21 m; state, reward and done follow the fp32 oracle in lock step."""
+    n = 32
+    env, orc = make_pair("standup", "ol", n, np.float32, seed=6)
+    obs, oobs = env.reset().cpu().numpy(), orc.reset()
+    ps, os_ = product_state_to_numeric(env.state), orc.get_state()
+    np.testing.assert_allclose(ps[:7], os_[:7], atol=2e-4)
+    np.testing.assert_allclose(ps[13:25], os_[13:25], atol=5e-4)
+    assert np.all(np.abs(ps[2] - 0.066) < 0.01) and np.all(np.abs(ps[[15, 18, 21, 24]] - 2.59) < 0.01)
+    np.testing.assert_allclose(obs, oobs, atol=2e-3)
+    rng = np.random.RandomState(3)
+    zmax = np.zeros(n)
+    for k in range(40):
+        a = rng.uniform(-0.1, 0.1, (n, 1)).astype(np.float32)
+        o, r, d, _ = env.step(torch.as_tensor(a, device="cuda"))
+        oo, orr, od, _ = orc.step(a)
+        ps, os_ = product_state_to_numeric(env.state), orc.get_state()
+        if k < 20:   # lock step while the trajectories are still within round-off of each other
+            np.testing.assert_allclose(ps[:3], os_[:3], atol=1e-3)
+            # the reward jumps by 1 where the distance to (0, 0, 0.21) crosses 0.1 and again at z = 0.21: an env that
+            # sits on a threshold within round-off may land on the other side
+            assert (np.abs(r.cpu().numpy() - orr) <= 5e-3).mean() > 0.9
+        np.testing.assert_array_equal(d.cpu().numpy(), od)
+        zmax = np.maximum(zmax, ps[2])
+    assert np.all(zmax > 0.15)
+    env.close()

@@ -148,3 +148,24 @@ def test_arm_mark_reset_holds_the_arm_on_its_limits():
     np.testing.assert_allclose(cmd[:, 12:], np.tile(ARM_REST, (2, 1)))
     np.testing.assert_allclose(o[:, 4:], env.get_state()[13:31].T, atol=1e-12)   # gallop obs = rpy rates + 18 angles
     env.close()
+
+
+def test_standup_env_starts_crouched_clear_of_the_ground_and_rises():
+    """RexStandupEnv: the reset motion folds the legs onto the foot joint bound (INIT_POSES['rest_position'] asks for
+    6 rad, the URDF allows 2.59); the base ends 66 mm above the ground -- the chassis box (35 mm half height) stays
+    clear, which is why this env needs no body-ground rows -- and the 'brake' signal then lifts it past 0.15 m."""
+    env = OracleEnv(default_config("standup", "ol", 1))
+    env.reset()
+    st = env.get_state()
+    assert 0.055 < st[2, 0] < 0.08 and st[2, 0] - 0.035 > 0.02
+    np.testing.assert_allclose(st[[15, 18, 21, 24], 0], 2.59, atol=5e-3)
+    zs, rewards = [], []
+    for k in range(40):
+        o, r, d, cmd = env.step(np.array([[0.05]]))
+        zs.append(env.get_state()[2, 0]); rewards.append(r[0])
+        if k == 0:   # t = 0: stand * ((0.1 + a) / 1 + 1.5)
+            np.testing.assert_allclose(cmd[0, :3], np.array([0.0, -0.88643435, 1.30197369]) * 1.65, atol=1e-12)
+        assert not d[0]
+    np.testing.assert_allclose(cmd[0, :3], [0.0, -0.88643435, 1.30197369], atol=1e-12)      # t > 0.1: the stand pose
+    assert max(zs) > 0.15 and max(rewards) > 0.9                                               # within 0.1 of (0, 0, 0.21)
+    env.close()
