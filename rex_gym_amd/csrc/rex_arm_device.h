@@ -296,6 +296,60 @@ struct ArmChain {
   __device__ __forceinline__ void finish(const Chol6& Lc) { arm_rows_finish(sma, Lc); }
   __device__ __forceinline__ void sweep(PgsX& x, float& worst) { pgs_arm_limits(sma, x, za, lam_a, active_any, worst); }
   __device__ __forceinline__ void back(const float* nu, PhysState& s) { arm_back(sma, za, nu, s.qd + 12); }
+
+  // ---- lane-distributed sweep (rex_device.h: pgs_dv): lane p owns arm component p (+ LPE) next to its share of y ----
+  // An arm limit row is 16 floats: g' 0..5, j' 6..11, (invd target, invd, diag, 0); float 15 is the zero that the
+  // lanes owning no component read.  The parked whitened arm velocity sits in floats 57..62 of the park chunks.
+  int oya[2], oaa[2];   // byte offsets from the LDS base of this lane's y / arm components in arm row 0
+  float as_[2];
+  static constexpr int kRowBytes = REX_ARM_ROW_F4 * EPW * 16;
+  __device__ __forceinline__ int foff(int f) const { return ((REX_LDS_F4_PER_ENV + REX_ARM_PARK_F4 + (f >> 2)) * EPW + sma.slot) * 16 + (f & 3) * 4; }
+  __device__ __forceinline__ float ldb(int off) const { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(sma.p) + off); }
+  __device__ __forceinline__ float& parkf(int f) const { return reinterpret_cast<float*>(&sma.park(f >> 2))[f & 3]; }
+  template <int LPE>
+  __device__ __forceinline__ void dv_begin(int p) {
+    constexpr int NY = (6 + LPE - 1) / LPE;
+#pragma unroll
+    for (int i = 0; i < NY; ++i) {
+      const int k = p + i * LPE;
+      oya[i] = foff(k < 6 ? k : 15);
+      oaa[i] = foff(k < 6 ? 6 + k : 15);
+      as_[i] = parkf(k < 6 ? 57 + k : 63);
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) lam_a[k] = 0.0f;
+  }
+  template <int LPE, int NY>
+  __device__ __forceinline__ void dv_sweep(float* ys, float& worst, float thr) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      if (!((active_any >> k) & 1u)) continue;   // wave-uniform
+      float jy[NY], ja[NY];
+#pragma unroll
+      for (int i = 0; i < NY; ++i) { jy[i] = ldb(k * kRowBytes + oya[i]); ja[i] = ldb(k * kRowBytes + oaa[i]); }
+      const float4 c3 = sma.row(k, 3);
+      float part = 0.0f;
+#pragma unroll
+      for (int i = 0; i < NY; ++i) part = fmaf(jy[i], ys[i], fmaf(ja[i], as_[i], part));
+      const float vel = group_sum<LPE>(part);
+      const float nl = fmaxf(fmaf(-c3.y, vel, lam_a[k] + c3.x), 0.0f);
+      const float dl = nl - lam_a[k];
+      lam_a[k] = nl;
+      worst = fmaxf(worst, fmaf(-thr, c3.y, fabsf(dl)));
+#pragma unroll
+      for (int i = 0; i < NY; ++i) { ys[i] = fmaf(jy[i], dl, ys[i]); as_[i] = fmaf(ja[i], dl, as_[i]); }
+    }
+  }
+  template <int LPE>
+  __device__ __forceinline__ void dv_end(int p) {
+    constexpr int NY = (6 + LPE - 1) / LPE;
+#pragma unroll
+    for (int i = 0; i < NY; ++i) { const int k = p + i * LPE; parkf(k < 6 ? 57 + k : 63) = as_[i]; }
+  }
+  __device__ __forceinline__ void dv_gather() {   // after the group's sync: every lane needs the whole arm velocity
+    const float4 a = sma.park(14), b = sma.park(15);
+    za[0] = a.y; za[1] = a.z; za[2] = a.w; za[3] = b.x; za[4] = b.y; za[5] = b.z;
+  }
 };
 
 // picks the physics_substep hook of a kernel instantiation

@@ -29,7 +29,11 @@
 #define REX_ROW_F4 3                  /* float4 chunks per row in LDS */
 #define REX_LEG_F4 7                  /* float4 chunks per leg parked in LDS (Bw 18 + G 6 + z 3) */
 #define REX_LDS_F4_PER_ENV (REX_NROW * REX_ROW_F4 + REX_NLEG * REX_LEG_F4)   /* 136 float4 = 2.2 KB per env */
-#define REX_PARK_F4 18                /* small-batch waves only: env state parked while the solver owns the registers */
+/* small-batch waves (EPW <= 16) only: chunks 0..13 env state parked while the solver owns the registers, 14..15 the
+   whitened base velocity y on its way to / from the lanes that own its components, 16..21 row couplings A(r, r-1) */
+#define REX_PARK_F4 22
+#define REX_PARK_XY 14
+#define REX_PARK_CPL 16
 
 namespace rex {
 
@@ -55,6 +59,10 @@ struct Lds {
   float4* p; int slot;
   float4* pk;   // park region (REX_PARK_F4 chunks per env, behind the rows of all marks); null when EPW = 64
   __device__ __forceinline__ float4& park(int c) const { return pk[c * EPW + slot]; }
+  // scalar views for the lanes that own single components (pgs_dv): float f of a chunk sequence starting at chunk c0
+  __device__ __forceinline__ float& parkf(int c0, int f) const { return reinterpret_cast<float*>(&pk[(c0 + (f >> 2)) * EPW + slot])[f & 3]; }
+  __device__ __forceinline__ float& legf(int l, int c0, int f) const { return reinterpret_cast<float*>(&leg(l, c0 + (f >> 2)))[f & 3]; }
+  __device__ __forceinline__ float& rowf(int r, int f) const { return reinterpret_cast<float*>(&row(r, f >> 2))[f & 3]; }
   __device__ __forceinline__ float4& row(int r, int c) const { return p[(r * REX_ROW_F4 + c) * EPW + slot]; }
   __device__ __forceinline__ float4& leg(int l, int c) const { return p[(REX_NROW * REX_ROW_F4 + l * REX_LEG_F4 + c) * EPW + slot]; }
 };
@@ -543,6 +551,10 @@ struct NoArm {
   __device__ __forceinline__ void finish(const Chol6&) {}
   __device__ __forceinline__ void sweep(PgsX&, float&) {}
   __device__ __forceinline__ void back(const float*, PhysState&) {}
+  template <int LPE> __device__ __forceinline__ void dv_begin(int) {}
+  template <int LPE, int NY> __device__ __forceinline__ void dv_sweep(float*, float&, float) {}
+  template <int LPE> __device__ __forceinline__ void dv_end(int) {}
+  __device__ __forceinline__ void dv_gather() {}
 };
 
 // whitened solver state: y = 3 packed pairs, per leg z = (pair, scalar)
@@ -619,7 +631,7 @@ __device__ __forceinline__ void pgs_leg_friction(const SM& sm, PgsX& x, float* l
 // EPW = 16; lane = LPE * slot + p; for EPW = 4 the upper 32 lanes repeat the lower 32) that run the same arithmetic on
 // the same state (see rex_step_kernel).  The four legs of an env are independent until the base Cholesky, so a lane
 // factorises ONE leg (leg p for LPE = 4, leg p / 2 for LPE = 8) and the per-leg partial sums meet in an xor butterfly
-// inside the group (DPP, no LDS); the row finishing, the sweep loop (pgs_lanes) and the back-substitution are split
+// inside the group (DPP, no LDS); the row finishing, the sweep loop (pgs_dv) and the back-substitution are split
 // over the lanes as well.  Each butterfly step adds the same two numbers in both lanes, so the lanes of a group stay
 // bit-identical.
 __device__ __forceinline__ constexpr int lanes_per_env(int epw) { return epw <= 8 ? 8 : 4; }
@@ -660,128 +672,155 @@ __device__ __forceinline__ float pick_leg(const float* a, int m, int j) {   // a
 // LDS rows / parked factors written by one lane of a group are read by the others: order the accesses of the wave
 __device__ __forceinline__ void mirror_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
 
-// ---- the sweep loop of a lane group (EPW <= 16), contact rows only, in impulse space ----
-// The same Gauss-Seidel iterates as the row-by-row velocity form below (same row order, same clamps, same residual
-// test), written on the Delassus matrix A = J~ J~^T of the 24 contact rows: vel_r = b_r + sum_s A_rs lam_s.  A lane
-// keeps the columns of A that belong to ITS rows (LPE = 8: the normal and the two friction rows of contact point p,
-// 24 x 3 registers; LPE = 4: the six rows of leg p) and the impulses of those rows; the partial sums of a row meet
-// in a DPP sum over the group.  The sweep is software-pipelined: the group sum of row r+1 is taken over the impulses
-// as they stand BEFORE row r is solved and corrected by A(r+1,r) dl_r afterwards, so the dependent chain of a row is
-// fma - fma - clamp - subtract (the velocity form has 9 dependent operations per row, 21 instructions and three LDS
-// reads; this has about 15 instructions and none).  A lone wave issues one VALU instruction per 4 cycles, which is
-// what bounds a small batch.  Rows no env of the group has within reach have invd = 0: they produce zero impulses
-// and are not skipped (a wave rarely has a whole leg out of reach, and a static row sequence is what lets the
-// pipeline run across rows and sweeps).
-__device__ __forceinline__ constexpr int crow_point(int r) { return r < REX_NPOINT ? r : (r - REX_NPOINT) / 2; }
-template <int LPE> __device__ __forceinline__ constexpr int crow_owner(int r) { return LPE == 8 ? crow_point(r) : crow_point(r) / 2; }
-template <int LPE> __device__ __forceinline__ constexpr int crow_own(int r) {   // index of row r among its owner's rows
-  return LPE == 8 ? (r < REX_NPOINT ? 0 : 1 + (r - REX_NPOINT) % 2) : (r < REX_NPOINT ? r % 2 : 2 + (r - REX_NPOINT) % 4);
-}
+// ---- the sweep loop of a lane group (EPW <= 16): velocity form with the whitened velocity DISTRIBUTED over the lanes ----
+// Lane p of a group owns component p (+ LPE, ...) of the base part y and component p of every leg's part z_L (lanes
+// that own none read the zero in chunk 2 .w of a row and never change).  A row is then: one or two scalar LDS reads of
+// the lane's components of J~, that many FMAs, a DPP sum over the group, the clamp (every lane, redundantly) and that
+// many FMAs for x += J~ dl -- 17 instructions against 21 + three 16-byte LDS reads per row when every lane carries the
+// whole of x, with no per-substep solver set-up, and it takes any row (contact, joint limit, arm limit) alike.
+// The 24 contact rows run software-pipelined: the group sum of row r+1 is taken over x as it stands BEFORE row r is
+// solved and corrected by A(r+1, r) dl_r (cpl[], one 9-term inner product per row and substep, computed by the lanes in
+// turn), which leaves fma - fma - clamp - subtract on the dependent chain.  Joint-limit rows come first, as in Bullet,
+// group by group and skipped while no env of the wave has a bound in reach.  Contact rows out of reach have invd = 0,
+// produce zero impulses and are not skipped: a static row sequence is what lets the pipeline run.
+__device__ __forceinline__ constexpr int crow_leg(int r) { return r < REX_NPOINT ? r / 2 : (r - REX_NPOINT) / 4; }
 
-template <int LPE, class SM>
-__device__ __forceinline__ void pgs_lanes(const SM& sm, PgsX& x, int p, float mu, int iterations, float thr, int& nsweeps) {
-  constexpr int NO = REX_NCROW / LPE;   // rows owned by a lane: 3 or 6
-  constexpr int kN = REX_NCROW;
-  float Jo[NO][9];
-#pragma unroll
-  for (int j = 0; j < NO; ++j) {
-    int r;
-    if (LPE == 8) r = j == 0 ? p : REX_NPOINT + 2 * p + (j - 1);
-    else r = j < 2 ? 2 * p + j : REX_NPOINT + 4 * p + (j - 2);
-    const float4 c0 = sm.row(r, 0), c1 = sm.row(r, 1), c2 = sm.row(r, 2);
-    Jo[j][0] = c0.x; Jo[j][1] = c0.y; Jo[j][2] = c0.z; Jo[j][3] = c0.w; Jo[j][4] = c1.x; Jo[j][5] = c1.y;
-    Jo[j][6] = c1.z; Jo[j][7] = c1.w; Jo[j][8] = c2.x;
+template <int NY, int EPW>
+struct DvLane {
+  int oy[NY], oz;   // byte offsets (from the LDS base) of this lane's components in row 0
+  __device__ __forceinline__ static float ld(const Lds<EPW>& sm, int off) {
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(sm.p) + off);
   }
-  const int myleg = LPE == 8 ? p >> 1 : p;
-  const float y[6] = {x.y01.x, x.y01.y, x.y23.x, x.y23.y, x.y45.x, x.y45.y};
-  // cpl[r] = A(r, r-1), needed by every lane; cv[r] = b_r - target_r (free velocity minus the row's target) in lane 0 of
-  // the group and 0 elsewhere: it enters the group sum as the addend of the row's first product
-  float A[kN][NO], invd[kN], cv[kN], cpl[kN], S0 = 0.0f;
-  // one row at a time (hoisting all 72 row reads costs more registers than it hides), the next row's reads in flight;
-  // `pg`, `pj` walk one row behind for the coupling A(r, r-1)
-  float pg[6], pj[3];
+};
+
+template <int LPE, class SM, class ARMP>
+__device__ __forceinline__ void pgs_dv(const SM& sm, ARMP& armp, PgsX& x, int p, const bool (&lim)[4], bool any_contact,
+                                       float mu, int iterations, float thr, int& nsweeps) {
+  constexpr int EPW = SM::kEpw, NY = (6 + LPE - 1) / LPE;
+  constexpr int kRow = REX_ROW_F4 * EPW * 16;   // bytes from a row to the next
+  DvLane<NY, EPW> ln;
+  float ys[NY], zs[REX_NLEG];
   {
-    const float4 c0 = sm.row(kN - 1, 0), c1 = sm.row(kN - 1, 1), c2 = sm.row(kN - 1, 2);
-    pg[0] = c0.x; pg[1] = c0.y; pg[2] = c0.z; pg[3] = c0.w; pg[4] = c1.x; pg[5] = c1.y; pj[0] = c1.z; pj[1] = c1.w; pj[2] = c2.x;
-  }
-  float4 n0 = sm.row(0, 0), n1 = sm.row(0, 1), n2 = sm.row(0, 2);
+    const float yv[6] = {x.y01.x, x.y01.y, x.y23.x, x.y23.y, x.y45.x, x.y45.y};
+    sm.park(REX_PARK_XY) = make_float4(yv[0], yv[1], yv[2], yv[3]);
+    sm.park(REX_PARK_XY + 1) = make_float4(yv[4], yv[5], 0.0f, 0.0f);
+    mirror_sync();
 #pragma unroll
-  for (int r = 0; r < kN; ++r) {
-    const int Lr = crow_point(r) / 2, Lp = crow_point((r + kN - 1) % kN) / 2;
-    const float4 c0 = n0, c1 = n1, c2 = n2;
-    if (r + 1 < kN) { n0 = sm.row(r + 1, 0); n1 = sm.row(r + 1, 1); n2 = sm.row(r + 1, 2); }
-    __builtin_amdgcn_sched_barrier(0);
-    const float g[6] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y};
-    const float jr[3] = {c1.z, c1.w, c2.x};
-    float b = jr[0] * x.z01[Lr].x + jr[1] * x.z01[Lr].y + jr[2] * x.z2[Lr];   // free velocity of the row
-    float cp = Lr == Lp ? jr[0] * pj[0] + jr[1] * pj[1] + jr[2] * pj[2] : 0.0f;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) { b = fmaf(g[k], y[k], b); cp = fmaf(g[k], pg[k], cp); }
-    invd[r] = c2.z;
-    const float bt = fmaf(-c2.y, c2.w, b);        // c2.y = target * invd, c2.w = 1 / invd
-    cv[r] = p == 0 ? bt : 0.0f;
-    if (r == 0) S0 = bt;
-    cpl[r] = cp;
-    const bool same = myleg == Lr;                // rows of other legs couple through the base part only
-    const float j0 = same ? jr[0] : 0.0f, j1 = same ? jr[1] : 0.0f, j2 = same ? jr[2] : 0.0f;
-#pragma unroll
-    for (int j = 0; j < NO; ++j) {
-      float t0 = j0 * Jo[j][6] + g[0] * Jo[j][0], t1 = j1 * Jo[j][7] + g[1] * Jo[j][1], t2 = j2 * Jo[j][8] + g[2] * Jo[j][2];
-      t0 = fmaf(g[3], Jo[j][3], t0); t1 = fmaf(g[4], Jo[j][4], t1); t2 = fmaf(g[5], Jo[j][5], t2);
-      A[r][j] = (t0 + t1) + t2;
+    for (int i = 0; i < NY; ++i) {
+      const int k = p + i * LPE;
+      const int f = k < 6 ? k : 11;
+      ln.oy[i] = ((f >> 2) * EPW + sm.slot) * 16 + (f & 3) * 4;
+      ys[i] = sm.parkf(REX_PARK_XY, k < 6 ? k : 6);
     }
+    const int f = p < 3 ? 6 + p : 11;
+    ln.oz = ((f >> 2) * EPW + sm.slot) * 16 + (f & 3) * 4;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) pg[k] = g[k];
-    pj[0] = jr[0]; pj[1] = jr[1]; pj[2] = jr[2];
+    for (int l = 0; l < REX_NLEG; ++l) zs[l] = sm.legf(l, 6, p < 3 ? p : 3);
   }
-  float lam[kN], lo[NO];
+  armp.template dv_begin<LPE>(p);
+  float cpl[REX_NCROW];
 #pragma unroll
-  for (int r = 0; r < kN; ++r) lam[r] = 0.0f;
+  for (int c = 0; c < REX_NCROW / 4; ++c) {
+    const float4 v = sm.park(REX_PARK_CPL + c);
+    cpl[4 * c] = v.x; cpl[4 * c + 1] = v.y; cpl[4 * c + 2] = v.z; cpl[4 * c + 3] = v.w;
+  }
+  float lam[REX_NROW];
 #pragma unroll
-  for (int j = 0; j < NO; ++j) lo[j] = 0.0f;
-  float S = S0, dlp = 0.0f;     // group sum of the row about to be solved (without its predecessor's step), that step
+  for (int r = 0; r < REX_NROW; ++r) lam[r] = 0.0f;
+  // this lane's slice of the 24 contact rows, read once per substep: its components of J~, invd target, invd
+  float Jy[REX_NCROW][NY], Jz[REX_NCROW], Kc[REX_NCROW], Ki[REX_NCROW];
+#pragma unroll
+  for (int r = 0; r < REX_NCROW; ++r) {
+#pragma unroll
+    for (int i = 0; i < NY; ++i) Jy[r][i] = ln.ld(sm, r * kRow + ln.oy[i]);
+    Jz[r] = ln.ld(sm, r * kRow + ln.oz);
+    Kc[r] = sm.rowf(r, 9);
+    Ki[r] = sm.rowf(r, 10);
+  }
+
   bool running = true;
   for (int it = 0; it < iterations; ++it) {
     ++nsweeps;
     if (running) {
       float worst = 0.0f;
+      // joint-limit rows (non-contact rows come first in Bullet's sweep): plain Gauss-Seidel steps
 #pragma unroll
-      for (int r = 0; r < kN; ++r) {
-        const int rn = (r + 1) % kN;
-        const float sum = fmaf(cpl[r], dlp, S);
-        float nl = fmaf(-invd[r], sum, lam[r]);
-        if (r < REX_NPOINT) nl = fmaxf(nl, 0.0f);
-        else {
-          const float lim = mu * lam[(r - REX_NPOINT) / 2];
-          nl = __builtin_amdgcn_fmed3f(nl, -lim, lim);
+      for (int l = 0; l < REX_NLEG; ++l) {
+        if (!lim[l]) continue;                     // wave-uniform
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const int r = REX_NCROW + 3 * l + k;
+          float jy[NY];
+#pragma unroll
+          for (int i = 0; i < NY; ++i) jy[i] = ln.ld(sm, r * kRow + ln.oy[i]);
+          const float jz = ln.ld(sm, r * kRow + ln.oz);
+          const float4 c2 = sm.row(r, 2);
+          float part = jz * zs[l];
+#pragma unroll
+          for (int i = 0; i < NY; ++i) part = fmaf(jy[i], ys[i], part);
+          const float vel = group_sum<LPE>(part);
+          const float nl = fmaxf(fmaf(-c2.z, vel, lam[r] + c2.y), 0.0f);
+          const float dl = nl - lam[r];
+          lam[r] = nl;
+          worst = fmaxf(worst, fmaf(-thr, c2.z, fabsf(dl)));
+#pragma unroll
+          for (int i = 0; i < NY; ++i) ys[i] = fmaf(jy[i], dl, ys[i]);
+          zs[l] = fmaf(jz, dl, zs[l]);
         }
-        const float dl = nl - lam[r];
-        // group sum of the next row over the impulses through row r-1
-        float part = fmaf(A[rn][0], lo[0], cv[rn]);
+      }
+      armp.template dv_sweep<LPE, NY>(ys, worst, thr);
+      if (any_contact) {
+        // contact rows, pipelined; this lane's slice of the rows sits in registers (Jy, Jz, Kc, Ki)
+        float S, dlp = 0.0f;
+        {
+          float part = Jz[0] * zs[0];
 #pragma unroll
-        for (int j = 1; j < NO; ++j) part = fmaf(A[rn][j], lo[j], part);
-        S = group_sum<LPE>(part);
-        worst = fmaxf(worst, fmaf(-thr, invd[r], fabsf(dl)));   // |dl| / invd > thr: Bullet's velocity residual
-        lam[r] = nl;
-        dlp = dl;
-        if (p == crow_owner<LPE>(r)) lo[crow_own<LPE>(r)] = nl;
+          for (int i = 0; i < NY; ++i) part = fmaf(Jy[0][i], ys[i], part);
+          S = group_sum<LPE>(part);
+        }
+#pragma unroll
+        for (int r = 0; r < REX_NCROW; ++r) {
+          const int L = crow_leg(r);
+          const float sum = fmaf(cpl[r], dlp, S);
+          float nl = fmaf(-Ki[r], sum, lam[r] + Kc[r]);
+          if (r < REX_NPOINT) nl = fmaxf(nl, 0.0f);
+          else {
+            const float lm = mu * lam[(r - REX_NPOINT) / 2];
+            nl = __builtin_amdgcn_fmed3f(nl, -lm, lm);
+          }
+          const float dl = nl - lam[r];
+          if (r + 1 < REX_NCROW) {   // group sum of the next row over x as it stands before this row's step
+            float part = Jz[r + 1] * zs[crow_leg(r + 1)];
+#pragma unroll
+            for (int i = 0; i < NY; ++i) part = fmaf(Jy[r + 1][i], ys[i], part);
+            S = group_sum<LPE>(part);
+          }
+          worst = fmaxf(worst, fmaf(-thr, Ki[r], fabsf(dl)));   // |dl| / invd > thr: Bullet's velocity residual
+          lam[r] = nl;
+          dlp = dl;
+#pragma unroll
+          for (int i = 0; i < NY; ++i) ys[i] = fmaf(Jy[r][i], dl, ys[i]);
+          zs[L] = fmaf(Jz[r], dl, zs[L]);
+        }
       }
       running = worst > 0.0f;
     }
     if (__builtin_amdgcn_ballot_w64(running) == 0) break;
   }
-  // x = x0 + sum_r J~_r lam_r
-  float yn[6] = {y[0], y[1], y[2], y[3], y[4], y[5]};
+  // hand the components back: every lane needs the whole of x for the back-substitution
 #pragma unroll
-  for (int r = 0; r < kN; ++r) {
-    const int Lr = crow_point(r) / 2;
-    const float4 c0 = sm.row(r, 0), c1 = sm.row(r, 1), c2 = sm.row(r, 2);
-    const float l = lam[r];
-    yn[0] = fmaf(c0.x, l, yn[0]); yn[1] = fmaf(c0.y, l, yn[1]); yn[2] = fmaf(c0.z, l, yn[2]);
-    yn[3] = fmaf(c0.w, l, yn[3]); yn[4] = fmaf(c1.x, l, yn[4]); yn[5] = fmaf(c1.y, l, yn[5]);
-    x.z01[Lr].x = fmaf(c1.z, l, x.z01[Lr].x); x.z01[Lr].y = fmaf(c1.w, l, x.z01[Lr].y); x.z2[Lr] = fmaf(c2.x, l, x.z2[Lr]);
+  for (int i = 0; i < NY; ++i) { const int k = p + i * LPE; sm.parkf(REX_PARK_XY, k < 6 ? k : 7) = ys[i]; }
+#pragma unroll
+  for (int l = 0; l < REX_NLEG; ++l) sm.legf(l, 6, p < 3 ? p : 3) = zs[l];
+  armp.template dv_end<LPE>(p);
+  mirror_sync();
+  {
+    const float4 a = sm.park(REX_PARK_XY), b = sm.park(REX_PARK_XY + 1);
+    x.y01 = v2{a.x, a.y}; x.y23 = v2{a.z, a.w}; x.y45 = v2{b.x, b.y};
+#pragma unroll
+    for (int l = 0; l < REX_NLEG; ++l) { const float4 z = sm.leg(l, 6); x.z01[l] = v2{z.x, z.y}; x.z2[l] = z.z; }
   }
-  x.y01 = v2{yn[0], yn[1]}; x.y23 = v2{yn[2], yn[3]}; x.y45 = v2{yn[4], yn[5]};
+  armp.dv_gather();
 }
 
 // The restated pybullet.stepSimulation for one env (one lane): tau is held for this substep.
@@ -935,7 +974,7 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
     const float invd = c2.z != 0.0f ? __builtin_amdgcn_rcpf(diag) : 0.0f;
     sm.row(r, 0) = make_float4(gw[0], gw[1], gw[2], gw[3]);
     sm.row(r, 1) = make_float4(gw[4], gw[5], c1.z, c1.w);
-    sm.row(r, 2) = make_float4(c2.x, c2.y * invd, invd, diag);
+    sm.row(r, 2) = make_float4(c2.x, c2.y * invd, invd, kSplitLegs ? 0.0f : diag);   // .w = 0: see pgs_dv
   }
 
   if constexpr (kSplitLegs) mirror_sync();
@@ -959,34 +998,45 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
   // loop when its last lane has stopped.
   REX_STAMP(t_pgs0);
   int nsweeps = 0;
-  bool lanes_solved = false;
-  if constexpr (kSplitLegs && !ARMP::kHasRows) {
-    if (!any_limit) {                                  // wave-uniform; joint-limit rows are rare (pgs_lanes)
-      pgs_lanes<LPE>(sm, x, pl, ground.mu, iterations, sqrt_res_thr, nsweeps);
-      lanes_solved = true;
+  if constexpr (kSplitLegs) {
+    mirror_sync();
+    // couplings of consecutive contact rows, A(r, r-1) = J~_r . J~_(r-1): lane p takes rows 1 + p, 1 + p + LPE, ...
+    for (int r = 1 + pl; r < REX_NCROW; r += LPE) {
+      const float4 a0 = sm.row(r, 0), a1 = sm.row(r, 1), a2 = sm.row(r, 2);
+      const float4 b0 = sm.row(r - 1, 0), b1 = sm.row(r - 1, 1), b2 = sm.row(r - 1, 2);
+      const int La = r < REX_NPOINT ? r >> 1 : (r - REX_NPOINT) >> 2, Lb = r - 1 < REX_NPOINT ? (r - 1) >> 1 : (r - 1 - REX_NPOINT) >> 2;
+      float cp = La == Lb ? a1.z * b1.z + a1.w * b1.w + a2.x * b2.x : 0.0f;
+      cp += a0.x * b0.x + a0.y * b0.y + a0.z * b0.z + a0.w * b0.w + a1.x * b1.x + a1.y * b1.y;
+      sm.parkf(REX_PARK_CPL, r) = cp;
     }
-  }
-  bool running = !lanes_solved;
-  for (int it = 0; it < (lanes_solved ? 0 : iterations); ++it) {
-    ++nsweeps;
-    if (running) {
-      float worst = 0.0f;
-      if (lim0) pgs_leg_limits<0>(sm, x, lam, worst);   // non-contact rows first (Bullet's sweep order)
-      if (lim1) pgs_leg_limits<1>(sm, x, lam, worst);
-      if (lim2) pgs_leg_limits<2>(sm, x, lam, worst);
-      if (lim3) pgs_leg_limits<3>(sm, x, lam, worst);
-      armp.sweep(x, worst);
-      if (any0) pgs_leg_normals<0>(sm, x, lam, worst);
-      if (any1) pgs_leg_normals<1>(sm, x, lam, worst);
-      if (any2) pgs_leg_normals<2>(sm, x, lam, worst);
-      if (any3) pgs_leg_normals<3>(sm, x, lam, worst);
-      if (any0) pgs_leg_friction<0>(sm, x, lam, worst, ground.mu);
-      if (any1) pgs_leg_friction<1>(sm, x, lam, worst, ground.mu);
-      if (any2) pgs_leg_friction<2>(sm, x, lam, worst, ground.mu);
-      if (any3) pgs_leg_friction<3>(sm, x, lam, worst, ground.mu);
-      running = worst > sqrt_res_thr;
+    if (pl == 0) sm.parkf(REX_PARK_CPL, 0) = 0.0f;
+    mirror_sync();
+    const bool lim[4] = {lim0, lim1, lim2, lim3};
+    pgs_dv<LPE>(sm, armp, x, pl, lim, any0 || any1 || any2 || any3, ground.mu, iterations, sqrt_res_thr, nsweeps);
+  } else {
+    // one env per lane (EPW = 64): every lane carries the whole of x, row by row from LDS
+    bool running = true;
+    for (int it = 0; it < iterations; ++it) {
+      ++nsweeps;
+      if (running) {
+        float worst = 0.0f;
+        if (lim0) pgs_leg_limits<0>(sm, x, lam, worst);   // non-contact rows first (Bullet's sweep order)
+        if (lim1) pgs_leg_limits<1>(sm, x, lam, worst);
+        if (lim2) pgs_leg_limits<2>(sm, x, lam, worst);
+        if (lim3) pgs_leg_limits<3>(sm, x, lam, worst);
+        armp.sweep(x, worst);
+        if (any0) pgs_leg_normals<0>(sm, x, lam, worst);
+        if (any1) pgs_leg_normals<1>(sm, x, lam, worst);
+        if (any2) pgs_leg_normals<2>(sm, x, lam, worst);
+        if (any3) pgs_leg_normals<3>(sm, x, lam, worst);
+        if (any0) pgs_leg_friction<0>(sm, x, lam, worst, ground.mu);
+        if (any1) pgs_leg_friction<1>(sm, x, lam, worst, ground.mu);
+        if (any2) pgs_leg_friction<2>(sm, x, lam, worst, ground.mu);
+        if (any3) pgs_leg_friction<3>(sm, x, lam, worst, ground.mu);
+        running = worst > sqrt_res_thr;
+      }
+      if (__builtin_amdgcn_ballot_w64(running) == 0) break;
     }
-    if (__builtin_amdgcn_ballot_w64(running) == 0) break;
   }
   REX_STAMP(t_pgs1);
   y[0] = x.y01.x; y[1] = x.y01.y; y[2] = x.y23.x; y[3] = x.y23.y; y[4] = x.y45.x; y[5] = x.y45.y;
@@ -1062,7 +1112,7 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
       long long* p = g_prof + 8 * blockIdx.x;
       p[0] += t_pgs1 - t_pgs0; p[1] += nsweeps; p[2] += clock64() - t_begin; p[4] += 1;
       p[3] += t_pgs0 - t_chol; p[6] += t_legs - t_begin; p[7] += t_chol - t_legs;
-      p[5] += lanes_solved ? 0 : 1;   // substeps solved by the velocity-form fallback (joint-limit rows in reach)
+      p[5] += any_limit ? 1 : 0;      // substeps with joint-limit rows in reach of some env of the wave
     }
 #endif
   }

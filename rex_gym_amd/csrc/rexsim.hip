@@ -250,9 +250,9 @@ __device__ __forceinline__ void rex_substep(const DevCfg& c, EnvState& e, int i,
   // the old registers dead across the call, so the allocator has nothing of it to spill.
   constexpr bool kPark = SM::kEpw <= 16;
   if constexpr (kPark) {
-    float w[4 * REX_PARK_F4];
+    float w[4 * REX_PARK_XY];
 #pragma unroll
-    for (int k = 0; k < 4 * REX_PARK_F4; ++k) w[k] = 0.0f;
+    for (int k = 0; k < 4 * REX_PARK_XY; ++k) w[k] = 0.0f;
 #pragma unroll
     for (int j = 0; j < NM; ++j) { w[j] = cmd[j]; w[NM + j] = tau_obs[j]; }
 #pragma unroll
@@ -261,15 +261,15 @@ __device__ __forceinline__ void rex_substep(const DevCfg& c, EnvState& e, int i,
     t[0] = e.gait.phi; t[1] = e.gait.last_time; t[2] = e.gait.alpha; t[3] = e.target; t[4] = e.end_time; t[5] = e.aux;
     t[6] = __uint_as_float(e.flags); t[7] = __uint_as_float((uint32_t)e.steps); t[8] = __uint_as_float((uint32_t)e.episode);
     t[9] = __uint_as_float(e.motor_en); t[10] = __uint_as_float(e.hist);
-    static_assert(2 * 18 + 9 + 11 <= 4 * REX_PARK_F4, "park region too small");
+    static_assert(2 * 18 + 9 + 11 <= 4 * REX_PARK_XY, "park region too small");
 #pragma unroll
-    for (int k = 0; k < REX_PARK_F4; ++k) sm.park(k) = make_float4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
+    for (int k = 0; k < REX_PARK_XY; ++k) sm.park(k) = make_float4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
   }
   physics_substep(e.ph, tau, c.dt, c.iterations, c.res_thr, sm, ground, armp);
   if constexpr (kPark) {
-    float w[4 * REX_PARK_F4];
+    float w[4 * REX_PARK_XY];
 #pragma unroll
-    for (int k = 0; k < REX_PARK_F4; ++k) {
+    for (int k = 0; k < REX_PARK_XY; ++k) {
       const float4 v = sm.park(k);
       w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
     }

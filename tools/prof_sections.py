@@ -4,7 +4,7 @@
 Builds rexsim.hip with -DREX_PROF (clock64() stamps around the sections of physics_substep, accumulated per
 workgroup by lane 0) into scratch/librexsim_prof.so, runs walk-IK at N envs and prints cycles per substep for:
 leg factorisation, base Cholesky, row finishing, PGS sweeps, back-substitution + integration.
-  python tools/prof_sections.py [N=4096]
+  python tools/prof_sections.py [N=4096] [--arm] [--task=standup|poses|...] [--rebuild]
 """
 import ctypes
 import os
@@ -29,9 +29,12 @@ L = _lib.lib()
 L.rex_debug_prof.argtypes = [ctypes.c_void_p, ctypes.c_int]
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 n = int(args[0]) if args else 4096
-env = RexBatchEnv(n, seed=0, auto_reset=True, max_episode_steps=2000)
+mark = "arm" if "--arm" in sys.argv else "base"
+task = next((a.split("=")[1] for a in sys.argv if a.startswith("--task=")), "walk")
+env = RexBatchEnv(n, task=task, signal_type="ol" if task == "standup" else "ik", seed=0, auto_reset=True, max_episode_steps=2000, mark=mark)
 env.reset()
-acts = [torch.rand((n, 2), device="cuda") * 0.8 - 0.4 for _ in range(8)]
+_lo = torch.as_tensor(env.action_space.low, device="cuda").minimum(torch.as_tensor(env.action_space.high, device="cuda"))
+acts = [torch.rand((n, env.action_dim), device="cuda") * (-2 * _lo) + _lo for _ in range(8)]
 
 
 def window(steps, label):
@@ -47,7 +50,7 @@ def window(steps, label):
     rest = tot - pgs - fin - legs - chol
     fb = out[:, 5]
     print(f"{label}: {len(out)} workgroups sampled, sweeps/substep mean {np.mean(sw / sub):.1f} (slowest workgroup "
-          f"{np.max(sw / sub):.1f}), cycles/sweep {pgs.sum() / sw.sum():.0f}, velocity-form fallback in "
+          f"{np.max(sw / sub):.1f}), cycles/sweep {pgs.sum() / sw.sum():.0f}, joint-limit rows in reach in "
           f"{100 * fb.sum() / sub.sum():.2f} % of the substeps")
     print("  cycles/substep: total %.0f (slowest workgroup %.0f) = legs %.0f + base chol %.0f + finish rows %.0f + pgs %.0f "
           "+ back-subst/integrate %.0f" % (np.mean(tot / sub), np.max(tot / sub), np.mean(legs / sub), np.mean(chol / sub),
