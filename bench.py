@@ -184,8 +184,8 @@ def main():
                          "kernel": "rex_step_kernel", "kernel_ms": kernel_ms, "kernel_ms_min": kms[0],
                          "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP,
                          "layout_bytes_per_env_step": LAYOUT_BYTES_PER_ENV_STEP,
-                         "note": "the fused step is VALU/latency-bound (about 550 flop/B, SURVEY.md 8d): "
-                                 "see valu_frac for the compute roofline",
+                         "note": "the fused step is bound by the VALU issue rate of one wave per SIMD through the sequential "
+                                 "contact solver (about 550 flop/B, SURVEY.md 8d; DESIGN.md 5-6), not by HBM: see valu_frac",
                          "valu_tflops_est": ALGO_FLOP_PER_ENV_STEP * n / (kernel_ms * 1e-3) / 1e12,
                          "valu_frac": ALGO_FLOP_PER_ENV_STEP * n / (kernel_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS},
             "finite": finite,

@@ -170,10 +170,9 @@ __device__ __forceinline__ float pose_rest(int j) {
   const int k = j % 3;
   return k == 0 ? (((j / 3) & 1) ? 0.4f : -0.4f) : (k == 1 ? -1.5f : 6.0f);
 }
-__device__ __forceinline__ float init_pose(const DevCfg& c, int j) {
-  if (c.task == REX_TASK_STANDUP) return pose_rest(j);                          // standup_env.py:108-110
-  return c.signal == REX_SIGNAL_OL ? pose_stand_ol(j) : pose_stand(j);
-}
+__device__ __forceinline__ float init_pose(const DevCfg& c, int j) { return c.signal == REX_SIGNAL_OL ? pose_stand_ol(j) : pose_stand(j); }
+// the pose the reset motion drives to: reset(initial_motor_angles=...), standup_env.py:108-110 vs walk_env.py:125-131
+__device__ __forceinline__ float reset_pose(const DevCfg& c, int j) { return c.task == REX_TASK_STANDUP ? pose_rest(j) : init_pose(c, j); }
 
 // ---- latency model: Rex._observation_history / _GetDelayedObservation (model/rex.py:122,717-763) ----
 __device__ __forceinline__ float& hist_at(const DevCfg& c, int i, int slot, int w) {
@@ -554,6 +553,15 @@ __device__ __forceinline__ void turn_command(const DevCfg& c, EnvState& e, const
   }
 }
 
+// RexStandupEnv._signal (standup_env.py:113-120): the 'stand' pose, scaled by a 'brake' overshoot for the first 0.1 s
+__device__ __forceinline__ void standup_command(const DevCfg& c, const EnvState& e, const float* action, float* cmd) {
+  const float t = (float)(e.steps * c.action_repeat) * c.dt;               // GetTimeSinceReset, rex.py:155-156
+  const float f = t > 0.1f ? 1.0f : (0.1f + action[0]) / (t + 1.0f) + 1.5f;
+  const float leg = -0.88643435f * f, foot = 1.30197369f * f;
+#pragma unroll
+  for (int l = 0; l < 4; ++l) { cmd[3 * l] = 0.0f; cmd[3 * l + 1] = leg; cmd[3 * l + 2] = foot; }
+}
+
 // ------------------------------------------------------------------------------------------
 template <int EPW, bool ARM>
 __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __restrict__ state, const float* __restrict__ snap,
@@ -608,12 +616,7 @@ __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __r
     turn_command(c, e, cq, act, cmd);
   }
   else if (c.task == REX_TASK_POSES) poses_command(c, e, act, cmd);
-  else if (c.task == REX_TASK_STANDUP) {                                     // RexStandupEnv._signal, standup_env.py:113-120
-    const float t = (float)(e.steps * c.action_repeat) * c.dt;               // GetTimeSinceReset, rex.py:155-156
-    const float f = t > 0.1f ? 1.0f : (0.1f + act[0]) / (t + 1.0f) + 1.5f;   // the 'brake' function
-#pragma unroll
-    for (int j = 0; j < 12; ++j) cmd[j] = pose_stand(j) * f;
-  }
+  else if (c.task == REX_TASK_STANDUP) standup_command(c, e, act, cmd);
   else walk_command(c, e, act, cmd);
 
   float tau_obs[NM];
@@ -729,7 +732,7 @@ __global__ __launch_bounds__(REX_WAVE) void rex_settle_kernel(DevCfg c, float* _
     for (int j = 0; j < 12; ++j) cmd[j] = pose_stand(j);
     for (int k = 0; k < 100; ++k) rex_substep(cs, e, 0, false, cmd, tau_obs, sm, ground, armp);   // rex.py:315-318
 #pragma unroll
-    for (int j = 0; j < 12; ++j) cmd[j] = init_pose(c, j);
+    for (int j = 0; j < 12; ++j) cmd[j] = reset_pose(c, j);
     const int nreset = (int)(0.5f / c.dt);                                               // rex.py:319
     for (int k = 0; k < nreset; ++k) rex_substep(cs, e, 0, false, cmd, tau_obs, sm, ground, armp);
   }
