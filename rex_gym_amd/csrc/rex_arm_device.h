@@ -19,6 +19,7 @@ struct m33 { f3 x, y, z; };   // columns
 
 template <int EPW>
 struct LdsArm {
+  static constexpr int kEpw = EPW;
   float4* p; int slot;
   __device__ __forceinline__ float4& park(int c) const { return p[(REX_LDS_F4_PER_ENV + c) * EPW + slot]; }
   __device__ __forceinline__ float4& row(int k, int c) const {
@@ -38,9 +39,11 @@ template <class SMA>
 __device__ __forceinline__ unsigned arm_pass(const BaseKin& bk, const float* __restrict__ q, const float* __restrict__ qd,
                                              const float* __restrict__ tau, float dt, ArmFactor& L, BaseAccum& acc,
                                              const SMA& sma, const Ground& ground) {
-  f3 a[6], o[6], c[6], w[6], al[6], fo[6], no[6];   // axis, joint origin, COM (rel. base origin), ang. vel, ang. acc, force, moment
-  s33 Ib[6];
-  float m[6];
+  // Outward pass.  What the inward pass needs of joint k (axis, origin, COM, inertia, force, moment: 21 floats) is
+  // stashed in LDS -- in the chunks that will hold this env's arm limit rows and parked factors afterwards (every lane
+  // of the group writes the same numbers) -- instead of 126 registers staying live between the two passes.
+  auto stash = [&](int k, int c) -> float4& { return sma.p[(REX_LDS_F4_PER_ENV + 6 * k + c) * SMA::kEpw + sma.slot]; };
+  static_assert(6 * 6 <= REX_ARM_PARK_F4 + REX_ARM_NJ * REX_ARM_ROW_F4, "arm stash must fit the arm rows + park chunks");
   {
     m33 Rp{bk.ex, bk.ey, bk.ez};
     f3 op = mk(0.f, 0.f, 0.f), wp = bk.w, alp = mk(0.f, 0.f, 0.f);
@@ -48,6 +51,8 @@ __device__ __forceinline__ unsigned arm_pass(const BaseKin& bk, const float* __r
     f3 aop = mk(0.f, 0.f, kGravity);                  // acceleration of the parent origin (zero gen. acc., gravity as +g)
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
+      f3 a_k, o_k, c_k, w_k, al_k, fo_k, no_k;
+      s33 Ib_k;
       // joint frame in parent coordinates (signed permutation, constants fold), then the turn about +-z
       const float e00 = (float)REXA_E0[k][0], e01 = (float)REXA_E0[k][1], e02 = (float)REXA_E0[k][2];
       const float e10 = (float)REXA_E0[k][3], e11 = (float)REXA_E0[k][4], e12 = (float)REXA_E0[k][5];
@@ -61,43 +66,54 @@ __device__ __forceinline__ unsigned arm_pass(const BaseKin& bk, const float* __r
       R.x = cq * jx + sq * jy;
       R.y = cq * jy - sq * jx;
       R.z = jz;
-      a[k] = (float)REXA_AXIS_SIGN[k] * jz;
+      a_k = (float)REXA_AXIS_SIGN[k] * jz;
       const f3 d = (float)REXA_POS[k][0] * Rp.x + (float)REXA_POS[k][1] * Rp.y + (float)REXA_POS[k][2] * Rp.z;
-      o[k] = op + d;
+      o_k = op + d;
       const f3 e = (float)REXA_COM[k][0] * R.x + (float)REXA_COM[k][1] * R.y + (float)REXA_COM[k][2] * R.z;
-      c[k] = o[k] + e;
+      c_k = o_k + e;
       // kinematics (same recursion as the legs)
       const f3 vo = vop + cross(wp, d);
       const f3 ao = aop + cross(alp, d) + cross(wp, cross(wp, d));
-      w[k] = wp + qd[k] * a[k];
-      al[k] = alp + cross(wp, qd[k] * a[k]);
-      const f3 vc = vo + cross(w[k], e);
-      const f3 ac = ao + cross(al[k], e) + cross(w[k], cross(w[k], e));
-      m[k] = (float)REXA_MASS[k] * ground.leg_mass_scale;
-      Ib[k] = rot_inertia(R.x, R.y, R.z, (float)REXA_INERTIA[k][0], (float)REXA_INERTIA[k][1], (float)REXA_INERTIA[k][2]);
-      const f3 Iw = mul(Ib[k], w[k]);
+      w_k = wp + qd[k] * a_k;
+      al_k = alp + cross(wp, qd[k] * a_k);
+      const f3 vc = vo + cross(w_k, e);
+      const f3 ac = ao + cross(al_k, e) + cross(w_k, cross(w_k, e));
+      const float m_k = (float)REXA_MASS[k] * ground.leg_mass_scale;
+      Ib_k = rot_inertia(R.x, R.y, R.z, (float)REXA_INERTIA[k][0], (float)REXA_INERTIA[k][1], (float)REXA_INERTIA[k][2]);
+      const f3 Iw = mul(Ib_k, w_k);
       const float dl = kLinDamp + kLinDamp * sqrtf(dot(vc, vc));
-      const float da = kAngDamp + kAngDamp * sqrtf(dot(w[k], w[k]));
-      fo[k] = m[k] * ac + (m[k] * dl) * vc;
-      no[k] = mul(Ib[k], al[k]) + cross(w[k], Iw) + da * Iw + cross(c[k], fo[k]);   // moment about the base origin
-      Rp = R; op = o[k]; wp = w[k]; alp = al[k]; vop = vo; aop = ao;
+      const float da = kAngDamp + kAngDamp * sqrtf(dot(w_k, w_k));
+      fo_k = m_k * ac + (m_k * dl) * vc;
+      no_k = mul(Ib_k, al_k) + cross(w_k, Iw) + da * Iw + cross(c_k, fo_k);   // moment about the base origin
+      stash(k, 0) = make_float4(a_k.x, a_k.y, a_k.z, o_k.x);
+      stash(k, 1) = make_float4(o_k.y, o_k.z, c_k.x, c_k.y);
+      stash(k, 2) = make_float4(c_k.z, fo_k.x, fo_k.y, fo_k.z);
+      stash(k, 3) = make_float4(no_k.x, no_k.y, no_k.z, Ib_k.xx);
+      stash(k, 4) = make_float4(Ib_k.yy, Ib_k.zz, Ib_k.xy, Ib_k.xz);
+      stash(k, 5) = make_float4(Ib_k.yz, 0.0f, 0.0f, 0.0f);
+      Rp = R; op = o_k; wp = w_k; alp = al_k; vop = vo; aop = ao;
     }
   }
   // inward: subtree wrenches, joint bias, composite inertias, joint columns
   float C[6];
-  f3 Fl[6], Fa[6], v[6];
+  f3 a[6], Fl[6], Fa[6], v[6];
   {
     f3 F = mk(0.f, 0.f, 0.f), N = F, h = F;
     s33 Io{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float mc = 0.0f;
 #pragma unroll
     for (int k = 5; k >= 0; --k) {
-      F = F + fo[k]; N = N + no[k];
-      C[k] = dot(a[k], N - cross(o[k], F));
-      add(Io, Ib[k]); add_point(Io, m[k], c[k]);
-      h = h + m[k] * c[k];
-      mc += m[k];
-      v[k] = cross(o[k], a[k]);
+      const float4 s0 = stash(k, 0), s1 = stash(k, 1), s2 = stash(k, 2), s3 = stash(k, 3), s4 = stash(k, 4), s5 = stash(k, 5);
+      a[k] = mk(s0.x, s0.y, s0.z);
+      const f3 o_k = mk(s0.w, s1.x, s1.y), c_k = mk(s1.z, s1.w, s2.x);
+      const s33 Ib_k{s3.w, s4.x, s4.y, s4.z, s4.w, s5.x};
+      const float m_k = (float)REXA_MASS[k] * ground.leg_mass_scale;
+      F = F + mk(s2.y, s2.z, s2.w); N = N + mk(s3.x, s3.y, s3.z);
+      C[k] = dot(a[k], N - cross(o_k, F));
+      add(Io, Ib_k); add_point(Io, m_k, c_k);
+      h = h + m_k * c_k;
+      mc += m_k;
+      v[k] = cross(o_k, a[k]);
       Fl[k] = mc * v[k] + cross(a[k], h);
       Fa[k] = mul(Io, a[k]) + cross(h, v[k]);
     }

@@ -1,4 +1,6 @@
-// rex_device.h -- gfx950 device code of the batched Rex simulator: one environment per lane.
+// rex_device.h -- gfx950 device code of the batched Rex simulator: one physics substep of one environment, carried
+// by one lane (64 envs per wave) or by a group of 4 / 8 adjacent lanes that split the legs, the constraint rows and
+// the velocity components between them (<= 16 envs per wave; "lanes-per-env helpers" and pgs_dv below).
 //
 // Physics formulation (differs on purpose from the CPU oracle's body-coordinate ABA; the two must
 // agree to rounding -- tests/test_gpu_parity.py):
