@@ -8,10 +8,12 @@
 #include "rex_arm_model_gen.h"
 #include "rex_device.h"
 
+/* the arm kernels run 4..16 envs per wave with the leg factors in registers: its chunks start behind 112 row + z chunks */
+#define REX_ARM_BASE_F4 REX_ROWS_F4_OF(1)
 #define REX_ARM_NJ 6
 #define REX_ARM_PARK_F4 16   /* Bw 36 + G 21 + z 6 = 63 floats */
 #define REX_ARM_ROW_F4 4     /* g' 6 + j' 6 + (invd*target, invd, diag, active) */
-#define REX_LDS_F4_PER_ENV_ARM (REX_LDS_F4_PER_ENV + REX_ARM_PARK_F4 + REX_ARM_NJ * REX_ARM_ROW_F4)
+#define REX_LDS_F4_PER_ENV_ARM_OF(EPW) (REX_ARM_BASE_F4 + REX_ARM_PARK_F4 + REX_ARM_NJ * REX_ARM_ROW_F4)
 
 namespace rex {
 
@@ -21,9 +23,9 @@ template <int EPW>
 struct LdsArm {
   static constexpr int kEpw = EPW;
   float4* p; int slot;
-  __device__ __forceinline__ float4& park(int c) const { return p[(REX_LDS_F4_PER_ENV + c) * EPW + slot]; }
+  __device__ __forceinline__ float4& park(int c) const { return p[(REX_ARM_BASE_F4 + c) * EPW + slot]; }
   __device__ __forceinline__ float4& row(int k, int c) const {
-    return p[(REX_LDS_F4_PER_ENV + REX_ARM_PARK_F4 + k * REX_ARM_ROW_F4 + c) * EPW + slot];
+    return p[(REX_ARM_BASE_F4 + REX_ARM_PARK_F4 + k * REX_ARM_ROW_F4 + c) * EPW + slot];
   }
 };
 
@@ -42,7 +44,7 @@ __device__ __forceinline__ unsigned arm_pass(const BaseKin& bk, const float* __r
   // Outward pass.  What the inward pass needs of joint k (axis, origin, COM, inertia, force, moment: 21 floats) is
   // stashed in LDS -- in the chunks that will hold this env's arm limit rows and parked factors afterwards (every lane
   // of the group writes the same numbers) -- instead of 126 registers staying live between the two passes.
-  auto stash = [&](int k, int c) -> float4& { return sma.p[(REX_LDS_F4_PER_ENV + 6 * k + c) * SMA::kEpw + sma.slot]; };
+  auto stash = [&](int k, int c) -> float4& { return sma.p[(REX_ARM_BASE_F4 + 6 * k + c) * SMA::kEpw + sma.slot]; };
   static_assert(6 * 6 <= REX_ARM_PARK_F4 + REX_ARM_NJ * REX_ARM_ROW_F4, "arm stash must fit the arm rows + park chunks");
   {
     m33 Rp{bk.ex, bk.ey, bk.ez};
@@ -319,7 +321,7 @@ struct ArmChain {
   int oya[2], oaa[2];   // byte offsets from the LDS base of this lane's y / arm components in arm row 0
   float as_[2];
   static constexpr int kRowBytes = REX_ARM_ROW_F4 * EPW * 16;
-  __device__ __forceinline__ int foff(int f) const { return ((REX_LDS_F4_PER_ENV + REX_ARM_PARK_F4 + (f >> 2)) * EPW + sma.slot) * 16 + (f & 3) * 4; }
+  __device__ __forceinline__ int foff(int f) const { return ((REX_ARM_BASE_F4 + REX_ARM_PARK_F4 + (f >> 2)) * EPW + sma.slot) * 16 + (f & 3) * 4; }
   __device__ __forceinline__ float ldb(int off) const { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(sma.p) + off); }
   __device__ __forceinline__ float& parkf(int f) const { return reinterpret_cast<float*>(&sma.park(f >> 2))[f & 3]; }
   template <int LPE>

@@ -29,13 +29,20 @@
 #define REX_NLROW (3 * REX_NLEG)      /* joint-limit rows: the near bound of each of the 12 joints */
 #define REX_NROW (REX_NCROW + REX_NLROW)
 #define REX_ROW_F4 3                  /* float4 chunks per row in LDS */
-#define REX_LEG_F4 7                  /* float4 chunks per leg parked in LDS (Bw 18 + G 6 + z 3) */
-#define REX_LDS_F4_PER_ENV (REX_NROW * REX_ROW_F4 + REX_NLEG * REX_LEG_F4)   /* 136 float4 = 2.2 KB per env */
-/* small-batch waves (EPW <= 16) only: chunks 0..13 env state parked while the solver owns the registers, 14..15 the
-   whitened base velocity y on its way to / from the lanes that own its components, 16..21 row couplings A(r, r-1) */
-#define REX_PARK_F4 22
-#define REX_PARK_XY 14
-#define REX_PARK_CPL 16
+#define REX_LEG_F4 7                  /* float4 chunks per leg parked in LDS (Bw 18 + G 6 + z 3) when one lane carries an env */
+/* Leg chunks of one env in LDS.  One lane per env (EPW = 64): a lane parks all four leg factors around the sweep loop
+   (7 chunks per leg).  Lane groups: a lane needs the factor of ITS leg only; it stays in registers (1 chunk per leg: the
+   whitened leg velocity z, which every lane reads) where registers are cheaper than LDS -- 8 lanes per env (200 VGPRs)
+   and mark 'arm' (LDS-bound: 3 -> 4 workgroups per CU at 16 envs per wave) -- and is parked at 16 envs per wave of mark
+   'base', whose 4 lanes per env already run into the AGPRs. */
+#define REX_LEG_F4_OF(EPW, ARM) (((EPW) <= 8 || ((EPW) <= 16 && (ARM))) ? 1 : REX_LEG_F4)
+#define REX_ROWS_F4_OF(LEGF4) (REX_NROW * REX_ROW_F4 + REX_NLEG * (LEGF4))   /* rows + leg chunks: 136 (2.2 KB) or 112 */
+#define REX_LDS_F4_PER_ENV REX_ROWS_F4_OF(REX_LEG_F4)
+/* small-batch waves (EPW <= 16) only: chunks 0..1 the whitened base velocity y on its way to / from the lanes that own
+   its components (pgs_dv), 2..7 the couplings A(r, r-1) of consecutive contact rows */
+#define REX_PARK_F4 8
+#define REX_PARK_XY 0
+#define REX_PARK_CPL 2
 
 namespace rex {
 
@@ -55,18 +62,20 @@ constexpr float kToeHalf = (float)REX_TOE_HALFLEN;
 // LDS view of one workgroup.  EPW = envs per wave (compile-time power of two <= 64): lane l works on env
 // slot l & (EPW-1); lanes beyond EPW mirror a live lane (see rex_step_kernel).  Layout float4[chunk][slot]:
 // lanes of different slots hit consecutive 16 B -> conflict-free ds_read_b128.
-template <int EPW>
+template <int EPW, int LEGF4 = REX_LEG_F4>
 struct Lds {
   static constexpr int kEpw = EPW;
   float4* p; int slot;
-  float4* pk;   // park region (REX_PARK_F4 chunks per env, behind the rows of all marks); null when EPW = 64
+  float4* pk;   // hand-over region of pgs_dv (REX_PARK_F4 chunks per env, behind the rows of all marks); null when EPW = 64
   __device__ __forceinline__ float4& park(int c) const { return pk[c * EPW + slot]; }
   // scalar views for the lanes that own single components (pgs_dv): float f of a chunk sequence starting at chunk c0
   __device__ __forceinline__ float& parkf(int c0, int f) const { return reinterpret_cast<float*>(&pk[(c0 + (f >> 2)) * EPW + slot])[f & 3]; }
-  __device__ __forceinline__ float& legf(int l, int c0, int f) const { return reinterpret_cast<float*>(&leg(l, c0 + (f >> 2)))[f & 3]; }
+  __device__ __forceinline__ float& zf(int l, int f) const { return reinterpret_cast<float*>(&zc(l))[f]; }
   __device__ __forceinline__ float& rowf(int r, int f) const { return reinterpret_cast<float*>(&row(r, f >> 2))[f & 3]; }
   __device__ __forceinline__ float4& row(int r, int c) const { return p[(r * REX_ROW_F4 + c) * EPW + slot]; }
-  __device__ __forceinline__ float4& leg(int l, int c) const { return p[(REX_NROW * REX_ROW_F4 + l * REX_LEG_F4 + c) * EPW + slot]; }
+  static constexpr int kLegF4 = LEGF4;
+  __device__ __forceinline__ float4& leg(int l, int c) const { return p[(REX_NROW * REX_ROW_F4 + l * kLegF4 + c) * EPW + slot]; }
+  __device__ __forceinline__ float4& zc(int l) const { return leg(l, kLegF4 - 1); }   // (z0, z1, z2, 0) of leg l
 };
 
 struct f3 { float x, y, z; };
@@ -199,7 +208,7 @@ __device__ __forceinline__ void leg_park(const SM& sm, int leg, const LegFactor&
   sm.leg(leg, 3) = make_float4(L.Bw[2][0], L.Bw[2][1], L.Bw[2][2], L.Bw[2][3]);
   sm.leg(leg, 4) = make_float4(L.Bw[2][4], L.Bw[2][5], L.gi1, L.gi2);
   sm.leg(leg, 5) = make_float4(L.gi3, L.g21, L.g31, L.g32);
-  sm.leg(leg, 6) = make_float4(L.z[0], L.z[1], L.z[2], 0.0f);
+  sm.zc(leg) = make_float4(L.z[0], L.z[1], L.z[2], 0.0f);
 }
 template <class SM>
 __device__ __forceinline__ void leg_unpark(const SM& sm, int leg, LegFactor& L) {
@@ -690,7 +699,8 @@ __device__ __forceinline__ constexpr int crow_leg(int r) { return r < REX_NPOINT
 template <int NY, int EPW>
 struct DvLane {
   int oy[NY], oz;   // byte offsets (from the LDS base) of this lane's components in row 0
-  __device__ __forceinline__ static float ld(const Lds<EPW>& sm, int off) {
+  template <class SM>
+  __device__ __forceinline__ static float ld(const SM& sm, int off) {
     return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(sm.p) + off);
   }
 };
@@ -717,7 +727,7 @@ __device__ __forceinline__ void pgs_dv(const SM& sm, ARMP& armp, PgsX& x, int p,
     const int f = p < 3 ? 6 + p : 11;
     ln.oz = ((f >> 2) * EPW + sm.slot) * 16 + (f & 3) * 4;
 #pragma unroll
-    for (int l = 0; l < REX_NLEG; ++l) zs[l] = sm.legf(l, 6, p < 3 ? p : 3);
+    for (int l = 0; l < REX_NLEG; ++l) zs[l] = sm.zf(l, p < 3 ? p : 3);
   }
   armp.template dv_begin<LPE>(p);
   float cpl[REX_NCROW];
@@ -813,14 +823,14 @@ __device__ __forceinline__ void pgs_dv(const SM& sm, ARMP& armp, PgsX& x, int p,
 #pragma unroll
   for (int i = 0; i < NY; ++i) { const int k = p + i * LPE; sm.parkf(REX_PARK_XY, k < 6 ? k : 7) = ys[i]; }
 #pragma unroll
-  for (int l = 0; l < REX_NLEG; ++l) sm.legf(l, 6, p < 3 ? p : 3) = zs[l];
+  for (int l = 0; l < REX_NLEG; ++l) sm.zf(l, p < 3 ? p : 3) = zs[l];
   armp.template dv_end<LPE>(p);
   mirror_sync();
   {
     const float4 a = sm.park(REX_PARK_XY), b = sm.park(REX_PARK_XY + 1);
     x.y01 = v2{a.x, a.y}; x.y23 = v2{a.z, a.w}; x.y45 = v2{b.x, b.y};
 #pragma unroll
-    for (int l = 0; l < REX_NLEG; ++l) { const float4 z = sm.leg(l, 6); x.z01[l] = v2{z.x, z.y}; x.z2[l] = z.z; }
+    for (int l = 0; l < REX_NLEG; ++l) { const float4 z = sm.zc(l); x.z01[l] = v2{z.x, z.y}; x.z2[l] = z.z; }
   }
   armp.dv_gather();
 }
@@ -884,6 +894,7 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
   constexpr int LPE = lanes_per_env(EPW);
   const int pl = kSplitLegs ? (int)(threadIdx.x & (unsigned)(LPE - 1)) : 0;   // lane of the group
   const int mleg = LPE == 8 ? pl >> 1 : pl;                                   // the leg this lane factorises
+  LegFactor Lown;   // lane group: the factor of this lane's leg (in registers or parked: REX_LEG_F4_OF)
   if constexpr (kSplitLegs) {
     const float ql[3] = {pick_leg(s.q, mleg, 0), pick_leg(s.q, mleg, 1), pick_leg(s.q, mleg, 2)};
     const float qdl[3] = {pick_leg(s.qd, mleg, 0), pick_leg(s.qd, mleg, 1), pick_leg(s.qd, mleg, 2)};
@@ -896,9 +907,9 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
     for (int k = 0; k < 21; ++k) part.S[k] = 0.0f;
 #pragma unroll
     for (int k = 0; k < 6; ++k) part.bz[k] = 0.0f;
-    LegFactor L;
-    leg_pass(mleg, bk, ql, qdl, tl, dt, L, part, sm, active, ground, LPE == 8 ? (pl & 1) : -1);
-    leg_park(sm, mleg, L);
+    leg_pass(mleg, bk, ql, qdl, tl, dt, Lown, part, sm, active, ground, LPE == 8 ? (pl & 1) : -1);
+    if constexpr (SM::kLegF4 == 1) sm.zc(mleg) = make_float4(Lown.z[0], Lown.z[1], Lown.z[2], 0.0f);
+    else leg_park(sm, mleg, Lown);
     active = leg_or<LPE>(active);
     acc.Io.xx += leg_sum<LPE>(part.Io.xx); acc.Io.yy += leg_sum<LPE>(part.Io.yy); acc.Io.zz += leg_sum<LPE>(part.Io.zz);
     acc.Io.xy += leg_sum<LPE>(part.Io.xy); acc.Io.xz += leg_sum<LPE>(part.Io.xz); acc.Io.yz += leg_sum<LPE>(part.Io.yz);
@@ -924,7 +935,7 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
   }
 #pragma unroll
   for (int k = 0; k < REX_NLEG; ++k) {
-    const float4 zc = sm.leg(k, 6);
+    const float4 zc = sm.zc(k);
     x.z01[k] = v2{zc.x, zc.y}; x.z2[k] = zc.z;
   }
   REX_STAMP(t_legs);
@@ -1050,23 +1061,23 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
 #pragma unroll
   for (int k = 0; k < REX_NLEG; ++k) { zt[3 * k] = x.z01[k].x; zt[3 * k + 1] = x.z01[k].y; zt[3 * k + 2] = x.z2[k]; }
   if constexpr (kSplitLegs) {
-    LegFactor L;
-    leg_unpark(sm, mleg, L);
+    if constexpr (SM::kLegF4 != 1) leg_unpark(sm, mleg, Lown);
+    const LegFactor& L = Lown;
     float t1 = pick_leg(zt, mleg, 0), t2 = pick_leg(zt, mleg, 1), t3 = pick_leg(zt, mleg, 2);
 #pragma unroll
     for (int k = 0; k < 6; ++k) { t1 -= L.Bw[0][k] * nu[k]; t2 -= L.Bw[1][k] * nu[k]; t3 -= L.Bw[2][k] * nu[k]; }
     const float u3 = t3 * L.gi3;
     const float u2 = (t2 - L.g32 * u3) * L.gi2;
     const float u1 = (t1 - L.g21 * u2 - L.g31 * u3) * L.gi1;
-    sm.leg(mleg, 6) = make_float4(clampf(u1, -kMaxCoordVel, kMaxCoordVel), clampf(u2, -kMaxCoordVel, kMaxCoordVel),
+    sm.zc(mleg) = make_float4(clampf(u1, -kMaxCoordVel, kMaxCoordVel), clampf(u2, -kMaxCoordVel, kMaxCoordVel),
                                   clampf(u3, -kMaxCoordVel, kMaxCoordVel), 0.0f);
     mirror_sync();
 #pragma unroll
     for (int k = 0; k < REX_NLEG; ++k) {
-      const float4 u = sm.leg(k, 6);
+      const float4 u = sm.zc(k);
       s.qd[3 * k] = u.x; s.qd[3 * k + 1] = u.y; s.qd[3 * k + 2] = u.z;
     }
-    mirror_sync();   // the next substep's leg_park overwrites these chunks
+    mirror_sync();   // the next substep's leg pass overwrites these chunks
   } else {
 #pragma unroll 1
     for (int leg = 0; leg < REX_NLEG; ++leg) {

@@ -218,7 +218,7 @@ __device__ __forceinline__ Ground env_ground(const DevCfg& c, int i, int gidx, i
 // Rex.ApplyAction + stepSimulation + ReceiveObservation (rex.py:158-163, 568-641).  The latency model (c.hist) is
 // only offered for mark 'base' (43-word history records); rex_create rejects it for mark 'arm'.
 template <class SM, class ARMP>
-__device__ __forceinline__ void rex_substep(const DevCfg& c, EnvState& e, int i, bool live, float* cmd, float* tau_obs,
+__device__ __forceinline__ void rex_substep(const DevCfg& c, EnvState& e, int i, bool live, const float* cmd, float* tau_obs,
                                             const SM& sm, const Ground& ground, ARMP& armp) {
   constexpr int NM = ARMP::NM;
   float tau[18];
@@ -244,46 +244,7 @@ __device__ __forceinline__ void rex_substep(const DevCfg& c, EnvState& e, int i,
     tau_obs[j] = obs;
     tau[j] = ((e.motor_en >> j) & 1u) ? act : 0.0f;                             // rex.py:617-623
   }
-  // Small-batch waves: what the physics does not touch (motor command, observed torques, overheat counters, the
-  // controller's words) waits in LDS while the factorisation and the solver own the registers; reading it back makes
-  // the old registers dead across the call, so the allocator has nothing of it to spill.
-  constexpr bool kPark = SM::kEpw <= 16;
-  if constexpr (kPark) {
-    float w[4 * REX_PARK_XY];
-#pragma unroll
-    for (int k = 0; k < 4 * REX_PARK_XY; ++k) w[k] = 0.0f;
-#pragma unroll
-    for (int j = 0; j < NM; ++j) { w[j] = cmd[j]; w[NM + j] = tau_obs[j]; }
-#pragma unroll
-    for (int j = 0; j < NM / 2; ++j) w[2 * NM + j] = __uint_as_float(e.overheat[2 * j] | (e.overheat[2 * j + 1] << 16));
-    float* t = w + 2 * NM + NM / 2;
-    t[0] = e.gait.phi; t[1] = e.gait.last_time; t[2] = e.gait.alpha; t[3] = e.target; t[4] = e.end_time; t[5] = e.aux;
-    t[6] = __uint_as_float(e.flags); t[7] = __uint_as_float((uint32_t)e.steps); t[8] = __uint_as_float((uint32_t)e.episode);
-    t[9] = __uint_as_float(e.motor_en); t[10] = __uint_as_float(e.hist);
-    static_assert(2 * 18 + 9 + 11 <= 4 * REX_PARK_XY, "park region too small");
-#pragma unroll
-    for (int k = 0; k < REX_PARK_XY; ++k) sm.park(k) = make_float4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
-  }
   physics_substep(e.ph, tau, c.dt, c.iterations, c.res_thr, sm, ground, armp);
-  if constexpr (kPark) {
-    float w[4 * REX_PARK_XY];
-#pragma unroll
-    for (int k = 0; k < REX_PARK_XY; ++k) {
-      const float4 v = sm.park(k);
-      w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
-    }
-#pragma unroll
-    for (int j = 0; j < NM; ++j) { cmd[j] = w[j]; tau_obs[j] = w[NM + j]; }
-#pragma unroll
-    for (int j = 0; j < NM / 2; ++j) {
-      const uint32_t u = __float_as_uint(w[2 * NM + j]);
-      e.overheat[2 * j] = u & 0xFFFFu; e.overheat[2 * j + 1] = u >> 16;
-    }
-    const float* t = w + 2 * NM + NM / 2;
-    e.gait.phi = t[0]; e.gait.last_time = t[1]; e.gait.alpha = t[2]; e.target = t[3]; e.end_time = t[4]; e.aux = t[5];
-    e.flags = __float_as_uint(t[6]); e.steps = (int32_t)__float_as_uint(t[7]); e.episode = (int32_t)__float_as_uint(t[8]);
-    e.motor_en = __float_as_uint(t[9]); e.hist = __float_as_uint(t[10]);
-  }
   if (c.hist) {                                                                  // ReceiveObservation, rex.py:726-733
     const int head = ((int)(e.hist & 0xFFu) + 1) % REX_HISTORY_LEN;
     const int len = min((int)((e.hist >> 8) & 0xFFu) + 1, REX_HISTORY_LEN);
@@ -575,7 +536,8 @@ __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __r
   // upper 32 lanes repeat the lower 32): the lanes of a group run the same arithmetic on the same state, split the
   // per-leg and per-row work of a substep between them (rex_device.h) and only lane 0 of the group stores.
   constexpr int NM = ARM ? 18 : 12;   // mark='arm': 6 more motors held at ARM_POSES['rest'] (rex_gym_env.py:347-353)
-  constexpr int kRowsF4 = ARM ? REX_LDS_F4_PER_ENV_ARM : REX_LDS_F4_PER_ENV;
+  constexpr int kLegF4 = REX_LEG_F4_OF(EPW, ARM);
+  constexpr int kRowsF4 = ARM ? REX_LDS_F4_PER_ENV_ARM_OF(EPW) : REX_ROWS_F4_OF(kLegF4);
   __shared__ float4 lds[(kRowsF4 + (EPW <= 16 ? REX_PARK_F4 : 0)) * EPW];
   const int lane = threadIdx.x;
   constexpr int LPE = EPW < 64 ? lanes_per_env(EPW) : 1;     // EPW <= 16: lane = LPE * slot + p (rex_device.h, group layout)
@@ -583,7 +545,7 @@ __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __r
   const int gi = blockIdx.x * EPW + slot;
   const bool live = lane < LPE * EPW && (lane & (LPE - 1)) == 0 && gi < c.n;
   const int i = gi < c.n ? gi : c.n - 1;   // tail slots shadow the last env (keeps the wave convergent)
-  const Lds<EPW> sm{lds, slot, EPW <= 16 ? lds + kRowsF4 * EPW : nullptr};
+  const Lds<EPW, kLegF4> sm{lds, slot, EPW <= 16 ? lds + kRowsF4 * EPW : nullptr};
   typename ArmHook<EPW, ARM>::type armp = ArmHook<EPW, ARM>::make(lds, slot);
 
   EnvState e;
@@ -698,11 +660,12 @@ template <bool ARM>
 __global__ __launch_bounds__(REX_WAVE) void rex_settle_kernel(DevCfg c, float* __restrict__ snap) {
   constexpr int NM = ARM ? 18 : 12;
   constexpr int EPW = ARM ? 16 : REX_WAVE;   // the arm rows do not fit 64 envs per workgroup in LDS
-  constexpr int kRowsF4 = ARM ? REX_LDS_F4_PER_ENV_ARM : REX_LDS_F4_PER_ENV;
+  constexpr int kLegF4 = REX_LEG_F4_OF(EPW, ARM);
+  constexpr int kRowsF4 = ARM ? REX_LDS_F4_PER_ENV_ARM_OF(EPW) : REX_ROWS_F4_OF(kLegF4);
   __shared__ float4 lds[(kRowsF4 + (EPW <= 16 ? REX_PARK_F4 : 0)) * EPW];
   constexpr int LPE = EPW < 64 ? lanes_per_env(EPW) : 1;
   const int lane = (int)(threadIdx.x / LPE) & (EPW - 1);
-  const Lds<EPW> sm{lds, lane, EPW <= 16 ? lds + kRowsF4 * EPW : nullptr};
+  const Lds<EPW, kLegF4> sm{lds, lane, EPW <= 16 ? lds + kRowsF4 * EPW : nullptr};
   typename ArmHook<EPW, ARM>::type armp = ArmHook<EPW, ARM>::make(lds, lane);
   const int nrec = c.n_terrain > 0 ? c.n_terrain : 1;
   const int rec = (threadIdx.x & (LPE - 1)) == 0 ? blockIdx.x * EPW + lane : nrec;
