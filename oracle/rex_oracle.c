@@ -642,19 +642,20 @@ static void impulse_response_at(const Aba* A, int kbody, const real fk[6], real 
  * Cell triangulation: Bullet's default (diagonal from vertex (i,j+1) to (i+1,j)). ---- */
 #define HF_N 256
 #define HF_CELL ((real)0.05)
+#define HF_INV_CELL ((real)20.0)    /* 1 / HF_CELL: written as a product on both sides (oracle and kernels) */
 typedef struct { const float* h; real mid; real base_mass_scale, leg_mass_scale, mu; int has_params; } Ground;
 
 static void ground_query(const Ground* g, real x, real y, real* height, real n[3]) {
   n[0] = 0; n[1] = 0; n[2] = 1; *height = 0;
   if (!g || !g->h) return;
-  real fx = x / HF_CELL + (real)127.5, fy = y / HF_CELL + (real)127.5;
+  real fx = x * HF_INV_CELL + (real)127.5, fy = y * HF_INV_CELL + (real)127.5;
   fx = clampr(fx, 0, (real)254.999); fy = clampr(fy, 0, (real)254.999);
   int i = (int)fx, j = (int)fy;
   real u = fx - i, v = fy - j;
   real h00 = g->h[j * HF_N + i], h10 = g->h[j * HF_N + i + 1], h01 = g->h[(j + 1) * HF_N + i], h11 = g->h[(j + 1) * HF_N + i + 1];
   real hh, gx, gy;
-  if (u + v <= 1) { hh = h00 + u * (h10 - h00) + v * (h01 - h00); gx = (h10 - h00) / HF_CELL; gy = (h01 - h00) / HF_CELL; }
-  else { hh = h11 + (1 - u) * (h01 - h11) + (1 - v) * (h10 - h11); gx = (h11 - h01) / HF_CELL; gy = (h11 - h10) / HF_CELL; }
+  if (u + v <= 1) { hh = h00 + u * (h10 - h00) + v * (h01 - h00); gx = (h10 - h00) * HF_INV_CELL; gy = (h01 - h00) * HF_INV_CELL; }
+  else { hh = h11 + (1 - u) * (h01 - h11) + (1 - v) * (h10 - h11); gx = (h11 - h01) * HF_INV_CELL; gy = (h11 - h10) * HF_INV_CELL; }
   hh -= g->mid;
   if (hh <= 0) return;                      /* the plane is on top here */
   real inv = 1 / sqrt(gx * gx + gy * gy + 1);

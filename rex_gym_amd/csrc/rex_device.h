@@ -163,15 +163,16 @@ struct Ground {
   // inertia tensors computed at load time; plus the foot friction coefficient)
   float base_mass_scale, leg_mass_scale, mu;
 };
+// (cell size 0.05 m: every division by it is a multiplication by 20, here and in the oracle)
 __device__ __forceinline__ void ground_query(const Ground& g, float x, float y, float& height, f3& n) {
   n = f3{0.f, 0.f, 1.f}; height = 0.0f;
-  float fx = fminf(fmaxf(x / 0.05f + 127.5f, 0.0f), 254.999f), fy = fminf(fmaxf(y / 0.05f + 127.5f, 0.0f), 254.999f);
+  float fx = fminf(fmaxf(x * 20.0f + 127.5f, 0.0f), 254.999f), fy = fminf(fmaxf(y * 20.0f + 127.5f, 0.0f), 254.999f);
   const int i = (int)fx, j = (int)fy;
   const float u = fx - (float)i, v = fy - (float)j;
   const float h00 = g.h[j * 256 + i], h10 = g.h[j * 256 + i + 1], h01 = g.h[(j + 1) * 256 + i], h11 = g.h[(j + 1) * 256 + i + 1];
   float hh, gx, gy;
-  if (u + v <= 1.0f) { hh = h00 + u * (h10 - h00) + v * (h01 - h00); gx = (h10 - h00) / 0.05f; gy = (h01 - h00) / 0.05f; }
-  else { hh = h11 + (1.0f - u) * (h01 - h11) + (1.0f - v) * (h10 - h11); gx = (h11 - h01) / 0.05f; gy = (h11 - h10) / 0.05f; }
+  if (u + v <= 1.0f) { hh = h00 + u * (h10 - h00) + v * (h01 - h00); gx = (h10 - h00) * 20.0f; gy = (h01 - h00) * 20.0f; }
+  else { hh = h11 + (1.0f - u) * (h01 - h11) + (1.0f - v) * (h10 - h11); gx = (h11 - h01) * 20.0f; gy = (h11 - h10) * 20.0f; }
   hh -= g.mid;
   if (hh > 0.0f) {
     const float inv = rsqrtf(gx * gx + gy * gy + 1.0f);

@@ -469,17 +469,20 @@ def test_reset_indices_and_sharding_invariance(torch):
         e.close()
 
 
-@pytest.mark.parametrize("n", [1, 3, 63, 65, 1000, 4097])
+@pytest.mark.parametrize("n", [1, 3, 63, 65, 1000, 4097, 8195])   # 4 / 8 / 16 envs per wave, each with a ragged last wave
 def test_ragged_batch_sizes(torch, n):
-    """Batch sizes that are not multiples of the wave / envs-per-wave: tail lanes must not corrupt neighbours."""
+    """Batch sizes that are not multiples of the wave / envs-per-wave: tail lanes must not corrupt neighbours.  The
+    reference batch is larger and runs the same lanes-per-env mode (4 and 8 envs per wave are both 8 lanes per env and
+    bit-identical; above 8 192 envs both batches run 16 envs per wave)."""
     from rex_gym_amd import RexBatchEnv
+    nref = 4100 if n <= 4100 else n + 5
     env = RexBatchEnv(n, seed=2, auto_reset=True, max_episode_steps=7)
-    ref = RexBatchEnv(4100, seed=2, auto_reset=True, max_episode_steps=7)
+    ref = RexBatchEnv(nref, seed=2, auto_reset=True, max_episode_steps=7)
     o, o_ref = env.reset(), ref.reset()
     assert o.shape == (n, 4) and torch.equal(o, o_ref[:n])
     g = torch.Generator(device="cuda"); g.manual_seed(1)
     for k in range(9):
-        a = torch.rand((4100, 2), device="cuda", generator=g) * 0.8 - 0.4
+        a = torch.rand((nref, 2), device="cuda", generator=g) * 0.8 - 0.4
         on, rn, dn, _ = env.step(a[:n].contiguous())
         orf, rr, dr, _ = ref.step(a)
         assert torch.equal(on, orf[:n]) and torch.equal(rn, rr[:n]) and torch.equal(dn, dr[:n])
