@@ -740,15 +740,18 @@ __device__ __forceinline__ void pgs_dv(const SM& sm, ARMP& armp, PgsX& x, int p,
   float lam[REX_NROW];
 #pragma unroll
   for (int r = 0; r < REX_NROW; ++r) lam[r] = 0.0f;
-  // this lane's slice of the 24 contact rows, read once per substep: its components of J~, invd target, invd
-  float Jy[REX_NCROW][NY], Jz[REX_NCROW], Kc[REX_NCROW], Ki[REX_NCROW];
+  // this lane's slice of the 24 contact rows, read once per substep: its components of J~, invd, and -target in lane 0
+  // of the group (0 elsewhere): the addend of the lane's first product, so that the group sum is vel - target and the
+  // impulse step is one fma, nl = lam - invd (vel - target)
+  float Jy[REX_NCROW][NY], Jz[REX_NCROW], Kt[REX_NCROW], Ki[REX_NCROW];
 #pragma unroll
   for (int r = 0; r < REX_NCROW; ++r) {
 #pragma unroll
     for (int i = 0; i < NY; ++i) Jy[r][i] = ln.ld(sm, r * kRow + ln.oy[i]);
     Jz[r] = ln.ld(sm, r * kRow + ln.oz);
-    Kc[r] = sm.rowf(r, 9);
     Ki[r] = sm.rowf(r, 10);
+    // chunk 2 .y holds invd * target; rows out of reach have invd = 0 and never move, whatever their target
+    Kt[r] = (p == 0 && Ki[r] > 0.0f) ? -sm.rowf(r, 9) * __builtin_amdgcn_rcpf(Ki[r]) : 0.0f;
   }
 
   bool running = true;
@@ -786,7 +789,7 @@ __device__ __forceinline__ void pgs_dv(const SM& sm, ARMP& armp, PgsX& x, int p,
         // contact rows, pipelined; this lane's slice of the rows sits in registers (Jy, Jz, Kc, Ki)
         float S, dlp = 0.0f;
         {
-          float part = Jz[0] * zs[0];
+          float part = fmaf(Jz[0], zs[0], Kt[0]);
 #pragma unroll
           for (int i = 0; i < NY; ++i) part = fmaf(Jy[0][i], ys[i], part);
           S = group_sum<LPE>(part);
@@ -795,7 +798,7 @@ __device__ __forceinline__ void pgs_dv(const SM& sm, ARMP& armp, PgsX& x, int p,
         for (int r = 0; r < REX_NCROW; ++r) {
           const int L = crow_leg(r);
           const float sum = fmaf(cpl[r], dlp, S);
-          float nl = fmaf(-Ki[r], sum, lam[r] + Kc[r]);
+          float nl = fmaf(-Ki[r], sum, lam[r]);
           if (r < REX_NPOINT) nl = fmaxf(nl, 0.0f);
           else {
             const float lm = mu * lam[(r - REX_NPOINT) / 2];
@@ -803,7 +806,7 @@ __device__ __forceinline__ void pgs_dv(const SM& sm, ARMP& armp, PgsX& x, int p,
           }
           const float dl = nl - lam[r];
           if (r + 1 < REX_NCROW) {   // group sum of the next row over x as it stands before this row's step
-            float part = Jz[r + 1] * zs[crow_leg(r + 1)];
+            float part = fmaf(Jz[r + 1], zs[crow_leg(r + 1)], Kt[r + 1]);
 #pragma unroll
             for (int i = 0; i < NY; ++i) part = fmaf(Jy[r + 1][i], ys[i], part);
             S = group_sum<LPE>(part);

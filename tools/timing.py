@@ -1,5 +1,6 @@
+"""Steady-state and first-steps ms/step of walk-IK (and mark arm with an argument) at a few batch sizes: the quick
+check used between kernel changes.  Needs a GPU: python tools/timing.py [arm]"""
 import sys, time; sys.path.insert(0,'.')
-"""Steady-state and first-steps ms/step of walk-IK (and mark arm with an argument) at a few batch sizes: the quick check used\nbetween kernel changes.  Needs a GPU: python tools/timing.py [arm]"""
 import torch
 from rex_gym_amd import RexBatchEnv
 def run(n, steps=300, warm=300, **kw):
