@@ -668,8 +668,9 @@ __global__ __launch_bounds__(REX_WAVE) void rex_settle_kernel(DevCfg c, float* _
   const Lds<EPW, kLegF4> sm{lds, lane, EPW <= 16 ? lds + kRowsF4 * EPW : nullptr};
   typename ArmHook<EPW, ARM>::type armp = ArmHook<EPW, ARM>::make(lds, lane);
   const int nrec = c.n_terrain > 0 ? c.n_terrain : 1;
-  const int rec = (threadIdx.x & (LPE - 1)) == 0 ? blockIdx.x * EPW + lane : nrec;
-  const int t = blockIdx.x * EPW + lane < nrec ? blockIdx.x * EPW + lane : nrec - 1;
+  const int first = (int)blockIdx.x * EPW + lane;                       // the terrain record this lane group settles on
+  const int rec = (threadIdx.x & (LPE - 1)) == 0 ? first : nrec;        // one lane of the group stores it
+  const int t = first < nrec ? first : nrec - 1;
   Ground ground{nullptr, 0.0f, 1.0f, 1.0f, kMu};
   if (c.n_terrain > 0) { ground.h = c.terrain + (size_t)t * 65536; ground.mid = c.terrain_mid[t]; }
   EnvState e;
