@@ -1,0 +1,365 @@
+"""KL-penalty PPO of the reference (rex_gym/agents/ppo/algorithm.py, a TF1 graph) restated in PyTorch on the device.
+
+The reference learner pulls numpy arrays out of N environment processes every step; here observations, rewards and
+done flags are the device tensors RexBatchEnv returns, the episode buffers live in HBM and nothing crosses PCIe.
+
+What is restated, piece by piece:
+  StreamingNormalize     agents/ppo/normalize.py:18-153   (Welford mean / variance, centre, scale, clip)
+  discounted_return ...  agents/ppo/utility.py:71-143     (Monte-Carlo return, TD-lambda return, diagonal normals)
+  ForwardGaussianPolicy  agents/scripts/networks.py:69-112, scripts/utility.py:100-117 (initialisers)
+  PPOAgent               agents/ppo/algorithm.py:26-531   (episode buffers, memory of `update_every` episodes, policy /
+                                                           value updates, KL penalty adaptation)
+  train                  agents/tools/simulate.py:15-131  (reset done envs, act, step, hand transitions to the agent)
+Defaults are agents/scripts/configs.py:24-52.  Multi-GPU: each rank trains on its own shard's episodes and the
+gradients are averaged (torch.distributed all-reduce = RCCL over xGMI), see PPOAgent(sync_gradients=True).
+"""
+import math
+from dataclasses import dataclass
+
+import torch
+
+
+@dataclass
+class PPOConfig:
+    """agents/scripts/configs.py:24-52 (default()) + the per-task max_length."""
+    policy_layers: tuple = (200, 100)
+    value_layers: tuple = (200, 100)
+    init_mean_factor: float = 0.05
+    init_logstd: float = -1.0
+    update_every: int = 25
+    update_epochs_policy: int = 50
+    update_epochs_value: int = 50
+    policy_lr: float = 1e-4
+    value_lr: float = 3e-4
+    discount: float = 0.985
+    gae_lambda: float = None
+    kl_target: float = 1e-2
+    kl_cutoff_factor: float = 2.0
+    kl_cutoff_coef: float = 1000.0
+    kl_init_penalty: float = 1.0
+    max_length: int = 2000
+
+
+class StreamingNormalize:
+    """normalize.py:18-153.  Running mean / variance over everything seen by update(); transform() centres, scales by
+    std + 1e-8 (std = sqrt(var_sum / (count - 1) + 1e-4), 1 until two samples were seen) and clips."""
+
+    def __init__(self, shape, center=True, scale=True, clip=10.0, device="cpu"):
+        self.center, self.scale, self.clip = center, scale, clip
+        self.count = 0
+        self.mean = torch.zeros(shape, device=device)
+        self.var_sum = torch.zeros(shape, device=device)
+
+    def std(self):
+        return torch.sqrt(self.var_sum / (self.count - 1) + 1e-4)
+
+    def transform(self, value):
+        if self.center:
+            value = value - self.mean
+        if self.scale:
+            value = value / (self.std() + 1e-8 if self.count > 1 else torch.ones_like(self.var_sum))
+        if self.clip:
+            value = value.clamp(-self.clip, self.clip)
+        return value
+
+    def update(self, value):
+        """value: a batch [B, *shape] (normalize.py:70-95: a batch update of Welford's recurrence)."""
+        first = self.count == 0
+        self.count += value.shape[0]
+        mean_delta = (value - self.mean).sum(0)
+        new_mean = self.mean + mean_delta / self.count
+        if self.count <= 1:
+            new_mean = value[0].clone()
+        self.var_sum = self.var_sum + ((value - self.mean) * (value - new_mean)).sum(0)
+        self.mean = new_mean
+        return first
+
+
+# ---- utility.py:71-143 on [B, T] sequences with a length per row -------------------------------------------------
+def _mask(length, steps, dtype=torch.float32):
+    return (torch.arange(steps, device=length.device)[None, :] < length[:, None]).to(dtype)
+
+
+def discounted_return(reward, length, discount):
+    """utility.py:71-81: Monte-Carlo return of every step, zero beyond the episode's length."""
+    r = reward * _mask(length, reward.shape[1], reward.dtype)
+    out = torch.zeros_like(r)
+    agg = torch.zeros_like(r[:, 0])
+    for t in range(r.shape[1] - 1, -1, -1):
+        agg = r[:, t] + discount * agg
+        out[:, t] = agg
+    return out
+
+
+def lambda_return(reward, value, length, discount, lambda_):
+    """utility.py:97-110 (TD-lambda return; used as the advantage when gae_lambda is set, algorithm.py:336-338)."""
+    mask = _mask(length, reward.shape[1], reward.dtype)
+    seq = mask * reward + discount * value * (1 - lambda_)
+    disc = mask * discount * lambda_
+    out = torch.zeros_like(seq)
+    agg = torch.zeros_like(seq[:, 0])
+    for t in range(seq.shape[1] - 1, -1, -1):
+        agg = seq[:, t] + disc[:, t] * agg
+        out[:, t] = agg
+    return out
+
+
+def diag_normal_kl(mean0, logstd0, mean1, logstd1):
+    """utility.py:127-132."""
+    l0, l1 = 2 * logstd0, 2 * logstd1
+    return 0.5 * (torch.exp(l0 - l1).sum(-1) + ((mean1 - mean0) ** 2 / torch.exp(l1)).sum(-1) + l1.sum(-1) - l0.sum(-1)
+                  - mean0.shape[-1])
+
+
+def diag_normal_logpdf(mean, logstd, loc):
+    """utility.py:135-139, as written there: the constant is -0.5 (log 2 pi + logstd), not -0.5 log 2 pi - logstd, so
+    this is the log density plus 0.5 sum(logstd).  Kept: the importance ratio of the reference's PPO is built on it."""
+    return (-0.5 * (math.log(2 * math.pi) + logstd) - 0.5 * ((loc - mean) / torch.exp(logstd)) ** 2).sum(-1)
+
+
+def diag_normal_entropy(mean, logstd):
+    """utility.py:142-145."""
+    return (mean.shape[-1] * math.log(2 * math.pi * math.e) + (2 * logstd).sum(-1)) / 2
+
+
+class ForwardGaussianPolicy(torch.nn.Module):
+    """networks.py:69-112: separate ReLU MLPs for the policy mean (tanh output) and the value; the log standard
+    deviation is a free parameter vector.  Initialisers: xavier-uniform weights / zero biases (tf.contrib.layers
+    .fully_connected defaults), mean layer variance_scaling(factor=init_mean_factor) = truncated normal with std
+    sqrt(1.3 factor / fan_in), logstd = init_logstd (scripts/utility.py:108-111)."""
+
+    def __init__(self, obs_dim, action_dim, cfg):
+        super().__init__()
+        def mlp(sizes):
+            layers, last = [], obs_dim
+            for s in sizes:
+                lin = torch.nn.Linear(last, s)
+                torch.nn.init.xavier_uniform_(lin.weight)
+                torch.nn.init.zeros_(lin.bias)
+                layers += [lin, torch.nn.ReLU()]
+                last = s
+            return torch.nn.Sequential(*layers), last
+        self.policy, last = mlp(cfg.policy_layers)
+        self.mean = torch.nn.Linear(last, action_dim)
+        std = math.sqrt(1.3 * cfg.init_mean_factor / last)
+        torch.nn.init.trunc_normal_(self.mean.weight, std=std, a=-2 * std, b=2 * std)
+        torch.nn.init.zeros_(self.mean.bias)
+        self.logstd = torch.nn.Parameter(torch.full((action_dim,), float(cfg.init_logstd)))
+        self.value, last = mlp(cfg.value_layers)
+        self.value_out = torch.nn.Linear(last, 1)
+        torch.nn.init.xavier_uniform_(self.value_out.weight)
+        torch.nn.init.zeros_(self.value_out.bias)
+
+    def policy_parameters(self):
+        return list(self.policy.parameters()) + list(self.mean.parameters()) + [self.logstd]
+
+    def value_parameters(self):
+        return list(self.value.parameters()) + list(self.value_out.parameters())
+
+    def forward(self, observ):
+        mean = torch.tanh(self.mean(self.policy(observ)))
+        logstd = self.logstd.expand_as(mean)
+        value = self.value_out(self.value(observ))[..., 0]
+        return mean, logstd, value
+
+
+class PPOAgent:
+    """algorithm.py:26-531 for `num_agents` parallel environments whose tensors live on `device`."""
+
+    def __init__(self, num_agents, obs_dim, action_dim, cfg=None, device="cuda", seed=0, sync_gradients=False):
+        self.cfg = cfg = cfg or PPOConfig()
+        self.n, self.device = num_agents, torch.device(device)
+        gen = torch.Generator(device="cpu"); gen.manual_seed(seed)
+        with torch.random.fork_rng(devices=[]):
+            torch.manual_seed(seed)
+            self.net = ForwardGaussianPolicy(obs_dim, action_dim, cfg).to(self.device)
+        self._gen = torch.Generator(device=self.device); self._gen.manual_seed(seed + 1)
+        self.observ_filter = StreamingNormalize((obs_dim,), center=True, scale=True, clip=5, device=self.device)   # :48-52
+        self.reward_filter = StreamingNormalize((), center=False, scale=True, clip=10, device=self.device)         # :53-57
+        T = cfg.max_length
+        def buffers(rows):
+            return [torch.zeros((rows, T, obs_dim), device=self.device), torch.zeros((rows, T, action_dim), device=self.device),
+                    torch.zeros((rows, T, action_dim), device=self.device), torch.zeros((rows, T, action_dim), device=self.device),
+                    torch.zeros((rows, T), device=self.device)]
+        self.episodes, self.episode_length = buffers(num_agents), torch.zeros(num_agents, dtype=torch.long, device=self.device)
+        self.memory, self.memory_length = buffers(cfg.update_every), torch.zeros(cfg.update_every, dtype=torch.long, device=self.device)
+        self.memory_index = 0
+        self.penalty = float(cfg.kl_init_penalty)
+        self.policy_opt = torch.optim.Adam(self.net.policy_parameters(), lr=cfg.policy_lr, eps=1e-8)
+        self.value_opt = torch.optim.Adam(self.net.value_parameters(), lr=cfg.value_lr, eps=1e-8)
+        self.sync_gradients = sync_gradients
+        self.last = None
+        self.updates = 0
+        self.log = []
+
+    # ---- acting (algorithm.py:100-136) ----
+    def begin_episode(self, indices):
+        self.episode_length[indices] = 0
+
+    @torch.no_grad()
+    def perform(self, observ, training=True):
+        mean, logstd, _ = self.net(self.observ_filter.transform(observ))
+        if training:
+            action = mean + torch.exp(logstd) * torch.randn(mean.shape, device=self.device, generator=self._gen)
+        else:
+            action = mean
+        self.last = (action, mean, logstd)
+        return action
+
+    @torch.no_grad()
+    def experience(self, observ, action, reward):
+        """algorithm.py:138-180: update the filters, append the transition to every agent's running episode."""
+        self.observ_filter.update(observ)
+        self.reward_filter.update(reward)
+        _, mean, logstd = self.last
+        rows = torch.arange(self.n, device=self.device)
+        t = self.episode_length.clamp(max=self.cfg.max_length - 1)
+        for buf, val in zip(self.episodes, (observ, action, mean, logstd, reward)):
+            buf[rows, t] = val
+        self.episode_length += 1
+
+    def end_episode(self, indices):
+        """algorithm.py:182-212: finished episodes go to the memory while it has room; train when it is full."""
+        space = self.cfg.update_every - self.memory_index
+        use = indices[:space]
+        k = use.numel()
+        if k:
+            dst = torch.arange(self.memory_index, self.memory_index + k, device=self.device)
+            for mem, epi in zip(self.memory, self.episodes):
+                mem[dst] = epi[use]
+            self.memory_length[dst] = self.episode_length[use].clamp(max=self.cfg.max_length)
+            self.memory_index += k
+        if self.memory_index >= self.cfg.update_every:
+            return self._training()
+        return None
+
+    # ---- learning (algorithm.py:214-470) ----
+    def _training(self):
+        cfg = self.cfg
+        observ, action, old_mean, old_logstd, reward = [m.clone() for m in self.memory]
+        length = self.memory_length.clone()
+        observ = self.observ_filter.transform(observ)
+        reward = self.reward_filter.transform(reward)
+        stats = {}
+        stats.update(self._update_policy(observ, action, old_mean, old_logstd, reward, length))
+        stats.update(self._update_value(observ, reward, length))
+        stats.update(self._adjust_penalty(observ, old_mean, old_logstd, length))
+        self.memory_index = 0
+        self.memory_length.zero_()
+        self.updates += 1
+        self.log.append(stats)
+        return stats
+
+    def _sync(self, params):
+        if self.sync_gradients and torch.distributed.is_available() and torch.distributed.is_initialized():
+            world = torch.distributed.get_world_size()
+            for p in params:
+                if p.grad is not None:
+                    torch.distributed.all_reduce(p.grad)
+                    p.grad /= world
+
+    def _update_value(self, observ, reward, length):
+        mask = _mask(length, reward.shape[1])
+        return_ = discounted_return(reward, length, self.cfg.discount)
+        losses = []
+        for _ in range(self.cfg.update_epochs_value):
+            value = self.net(observ)[2]
+            loss = (0.5 * mask * (return_ - value) ** 2).mean()                     # :289-301
+            self.value_opt.zero_grad(set_to_none=True)
+            loss.backward()
+            self._sync(self.net.value_parameters())
+            self.value_opt.step()
+            losses.append(loss.detach())
+        return {"value_loss": float(torch.stack(losses).mean())}
+
+    def _update_policy(self, observ, action, old_mean, old_logstd, reward, length):
+        cfg = self.cfg
+        with torch.no_grad():
+            return_ = discounted_return(reward, length, cfg.discount)
+            value = self.net(observ)[2]
+            if cfg.gae_lambda:
+                advantage = lambda_return(reward, value, length, cfg.discount, cfg.gae_lambda)   # :336-338
+            else:
+                advantage = return_ - value
+            advantage = (advantage - advantage.mean()) / (advantage.var(unbiased=False).sqrt() + 1e-8)   # :341-342
+        mask = _mask(length, reward.shape[1])
+        losses = []
+        for _ in range(cfg.update_epochs_policy):
+            mean, logstd, _ = self.net(observ)
+            kl = (mask * diag_normal_kl(old_mean, old_logstd, mean, logstd)).mean(1)                      # :399-401
+            ratio = torch.exp(diag_normal_logpdf(mean, logstd, action) - diag_normal_logpdf(old_mean, old_logstd, action))
+            surrogate = -(mask * ratio * advantage).mean(1)                                               # :402-406
+            cutoff = cfg.kl_target * cfg.kl_cutoff_factor
+            kl_cutoff = cfg.kl_cutoff_coef * (kl > cutoff).float() * (kl - cutoff) ** 2                   # :407-414
+            loss = (surrogate + self.penalty * kl + kl_cutoff).mean()
+            self.policy_opt.zero_grad(set_to_none=True)
+            loss.backward()
+            self._sync(self.net.policy_parameters())
+            self.policy_opt.step()
+            losses.append(loss.detach())
+        return {"policy_loss": float(torch.stack(losses).mean()), "return": float(return_[:, 0].mean())}
+
+    @torch.no_grad()
+    def _adjust_penalty(self, observ, old_mean, old_logstd, length):
+        """algorithm.py:436-474: x1.5 when the policy moved more than 1.3 kl_target, /1.5 below 0.7 kl_target."""
+        mean, logstd, _ = self.net(observ)
+        kl_change = float((_mask(length, observ.shape[1]) * diag_normal_kl(old_mean, old_logstd, mean, logstd)).mean())
+        if kl_change > 1.3 * self.cfg.kl_target:
+            self.penalty *= 1.5
+        if kl_change < 0.7 * self.cfg.kl_target:
+            self.penalty /= 1.5
+        return {"kl_change": kl_change, "penalty": self.penalty}
+
+
+def train(env, agent, steps, training=True):
+    """agents/tools/simulate.py:15-131 for an env with the RexBatchEnv surface (reset(indices), step(actions) on device
+    tensors; auto_reset must be off: finished envs are reset here, by index, as simulate() does).
+    Returns the mean score (undiscounted episode reward) and length of the episodes that ended."""
+    dev = agent.device
+    observ = env.reset().to(dev).clone()
+    agent.begin_episode(torch.arange(agent.n, device=dev))
+    score = torch.zeros(agent.n, device=dev)
+    length = torch.zeros(agent.n, dtype=torch.long, device=dev)
+    done = torch.zeros(agent.n, dtype=torch.bool, device=dev)
+    scores, lengths = [], []
+    for _ in range(int(steps)):
+        idx = done.nonzero()[:, 0]
+        if idx.numel():
+            observ[idx] = env.reset(idx.to(torch.int32)).to(dev)
+            score[idx] = 0
+            length[idx] = 0
+            agent.begin_episode(idx)
+        action = agent.perform(observ, training)
+        nobs, reward, done, _ = env.step(action)
+        nobs, reward, done = nobs.to(dev), reward.to(dev), done.to(dev).bool()
+        score += reward
+        length += 1
+        if training:
+            agent.experience(observ, action, reward)
+        timeout = agent.episode_length >= agent.cfg.max_length            # LimitDuration (wrappers.py:268-291)
+        done = done | timeout
+        idx = done.nonzero()[:, 0]
+        if idx.numel():
+            scores.append(score[idx].clone()); lengths.append(length[idx].clone())
+            if training:
+                agent.end_episode(idx)
+        observ = nobs.clone()
+    if not scores:
+        return float("nan"), float("nan")
+    return float(torch.cat(scores).mean()), float(torch.cat(lengths).float().mean())
+
+
+if __name__ == "__main__":   # python -m rex_gym_amd.agents.ppo --task walk --envs 1024 --iterations 20
+    import argparse
+    from ..envs.batch_env import RexBatchEnv
+    ap = argparse.ArgumentParser(description="train the reference's PPO on the batched HIP simulator")
+    ap.add_argument("--task", default="walk"); ap.add_argument("--signal", default="ik")
+    ap.add_argument("--envs", type=int, default=1024); ap.add_argument("--iterations", type=int, default=20)
+    ap.add_argument("--max-length", type=int, default=500); ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args()
+    env = RexBatchEnv(a.envs, task=a.task, signal_type=a.signal, seed=a.seed, max_episode_steps=a.max_length)
+    agent = PPOAgent(a.envs, env.obs_dim, env.action_dim, PPOConfig(update_every=a.envs, max_length=a.max_length), seed=a.seed)
+    for it in range(a.iterations):
+        score, length = train(env, agent, a.max_length)
+        print(f"iteration {it}: mean score {score:.3f}, mean length {length:.1f}, updates {agent.updates}, "
+              f"penalty {agent.penalty:.3g}", flush=True)

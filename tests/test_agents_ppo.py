@@ -1,0 +1,125 @@
+"""The PyTorch PPO learner (rex_gym_amd/agents/ppo.py) against direct restatements of the reference's formulas
+(agents/ppo/normalize.py, utility.py, algorithm.py) and on a toy batch env.  CPU only."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from rex_gym_amd.agents import PPOAgent, PPOConfig, StreamingNormalize, train
+from rex_gym_amd.agents import ppo
+
+
+def test_streaming_normalize_matches_welford_and_the_reference_constants():
+    rng = np.random.RandomState(0)
+    data = rng.randn(7, 5, 3) * np.array([1.0, 10.0, 0.1]) + np.array([0.0, -3.0, 7.0])
+    f = StreamingNormalize((3,), center=True, scale=True, clip=5)
+    x0 = torch.tensor(data[0, :1], dtype=torch.float32)
+    assert torch.equal(f.transform(x0), x0.clamp(-5, 5))           # count 0: mean 0, scale 1 (normalize.py:58-60)
+    for b in data:
+        f.update(torch.tensor(b, dtype=torch.float32))
+    flat = data.reshape(-1, 3)
+    np.testing.assert_allclose(f.mean.numpy(), flat.mean(0), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(f.std().numpy(), np.sqrt(flat.var(0, ddof=1) + 1e-4), rtol=1e-4)   # normalize.py:131-141
+    v = torch.tensor(flat[:4], dtype=torch.float32)
+    want = np.clip((flat[:4] - flat.mean(0)) / (np.sqrt(flat.var(0, ddof=1) + 1e-4) + 1e-8), -5, 5)
+    np.testing.assert_allclose(f.transform(v).numpy(), want, rtol=1e-4, atol=1e-5)
+    g = StreamingNormalize((), center=False, scale=True, clip=10)  # the reward filter: scale only
+    g.update(torch.tensor([2.0])); assert float(g.transform(torch.tensor(3.0))) == 3.0   # one sample: scale 1
+    g.update(torch.tensor([4.0, 6.0]))
+    np.testing.assert_allclose(float(g.transform(torch.tensor(3.0))), 3.0 / (math.sqrt(4.0 + 1e-4) + 1e-8), rtol=1e-6)
+
+
+def test_returns_match_brute_force():
+    rng = np.random.RandomState(1)
+    B, T, disc, lam = 5, 12, 0.9, 0.7
+    r, v = rng.randn(B, T), rng.randn(B, T)
+    length = np.array([12, 1, 7, 3, 10])
+    ret = ppo.discounted_return(torch.tensor(r), torch.tensor(length), disc).numpy()
+    lr = ppo.lambda_return(torch.tensor(r), torch.tensor(v), torch.tensor(length), disc, lam).numpy()
+    for b in range(B):
+        for t in range(T):
+            want = sum(disc ** (k - t) * r[b, k] for k in range(t, length[b])) if t < length[b] else 0.0
+            assert abs(ret[b, t] - want) < 1e-10
+        agg = 0.0                                                       # utility.py:97-110, written as its recurrence
+        for t in range(T - 1, -1, -1):
+            m = 1.0 if t < length[b] else 0.0
+            agg = m * r[b, t] + disc * v[b, t] * (1 - lam) + m * disc * lam * agg
+            assert abs(lr[b, t] - agg) < 1e-10
+
+
+def test_diagonal_normal_formulas():
+    from scipy import stats
+    rng = np.random.RandomState(2)
+    m0, m1, s0, s1, x = rng.randn(4, 3), rng.randn(4, 3), rng.randn(4, 3) * 0.3, rng.randn(4, 3) * 0.3, rng.randn(4, 3)
+    t = lambda a: torch.tensor(a)
+    # utility.py:135-139 as written: the normalising term is -0.5 (log 2 pi + logstd), i.e. the true log density
+    # plus 0.5 sum(logstd) -- a quirk of the reference that the importance ratio of its PPO inherits, kept as is
+    np.testing.assert_allclose(ppo.diag_normal_logpdf(t(m0), t(s0), t(x)).numpy(),
+                               stats.norm.logpdf(x, m0, np.exp(s0)).sum(-1) + 0.5 * s0.sum(-1), rtol=1e-10)
+    np.testing.assert_allclose(ppo.diag_normal_entropy(t(m0), t(s0)).numpy(), stats.norm.entropy(m0, np.exp(s0)).sum(-1), rtol=1e-10)
+    kl = (s1 - s0 + (np.exp(2 * s0) + (m0 - m1) ** 2) / (2 * np.exp(2 * s1)) - 0.5).sum(-1)
+    np.testing.assert_allclose(ppo.diag_normal_kl(t(m0), t(s0), t(m1), t(s1)).numpy(), kl, rtol=1e-10)
+    assert float(ppo.diag_normal_kl(t(m0), t(s0), t(m0), t(s0)).abs().max()) < 1e-12
+
+
+def test_network_shapes_and_initialisers():
+    cfg = PPOConfig()
+    net = ppo.ForwardGaussianPolicy(4, 2, cfg)
+    assert [m.out_features for m in net.policy if isinstance(m, torch.nn.Linear)] == [200, 100]       # configs.py:31-32
+    assert [m.out_features for m in net.value if isinstance(m, torch.nn.Linear)] == [200, 100]
+    assert torch.all(net.logstd == -1.0)                                                              # init_logstd
+    std = math.sqrt(1.3 * 0.05 / 100)
+    w = net.mean.weight.detach()
+    assert float(w.abs().max()) <= 2 * std + 1e-7 and 0.5 * std < float(w.std()) < 1.2 * std
+    mean, logstd, value = net(torch.zeros(7, 4))
+    assert mean.shape == (7, 2) and logstd.shape == (7, 2) and value.shape == (7,) and float(mean.abs().max()) < 1.0
+
+
+class _PointEnv:
+    """N points on a line; action moves the point, reward = -|x|; episodes of fixed length."""
+    def __init__(self, n, seed=0):
+        self.n, self.g = n, torch.Generator().manual_seed(seed)
+        self.x = torch.zeros(n, 1)
+    def reset(self, indices=None):
+        if indices is None:
+            self.x = torch.rand((self.n, 1), generator=self.g) * 4 - 2
+            return self.x.clone()
+        idx = indices.long()
+        self.x[idx] = torch.rand((idx.numel(), 1), generator=self.g) * 4 - 2
+        return self.x[idx].clone()
+    def step(self, a):
+        self.x = self.x + 0.5 * a.clamp(-1, 1)
+        return self.x.clone(), -self.x[:, 0].abs(), torch.zeros(self.n, dtype=torch.bool), {}
+
+
+def test_ppo_learns_a_toy_task_and_adapts_its_penalty():
+    torch.manual_seed(0)
+    n = 64
+    cfg = PPOConfig(policy_layers=(32,), value_layers=(32,), update_every=n, update_epochs_policy=15, update_epochs_value=15,
+                    policy_lr=3e-3, value_lr=3e-3, max_length=12, discount=0.9, init_mean_factor=0.1)
+    env, agent = _PointEnv(n), PPOAgent(n, 1, 1, cfg, device="cpu", seed=3)
+    first, _ = train(env, agent, 12 * 3)
+    for _ in range(12):
+        last, length = train(env, agent, 12 * 3)
+    assert agent.updates >= 30 and length == 12
+    assert last > first + 1.0, (first, last)                     # mean episode score rises (less distance from 0)
+    kls = [s["kl_change"] for s in agent.log]
+    assert all(np.isfinite(k) for k in kls) and max(kls) < 1.0
+    pens = [s["penalty"] for s in agent.log]
+    assert len(set(pens)) > 1                                     # x1.5 / /1.5 steps happened (algorithm.py:458-469)
+    assert all(abs(math.log(pens[i + 1] / pens[i]) / math.log(1.5)) in (0.0, 1.0) or abs(abs(math.log(pens[i + 1] / pens[i]) / math.log(1.5)) - 1) < 1e-6
+               for i in range(len(pens) - 1))
+
+
+def test_memory_takes_only_the_episodes_it_has_room_for():
+    cfg = PPOConfig(policy_layers=(8,), value_layers=(8,), update_every=4, update_epochs_policy=1, update_epochs_value=1, max_length=5)
+    agent = PPOAgent(6, 2, 1, cfg, device="cpu")
+    obs = torch.zeros(6, 2)
+    for _ in range(3):
+        a = agent.perform(obs)
+        agent.experience(obs, a, torch.ones(6))
+    assert agent.end_episode(torch.tensor([0, 2])) is None and agent.memory_index == 2
+    assert list(agent.memory_length[:2]) == [3, 3]
+    stats = agent.end_episode(torch.tensor([1, 3, 4, 5]))         # room for two more: trains, then the memory is empty
+    assert stats is not None and agent.memory_index == 0 and agent.updates == 1

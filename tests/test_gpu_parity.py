@@ -634,3 +634,21 @@ def test_standup_env_crouch_and_rise(torch):
         zmax = np.maximum(zmax, ps[2])
     assert np.all(zmax > 0.15)
     env.close()
+
+
+def test_ppo_learner_runs_on_the_batch_env_tensors(torch):
+    """The PPO learner takes RexBatchEnv's device tensors as they are: a few hundred control steps of
+    walk-IK with short episodes fill its memory, it trains, the policy changes and everything stays finite."""
+    from rex_gym_amd import RexBatchEnv
+    from rex_gym_amd.agents import PPOAgent, PPOConfig, train
+    n = 256
+    env = RexBatchEnv(n, task="walk", signal_type="ik", seed=5, max_episode_steps=40)
+    cfg = PPOConfig(update_every=n, update_epochs_policy=5, update_epochs_value=5, max_length=40)
+    agent = PPOAgent(n, env.obs_dim, env.action_dim, cfg, device="cuda", seed=1)
+    before = [p.detach().clone() for p in agent.net.parameters()]
+    score, length = train(env, agent, 130)
+    assert agent.updates >= 2 and np.isfinite(score) and 1 <= length <= 40
+    assert all(np.isfinite(v) for s in agent.log for v in s.values())
+    assert any(not torch.equal(a, b.detach()) for a, b in zip(before, agent.net.parameters()))
+    assert int(agent.observ_filter.count) == 130 * n
+    env.close()
