@@ -64,3 +64,38 @@ def test_two_rank_shards_match_single_rank_and_gather():
             assert got.shape[:2] == (8, 8)
             np.testing.assert_array_equal(got, ref[k].astype(np.float32), err_msg=f"rank {rank} {k}")
     assert ref["done"][5].all()   # episode limit 6 hit on every env, auto-reset drew new targets
+
+
+def _ppo_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT); sys.path.insert(0, HERE)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rex_gym_amd.agents import PPOAgent, PPOConfig, train
+    from test_agents_ppo import _PointEnv
+    n = 16
+    cfg = PPOConfig(policy_layers=(16,), value_layers=(16,), update_every=n, update_epochs_policy=3, update_epochs_value=3,
+                    policy_lr=1e-3, value_lr=1e-3, max_length=8)
+    agent = PPOAgent(n, 1, 1, cfg, device="cpu", seed=2, sync_gradients=True)   # same initial weights on every rank
+    train(_PointEnv(n, seed=100 + rank), agent, 8 * 3)                           # different data on every rank
+    flat = torch.cat([p.detach().reshape(-1) for p in agent.net.parameters()])
+    q.put((rank, flat.numpy(), agent.updates))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ppo_ranks_stay_in_step_when_gradients_are_averaged():
+    """The learner's multi-rank mode: every rank trains on its own shard's episodes, gradients are all-reduced, so the
+    weights stay identical on all ranks (and differ from a run on one rank's data alone)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29810 + (os.getpid() % 150)
+    procs = [ctx.Process(target=_ppo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {r: (w, u) for r, w, u in (q.get(timeout=240) for _ in range(2))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == res[1][1] >= 2
+    np.testing.assert_array_equal(res[0][0], res[1][0])
