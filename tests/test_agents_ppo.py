@@ -73,7 +73,7 @@ def test_network_shapes_and_initialisers():
     w = net.mean.weight.detach()
     assert float(w.abs().max()) <= 2 * std + 1e-7 and 0.5 * std < float(w.std()) < 1.2 * std
     mean, logstd, value = net(torch.zeros(7, 4))
-    assert mean.shape == (7, 2) and logstd.shape == (7, 2) and value.shape == (7,) and float(mean.abs().max()) < 1.0
+    assert mean.shape == (7, 2) and logstd.shape == (7, 2) and value.shape == (7,) and float(mean.detach().abs().max()) < 1.0
 
 
 class _PointEnv:
