@@ -652,3 +652,25 @@ def test_ppo_learner_runs_on_the_batch_env_tensors(torch):
     assert any(not torch.equal(a, b.detach()) for a, b in zip(before, agent.net.parameters()))
     assert int(agent.observ_filter.count) == 130 * n
     env.close()
+
+
+def test_bench_prints_one_json_line_with_the_contract_fields(torch):
+    """bench.py --gpus 1 with a short run: ONE JSON line carrying the driver's contract fields, the roofline object
+    and (bounded) the CPU baseline of the oracle."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "60", "--warmup", "20",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 60 and d["warmup"] == 20 and d["unit"] == "env-steps/s" and d["finite"]
+    assert d["scaling"] == "weak" and d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert abs(d["value"] - 4096 * 60 / (d["ms_per_step"] * 1e-3 * 60)) / d["value"] < 1e-9
+    assert 0.05 < r["kernel_ms"] < 5.0 and r["kernel_ms_min"] <= r["kernel_ms"]
