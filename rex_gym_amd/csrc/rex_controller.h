@@ -34,14 +34,14 @@ __device__ __forceinline__ void ik_leg(const float* c, bool right_side, float* o
   float domain = (c[1] * c[1] + c[2] * c[2] - hip * hip + c[0] * c[0] - leg * leg - foot * foot) / (2.0f * foot * leg);
   if (domain > 1.0f) domain = 0.99f;
   else if (domain < -1.0f) domain = -0.99f;
-  const float gamma = atan2f(-sqrtf(1.0f - domain * domain), domain);
+  const float gamma = atan2_fast(-sqrtf(1.0f - domain * domain), domain);
   float sq = c[1] * c[1] + c[2] * c[2] - hip * hip;
   if (sq < 0.0f) sq = 0.0f;
   const float rs = sqrtf(sq);
   float sg, cg;
   sincos_fast(gamma, sg, cg);
-  const float alpha = atan2f(-c[0], rs) - atan2f(foot * sg, leg + foot * cg);
-  const float theta = -atan2f(c[2], c[1]) - atan2f(rs, right_side ? -hip : hip);
+  const float alpha = atan2_fast(-c[0], rs) - atan2_fast(foot * sg, leg + foot * cg);
+  const float theta = -atan2_fast(c[2], c[1]) - atan2_fast(rs, right_side ? -hip : hip);
   out[0] = theta; out[1] = -alpha; out[2] = -gamma;
 }
 
@@ -116,7 +116,7 @@ __device__ __forceinline__ void gait_loop(GaitState& g, int mode, float v, float
     float phi = g.phi + off;
     if (phi >= 1.0f) phi -= 1.0f;
     const float r = sqrtf(bx0[l] * bx0[l] + by0[l] * by0[l]);
-    const float foot_angle = atan2f(by0[l], bx0[l]);
+    const float foot_angle = atan2_fast(by0[l], bx0[l]);
     const float circle = (w_rot >= 0.0f ? 90.0f : 270.0f) - (foot_angle - g.alpha) * (180.0f / kPi);
     const bool stance = phi <= 0.5f;
     const float ph = stance ? phi / 0.5f : (phi - 0.5f) / (1.0f - 0.5f);
@@ -125,7 +125,7 @@ __device__ __forceinline__ void gait_loop(GaitState& g, int mode, float v, float
     float lng[3], rot[3];
     gait_component(stance, ph, bx, bz, v, angle, direction, lng);
     gait_component(stance, ph, bx, bz, w_rot, circle, direction, rot);
-    const float mag = atan2f(sqrtf(rot[0] * rot[0] + rot[1] * rot[1]), r);
+    const float mag = atan2_fast(sqrtf(rot[0] * rot[0] + rot[1] * rot[1]), r);
     if (by0[l] > 0.0f) g.alpha = rot[0] < 0.0f ? -mag : mag;
     else g.alpha = rot[0] < 0.0f ? mag : -mag;
     frame[3 * l + 0] = bx0[l] + lng[0] + rot[0];

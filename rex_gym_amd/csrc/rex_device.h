@@ -117,6 +117,26 @@ __device__ __forceinline__ void sincos_fast(float x, float& s, float& c) {
 
 __device__ __forceinline__ float cos_half(float a) { float s, c; sincos_fast(a, s, c); return c; }
 
+// atan2 to 3e-7 rad (what a float32 libm gives) in ~25 branch-free instructions: octant reduction to t = min/max in
+// [0, 1], Cephes' atanf split at tan(pi/8) with its degree-4 polynomial in t^2, hardware reciprocals.  A step calls it
+// ~30 times (leg IK, gait planner, Euler angles); the libm version is several times that size.
+__device__ __forceinline__ float atan2_fast(float y, float x) {
+  const float ax = fabsf(x), ay = fabsf(y);
+  const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+  const float t = mx > 0.0f ? mn * __builtin_amdgcn_rcpf(mx) : 0.0f;
+  const bool big = t > 0.41421356237f;
+  const float u = big ? (t - 1.0f) * __builtin_amdgcn_rcpf(t + 1.0f) : t;
+  const float z = u * u;
+  float p = fmaf(8.05374449538e-2f, z, -1.38776856032e-1f);
+  p = fmaf(p, z, 1.99777106478e-1f);
+  p = fmaf(p, z, -3.33329491539e-1f);
+  float a = (big ? 0.78539816339744831f : 0.0f) + fmaf(p * z, u, u);
+  a = ay > ax ? 1.57079632679489662f - a : a;
+  a = x < 0.0f ? 3.14159265358979324f - a : a;
+  return copysignf(a, y);
+}
+__device__ __forceinline__ float asin_fast(float s) { return atan2_fast(s, sqrtf(fmaxf(fmaf(-s, s, 1.0f), 0.0f))); }
+
 // symmetric 3x3: xx yy zz xy xz yz
 struct s33 { float xx, yy, zz, xy, xz, yz; };
 __device__ __forceinline__ f3 mul(const s33& m, f3 v) {
@@ -849,7 +869,7 @@ __device__ __forceinline__ void rotate_leg(T* a) {   // 12-entry per-joint array
 }
 
 #ifdef REX_PROF
-__device__ long long g_prof[8 * 1024];   // per block: cycle counters of the sections of physics_substep
+__device__ long long g_prof[10 * 1024];  // per block: cycle counters of the sections of physics_substep (+ [8] whole kernel, [9] launches)
 #define REX_STAMP(var) const long long var = clock64()
 #else
 #define REX_STAMP(var)
@@ -1126,7 +1146,7 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
     s.quat[0] = nx * nn; s.quat[1] = ny * nn; s.quat[2] = nz * nn; s.quat[3] = nw * nn;
 #ifdef REX_PROF
     if (threadIdx.x == 0 && blockIdx.x < 1024) {
-      long long* p = g_prof + 8 * blockIdx.x;
+      long long* p = g_prof + 10 * blockIdx.x;
       p[0] += t_pgs1 - t_pgs0; p[1] += nsweeps; p[2] += clock64() - t_begin; p[4] += 1;
       p[3] += t_pgs0 - t_chol; p[6] += t_legs - t_begin; p[7] += t_chol - t_legs;
       p[5] += any_limit ? 1 : 0;      // substeps with joint-limit rows in reach of some env of the wave

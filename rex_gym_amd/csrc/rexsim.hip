@@ -106,12 +106,12 @@ __device__ __forceinline__ void quat_to_euler(const float* q, float* rpy) {
   const float x = q[0], y = q[1], z = q[2], w = q[3];
   const float sqx = x * x, sqy = y * y, sqz = z * z, squ = w * w;
   const float sarg = -2.0f * (x * z - w * y);
-  if (sarg <= -0.99999f) { rpy[1] = -0.5f * kPi; rpy[0] = 0.0f; rpy[2] = 2.0f * atan2f(x, -y); }
-  else if (sarg >= 0.99999f) { rpy[1] = 0.5f * kPi; rpy[0] = 0.0f; rpy[2] = 2.0f * atan2f(-x, y); }
+  if (sarg <= -0.99999f) { rpy[1] = -0.5f * kPi; rpy[0] = 0.0f; rpy[2] = 2.0f * atan2_fast(x, -y); }
+  else if (sarg >= 0.99999f) { rpy[1] = 0.5f * kPi; rpy[0] = 0.0f; rpy[2] = 2.0f * atan2_fast(-x, y); }
   else {
-    rpy[1] = asinf(sarg);
-    rpy[0] = atan2f(2.0f * (y * z + w * x), squ - sqx - sqy + sqz);
-    rpy[2] = atan2f(2.0f * (x * y + w * z), squ + sqx - sqy - sqz);
+    rpy[1] = asin_fast(sarg);
+    rpy[0] = atan2_fast(2.0f * (y * z + w * x), squ - sqx - sqy + sqz);
+    rpy[2] = atan2_fast(2.0f * (x * y + w * z), squ + sqx - sqy - sqz);
   }
 }
 // third row (R20, R21, R22) of the matrix of the quaternion rebuilt from Euler angles
@@ -539,6 +539,7 @@ __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __r
   constexpr int kLegF4 = REX_LEG_F4_OF(EPW, ARM);
   constexpr int kRowsF4 = ARM ? REX_LDS_F4_PER_ENV_ARM_OF(EPW) : REX_ROWS_F4_OF(kLegF4);
   __shared__ float4 lds[(kRowsF4 + (EPW <= 16 ? REX_PARK_F4 : 0)) * EPW];
+  REX_STAMP(t_kernel);
   const int lane = threadIdx.x;
   constexpr int LPE = EPW < 64 ? lanes_per_env(EPW) : 1;     // EPW <= 16: lane = LPE * slot + p (rex_device.h, group layout)
   const int slot = (lane / LPE) & (EPW - 1);
@@ -652,6 +653,9 @@ __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __r
       for (int j = 0; j < NM; ++j) cmd_out[(size_t)is * NM + j] = cmd[j];
     }
   }
+#ifdef REX_PROF
+  if (threadIdx.x == 0 && blockIdx.x < 1024) { g_prof[10 * blockIdx.x + 8] += clock64() - t_kernel; g_prof[10 * blockIdx.x + 9] += 1; }
+#endif
 }
 
 // The reset motion of Rex.Reset (rex.py:296-324).  Plane: ONE robot, lane 0 writes the snapshot.  Terrain pool:
@@ -1043,8 +1047,8 @@ int rex_gait_loop(int n, int mode, float* d_planner, const float* d_params, floa
 
 #ifdef REX_PROF   /* developer build only (tools/prof_sections.py): cycle counters of the sections of a substep */
 REX_API int rex_debug_prof(long long* out, int reset) {
-  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(rex::g_prof), sizeof(long long) * 8 * 1024) != hipSuccess) return REX_EHIP;
-  if (reset) { static long long z[8 * 1024]; if (hipMemcpyToSymbol(HIP_SYMBOL(rex::g_prof), z, sizeof(z)) != hipSuccess) return REX_EHIP; }
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(rex::g_prof), sizeof(long long) * 10 * 1024) != hipSuccess) return REX_EHIP;
+  if (reset) { static long long z[10 * 1024]; if (hipMemcpyToSymbol(HIP_SYMBOL(rex::g_prof), z, sizeof(z)) != hipSuccess) return REX_EHIP; }
   return REX_OK;
 }
 #endif

@@ -43,7 +43,7 @@ def window(steps, label):
     for k in range(steps):
         env.step(acts[k % 8])
     torch.cuda.synchronize()
-    out = np.zeros((1024, 8), np.int64)
+    out = np.zeros((1024, 10), np.int64)
     L.rex_debug_prof(out.ctypes.data, 0)
     out = out[out[:, 4] > 0].astype(float)
     pgs, sw, tot, fin, sub, legs, chol = (out[:, i] for i in (0, 1, 2, 3, 4, 6, 7))
@@ -52,6 +52,8 @@ def window(steps, label):
     print(f"{label}: {len(out)} workgroups sampled, sweeps/substep mean {np.mean(sw / sub):.1f} (slowest workgroup "
           f"{np.max(sw / sub):.1f}), cycles/sweep {pgs.sum() / sw.sum():.0f}, joint-limit rows in reach in "
           f"{100 * fb.sum() / sub.sum():.2f} % of the substeps")
+    print("  cycles/step (whole kernel, per wave): mean %.0f, slowest workgroup %.0f; inside physics_substep %.0f" %
+          (np.mean(out[:, 8] / out[:, 9]), np.max(out[:, 8] / out[:, 9]), np.mean(tot / out[:, 9])))
     print("  cycles/substep: total %.0f (slowest workgroup %.0f) = legs %.0f + base chol %.0f + finish rows %.0f + pgs %.0f "
           "+ back-subst/integrate %.0f" % (np.mean(tot / sub), np.max(tot / sub), np.mean(legs / sub), np.mean(chol / sub),
                                            np.mean(fin / sub), np.mean(pgs / sub), np.mean(rest / sub)))
