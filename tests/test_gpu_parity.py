@@ -513,6 +513,25 @@ def test_gym_surface_single_env(torch):
     env.close()
 
 
+def test_every_reference_env_class_has_its_single_env_counterpart(torch):
+    """The five task envs of the reference (envs/gym/*.py) with their default constructors: spaces, one reset, a few
+    steps, the reference's return types; mark 'arm' widens info['action'] to 18."""
+    from rex_gym_amd.envs import gym as g
+    cases = [(g.RexWalkEnv, {}, 2, 4), (g.RexWalkEnv, {"signal_type": "ol"}, 8, 4), (g.RexReactiveEnv, {}, 2, 16),
+             (g.RexReactiveEnv, {"signal_type": "ol"}, 4, 16), (g.RexTurnEnv, {}, 2, 4), (g.RexPosesEnv, {"base_y": 0.05}, 1, 4),
+             (g.RexStandupEnv, {}, 1, 4), (g.RexWalkEnv, {"mark": "arm"}, 2, 4), (g.RexTurnEnv, {"terrain_type": "random"}, 2, 4)]
+    for cls, kw, adim, odim in cases:
+        env = cls(render=False, **kw)
+        assert env.action_space.shape == (adim,) and env.observation_space.shape == (odim,), (cls.__name__, kw)
+        obs = env.reset()
+        assert obs.shape == (odim,) and np.isfinite(obs).all()
+        for _ in range(3):
+            o, r, d, info = env.step(np.zeros(adim, np.float32))
+        assert o.shape == (odim,) and isinstance(r, float) and isinstance(d, bool)
+        assert info["action"].shape == ((18,) if kw.get("mark") == "arm" else (12,))
+        env.close()
+
+
 def test_step_before_reset_raises(torch):
     from rex_gym_amd import RexBatchEnv
     env = RexBatchEnv(8)
