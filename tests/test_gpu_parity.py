@@ -693,3 +693,41 @@ def test_bench_prints_one_json_line_with_the_contract_fields(torch):
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert abs(d["value"] - 4096 * 60 / (d["ms_per_step"] * 1e-3 * 60)) / d["value"] < 1e-9
     assert 0.05 < r["kernel_ms"] < 5.0 and r["kernel_ms_min"] <= r["kernel_ms"]
+
+
+@pytest.mark.parametrize("task,signal,mark,terrain", [
+    ("walk", "ik", "base", "random"), ("gallop", "ik", "base", "random"), ("poses", "ik", "base", "plane"),
+    ("standup", "ol", "base", "plane"), ("turn", "ol", "arm", "random"), ("gallop", "ol", "arm", "plane"),
+    ("standup", "ol", "arm", "plane"), ("walk", "ol", "base", "plane")])
+def test_single_step_parity_along_long_oracle_rollouts(torch, task, signal, mark, terrain):
+    """Combinations the other tests do not pair (terrain x mark x task), followed deep into their episodes -- falls,
+    joint limits, robots lying on the ground, auto-resets: the oracle runs 120 control steps and every third step the
+    HIP step is taken from the oracle's current state and compared (same tolerances as the single-step tests; the
+    quantile form allows for contacts that switch one substep apart)."""
+    n = 48
+    env, orc = make_pair(task, signal, n, np.float32, seed=31, mark=mark, terrain_type=terrain, terrain_pool=8,
+                         auto_reset=True, max_episode_steps=90)
+    env.reset(); orc.reset()
+    rng = np.random.RandomState(12)
+    lo, hi = np.minimum(env.action_space.low, env.action_space.high), np.maximum(env.action_space.low, env.action_space.high)
+    nm = env.num_motors
+    Q, QD, FL = 13, 13 + nm, 13 + 2 * nm + 6
+    bad = 0
+    for k in range(120):
+        a = (rng.uniform(lo, hi, (n, env.action_dim)) * 3.0).clip(lo * 3, hi * 3).astype(np.float32)   # also outside the Box
+        if k % 3 == 0:
+            env.state.copy_(numeric_to_product_state(orc.get_state(), torch, env.state.device))
+            obs, rew, done, info = env.step(torch.as_tensor(a, device="cuda"))
+            oobs, orew, odone, ocmd = orc.step(a.astype(np.float64))
+            ps, os_ = product_state_to_numeric(env.state), orc.get_state()
+            same = done.cpu().numpy() == odone
+            assert same.mean() >= 0.95, (k, same.mean())
+            live = same & ~odone                       # compare envs that did not just reset on one side only
+            for rows, tol in ((slice(Q, Q + nm), 2e-4), (slice(0, 7), 2e-4), (slice(QD, QD + nm), 5e-2)):
+                err = np.abs(ps[rows][:, live] - os_[rows][:, live])
+                bad += int((err > tol).any(axis=0).sum())
+            np.testing.assert_array_equal(ps[FL + 1:FL + 3][:, same], os_[FL + 1:FL + 3][:, same])   # steps, episode
+        else:
+            orc.step(a.astype(np.float64))
+    assert bad <= 0.02 * n * 40, bad                   # at most 2 % of the (env, step) samples off by more than round-off
+    env.close()
