@@ -954,6 +954,17 @@ static const real* init_pose(const RexConfig* c) {
   if (c->task == REX_TASK_STANDUP) return POSE_REST;                   /* standup_env.py:108-110 */
   return c->signal == REX_SIGNAL_OL ? POSE_STAND_OL : POSE_STAND;
 }
+/* Rex.GetTimeSinceReset (rex.py:155-156): step counter x time step, the env clock every ramp / brake / phase threshold
+ * is compared against.  RexConfig carries the time step as a float32 (0.001f = 0.001 (1 + 4.7e-8)); the reference
+ * multiplies by the Python float 0.001, and thresholds such as `t <= 0.8` sit exactly on multiples of the control
+ * step.  The fp64 build therefore runs its clock on the time step rounded to 1 ns, which reproduces the reference's
+ * comparisons exactly (tests/test_oracle_env_commands.py); the fp32 build multiplies in float like the HIP kernels,
+ * where the product rounds back onto the same float as the threshold. */
+static real env_time(const RexConfig* c, const Env* e) {
+  if (sizeof(real) == sizeof(double)) return (real)((double)(e->steps * c->action_repeat) * (floor((double)c->sim_time_step * 1e9 + 0.5) / 1e9));
+  return (real)(e->steps * c->action_repeat) * (real)c->sim_time_step;
+}
+
 /* RexGymEnv._transform_action_to_motor_command (rex_gym_env.py:363-367): the 12 leg targets, then ARM_POSES['rest'] */
 static void full_command(const real leg12[12], real cmd[NJ]) {
   memcpy(cmd, leg12, sizeof(real) * 12);
@@ -1117,7 +1128,7 @@ static void order_signal(const real ang[12], real cmd[12]) { /* FR,FL,RR,RL -> F
 static void walk_command(const RexConfig* c, Env* e, const real* action, real cmd[12]) {
   const real* ip = init_pose(c);
   if (e->flags & REX_F_STAY_STILL) { memcpy(cmd, ip, sizeof(real) * 12); return; }       /* walk_env.py:318-319 */
-  real t = (real)(e->steps * c->action_repeat) * (real)c->sim_time_step;               /* rex.py:155-156 */
+  real t = env_time(c, e);               /* rex.py:155-156 */
   if (e->target != 0) {                                                                 /* walk_env.py:207-215 */
     if (fabs(e->ph.pos[0]) >= fabs(e->target) - (real)0.15) {
       e->flags |= REX_F_GOAL_REACHED;
@@ -1148,8 +1159,11 @@ static void walk_command(const RexConfig* c, Env* e, const real* action, real cm
     if (e->flags & REX_F_GOAL_REACHED) {
       real b = walk_brake_coeff(t, 0, e->end_time);
       l_a *= b; f_a *= b;
-      /* `coeff is 0.0` in the reference is an identity test that never holds for a computed
-       * float: _stay_still is never set on this branch */
+      /* `if coeff is 0.0: self._stay_still = True` (walk_env.py:300) is an IDENTITY test: it holds exactly when
+       * _evaluate_brakes_stage_coeff hands back its `end_value=0.0` argument (the same constant object), i.e. when t
+       * lies outside the brake window -- never for the computed 1 - (t - end_t), even where that is 0
+       * (tests/golden/make_env_golden.py runs the reference's code: `stay` turns on one step past the window) */
+      if (!(e->end_time <= t && t <= (real)0.8 + e->end_time)) e->flags |= REX_F_STAY_STILL;
     }
     real sc = walk_gait_coeff(t, 0);
     l_a *= sc; f_a *= sc;
@@ -1169,7 +1183,7 @@ static real gallop_gait_coeff(real t, real a1) { real p = (real)1.0 + a1; return
 
 static void gallop_command(const RexConfig* c, Env* e, const real* action, real cmd[12]) {
   if (e->flags & REX_F_STAY_STILL) { memcpy(cmd, POSE_STAND, sizeof(real) * 12); return; } /* rex.initial_pose */
-  real t = (real)(e->steps * c->action_repeat) * (real)c->sim_time_step;
+  real t = env_time(c, e);
   if (e->target != 0) {                                                                 /* gallop_env.py:212-220 */
     if (fabs(e->ph.pos[0]) >= fabs(e->target)) {
       e->flags |= REX_F_GOAL_REACHED;
@@ -1190,6 +1204,8 @@ static void gallop_command(const RexConfig* c, Env* e, const real* action, real 
     if (e->flags & REX_F_GOAL_REACHED) {
       real b = gallop_brake_coeff(t, 0, e->end_time);
       for (int k = 0; k < 4; ++k) lp[k] *= b;
+      /* gallop_env.py:291: the same identity test as in walk_env.py:300 -- true outside the brake window */
+      if (!(e->end_time <= t && t <= (real)1.0 + e->end_time)) e->flags |= REX_F_STAY_STILL;
     }
     const real* ip = init_pose(c);
     for (int l = 0; l < 4; ++l) {
@@ -1210,7 +1226,7 @@ static int turn_clockwise(const Env* e) {
 /* RexTurnEnv._transform_action_to_motor_command (turn_env.py:239-347) */
 static void turn_command(const RexConfig* c, Env* e, const real* action, real cmd[12]) {
   const real* ip = init_pose(c);
-  real t = (real)(e->steps * c->action_repeat) * (real)c->sim_time_step;
+  real t = env_time(c, e);
   if (e->flags & REX_F_STAY_STILL) {
     if (t - e->end_time >= 1) e->flags |= REX_F_ENV_GOAL;                          /* _terminate_with_delay */
     memcpy(cmd, ip, sizeof(real) * 12);
@@ -1252,7 +1268,7 @@ static void turn_command(const RexConfig* c, Env* e, const real* action, real cm
 /* RexPosesEnv._signal (poses_env.py:186-225): one body-pose component ramps to its target, IK on the
  * default foot frames */
 static void poses_command(const RexConfig* c, Env* e, const real* action, real cmd[12]) {
-  real t = (real)(e->steps * c->action_repeat) * (real)c->sim_time_step;
+  real t = env_time(c, e);
   real p = (real)0.8 + action[0];
   real coeff = (0 <= t && t <= p) ? t : (real)1.0;
   real staged = e->target * coeff;
@@ -1323,6 +1339,20 @@ static void normalize_obs(const RexConfig* c, real* obs, int n) {
   for (int k = 0; k < n; ++k) { real hi = obs_bound(c, k), lo = -hi; obs[k] = 2 * (obs[k] - lo) / (hi - lo) - 1; }
 }
 
+/* <Env>._transform_action_to_motor_command of the five task envs: the 12 leg targets from the env action and the
+ * env's controller state (gait phase, goal / brake flags, end time) at t = steps * action_repeat * dt */
+static void env_command(const RexConfig* c, Env* e, const real* action, real* leg_cmd) {
+  if (c->task == REX_TASK_GALLOP) gallop_command(c, e, action, leg_cmd);
+  else if (c->task == REX_TASK_TURN) turn_command(c, e, action, leg_cmd);
+  else if (c->task == REX_TASK_POSES) poses_command(c, e, action, leg_cmd);
+  else if (c->task == REX_TASK_STANDUP) {                                           /* RexStandupEnv._signal, standup_env.py:113-120 */
+    real t = env_time(c, e);         /* GetTimeSinceReset, rex.py:155-156 */
+    real f = t > (real)0.1 ? 1 : ((real)0.1 + action[0]) / (t + 1) + (real)1.5;    /* the 'brake' function */
+    for (int j = 0; j < 12; ++j) leg_cmd[j] = POSE_STAND[j] * f;
+  }
+  else walk_command(c, e, action, leg_cmd);
+}
+
 static void env_step(Orc* o, int idx, const real* action_in, real* obs, real* reward, uint8_t* done, real* motor_cmd) {
   const RexConfig* c = &o->cfg;
   Env* e = &o->envs[idx];
@@ -1338,15 +1368,7 @@ static void env_step(Orc* o, int idx, const real* action_in, real* obs, real* re
       action[k] = a;
     }
   }
-  if (c->task == REX_TASK_GALLOP) gallop_command(c, e, action, leg_cmd);
-  else if (c->task == REX_TASK_TURN) turn_command(c, e, action, leg_cmd);
-  else if (c->task == REX_TASK_POSES) poses_command(c, e, action, leg_cmd);
-  else if (c->task == REX_TASK_STANDUP) {                                           /* RexStandupEnv._signal, standup_env.py:113-120 */
-    real t = (real)(e->steps * c->action_repeat) * (real)c->sim_time_step;         /* GetTimeSinceReset, rex.py:155-156 */
-    real f = t > (real)0.1 ? 1 : ((real)0.1 + action[0]) / (t + 1) + (real)1.5;    /* the 'brake' function */
-    for (int j = 0; j < 12; ++j) leg_cmd[j] = POSE_STAND[j] * f;
-  }
-  else walk_command(c, e, action, leg_cmd);
+  env_command(c, e, action, leg_cmd);
   full_command(leg_cmd, cmd);
   Ground ground = env_ground(o, idx, e->episode);
   for (int k = 0; k < c->action_repeat; ++k) rex_substep(c, e, cmd, &ground);    /* Rex.Step, rex.py:158-163 */
@@ -1436,6 +1458,16 @@ ORC_API void orc_step(void* h, const real* action, real* obs, real* reward, uint
 #endif
   for (int i = 0; i < n; ++i)
     env_step(o, i, action + (size_t)i * ad, obs + (size_t)i * od, reward + i, done + i, motor_cmd ? motor_cmd + (size_t)i * NJ : 0);
+}
+
+/* The command half of env.step() alone (no physics, no step counter): what the env would send to the motors for
+ * `action` from env idx's CURRENT state.  Lets tests replay scripted (time, base pose, action) sequences against
+ * vectors produced by the reference's own _transform_action_to_motor_command (tests/golden/make_env_golden.py). */
+ORC_API void orc_env_command(void* h, int idx, const real* action, real* cmd_out) {
+  Orc* o = (Orc*)h;
+  real leg_cmd[12];
+  env_command(&o->cfg, &o->envs[idx], action, leg_cmd);
+  full_command(leg_cmd, cmd_out);
 }
 
 /* state exchange: numeric values, word-major [REX_STATE_WORDS][N] as in rexsim.h (ints as numbers;

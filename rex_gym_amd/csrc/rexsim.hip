@@ -400,8 +400,12 @@ __device__ __forceinline__ void walk_command(const DevCfg& c, EnvState& e, const
   } else {                                                                       // walk_env.py:292-315
     float l_a = 0.1f, f_a = 0.2f;
     if (e.flags & REX_F_GOAL_REACHED) {
-      const float b = (e.end_time <= t && t <= 0.8f + e.end_time) ? 1.0f - (t - e.end_time) : 0.0f;
-      l_a *= b; f_a *= b;   // `coeff is 0.0` never holds for a computed float: no _stay_still here
+      const bool inside = e.end_time <= t && t <= 0.8f + e.end_time;
+      const float b = inside ? 1.0f - (t - e.end_time) : 0.0f;
+      l_a *= b; f_a *= b;
+      // `if coeff is 0.0` (walk_env.py:300) is an identity test: true exactly when the brake function returns its
+      // end_value argument, i.e. outside the brake window (pinned by tests/golden/env_command_golden.json)
+      if (!inside) e.flags |= REX_F_STAY_STILL;
     }
     const float sc = (0.0f <= t && t <= 0.8f) ? t : 1.0f;
     l_a *= sc; f_a *= sc;
@@ -443,9 +447,11 @@ __device__ __forceinline__ void gallop_command(const DevCfg& c, EnvState& e, con
   } else {                                                                       // gallop_env.py:287-304
     float lp[4] = {action[0], action[1], action[2], action[3]};
     if (e.flags & REX_F_GOAL_REACHED) {
-      const float b = (e.end_time <= t && t <= 1.0f + e.end_time) ? 1.0f - (t - e.end_time) : 0.0f;
+      const bool inside = e.end_time <= t && t <= 1.0f + e.end_time;
+      const float b = inside ? 1.0f - (t - e.end_time) : 0.0f;
 #pragma unroll
       for (int k = 0; k < 4; ++k) lp[k] *= b;
+      if (!inside) e.flags |= REX_F_STAY_STILL;   // gallop_env.py:291: `coeff is 0.0`, an identity test (see walk_command)
     }
 #pragma unroll
     for (int l = 0; l < 4; ++l) {

@@ -178,6 +178,13 @@ class OracleEnv:
         self.o.lib.orc_step(self.h, self.o._p(a), self.o._p(obs), self.o._p(rew), self.o._p(done), self.o._p(cmd))
         return obs, rew, done.astype(bool), cmd
 
+    def command(self, idx, action):
+        """The motor command env `idx` would issue for `action` from its current state (no physics)."""
+        a = self.o._arr(action)
+        cmd = np.zeros(self.o.num_motors, self.o.dtype)
+        self.o.lib.orc_env_command(self.h, int(idx), self.o._p(a), self.o._p(cmd))
+        return cmd
+
     def set_body_params(self, params):
         params = np.ascontiguousarray(params, np.float32)
         assert params.shape == (3, self.n)

@@ -731,3 +731,36 @@ def test_single_step_parity_along_long_oracle_rollouts(torch, task, signal, mark
             orc.step(a.astype(np.float64))
     assert bad <= 0.02 * n * 40, bad                   # at most 2 % of the (env, step) samples off by more than round-off
     env.close()
+
+
+@pytest.mark.parametrize("task,signal", [("walk", "ol"), ("gallop", "ol"), ("walk", "ik"), ("gallop", "ik")])
+def test_goal_brake_and_hold_sequence_on_the_gpu(torch, task, signal):
+    """Goal reached -> brake ramp -> hold pose (walk_env.py:207-324, gallop_env.py:212-313), the part of the command
+    logic a short rollout never reaches: the base is put past the target, then every step is taken from the oracle's
+    state on both sides and commands and flags are compared (the oracle itself is pinned to the reference's methods for
+    exactly these sequences, tests/test_oracle_env_commands.py -- including the `coeff is 0.0` identity test of the
+    open-loop branches)."""
+    n = 16
+    env, orc = make_pair(task, signal, n, np.float32, seed=3, target_position=0.375, backwards=False)
+    env.reset(); orc.reset()
+    rng = np.random.RandomState(2)
+    lo, hi = np.minimum(env.action_space.low, env.action_space.high), np.maximum(env.action_space.low, env.action_space.high)
+    seen = set()
+    for k in range(330):
+        st = orc.get_state()
+        if k >= 4:
+            st[0] = -0.45                                # |x| past the target (0.375, stop space 0.15 for walk)
+            st[1] = 0.0; st[2] = 0.19; st[3:7] = np.array([0, 0, 0, 1.0])[:, None]; st[7:13] = 0.0   # and upright, so that
+            st[orclib.S_FLAGS] = st[orclib.S_FLAGS].astype(np.int64) & ~16                          # nobody is done
+            orc.set_state(st)
+        env.state.copy_(numeric_to_product_state(st, torch, env.state.device))
+        a = rng.uniform(lo, hi, (n, env.action_dim)).astype(np.float32)
+        _, _, _, info = env.step(torch.as_tensor(a, device="cuda"))
+        _, _, _, ocmd = orc.step(a.astype(np.float64))
+        ps, os_ = product_state_to_numeric(env.state), orc.get_state()
+        np.testing.assert_allclose(info["action"].cpu().numpy(), ocmd, atol=3e-5)
+        np.testing.assert_array_equal(ps[orclib.S_FLAGS].astype(int) & 7, os_[orclib.S_FLAGS].astype(int) & 7)
+        np.testing.assert_allclose(ps[orclib.S_ENDTIME], os_[orclib.S_ENDTIME], atol=1e-6)
+        seen.update((os_[orclib.S_FLAGS].astype(int) & 7).tolist())
+    assert 3 in seen and (7 in seen or (task, signal) == ("gallop", "ik"))   # goal+terminating, then hold (gallop-IK never holds)
+    env.close()
