@@ -21,8 +21,9 @@
  *                   projected Gauss-Seidel in Bullet's row order (btMultiBodyConstraintSolver),
  *                   semi-implicit Euler.  SURVEY.md section 9.2 lists the Bullet behaviours assumed.
  *
- * PARITY STATUS: the controller half is pinned against golden vectors generated from the
- * reference's own numpy code (tests/golden/).  The physics half is **parity unpinned**: no
+ * PARITY STATUS: the controller half and the env-level command logic (goal / brake / hold
+ * state machines of the five envs) are pinned against golden vectors generated from the
+ * reference's own Python code (tests/golden/).  The physics half is **parity unpinned**: no
  * PyBullet here, no golden trajectories in the reference.
  *
  * Build: `make -C oracle` -> oracle/_build/librex_oracle_f64.so (REAL=double) and _f32.so (float).
