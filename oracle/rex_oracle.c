@@ -33,6 +33,7 @@
  */
 #include <math.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -961,10 +962,32 @@ static const real* init_pose(const RexConfig* c) {
  * step.  The fp64 build therefore runs its clock on the time step rounded to 1 ns, which reproduces the reference's
  * comparisons exactly (tests/test_oracle_env_commands.py); the fp32 build multiplies in float like the HIP kernels,
  * where the product rounds back onto the same float as the threshold. */
+/* RexConfig carries its real-valued settings as float32; the reference holds them as the Python floats the caller
+ * wrote (0.001, 0.02, 0.3 ...).  The fp64 build reads each setting back as the shortest decimal (7 significant digits)
+ * that float came from, so that its arithmetic is the reference's to the last bits. */
+static double as_written(float x) {
+  static __thread struct { uint32_t key; int used; double val; } memo[64];
+  uint32_t bits; memcpy(&bits, &x, 4);
+  unsigned slot = (bits * 2654435761u) >> 26;
+  if (memo[slot].used && memo[slot].key == bits) return memo[slot].val;
+  char buf[40];
+  snprintf(buf, sizeof buf, "%.7g", (double)x);
+  double v = strtod(buf, 0);
+  memo[slot].key = bits; memo[slot].used = 1; memo[slot].val = v;
+  return v;
+}
 static real env_time(const RexConfig* c, const Env* e) {
-  if (sizeof(real) == sizeof(double)) return (real)((double)(e->steps * c->action_repeat) * (floor((double)c->sim_time_step * 1e9 + 0.5) / 1e9));
+  if (sizeof(real) == sizeof(double)) return (real)((double)(e->steps * c->action_repeat) * as_written(c->sim_time_step));
   return (real)(e->steps * c->action_repeat) * (real)c->sim_time_step;
 }
+/* the simulation time step and the latencies as the physics / history code sees them: the reference holds them as
+ * Python floats (0.001, 0.02 ...), RexConfig as float32; the fp64 build undoes the float32 rounding so that its
+ * trajectories are the reference's to the last bits (tests/test_oracle_rollouts.py), the fp32 build computes in float */
+static real sim_dt(const RexConfig* c) { return sizeof(real) == sizeof(double) ? (real)as_written(c->sim_time_step) : (real)c->sim_time_step; }
+static real cfgf(float x) { return sizeof(real) == sizeof(double) ? (real)as_written(x) : (real)x; }
+/* substep counts are integers of the Python-float quotient (int(0.5 / 0.001) = 500, rex.py:319; int(latency /
+ * time_step), rex.py:747): always taken in double on the decimal values, a float quotient lands just below (499) */
+static int whole_steps(float duration, float dt) { return (int)(as_written(duration) / as_written(dt)); }
 
 /* RexGymEnv._transform_action_to_motor_command (rex_gym_env.py:363-367): the 12 leg targets, then ARM_POSES['rest'] */
 static void full_command(const real leg12[12], real cmd[NJ]) {
@@ -985,8 +1008,8 @@ static void delayed_observation(const RexConfig* c, const Env* e, real latency, 
   if (!e->hist) { true_observation(e, o); return; }
 #define SLOT(k) e->hist[(e->hist_head - (k) + 2 * REX_HISTORY_LEN) % REX_HISTORY_LEN]
   if (latency <= 0 || e->hist_len == 1) { memcpy(o, SLOT(0), sizeof(real) * HIST_WORDS); return; }
-  real dt = (real)c->sim_time_step;
-  int n = (int)(latency / dt);
+  real dt = sim_dt(c);
+  int n = (int)((double)latency / (double)dt);
   if (n + 1 >= e->hist_len) { memcpy(o, SLOT(e->hist_len - 1), sizeof(real) * HIST_WORDS); return; }
   real alpha = (latency - n * dt) / dt;
   for (int k = 0; k < HIST_WORDS; ++k) o[k] = (1 - alpha) * SLOT(n)[k] + alpha * SLOT(n + 1)[k];
@@ -994,53 +1017,58 @@ static void delayed_observation(const RexConfig* c, const Env* e, real latency, 
 }
 /* Rex.ReceiveObservation (rex.py:726-733) */
 static void receive_observation(const RexConfig* c, Env* e) {
-  if (!e->hist) return;
+  if (!e->hist) { true_observation(e, e->ctrl_obs); return; }   /* no latency anywhere: the deque's newest entry is all that is read */
   e->hist_head = (e->hist_head + 1) % REX_HISTORY_LEN;
   if (e->hist_len < REX_HISTORY_LEN) e->hist_len++;
   true_observation(e, e->hist[e->hist_head]);
-  delayed_observation(c, e, (real)c->control_latency, e->ctrl_obs);
+  delayed_observation(c, e, cfgf(c->control_latency), e->ctrl_obs);
 }
 
 /* Rex.ApplyAction + stepSimulation + ReceiveObservation (rex.py:158-163,568-641) */
 static void rex_substep(const RexConfig* c, Env* e, const real cmd[NJ], const Ground* ground) {
   real tau[NJ];
   real pd[HIST_WORDS];
-  delayed_observation(c, e, (real)c->pd_latency, pd);                  /* _GetPDObservation, rex.py:755-759 */
+  delayed_observation(c, e, cfgf(c->pd_latency), pd);                  /* _GetPDObservation, rex.py:755-759 */
   for (int j = 0; j < NJ; ++j) {
     real act, obs;
-    motor_torque(cmd[j], pd[j], pd[NJ + j], e->ph.qd[j], (real)c->motor_kp, (real)c->motor_kd, &act, &obs);
+    motor_torque(cmd[j], pd[j], pd[NJ + j], e->ph.qd[j], cfgf(c->motor_kp), cfgf(c->motor_kd), &act, &obs);
     if (fabs(act) > OVERHEAT_TORQUE) { if (e->overheat[j] < 65535) e->overheat[j]++; } else e->overheat[j] = 0;
-    if ((real)e->overheat[j] > OVERHEAT_TIME / (real)c->sim_time_step) e->motor_enabled &= ~(1u << j);
+    if ((real)e->overheat[j] > OVERHEAT_TIME / sim_dt(c)) e->motor_enabled &= ~(1u << j);
     e->tau_obs[j] = obs;
     tau[j] = ((e->motor_enabled >> j) & 1u) ? act : 0;
     if (DBG_JOINT_FRICTION > 0 && (j % 3) != 1) tau[j] -= clampr(DBG_JOINT_VISC * e->ph.qd[j], -DBG_JOINT_FRICTION, DBG_JOINT_FRICTION);
   }
-  physics_substep(&e->ph, tau, (real)c->sim_time_step, c->solver_iterations, (real)c->solver_residual_threshold, ground);
+  physics_substep(&e->ph, tau, sim_dt(c), c->solver_iterations, (real)c->solver_residual_threshold, ground);
   receive_observation(c, e);
 }
 
 static void settle(Orc* o, Env* e, const Ground* ground) {
+  real (*hist)[HIST_WORDS] = e->hist;     /* the snapshot keeps its own ring when a latency is configured */
   memset(e, 0, sizeof(*e));
+  if (!hist && (o->cfg.pd_latency > 0 || o->cfg.control_latency > 0)) hist = calloc(REX_HISTORY_LEN, sizeof(real[HIST_WORDS]));
+  e->hist = hist;
   e->ph.pos[2] = ROBOT_INIT_Z;
   e->ph.quat[3] = 1;
   full_command(POSE_STAND, e->ph.q); /* ResetPose: INIT_POSES[pose_id='stand'] (+ _ResetArmMotors: ARM_POSES['rest'], rex.py:395-400) */
   e->motor_enabled = (1u << NJ) - 1;
   /* RexPosesEnv.reset() calls the base reset with initial_motor_angles=None: the reset motion is
    * skipped (rex.py:308), the robot starts at the drop height in the 'stand' pose */
-  if (o->cfg.task == REX_TASK_POSES) return;
+  /* Rex.Reset: `_observation_history.clear()` (rex.py:309), then -- only when a reset motion follows -- one
+   * ReceiveObservation of the dropped robot (rex.py:314) */
+  e->hist_head = REX_HISTORY_LEN - 1; e->hist_len = 0;
+  if (o->cfg.task == REX_TASK_POSES) { receive_observation(&o->cfg, e); return; }   /* rex.py:323 alone */
+  receive_observation(&o->cfg, e);
   real cmd[NJ];
   full_command(POSE_STAND, cmd);
   for (int k = 0; k < 100; ++k) rex_substep(&o->cfg, e, cmd, ground);      /* rex.py:315-318 */
-  int nreset = (int)((real)0.5 / (real)o->cfg.sim_time_step);             /* rex.py:319 */
+  int nreset = whole_steps(0.5f, o->cfg.sim_time_step);             /* rex.py:319 */
   full_command(init_pose(&o->cfg), cmd);
   for (int k = 0; k < nreset; ++k) rex_substep(&o->cfg, e, cmd, ground);
+  receive_observation(&o->cfg, e);                                          /* rex.py:323: the last state once more */
 }
 
 /* the observation the controller-facing getters read (Rex._control_observation): delayed when a latency is set */
-static void control_observation(const Env* e, real o[HIST_WORDS]) {
-  if (e->hist) memcpy(o, e->ctrl_obs, sizeof(real) * HIST_WORDS);
-  else true_observation(e, o);
-}
+static void control_observation(const Env* e, real o[HIST_WORDS]) { memcpy(o, e->ctrl_obs, sizeof(real) * HIST_WORDS); }
 
 static void env_observation(const RexConfig* c, const Env* e, real* obs) {
   real co[HIST_WORDS], rpy[3];
@@ -1061,26 +1089,29 @@ static void env_reset(Orc* o, int idx) {
   Env* e = &o->envs[idx];
   int32_t episode = e->episode;
   real (*hist)[HIST_WORDS] = e->hist;
+  /* the env keeps ONE GaitPlanner for its lifetime (walk_env.py:99, turn_env.py:117): its turning-arc angle `_alpha`
+   * (gait_planner.py:76-85) survives reset() and enters the first step of the next episode */
+  real alpha = e->gait.alpha;
   {
     int t = terrain_index(o, idx, episode + 1);
     *e = t >= 0 ? o->terrain_snapshot[t] : o->snapshot;   /* settled on this episode's terrain */
   }
   e->episode = episode + 1;
   e->hist = hist;
-  e->gait.phi = 0; e->gait.last_time = 0; e->gait.alpha = 0;
+  e->gait.phi = 0; e->gait.last_time = 0; e->gait.alpha = alpha;
   uint32_t ctr[4] = {(uint32_t)e->episode, 0, 0, 0};
   philox4x32(ctr, (uint32_t)c->seed ^ (uint32_t)(c->env_index_base + idx), (uint32_t)(c->seed >> 32));
   e->flags = 0;
   if (c->task == REX_TASK_WALK) {
     int backwards = c->backwards < 0 ? (int)(ctr[0] >> 31) : c->backwards;     /* walk_env.py:133-136 */
     if (backwards) e->flags |= REX_F_BACKWARDS;
-    if (c->target_position != 0.0f) e->target = (real)c->target_position;
+    if (c->target_position != 0.0f) e->target = cfgf(c->target_position);
     else {                                                                      /* walk_env.py:143-147 */
       float u = u01(ctr[1]);
       e->target = backwards ? (real)(-2.0f - u) : (real)(1.0f + 2.0f * u);
     }
   } else if (c->task == REX_TASK_GALLOP) {
-    if (c->target_position != 0.0f) e->target = (real)c->target_position;
+    if (c->target_position != 0.0f) e->target = cfgf(c->target_position);
     else e->target = (real)(1.0f + 2.0f * u01(ctr[1]));                         /* gallop_env.py:150-152 */
   }
   e->end_time = 0; e->aux = 0; e->steps = 0;
@@ -1088,7 +1119,7 @@ static void env_reset(Orc* o, int idx) {
     /* _ranges (rex_gym_env.py:258-265): base_y, base_z, roll, pitch, yaw */
     static const float LO[5] = {-0.007f, -0.048f, -0.78539816339744830962f, -0.78539816339744830962f, -0.78539816339744830962f};
     static const float HI[5] = {0.007f, 0.021f, 0.78539816339744830962f, 0.78539816339744830962f, 0.78539816339744830962f};
-    if (c->pose_index >= 0) { e->aux = (real)c->pose_index; e->target = (real)c->pose_value; }
+    if (c->pose_index >= 0) { e->aux = (real)c->pose_index; e->target = cfgf(c->pose_value); }
     else {
       int k = e->episode % 5;               /* deque rotation: one pop per reset() */
       e->aux = (real)k;
@@ -1096,22 +1127,19 @@ static void env_reset(Orc* o, int idx) {
     }
   }
   if (c->task == REX_TASK_TURN) {                                               /* turn_env.py:129-160 */
-    float tgt = (c->orient_fixed & 1) ? c->target_orient : fmaf(5.8f, u01(ctr[1]), 0.2f);
-    float ini = (c->orient_fixed & 2) ? c->init_orient : fmaf(5.8f, u01(ctr[2]), 0.2f);
-    e->target = (real)tgt; e->aux = (real)ini;
-    real rpy[3] = {0, 0, (real)ini};
+    real tgt = (c->orient_fixed & 1) ? cfgf(c->target_orient) : (real)fmaf(5.8f, u01(ctr[1]), 0.2f);
+    real ini = (c->orient_fixed & 2) ? cfgf(c->init_orient) : (real)fmaf(5.8f, u01(ctr[2]), 0.2f);
+    e->target = tgt; e->aux = ini;
+    real rpy[3] = {0, 0, ini};
     euler_to_quat(rpy, e->ph.quat);                                             /* resetBasePositionAndOrientation */
     e->ph.pos[0] = 0; e->ph.pos[1] = 0; e->ph.pos[2] = ROBOT_INIT_Z;
   }
-  /* history restarts with the settled observation (the reference's deque holds the last 100 settle substeps,
-   * all within 1e-4 of it; the turn env's teleport does not touch the history either, turn_env.py:158-159) */
+  /* the reference's deque is not touched by reset() after Rex.Reset: it holds the last 100 observations of the reset
+   * motion (the newest twice, rex.py:323), and the turn env's teleport (turn_env.py:158-159) happens behind its back --
+   * the observation reset() returns and the first step's yaw reading are those of the settled, not yet turned robot */
   if (e->hist) {
-    Env snap = o->n_terrain ? o->terrain_snapshot[terrain_index(o, idx, e->episode)] : o->snapshot;
-    e->hist_head = 0; e->hist_len = 1;
-    memset(snap.tau_obs, 0, sizeof(snap.tau_obs));   /* the snapshot record does not carry the observed torques */
-    for (int k = 0; k < 4; ++k) snap.ph.quat[k] = e->ph.quat[k] * 0 + snap.ph.quat[k];
-    true_observation(&snap, e->hist[0]);
-    memcpy(e->ctrl_obs, e->hist[0], sizeof(real) * HIST_WORDS);
+    const Env* snap = o->n_terrain ? &o->terrain_snapshot[terrain_index(o, idx, e->episode)] : &o->snapshot;
+    memcpy(e->hist, snap->hist, sizeof(real[HIST_WORDS]) * REX_HISTORY_LEN);
   }
 }
 
@@ -1303,8 +1331,8 @@ static real base_reward(const RexConfig* c, Env* e) {
   real shake = -fabs(R[2][0] + R[2][1]);
   real dotp = 0;
   for (int j = 0; j < NJ; ++j) dotp += co[2 * NJ + j] * co[NJ + j];   /* GetMotorTorques . GetMotorVelocities */
-  real energy = -fabs(dotp) * (real)c->sim_time_step;
-  return (real)c->distance_weight * fwd + (real)c->energy_weight * energy + (real)c->drift_weight * drift + (real)c->shake_weight * shake;
+  real energy = -fabs(dotp) * sim_dt(c);
+  return cfgf(c->distance_weight) * fwd + cfgf(c->energy_weight) * energy + cfgf(c->drift_weight) * drift + cfgf(c->shake_weight) * shake;
 }
 
 static int env_fallen(const RexConfig* c, const Env* e) {
@@ -1333,7 +1361,7 @@ static void action_bounds(const RexConfig* c, real* lo, real* hi) {
 }
 static real obs_bound(const RexConfig* c, int k) {
   real two_pi = (real)(2 * M_PI);
-  if (k == 2 || k == 3) return two_pi / (real)c->sim_time_step + (real)0.01;
+  if (k == 2 || k == 3) return two_pi / sim_dt(c) + (real)0.01;
   return two_pi + (real)0.01;
 }
 static void normalize_obs(const RexConfig* c, real* obs, int n) {
@@ -1416,12 +1444,13 @@ ORC_API void orc_set_body_params(void* h, const float* params) {
     memcpy(o->body_params, params, sizeof(float) * 3 * (size_t)o->cfg.num_envs);
   }
 }
-ORC_API void orc_destroy(void* h) { Orc* o = (Orc*)h; for (int i = 0; i < o->cfg.num_envs; ++i) free(o->envs[i].hist); free(o->body_params); free(o->envs); free(o->heights); free(o->mids); free(o->terrain_snapshot); free(o); }
+ORC_API void orc_destroy(void* h) { Orc* o = (Orc*)h; for (int i = 0; i < o->cfg.num_envs; ++i) free(o->envs[i].hist); free(o->snapshot.hist); for (int t = 0; t < o->n_terrain; ++t) free(o->terrain_snapshot[t].hist); free(o->body_params); free(o->envs); free(o->heights); free(o->mids); free(o->terrain_snapshot); free(o); }
 
 /* terrain pool: heights [k][256*256] raw vertex heights (terrain.py:36-43 layout: data[i + j*rows], i along x),
  * mids [k] = (min+max)/2 of each field */
 ORC_API void orc_set_terrain(void* h, const float* heights, const float* mids, int k) {
   Orc* o = (Orc*)h;
+  for (int t = 0; t < o->n_terrain; ++t) free(o->terrain_snapshot[t].hist);
   free(o->heights); free(o->mids); free(o->terrain_snapshot);
   o->n_terrain = k;
   o->heights = (float*)malloc(sizeof(float) * (size_t)k * HF_N * HF_N);
@@ -1505,6 +1534,7 @@ ORC_API void orc_set_state(void* h, const double* in) {
     e->target = (real)W(SW_TARGET); e->end_time = (real)W(SW_ENDTIME); e->aux = (real)W(SW_AUX);
     e->flags = (uint32_t)W(SW_FLAGS); e->steps = (int32_t)W(SW_STEPS); e->episode = (int32_t)W(SW_EPISODE);
     e->motor_enabled = (uint32_t)W(SW_MOTOR_EN);
+    if (!e->hist) true_observation(e, e->ctrl_obs);   /* an injected state is also what the robot last observed */
     for (int k = 0; k < NJ / 2; ++k) {
       uint32_t v = (uint32_t)W(SW_OVERHEAT + k);
       e->overheat[2 * k] = (uint16_t)(v & 0xFFFFu); e->overheat[2 * k + 1] = (uint16_t)(v >> 16);

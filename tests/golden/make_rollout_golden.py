@@ -1,0 +1,246 @@
+#!/usr/bin/env python3
+"""Golden ROLLOUTS: the reference's complete env / robot code running over the oracle's rigid-body step.
+
+PyBullet is not installable here, so the physics half of the oracle cannot be pinned.  Everything
+AROUND `stepSimulation`, however, is plain Python in the reference: RexGymEnv.__init__/reset/step, the five env
+subclasses, Rex.Reset (drop, 100 + 500 settle substeps), Rex.Step (action repeat), ApplyAction (PD observation, motor
+model, overheat protection, torque application), ReceiveObservation (history deque, latency blend), the getters,
+_reward, _termination, _get_observation.  This script runs THAT code unmodified, constructors included, against a
+stand-in for the pybullet client whose `stepSimulation` is the oracle's `orc_physics_substep` (one 1 ms rigid-body
+step for the torques the reference just applied) and whose state getters read the same 37/49-word body state.  The
+resulting (action -> observation, reward, done, motor command, body state) sequences are what the reference's
+orchestration produces for this physics; the oracle's own orchestration (`orc_reset` / `orc_step`) must reproduce them
+(tests/test_oracle_rollouts.py), which pins every row of the hot path except the contents of `stepSimulation`.
+
+The stand-in implements only what a physics server would: joint table parsed from the reference's URDF, body state
+get / set, torque accumulation, Bullet's quaternion <-> Euler / matrix conventions.  No reference logic lives in it.
+
+Run in the build container:  PYTHONPATH=/root/reference python tests/golden/make_rollout_golden.py
+"""
+import json
+import math
+import os
+import random
+import sys
+import types
+import xml.etree.ElementTree as ET
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import orclib                                                    # noqa: E402
+
+np.math = math   # gait_planner.py:24 uses the numpy.math alias removed in numpy 2 (SURVEY.md 8c shim 1)
+sys.path.insert(0, os.environ.get("REX_REFERENCE", "/root/reference"))
+
+
+# ------------------------------------------------------------------ Bullet's math conventions (b3Quaternion / pybullet.c)
+def euler_from_quaternion(q):
+    x, y, z, w = (float(v) for v in q)
+    sqx, sqy, sqz, squ = x * x, y * y, z * z, w * w
+    sarg = -2.0 * (x * z - w * y)
+    if sarg <= -0.99999:
+        return (0.0, -0.5 * math.pi, 2 * math.atan2(x, -y))
+    if sarg >= 0.99999:
+        return (0.0, 0.5 * math.pi, 2 * math.atan2(-x, y))
+    return (math.atan2(2 * (y * z + w * x), squ - sqx - sqy + sqz), math.asin(sarg),
+            math.atan2(2 * (x * y + w * z), squ + sqx - sqy - sqz))
+
+
+def quaternion_from_euler(e):
+    r, p, y = (float(v) for v in e)
+    cr, sr, cp, sp, cy, sy = math.cos(r / 2), math.sin(r / 2), math.cos(p / 2), math.sin(p / 2), math.cos(y / 2), math.sin(y / 2)
+    return (sr * cp * cy - cr * sp * sy, cr * sp * cy + sr * cp * sy, cr * cp * sy - sr * sp * cy, cr * cp * cy + sr * sp * sy)
+
+
+def matrix_from_quaternion(q):
+    x, y, z, w = (float(v) for v in q)
+    d = x * x + y * y + z * z + w * w
+    s = 2.0 / d
+    xs, ys, zs = x * s, y * s, z * s
+    wx, wy, wz, xx, xy, xz, yy, yz, zz = w * xs, w * ys, w * zs, x * xs, x * ys, x * zs, y * ys, y * zs, z * zs
+    return (1 - (yy + zz), xy - wz, xz + wy, xy + wz, 1 - (xx + zz), yz - wx, xz - wy, yz + wx, 1 - (xx + yy))
+
+
+# ------------------------------------------------------------------ the physics-server stand-in
+class OraclePhysicsClient:
+    """What rex_gym talks to instead of pybullet: body state + one rigid-body step, both the oracle's."""
+    COV_ENABLE_RENDERING = COV_ENABLE_PLANAR_REFLECTION = COV_ENABLE_GUI = 0
+    TORQUE_CONTROL, VELOCITY_CONTROL, POSITION_CONTROL = 2, 0, 1
+    URDF_USE_SELF_COLLISION = 8
+    GUI, DIRECT, SHARED_MEMORY = 1, 2, 3
+    unknown_calls = set()
+
+    def __init__(self, connection_mode=None):
+        self.robot = None
+        self.dt, self.iterations = 1.0 / 240.0, 50
+        self.calls = 0
+
+    def __getattr__(self, name):                     # rendering / debug-visualiser calls: nothing to do
+        OraclePhysicsClient.unknown_calls.add(name)
+        return lambda *a, **k: None
+
+    # -- world
+    def resetSimulation(self): self.robot = None
+    def setTimeStep(self, dt): self.dt = dt
+    def setGravity(self, x, y, z): assert (x, y, z) == (0, 0, -10)
+    def setPhysicsEngineParameter(self, numSolverIterations=None, **kw):
+        if numSolverIterations is not None:
+            self.iterations = int(numSolverIterations)
+
+    def loadURDF(self, path, position=None, orientation=None, useFixedBase=False, flags=0):
+        if not path.endswith(("rex.urdf", "rex_arm.urdf")):
+            return 0                                 # plane.urdf: the ground of orc_physics_substep
+        assert not useFixedBase
+        mark = "arm" if path.endswith("rex_arm.urdf") else "base"
+        self.orc = orclib.Oracle(np.float64, mark)
+        nm = self.nm = self.orc.num_motors
+        joints = [j for j in ET.parse(path).getroot().findall("joint")]
+        self.joint_names = [j.get("name") for j in joints]
+        import rex_gym.model.mark_constants as mc
+        motor_names = mc.MARK_DETAILS["motors_names"][mark]
+        self.motor_of_joint = [motor_names.index(n) if n in motor_names else -1 for n in self.joint_names]
+        assert sorted(m for m in self.motor_of_joint if m >= 0) == list(range(nm))
+        self.st = np.zeros(13 + 2 * nm)
+        self.st[0:3], self.st[3:7] = position, orientation
+        self.tau = np.zeros(nm)
+        self.robot = 1
+        return 1
+
+    def getNumJoints(self, body): return len(self.joint_names)
+    def getJointInfo(self, body, i): return (i, self.joint_names[i].encode())
+    def getDynamicsInfo(self, body, link): return (1.0, 0.5, (1e-3, 1e-3, 1e-3))    # only read by the randomisers
+    def changeDynamics(self, *a, **k): raise AssertionError("randomisers are not part of these rollouts")
+
+    # -- body state
+    def resetBasePositionAndOrientation(self, body, pos, orn):
+        if body == self.robot:
+            self.st[0:3], self.st[3:7] = pos, orn
+    def resetBaseVelocity(self, body, lin, ang):
+        self.st[7:10], self.st[10:13] = lin, ang
+    def resetJointState(self, body, joint, value, targetVelocity=0):
+        m = self.motor_of_joint[joint]
+        self.st[13 + m], self.st[13 + self.nm + m] = value, targetVelocity
+    def getBasePositionAndOrientation(self, body):
+        return tuple(self.st[0:3].tolist()), tuple(self.st[3:7].tolist())
+    def getBaseVelocity(self, body):
+        return tuple(self.st[7:10].tolist()), tuple(self.st[10:13].tolist())
+    def getJointState(self, body, joint):
+        m = self.motor_of_joint[joint]
+        return (float(self.st[13 + m]), float(self.st[13 + self.nm + m]), (0.0,) * 6, 0.0)
+
+    # -- actuation and stepping
+    def setJointMotorControl2(self, bodyIndex, jointIndex, controlMode, force=0, targetVelocity=0, **kw):
+        if controlMode == self.TORQUE_CONTROL:
+            self.tau[self.motor_of_joint[jointIndex]] = force
+        else:
+            assert controlMode == self.VELOCITY_CONTROL and force == 0   # "disable the default motor", rex.py:369-388
+    def stepSimulation(self):
+        self.st = self.orc.physics_substep(self.st, self.tau, dt=self.dt, iterations=self.iterations, nsteps=1,
+                                           residual_threshold=float(np.float32(1e-7)))   # pybullet's default, never changed
+        self.tau[:] = 0                                                  # external torques last one step
+        self.calls += 1
+
+    getEulerFromQuaternion = staticmethod(euler_from_quaternion)
+    getQuaternionFromEuler = staticmethod(quaternion_from_euler)
+    getMatrixFromQuaternion = staticmethod(matrix_from_quaternion)
+
+
+for name in ["pybullet", "pybullet_data", "gym", "gym.spaces", "gym.utils", "gym.utils.seeding"]:
+    sys.modules[name] = types.ModuleType(name)
+pb = sys.modules["pybullet"]
+pb.getMatrixFromQuaternion = matrix_from_quaternion      # rex_gym_env.py:527 calls the module, not the client
+pb.GUI, pb.DIRECT, pb.SHARED_MEMORY = 1, 2, 3
+sys.modules["gym"].Env = type("Env", (), {})
+sys.modules["gym.spaces"].Box = lambda low, high, dtype=None: types.SimpleNamespace(low=np.asarray(low), high=np.asarray(high))
+sys.modules["gym"].spaces = sys.modules["gym.spaces"]
+sys.modules["gym"].utils = sys.modules["gym.utils"]
+sys.modules["gym.utils"].seeding = sys.modules["gym.utils.seeding"]
+sys.modules["gym.utils.seeding"].np_random = lambda seed=None: (np.random.RandomState(seed), seed)
+sys.modules["pybullet_data"].getDataPath = lambda: "/nonexistent"
+
+import rex_gym.model.gait_planner as gp                          # noqa: E402
+import rex_gym.util.bullet_client as bullet_client               # noqa: E402
+bullet_client.BulletClient = OraclePhysicsClient                 # the one substitution: the physics server
+from rex_gym.envs.gym import gallop_env, poses_env, standup_env, turn_env, walk_env   # noqa: E402
+
+SCENARIOS = [
+    # name, env class, constructor kwargs, oracle config kwargs, steps, episodes
+    ("walk_ik", walk_env.RexWalkEnv, dict(target_position=1.0, backwards=False, signal_type="ik"),
+     dict(task="walk", signal="ik", target_position=1.0, backwards=0), 60, 2),
+    ("walk_ik_backwards", walk_env.RexWalkEnv, dict(target_position=1.5, backwards=True, signal_type="ik"),
+     dict(task="walk", signal="ik", target_position=1.5, backwards=1), 40, 1),
+    ("walk_ol", walk_env.RexWalkEnv, dict(target_position=0.75, backwards=False, signal_type="ol"),
+     dict(task="walk", signal="ol", target_position=0.75, backwards=0), 60, 1),
+    ("walk_ik_latency", walk_env.RexWalkEnv, dict(target_position=1.0, backwards=False, signal_type="ik",
+                                                  control_latency=0.0125, pd_latency=0.003),
+     dict(task="walk", signal="ik", target_position=1.0, backwards=0, control_latency=0.0125, pd_latency=0.003), 50, 2),
+    ("walk_ik_arm", walk_env.RexWalkEnv, dict(target_position=1.0, backwards=False, signal_type="ik", mark="arm"),
+     dict(task="walk", signal="ik", target_position=1.0, backwards=0, mark=1), 30, 1),
+    ("gallop_ik", gallop_env.RexReactiveEnv, dict(target_position=2.0, signal_type="ik"),
+     dict(task="gallop", signal="ik", target_position=2.0), 50, 2),
+    ("gallop_ol", gallop_env.RexReactiveEnv, dict(target_position=2.0, signal_type="ol"),
+     dict(task="gallop", signal="ol", target_position=2.0), 50, 1),
+    ("turn_ik", turn_env.RexTurnEnv, dict(target_orient=2.0, init_orient=0.5, signal_type="ik"),
+     dict(task="turn", signal="ik", target_orient=2.0, init_orient=0.5, orient_fixed=3), 60, 2),
+    ("turn_ol", turn_env.RexTurnEnv, dict(target_orient=0.5, init_orient=2.5, signal_type="ol"),
+     dict(task="turn", signal="ol", target_orient=0.5, init_orient=2.5, orient_fixed=3), 40, 1),
+    ("poses_pitch", poses_env.RexPosesEnv, dict(base_y=0.0, base_z=0.0, base_roll=0.0, base_pitch=0.3, base_yaw=0.0),
+     dict(task="poses", signal="ik", pose_index=3, pose_value=0.3), 60, 1),
+    ("standup", standup_env.RexStandupEnv, dict(),
+     dict(task="standup", signal="ol"), 60, 2),
+]
+
+
+def action_space(env):
+    sp = env.action_space
+    lo, hi = np.minimum(sp.low, sp.high), np.maximum(sp.low, sp.high)     # the gallop Box is inverted in the reference
+    return lo, hi
+
+
+def body(env):
+    c = env._pybullet_client
+    return c.st.tolist()
+
+
+def run(name, cls, kwargs, steps, episodes, seed):
+    gp_clock = types.SimpleNamespace(env=None)
+    gp.time.time = lambda: gp_clock.env.rex.GetTimeSinceReset() if gp_clock.env is not None and hasattr(gp_clock.env, "rex") else 0.0
+    random.seed(seed)
+    env = cls(render=False, terrain_id="plane", **kwargs)   # the reference's constructor (terrain_id as its CLI passes it): hard reset, drop, settle
+    gp_clock.env = env
+    rng = np.random.RandomState(seed)
+    lo, hi = action_space(env)
+    events = []
+    for ep in range(episodes):
+        obs = env.reset()                             # soft reset (hard_reset=False after the constructor)
+        events.append(dict(kind="reset", obs=np.asarray(obs, float).tolist(), body=body(env)))
+        for k in range(steps):
+            a = rng.uniform(lo, hi)
+            obs, reward, done, info = env.step(a)
+            events.append(dict(kind="step", action=a.tolist(), obs=np.asarray(obs, float).tolist(), reward=float(reward),
+                               done=bool(done), cmd=np.asarray(info["action"], float).tolist(), body=body(env)))
+            if done:
+                break
+    return events
+
+
+def main():
+    out = dict(description="reference env/robot code over the oracle's rigid-body step; see make_rollout_golden.py",
+               scenarios=[])
+    for i, (name, cls, kwargs, ocfg, steps, episodes) in enumerate(SCENARIOS):
+        events = run(name, cls, kwargs, steps, episodes, seed=100 + i)
+        nstep = sum(e["kind"] == "step" for e in events)
+        ndone = sum(e.get("done", False) for e in events)
+        print(f"{name}: {nstep} steps, {ndone} done, last x = {events[-1]['body'][0]:+.4f}")
+        out["scenarios"].append(dict(name=name, oracle_config=ocfg, events=events))
+    print("client calls with nothing to do:", sorted(OraclePhysicsClient.unknown_calls))
+    path = os.path.join(HERE, "rollout_golden.json")
+    with open(path, "w") as f:
+        json.dump(out, f)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,52 @@
+"""The oracle's orchestration against the reference's own env / robot code (tests/golden/make_rollout_golden.py).
+
+The fixture holds rollouts of the reference's unmodified RexGymEnv / Rex / env-subclass code over a physics stand-in
+whose `stepSimulation` is the oracle's rigid-body step; here the oracle's own reset / step (`orc_reset`, `orc_step`)
+replays the same actions.  Agreement pins reset (drop, settle counts, teleports), action repeat, PD observation and
+latency blending, motor model composition, overheat bookkeeping, observation assembly, reward and termination of all
+five envs to the reference -- everything on the hot path except what happens inside `stepSimulation`.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import orclib
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+with open(os.path.join(HERE, "golden", "rollout_golden.json")) as f:
+    GOLDEN = json.load(f)
+
+# Both sides run the same fp64 rigid-body code; they differ in who computes the torques (numpy vs C, last-bit
+# differences) and contacts amplify that along a rollout, so the tolerance is far above 1 ulp and far below anything
+# a logic difference (an off-by-one substep, a wrong observation slot) would produce (>= 1e-4).
+TOL = 2e-7
+
+
+@pytest.mark.parametrize("sc", GOLDEN["scenarios"], ids=[s["name"] for s in GOLDEN["scenarios"]])
+def test_oracle_reproduces_reference_rollout(sc):
+    kw = dict(sc["oracle_config"])
+    mark = "arm" if kw.get("mark", 0) == 1 else "base"
+    cfg = orclib.default_config(kw.pop("task"), kw.pop("signal"), num_envs=1, auto_reset=0, **kw)
+    env = orclib.OracleEnv(cfg, np.float64, mark)
+    nm = env.o.num_motors
+    worst = dict(obs=0.0, reward=0.0, cmd=0.0, body=0.0)
+    for k, ev in enumerate(sc["events"]):
+        if ev["kind"] == "reset":
+            obs = env.reset()[0]
+        else:
+            o, r, d, c = env.step(np.asarray(ev["action"])[None, :])
+            obs = o[0]
+            assert bool(d[0]) == ev["done"], f"event {k}: done"
+            worst["reward"] = max(worst["reward"], abs(float(r[0]) - ev["reward"]))
+            worst["cmd"] = max(worst["cmd"], float(np.max(np.abs(c[0] - np.asarray(ev["cmd"])))))
+        body = env.get_state()[:13 + 2 * nm, 0]
+        worst["obs"] = max(worst["obs"], float(np.max(np.abs(obs - np.asarray(ev["obs"])))))
+        # velocities are O(1..10): compare relative to their scale
+        ref = np.asarray(ev["body"])
+        scale = np.maximum(1.0, np.abs(ref))
+        worst["body"] = max(worst["body"], float(np.max(np.abs(body - ref) / scale)))
+        assert max(worst.values()) < 1e-3, f"event {k} ({ev['kind']}): {worst}"
+    print(sc["name"], worst)
+    assert max(worst.values()) < TOL, worst
