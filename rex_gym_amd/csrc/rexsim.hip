@@ -160,6 +160,11 @@ struct DevCfg {
   int32_t n_terrain;
   float* hist;               // [100][43][n] observation history (nullptr: no latency model)
   float pd_latency, control_latency;
+  // int(latency / time_step) and the blend weight of the older slot (rex.py:747-751), taken on the host in double on
+  // the decimal values the caller wrote: the float quotient 0.02f / 0.001f is 19.999998
+  int32_t pd_slots, control_slots;
+  float pd_alpha, control_alpha;
+  int32_t reset_substeps;    // int(0.5 / time_step), rex.py:319 (the float quotient 0.5f / 0.001f truncates to 499)
   const float* body_params;  // [3][n] word-major: base mass scale, leg mass scale, foot friction (nullptr: 1, 1, 0.5)
   float act_lo, act_hi;      // Box bounds of the env's action space (host: rex_create)
   float obs_hi_ang, obs_hi_rate;
@@ -179,14 +184,13 @@ __device__ __forceinline__ float& hist_at(const DevCfg& c, int i, int slot, int 
   return c.hist[((size_t)slot * REX_HISTORY_WORDS + w) * c.n + i];
 }
 // which two ring slots to blend, and with which weight, for an observation `latency` seconds old
-__device__ __forceinline__ void delay_slots(const DevCfg& c, uint32_t hist, float latency, int& s0, int& s1, float& alpha) {
+__device__ __forceinline__ void delay_slots(uint32_t hist, float latency, int n, float blend, int& s0, int& s1, float& alpha) {
   const int head = (int)(hist & 0xFFu), len = (int)((hist >> 8) & 0xFFu);
   int k0 = 0, k1 = 0;
   alpha = 0.0f;
   if (latency > 0.0f && len != 1) {
-    const int n = (int)(latency / c.dt);
     if (n + 1 >= len) { k0 = k1 = len - 1; }
-    else { k0 = n; k1 = n + 1; alpha = (latency - (float)n * c.dt) / c.dt; }
+    else { k0 = n; k1 = n + 1; alpha = blend; }
   }
   s0 = (head - k0 + 2 * REX_HISTORY_LEN) % REX_HISTORY_LEN;
   s1 = (head - k1 + 2 * REX_HISTORY_LEN) % REX_HISTORY_LEN;
@@ -215,6 +219,22 @@ __device__ __forceinline__ Ground env_ground(const DevCfg& c, int i, int gidx, i
   return g;
 }
 
+// Rex.ReceiveObservation (rex.py:726-733): the true observation goes to the front of the history ring
+__device__ __forceinline__ void receive_observation(const DevCfg& c, EnvState& e, int i, bool live, const float* tau_obs) {
+  if (!c.hist) return;
+  const int head = ((int)(e.hist & 0xFFu) + 1) % REX_HISTORY_LEN;
+  const int len = min((int)((e.hist >> 8) & 0xFFu) + 1, REX_HISTORY_LEN);
+  e.hist = (uint32_t)head | ((uint32_t)len << 8);
+  if (live) {
+#pragma unroll
+    for (int j = 0; j < 12; ++j) { hist_at(c, i, head, j) = e.ph.q[j]; hist_at(c, i, head, 12 + j) = e.ph.qd[j]; hist_at(c, i, head, 24 + j) = tau_obs[j]; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) hist_at(c, i, head, 36 + k) = e.ph.quat[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) hist_at(c, i, head, 40 + k) = e.ph.ang[k];
+  }
+}
+
 // Rex.ApplyAction + stepSimulation + ReceiveObservation (rex.py:158-163, 568-641).  The latency model (c.hist) is
 // only offered for mark 'base' (43-word history records); rex_create rejects it for mark 'arm'.
 template <class SM, class ARMP>
@@ -229,7 +249,7 @@ __device__ __forceinline__ void rex_substep(const DevCfg& c, EnvState& e, int i,
   if (c.hist) {
     int s0, s1;
     float alpha;
-    delay_slots(c, e.hist, c.pd_latency, s0, s1, alpha);
+    delay_slots(e.hist, c.pd_latency, c.pd_slots, c.pd_alpha, s0, s1, alpha);
 #pragma unroll
     for (int j = 0; j < 12; ++j) { qo[j] = delayed_word(c, i, s0, s1, alpha, j); qdo[j] = delayed_word(c, i, s0, s1, alpha, 12 + j); }
   }
@@ -245,19 +265,7 @@ __device__ __forceinline__ void rex_substep(const DevCfg& c, EnvState& e, int i,
     tau[j] = ((e.motor_en >> j) & 1u) ? act : 0.0f;                             // rex.py:617-623
   }
   physics_substep(e.ph, tau, c.dt, c.iterations, c.res_thr, sm, ground, armp);
-  if (c.hist) {                                                                  // ReceiveObservation, rex.py:726-733
-    const int head = ((int)(e.hist & 0xFFu) + 1) % REX_HISTORY_LEN;
-    const int len = min((int)((e.hist >> 8) & 0xFFu) + 1, REX_HISTORY_LEN);
-    e.hist = (uint32_t)head | ((uint32_t)len << 8);
-    if (live) {
-#pragma unroll
-      for (int j = 0; j < 12; ++j) { hist_at(c, i, head, j) = e.ph.q[j]; hist_at(c, i, head, 12 + j) = e.ph.qd[j]; hist_at(c, i, head, 24 + j) = tau_obs[j]; }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) hist_at(c, i, head, 36 + k) = e.ph.quat[k];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) hist_at(c, i, head, 40 + k) = e.ph.ang[k];
-    }
-  }
+  receive_observation(c, e, i, live, tau_obs);
 }
 
 // Rex._control_observation as the env-level getters see it (delayed by control_latency when the model is on)
@@ -265,7 +273,7 @@ template <int NM>
 __device__ __forceinline__ void control_observation(const DevCfg& c, const EnvState& e, int i, const float* tau_obs, CtrlObs& o) {
   if (c.hist) {
     int s0, s1; float alpha;
-    delay_slots(c, e.hist, c.control_latency, s0, s1, alpha);
+    delay_slots(e.hist, c.control_latency, c.control_slots, c.control_alpha, s0, s1, alpha);
 #pragma unroll
     for (int j = 0; j < 12; ++j) {
       o.q[j] = delayed_word(c, i, s0, s1, alpha, j); o.qd[j] = delayed_word(c, i, s0, s1, alpha, 12 + j);
@@ -311,24 +319,30 @@ __device__ __forceinline__ void env_observation(const DevCfg& c, const CtrlObs& 
   }
 }
 
-// RexWalkEnv.reset / RexReactiveEnv.reset draws on top of the settled snapshot
+// RexWalkEnv.reset / RexReactiveEnv.reset ... draws on top of the settled snapshot.  `seen` receives what the robot last
+// observed of its base (quaternion, angular velocity): the settled one -- the turn env teleports the base behind the
+// observation's back (turn_env.py:158-160), and reset() returns that older reading.
 template <int NM>
-__device__ __forceinline__ void env_reset(const DevCfg& c, const float* snap, int i, bool live, int gidx, EnvState& e) {
+__device__ __forceinline__ void env_reset(const DevCfg& c, const float* snap, int i, bool live, int gidx, EnvState& e, float* seen) {
   const int32_t episode = e.episode + 1;
-  load_env<NM>(snap, c.n_terrain > 0 ? c.n_terrain : 1, c.n_terrain > 0 ? terrain_index(c, gidx, episode) : 0, e);   // settled on this episode's terrain
-  if (c.hist) {   // the history restarts with the settled observation (observed torques are not part of the snapshot: 0)
-    e.hist = 0u | (1u << 8);
+  const float alpha = e.gait.alpha;   // the env keeps one GaitPlanner for life: its arc angle survives reset() (gait_planner.py:76-85)
+  const int nrec = c.n_terrain > 0 ? c.n_terrain : 1;
+  const int rec = c.n_terrain > 0 ? terrain_index(c, gidx, episode) : 0;
+  load_env<NM>(snap, nrec, rec, e);   // settled on this episode's terrain
+  if (c.hist) {   // the deque as the reset motion left it: its last 100 observations, ring position included (e.hist)
     if (live) {
-#pragma unroll
-      for (int j = 0; j < 12; ++j) { hist_at(c, i, 0, j) = e.ph.q[j]; hist_at(c, i, 0, 12 + j) = e.ph.qd[j]; hist_at(c, i, 0, 24 + j) = 0.0f; }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) hist_at(c, i, 0, 36 + k) = e.ph.quat[k];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) hist_at(c, i, 0, 40 + k) = e.ph.ang[k];
+      const float* ring = snap + (size_t)Lay<NM>::WORDS * nrec;
+#pragma unroll 8
+      for (int k = 0; k < REX_HISTORY_LEN * REX_HISTORY_WORDS; ++k) c.hist[(size_t)k * c.n + i] = ring[(size_t)k * nrec + rec];
     }
+    mirror_sync();
   } else e.hist = 0u;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) seen[k] = e.ph.quat[k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) seen[4 + k] = e.ph.ang[k];
   e.episode = episode;
-  e.gait.phi = 0.0f; e.gait.last_time = 0.0f; e.gait.alpha = 0.0f;
+  e.gait.phi = 0.0f; e.gait.last_time = 0.0f; e.gait.alpha = alpha;
   uint32_t ctr[4] = {(uint32_t)episode, 0u, 0u, 0u};
   philox4x32(ctr, c.seed_lo ^ (uint32_t)gidx, c.seed_hi);
   e.flags = 0;
@@ -578,7 +592,7 @@ __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __r
     float cq[4] = {e.ph.quat[0], e.ph.quat[1], e.ph.quat[2], e.ph.quat[3]};
     if (c.hist) {
       int s0, s1; float alpha;
-      delay_slots(c, e.hist, c.control_latency, s0, s1, alpha);
+      delay_slots(e.hist, c.control_latency, c.control_slots, c.control_alpha, s0, s1, alpha);
 #pragma unroll
       for (int k = 0; k < 4; ++k) cq[k] = delayed_word(c, i, s0, s1, alpha, 36 + k);
     }
@@ -636,10 +650,17 @@ __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __r
   if (c.max_steps > 0 && e.steps >= c.max_steps) done = true;
   if (done) e.flags |= REX_F_DONE;
   if (done && c.auto_reset) {
-    env_reset<NM>(c, snap, i, live, c.env_index_base + i, e);
+    float seen[7];
+    env_reset<NM>(c, snap, i, live, c.env_index_base + i, e, seen);
 #pragma unroll
     for (int j = 0; j < NM; ++j) tau_obs[j] = 0.0f;
     control_observation<NM>(c, e, i, tau_obs, co);
+    if (!c.hist) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) co.quat[k] = seen[k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) co.w[k] = seen[4 + k];
+    }
   }
 
   float obs[22];
@@ -694,23 +715,34 @@ __global__ __launch_bounds__(REX_WAVE) void rex_settle_kernel(DevCfg c, float* _
     for (int j = 12; j < NM; ++j) e.ph.q[j] = (float)REXA_REST[j - 12];
   }
   e.motor_en = (1u << NM) - 1u;
+  // the latency model runs through the reset motion as well (rex.py:309-323): the snapshot's own ring sits behind its
+  // state words, [100][43][nrec]; Reset() clears the deque, observes the dropped robot once if a motion follows,
+  // and observes the final state once more after it
+  DevCfg cs = c;
+  cs.hist = (c.pd_latency > 0.0f || c.control_latency > 0.0f) ? snap + (size_t)Lay<NM>::WORDS * nrec : nullptr;
+  cs.n = nrec;
+  const bool keeps = rec < nrec;
+  e.hist = (uint32_t)(REX_HISTORY_LEN - 1);
+  float tau_obs[NM];
+#pragma unroll
+  for (int j = 0; j < NM; ++j) tau_obs[j] = 0.0f;
   if (c.task != REX_TASK_POSES) {   // RexPosesEnv: base reset() with initial_motor_angles=None skips the motion (rex.py:308)
-    DevCfg cs = c;
-    cs.hist = nullptr;              // the reset motion runs without the latency model (the snapshot carries no history)
-    float cmd[NM], tau_obs[NM];
+    receive_observation(cs, e, t, keeps, tau_obs);
+    float cmd[NM];
     if (ARM) {
 #pragma unroll
       for (int j = 12; j < NM; ++j) cmd[j] = (float)REXA_REST[j - 12];
     }
 #pragma unroll
     for (int j = 0; j < 12; ++j) cmd[j] = pose_stand(j);
-    for (int k = 0; k < 100; ++k) rex_substep(cs, e, 0, false, cmd, tau_obs, sm, ground, armp);   // rex.py:315-318
+    for (int k = 0; k < 100; ++k) rex_substep(cs, e, t, keeps, cmd, tau_obs, sm, ground, armp);   // rex.py:315-318
 #pragma unroll
     for (int j = 0; j < 12; ++j) cmd[j] = reset_pose(c, j);
-    const int nreset = (int)(0.5f / c.dt);                                               // rex.py:319
-    for (int k = 0; k < nreset; ++k) rex_substep(cs, e, 0, false, cmd, tau_obs, sm, ground, armp);
+    for (int k = 0; k < c.reset_substeps; ++k) rex_substep(cs, e, t, keeps, cmd, tau_obs, sm, ground, armp);   // rex.py:319-322
   }
-  if (rec < nrec) store_env<NM>(snap, nrec, rec, e);
+  receive_observation(cs, e, t, keeps, tau_obs);                                                               // rex.py:323
+  if (!cs.hist) e.hist = 0u;
+  if (keeps) store_env<NM>(snap, nrec, rec, e);
 }
 
 template <int NM>
@@ -722,13 +754,19 @@ __global__ void rex_reset_kernel(DevCfg c, float* __restrict__ state, const floa
   if (i < 0 || i >= c.n) return;
   EnvState e;
   e.episode = (int32_t)ldi(state, c.n, Lay<NM>::EPISODE, i);
-  env_reset<NM>(c, snap, i, true, c.env_index_base + i, e);
+  e.gait.alpha = state[(size_t)Lay<NM>::ALPHA * c.n + i];
+  float seen[7];
+  env_reset<NM>(c, snap, i, true, c.env_index_base + i, e, seen);
   store_env<NM>(state, c.n, i, e);
   float obs[22], tz[NM];
 #pragma unroll
   for (int j = 0; j < NM; ++j) tz[j] = 0.0f;
   CtrlObs co;
   control_observation<NM>(c, e, i, tz, co);
+  if (!c.hist) {
+    for (int k = 0; k < 4; ++k) co.quat[k] = seen[k];
+    for (int k = 0; k < 3; ++k) co.w[k] = seen[4 + k];
+  }
   env_observation<NM>(c, co, obs);
   if (c.range_normalize) normalize_obs(c, obs);
   if (obs_out) for (int k = 0; k < c.obs_dim; ++k) obs_out[(size_t)r * c.obs_dim + k] = obs[k];
@@ -779,7 +817,7 @@ struct RexSim {
   int epw;          // envs per wave of rex_step_kernel
   int device;
   float* d_state;   // caller-owned
-  float* d_snap;    // REX_STATE_WORDS x (n_terrain or 1) floats, word-major
+  float* d_snap;    // state words x (n_terrain or 1) floats, word-major; then, with a latency, [100][43][records] rings
   hipEvent_t ev0, ev1;
   int timing;
   int have_timing;
@@ -869,6 +907,16 @@ static int pick_envs_per_wave(int n) {
 static void launch_step(RexSim* s, int blocks, hipStream_t st, const float* a, float* o, float* r, uint8_t* d, float* m);
 static void launch_settle(RexSim* s, int nrec, hipStream_t st, float* snap);
 
+// RexConfig carries its settings as float32; the reference computes its substep counts from the Python floats the
+// caller wrote (int(0.5 / 0.001) = 500, int(0.02 / 0.001) = 20), whose float32 quotients fall just below the integer.
+// The counts are therefore taken in double on the shortest decimal each float came from.
+static double as_written(float x) {
+  char buf[40];
+  snprintf(buf, sizeof buf, "%.7g", (double)x);
+  return strtod(buf, nullptr);
+}
+static size_t snapshot_floats(const RexSim* s, int nrec);
+
 static int validate(const RexConfig* c) {
   if (!c) return fail(REX_EINVAL, "null config%s", "");
   if (c->abi_version != REX_ABI_VERSION) return fail(REX_EINVAL, "RexConfig.abi_version mismatch%s", "");
@@ -881,6 +929,12 @@ static int validate(const RexConfig* c) {
   if (c->mark == REX_MARK_ARM && (c->pd_latency > 0.0f || c->control_latency > 0.0f))
     return fail(REX_EINVAL, "the latency model is not available with mark 'arm'%s", "");
   return REX_OK;
+}
+
+// a snapshot record: the state words, and behind all records the observation rings the reset motion leaves behind
+static size_t snapshot_floats(const RexSim* s, int nrec) {
+  const bool ring = s->cfg.pd_latency > 0.0f || s->cfg.control_latency > 0.0f;
+  return (size_t)nrec * ((size_t)s->words + (ring ? (size_t)REX_HISTORY_LEN * REX_HISTORY_WORDS : 0));
 }
 
 int rex_create(const RexConfig* cfg, int device, float* d_state, void* stream, RexSim** out) {
@@ -913,6 +967,12 @@ int rex_create(const RexConfig* cfg, int device, float* d_state, void* stream, R
   d.terrain = nullptr; d.terrain_mid = nullptr; d.n_terrain = 0; d.body_params = nullptr;
   d.hist = nullptr; d.pd_latency = cfg->pd_latency; d.control_latency = cfg->control_latency;
   {
+    const double dt = as_written(cfg->sim_time_step), pl = as_written(cfg->pd_latency), cl = as_written(cfg->control_latency);
+    d.pd_slots = (int)(pl / dt); d.pd_alpha = (float)((pl - d.pd_slots * dt) / dt);
+    d.control_slots = (int)(cl / dt); d.control_alpha = (float)((cl - d.control_slots * dt) / dt);
+    d.reset_substeps = (int)(0.5 / dt);
+  }
+  {
     float b;   /* walk_env.py:104-114, gallop_env.py:119-130 (low=+b, high=-b), turn_env.py:100-110, poses_env.py:115-117 */
     if (cfg->task == REX_TASK_WALK) b = cfg->signal == REX_SIGNAL_IK ? 0.4f : 0.01f;
     else if (cfg->task == REX_TASK_GALLOP) b = cfg->signal == REX_SIGNAL_IK ? -0.4f : -0.3f;
@@ -923,7 +983,7 @@ int rex_create(const RexConfig* cfg, int device, float* d_state, void* stream, R
     d.obs_hi_rate = (float)(2.0 * M_PI) / cfg->sim_time_step + 0.01f;
   }
   d.target_orient = cfg->target_orient; d.init_orient = cfg->init_orient; d.orient_fixed = cfg->orient_fixed;
-  hipError_t e = hipMalloc(&s->d_snap, sizeof(float) * s->words);
+  hipError_t e = hipMalloc(&s->d_snap, sizeof(float) * snapshot_floats(s, 1));
   if (e != hipSuccess) { delete s; return fail(REX_ENOMEM, "hipMalloc(snapshot): %s", hipGetErrorString(e)); }
   (void)hipEventCreate(&s->ev0);
   (void)hipEventCreate(&s->ev1);
@@ -947,7 +1007,7 @@ int rex_set_terrain(RexSim* s, const float* d_heights, const float* d_mids, int 
   hipStream_t st = (hipStream_t)stream;
   float* snap = nullptr;
   const int nrec = k > 0 ? k : 1;
-  HIPCHK(hipMalloc(&snap, sizeof(float) * s->words * (size_t)nrec));
+  HIPCHK(hipMalloc(&snap, sizeof(float) * snapshot_floats(s, nrec)));
   HIPCHK(hipStreamSynchronize(st));
   (void)hipFree(s->d_snap);
   s->d_snap = snap;
@@ -963,7 +1023,9 @@ int rex_set_terrain(RexSim* s, const float* d_heights, const float* d_mids, int 
 int rex_set_history(RexSim* s, float* d_history) {
   if (!s) return fail(REX_EINVAL, "rex_set_history: null sim%s", "");
   if (s->cfg.mark == REX_MARK_ARM && d_history) return fail(REX_EINVAL, "rex_set_history: not available with mark 'arm'%s", "");
-  s->dev.hist = d_history;
+  // without a latency the delayed observation IS the newest one (rex.py:744-745): the ring is not needed, and the
+  // snapshot holds none to restore from
+  s->dev.hist = (s->cfg.pd_latency > 0.0f || s->cfg.control_latency > 0.0f) ? d_history : nullptr;
   return REX_OK;
 }
 

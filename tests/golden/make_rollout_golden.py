@@ -234,7 +234,7 @@ def main():
         nstep = sum(e["kind"] == "step" for e in events)
         ndone = sum(e.get("done", False) for e in events)
         print(f"{name}: {nstep} steps, {ndone} done, last x = {events[-1]['body'][0]:+.4f}")
-        out["scenarios"].append(dict(name=name, oracle_config=ocfg, events=events))
+        out["scenarios"].append(dict(name=name, env_class=cls.__name__, env_kwargs=kwargs, oracle_config=ocfg, events=events))
     print("client calls with nothing to do:", sorted(OraclePhysicsClient.unknown_calls))
     path = os.path.join(HERE, "rollout_golden.json")
     with open(path, "w") as f:

@@ -2,6 +2,7 @@
 and is checked against the CPU oracle / the golden vectors.  Tolerances are written next to each check.
 Run on the MI355X box: python -m pytest tests -m gpu"""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -763,4 +764,50 @@ def test_goal_brake_and_hold_sequence_on_the_gpu(torch, task, signal):
         np.testing.assert_allclose(ps[orclib.S_ENDTIME], os_[orclib.S_ENDTIME], atol=1e-6)
         seen.update((os_[orclib.S_FLAGS].astype(int) & 7).tolist())
     assert 3 in seen and (7 in seen or (task, signal) == ("gallop", "ik"))   # goal+terminating, then hold (gallop-IK never holds)
+    env.close()
+
+
+def _rollout_scenarios():
+    import json
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rollout_golden.json")) as f:
+        return json.load(f)["scenarios"]
+
+
+@pytest.mark.parametrize("sc", _rollout_scenarios(), ids=lambda s: s["name"])
+def test_hip_path_reproduces_reference_rollouts(torch, sc):
+    """The rollouts the reference's own env / robot code produced over the oracle's rigid-body step
+    (tests/golden/make_rollout_golden.py), replayed on the HIP path through the reference's constructor arguments:
+    reset observation, then per step observation, reward, done and motor command.  fp32 against fp64 along a contact-rich
+    trajectory: the command (no physics in it until the goal logic reads the base) must agree to float rounding, the
+    rest to the single-step tolerances of this file accumulated over the episode."""
+    from rex_gym_amd import RexBatchEnv
+    n = 8
+    kw = dict(sc["env_kwargs"])
+    task = sc["oracle_config"]["task"]
+    signal = kw.pop("signal_type", sc["oracle_config"]["signal"])
+    env = RexBatchEnv(n, task=task, signal_type=signal, **kw)
+    worst = dict(obs=0.0, rate=0.0, reward=0.0, cmd=0.0)
+    since_reset = 0
+    for k, ev in enumerate(sc["events"]):
+        if ev["kind"] == "reset":
+            obs = env.reset().cpu().numpy()
+            since_reset = 0
+        else:
+            a = np.tile(np.asarray(ev["action"], np.float32), (n, 1))
+            o, r, d, info = env.step(torch.as_tensor(a, device="cuda"))
+            obs = o.cpu().numpy()
+            since_reset += 1
+            if since_reset > 25:     # fp32 vs fp64 along contacts: the comparison stops before rounding differences dominate
+                continue
+            assert d.cpu().numpy().astype(bool).tolist() == [ev["done"]] * n, f"event {k}: done"
+            worst["reward"] = max(worst["reward"], float(np.max(np.abs(r.cpu().numpy() - ev["reward"]))))
+            worst["cmd"] = max(worst["cmd"], float(np.max(np.abs(info["action"].cpu().numpy() - np.asarray(ev["cmd"])))))
+        ref = np.asarray(ev["obs"])
+        assert np.all(obs == obs[0]), "identical envs must stay identical"
+        err = np.abs(obs[0] - ref)
+        rates = np.zeros(len(ref), bool); rates[2:4] = True          # roll / pitch rate: O(1) rad/s signals
+        worst["obs"] = max(worst["obs"], float(err[~rates].max()))
+        worst["rate"] = max(worst["rate"], float(err[rates].max()))
+    print(sc["name"], worst)
+    assert worst["cmd"] < 2e-5 and worst["obs"] < 2e-3 and worst["rate"] < 5e-2 and worst["reward"] < 2e-3, worst
     env.close()
