@@ -811,3 +811,20 @@ def test_hip_path_reproduces_reference_rollouts(torch, sc):
     print(sc["name"], worst)
     assert worst["cmd"] < 2e-5 and worst["obs"] < 2e-3 and worst["rate"] < 5e-2 and worst["reward"] < 2e-3, worst
     env.close()
+
+
+def test_policy_player_runs_a_checkpoint_on_the_batch_env(torch, tmp_path):
+    """SimplePPOPolicy + play() on device tensors: a bundle written here stands in for a shipped checkpoint."""
+    from test_agents_policy_player import policy_tensors, write_bundle
+    from rex_gym_amd import RexBatchEnv
+    from rex_gym_amd.agents.policy_player import SimplePPOPolicy, play
+    prefix = str(tmp_path / "model.ckpt-9")
+    write_bundle(prefix, policy_tensors(np.random.RandomState(5), obs_dim=4, layers=(200, 100), action_dim=2))
+    env = RexBatchEnv(96, task="walk", signal_type="ik", seed=4)
+    policy = SimplePPOPolicy(env, prefix)
+    obs = env.reset()
+    a = policy.get_action(obs)
+    assert a.is_cuda and tuple(a.shape) == (96, 2) and bool((a.abs() <= 0.4 + 1e-6).all())
+    ret, length, ended = play(env, policy, max_steps=60)
+    assert tuple(ret.shape) == (96,) and bool(torch.isfinite(ret).all()) and int(length.max()) == 60 and not bool(ended.any())
+    env.close()
