@@ -147,13 +147,17 @@ class OraclePhysicsClient:
     getMatrixFromQuaternion = staticmethod(matrix_from_quaternion)
 
 
-for name in ["pybullet", "pybullet_data", "gym", "gym.spaces", "gym.utils", "gym.utils.seeding"]:
+for name in ["pybullet", "pybullet_data", "gym", "gym.spaces", "gym.utils", "gym.utils.seeding", "tensorflow"]:
     sys.modules[name] = types.ModuleType(name)
+_quiet = types.SimpleNamespace(info=lambda *a, **k: None, warning=lambda *a, **k: None, error=lambda *a, **k: None)
+sys.modules["tensorflow"].logging = _quiet               # agents/tools/wrappers.py only logs through tensorflow
+sys.modules["tensorflow"].compat = types.SimpleNamespace(v1=types.SimpleNamespace(logging=_quiet))
 pb = sys.modules["pybullet"]
 pb.getMatrixFromQuaternion = matrix_from_quaternion      # rex_gym_env.py:527 calls the module, not the client
 pb.GUI, pb.DIRECT, pb.SHARED_MEMORY = 1, 2, 3
 sys.modules["gym"].Env = type("Env", (), {})
-sys.modules["gym.spaces"].Box = lambda low, high, dtype=None: types.SimpleNamespace(low=np.asarray(low), high=np.asarray(high))
+sys.modules["gym.spaces"].Box = lambda low, high, dtype=None: types.SimpleNamespace(low=np.asarray(low), high=np.asarray(high),
+                                                                                     shape=np.asarray(low).shape)
 sys.modules["gym"].spaces = sys.modules["gym.spaces"]
 sys.modules["gym"].utils = sys.modules["gym.utils"]
 sys.modules["gym.utils"].seeding = sys.modules["gym.utils.seeding"]
@@ -164,6 +168,7 @@ import rex_gym.model.gait_planner as gp                          # noqa: E402
 import rex_gym.util.bullet_client as bullet_client               # noqa: E402
 bullet_client.BulletClient = OraclePhysicsClient                 # the one substitution: the physics server
 from rex_gym.envs.gym import gallop_env, poses_env, standup_env, turn_env, walk_env   # noqa: E402
+from rex_gym.agents.tools import wrappers                        # noqa: E402
 
 SCENARIOS = [
     # name, env class, constructor kwargs, oracle config kwargs, steps, episodes
@@ -190,6 +195,12 @@ SCENARIOS = [
      dict(task="poses", signal="ik", pose_index=3, pose_value=0.3), 60, 1),
     ("standup", standup_env.RexStandupEnv, dict(),
      dict(task="standup", signal="ol"), 60, 2),
+    # the training stack of playground/trainer.py:47-52 around the env: LimitDuration, RangeNormalize, ClipAction,
+    # ConvertTo32Bit; actions are drawn beyond [-1, 1] so that the clip is exercised
+    ("walk_ik_wrapped", walk_env.RexWalkEnv, dict(target_position=1.0, backwards=False, signal_type="ik", wrap=25),
+     dict(task="walk", signal="ik", target_position=1.0, backwards=0, range_normalize=1, max_episode_steps=25), 40, 3),
+    ("gallop_ol_wrapped", gallop_env.RexReactiveEnv, dict(target_position=2.0, signal_type="ol", wrap=20),
+     dict(task="gallop", signal="ol", target_position=2.0, range_normalize=1, max_episode_steps=20), 40, 2),
 ]
 
 
@@ -199,28 +210,33 @@ def action_space(env):
     return lo, hi
 
 
-def body(env):
-    c = env._pybullet_client
-    return c.st.tolist()
+def body(client):
+    return client.st.tolist()
 
 
 def run(name, cls, kwargs, steps, episodes, seed):
     gp_clock = types.SimpleNamespace(env=None)
     gp.time.time = lambda: gp_clock.env.rex.GetTimeSinceReset() if gp_clock.env is not None and hasattr(gp_clock.env, "rex") else 0.0
     random.seed(seed)
+    kwargs = dict(kwargs)
+    wrap = kwargs.pop("wrap", None)
     env = cls(render=False, terrain_id="plane", **kwargs)   # the reference's constructor (terrain_id as its CLI passes it): hard reset, drop, settle
     gp_clock.env = env
     rng = np.random.RandomState(seed)
     lo, hi = action_space(env)
+    client = env._pybullet_client
+    if wrap:                                          # playground/trainer.py:47-52
+        env = wrappers.ConvertTo32Bit(wrappers.ClipAction(wrappers.RangeNormalize(wrappers.LimitDuration(env, wrap))))
+        lo, hi = -1.5 * np.ones_like(lo), 1.5 * np.ones_like(hi)
     events = []
     for ep in range(episodes):
         obs = env.reset()                             # soft reset (hard_reset=False after the constructor)
-        events.append(dict(kind="reset", obs=np.asarray(obs, float).tolist(), body=body(env)))
+        events.append(dict(kind="reset", obs=np.asarray(obs, float).tolist(), body=body(client)))
         for k in range(steps):
             a = rng.uniform(lo, hi)
             obs, reward, done, info = env.step(a)
             events.append(dict(kind="step", action=a.tolist(), obs=np.asarray(obs, float).tolist(), reward=float(reward),
-                               done=bool(done), cmd=np.asarray(info["action"], float).tolist(), body=body(env)))
+                               done=bool(done), cmd=np.asarray(info["action"], float).tolist(), body=body(client)))
             if done:
                 break
     return events

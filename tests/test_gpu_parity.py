@@ -785,6 +785,8 @@ def test_hip_path_reproduces_reference_rollouts(torch, sc):
     kw = dict(sc["env_kwargs"])
     task = sc["oracle_config"]["task"]
     signal = kw.pop("signal_type", sc["oracle_config"]["signal"])
+    if "wrap" in kw:    # the reference's training stack around the env (LimitDuration, RangeNormalize, ClipAction): folded into the launch
+        kw.update(range_normalize=True, max_episode_steps=kw.pop("wrap"))
     env = RexBatchEnv(n, task=task, signal_type=signal, **kw)
     worst = dict(obs=0.0, rate=0.0, reward=0.0, cmd=0.0)
     since_reset = 0
