@@ -195,6 +195,9 @@ SCENARIOS = [
      dict(task="poses", signal="ik", pose_index=3, pose_value=0.3), 60, 1),
     ("standup", standup_env.RexStandupEnv, dict(),
      dict(task="standup", signal="ol"), 60, 2),
+    # a forward walk until the robot falls (is_fallen -> done, rex_gym_env.py:490-499), then the next episode
+    ("walk_ik_until_fallen", walk_env.RexWalkEnv, dict(target_position=2.0, backwards=False, signal_type="ik"),
+     dict(task="walk", signal="ik", target_position=2.0, backwards=0), 400, 2),
     # the training stack of playground/trainer.py:47-52 around the env: LimitDuration, RangeNormalize, ClipAction,
     # ConvertTo32Bit; actions are drawn beyond [-1, 1] so that the clip is exercised
     ("walk_ik_wrapped", walk_env.RexWalkEnv, dict(target_position=1.0, backwards=False, signal_type="ik", wrap=25),
@@ -224,13 +227,19 @@ def run(name, cls, kwargs, steps, episodes, seed):
     gp_clock.env = env
     rng = np.random.RandomState(seed)
     lo, hi = action_space(env)
-    client = env._pybullet_client
+    client, client_env = env._pybullet_client, env
     if wrap:                                          # playground/trainer.py:47-52
         env = wrappers.ConvertTo32Bit(wrappers.ClipAction(wrappers.RangeNormalize(wrappers.LimitDuration(env, wrap))))
         lo, hi = -1.5 * np.ones_like(lo), 1.5 * np.ones_like(hi)
     events = []
     for ep in range(episodes):
         obs = env.reset()                             # soft reset (hard_reset=False after the constructor)
+        # The reference's planner phase runs on the wall clock (gait_planner.py:108-110) and simply continues across
+        # episodes; here the phase clock is simulation time since reset ("clock deviation"), so the
+        # phase bookkeeping restarts with it.  The arc angle `_alpha` is NOT touched: it carries over, as in the reference.
+        planner = getattr(client_env, "_gait_planner", None)
+        if planner is not None:
+            planner._phi, planner._last_time = 0.0, 0.0
         events.append(dict(kind="reset", obs=np.asarray(obs, float).tolist(), body=body(client)))
         for k in range(steps):
             a = rng.uniform(lo, hi)
