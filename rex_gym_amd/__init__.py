@@ -9,3 +9,4 @@ __version__ = "0.1.0"
 from .envs.batch_env import RexBatchEnv  # noqa: F401
 from .envs.mixed_env import RexMixedBatchEnv  # noqa: F401
 from .envs.spaces import Box  # noqa: F401
+from .envs.registry import ENV_IDS, make  # noqa: F401

@@ -830,3 +830,19 @@ def test_policy_player_runs_a_checkpoint_on_the_batch_env(torch, tmp_path):
     ret, length, ended = play(env, policy, max_steps=60)
     assert tuple(ret.shape) == (96,) and bool(torch.isfinite(ret).all()) and int(length.max()) == 60 and not bool(ended.any())
     env.close()
+
+
+def test_make_builds_the_registered_envs_with_their_step_limits(torch):
+    import rex_gym_amd
+    for env_id, (task, limit) in rex_gym_amd.ENV_IDS.items():
+        env = rex_gym_amd.make(env_id, num_envs=8)
+        assert env.task == task and env.num_envs == 8
+        env.reset()
+        _, _, done, _ = env.step(torch.zeros((8, env.action_dim), device="cuda"))
+        assert done.shape == (8,)
+        env.close()
+    env = rex_gym_amd.make("RexPoses-v0", num_envs=4, max_episode_steps=3)       # the limit ends the episode (poses never falls)
+    env.reset()
+    dones = [bool(env.step(torch.zeros((4, 1), device="cuda"))[2].all()) for _ in range(3)]
+    assert dones == [False, False, True]
+    env.close()

@@ -125,3 +125,14 @@ def test_shard_arithmetic():
     assert s.env_kwargs() == {"num_envs": 8192, "env_index_base": 24576}
     with pytest.raises(ValueError):
         Shard(0, 3, 10)
+
+
+def test_registered_env_ids_mirror_the_reference():
+    """playground/__init__.py:19-58: ids, step limits; RexGo-v0 dangles there and fails here too."""
+    from rex_gym_amd.envs import registry
+    assert registry.ENV_IDS == {"RexGalloping-v0": ("gallop", 1000), "RexWalk-v0": ("walk", 2500), "RexTurn-v0": ("turn", 1000),
+                                "RexStandup-v0": ("standup", 400), "RexPoses-v0": ("poses", 400)}
+    with pytest.raises(ModuleNotFoundError):
+        registry.make("RexGo-v0")
+    with pytest.raises(KeyError):
+        registry.make("RexFly-v0")
