@@ -31,16 +31,38 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
 FP32_PEAK_TFLOPS = 157.3
 
 
+def usable_cores():
+    """CPUs this process may actually run on: the affinity mask, capped by the cgroup CPU quota (the GPU boxes show 256
+    logical CPUs but grant 16 CPUs of time; 256 OpenMP threads on that quota run 5x slower than 16-32)."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                      # cgroup v2: "<quota> <period>" or "max <period>"
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            cores = min(cores, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:     # cgroup v1
+                quota = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                period = int(f.read())
+            if quota > 0:
+                cores = min(cores, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    return cores
+
+
 def cpu_baseline(max_seconds=20.0):
     """Time the CPU oracle (a restatement, NOT PyBullet) on the host cores: bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
     import orclib
-    cores = os.cpu_count() or 1
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
-    n = 32 * cores
+    cores = usable_cores()
+    n = ENVS_PER_GPU            # the GPU line's own batch
     cfg = orclib.default_config("walk", "ik", n, seed=0, auto_reset=1, max_episode_steps=2000)
     env = orclib.OracleEnv(cfg, np.float32)
+    threads = int(env.o.lib.orc_set_threads(cores))
     env.reset()
     rng = np.random.RandomState(0)
     acts = rng.uniform(-0.4, 0.4, (8, n, 2)).astype(np.float32)
@@ -51,11 +73,12 @@ def cpu_baseline(max_seconds=20.0):
         env.step(acts[steps % 8])
         steps += 1
         dt = time.perf_counter() - t0
-        if dt > max_seconds or steps >= 200:
+        if dt > max_seconds or steps >= 2000:
             break
     env.close()
-    return {"value": n * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{n} envs x {steps} steps walk-IK, oracle/rex_oracle.c fp32 build, OpenMP over envs "
+    return {"value": n * steps / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
+            "sample": f"{n} envs x {steps} steps walk-IK, oracle/rex_oracle.c fp32 build, OpenMP over envs on "
+                      f"{threads} threads = the CPUs this container is granted "
                       f"({dt:.1f} s); CPU restatement, not PyBullet (pybullet is not installable here)"}
 
 

@@ -1426,6 +1426,14 @@ static void env_step(Orc* o, int idx, const real* action_in, real* obs, real* re
 
 /* ---------------------------------- batch API (mirrors include/rexsim.h) ---------------------------------- */
 ORC_API int orc_sizeof_real(void) { return (int)sizeof(real); }
+/* thread count of the OpenMP loops over envs (the environment variable is read once, when the first OpenMP runtime of
+ * the process initialises -- in a torch process long before this library is loaded) */
+#ifdef _OPENMP
+#include <omp.h>
+ORC_API int orc_set_threads(int n) { if (n > 0) omp_set_num_threads(n); return omp_get_max_threads(); }
+#else
+ORC_API int orc_set_threads(int n) { (void)n; return 1; }
+#endif
 
 ORC_API void* orc_create(const RexConfig* cfg) {
   Orc* o = (Orc*)calloc(1, sizeof(Orc));
