@@ -357,7 +357,8 @@ if __name__ == "__main__":   # python -m rex_gym_amd.agents.ppo --task walk --en
     ap.add_argument("--envs", type=int, default=1024); ap.add_argument("--iterations", type=int, default=20)
     ap.add_argument("--max-length", type=int, default=500); ap.add_argument("--seed", type=int, default=0)
     a = ap.parse_args()
-    env = RexBatchEnv(a.envs, task=a.task, signal_type=a.signal, seed=a.seed, max_episode_steps=a.max_length)
+    # the reference trains through RangeNormalize + ClipAction (playground/trainer.py:48-52): actions in [-1, 1]
+    env = RexBatchEnv(a.envs, task=a.task, signal_type=a.signal, seed=a.seed, max_episode_steps=a.max_length, range_normalize=True)
     agent = PPOAgent(a.envs, env.obs_dim, env.action_dim, PPOConfig(update_every=a.envs, max_length=a.max_length), seed=a.seed)
     for it in range(a.iterations):
         score, length = train(env, agent, a.max_length)
