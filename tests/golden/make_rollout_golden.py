@@ -147,26 +147,33 @@ class OraclePhysicsClient:
     getMatrixFromQuaternion = staticmethod(matrix_from_quaternion)
 
 
-for name in ["pybullet", "pybullet_data", "gym", "gym.spaces", "gym.utils", "gym.utils.seeding", "tensorflow"]:
+# `--real-pybullet` (on a machine where `import pybullet, pybullet_data, gym` work; not possible in the build container, so
+# this branch has never run): nothing is substituted, the very same scenarios run on the real engine and go to
+# pybullet_rollout_golden.json -- the fixture that would pin the physics half (tests/test_oracle_rollouts.py picks it up
+# and reports the oracle's trajectory error against it).
+REAL = "--real-pybullet" in sys.argv
+for name in ["tensorflow"] if REAL else ["pybullet", "pybullet_data", "gym", "gym.spaces", "gym.utils", "gym.utils.seeding", "tensorflow"]:
     sys.modules[name] = types.ModuleType(name)
 _quiet = types.SimpleNamespace(info=lambda *a, **k: None, warning=lambda *a, **k: None, error=lambda *a, **k: None)
 sys.modules["tensorflow"].logging = _quiet               # agents/tools/wrappers.py only logs through tensorflow
 sys.modules["tensorflow"].compat = types.SimpleNamespace(v1=types.SimpleNamespace(logging=_quiet))
-pb = sys.modules["pybullet"]
-pb.getMatrixFromQuaternion = matrix_from_quaternion      # rex_gym_env.py:527 calls the module, not the client
-pb.GUI, pb.DIRECT, pb.SHARED_MEMORY = 1, 2, 3
-sys.modules["gym"].Env = type("Env", (), {})
-sys.modules["gym.spaces"].Box = lambda low, high, dtype=None: types.SimpleNamespace(low=np.asarray(low), high=np.asarray(high),
-                                                                                     shape=np.asarray(low).shape)
-sys.modules["gym"].spaces = sys.modules["gym.spaces"]
-sys.modules["gym"].utils = sys.modules["gym.utils"]
-sys.modules["gym.utils"].seeding = sys.modules["gym.utils.seeding"]
-sys.modules["gym.utils.seeding"].np_random = lambda seed=None: (np.random.RandomState(seed), seed)
-sys.modules["pybullet_data"].getDataPath = lambda: "/nonexistent"
+if not REAL:
+    pb = sys.modules["pybullet"]
+    pb.getMatrixFromQuaternion = matrix_from_quaternion      # rex_gym_env.py:527 calls the module, not the client
+    pb.GUI, pb.DIRECT, pb.SHARED_MEMORY = 1, 2, 3
+    sys.modules["gym"].Env = type("Env", (), {})
+    sys.modules["gym.spaces"].Box = lambda low, high, dtype=None: types.SimpleNamespace(low=np.asarray(low), high=np.asarray(high),
+                                                                                         shape=np.asarray(low).shape)
+    sys.modules["gym"].spaces = sys.modules["gym.spaces"]
+    sys.modules["gym"].utils = sys.modules["gym.utils"]
+    sys.modules["gym.utils"].seeding = sys.modules["gym.utils.seeding"]
+    sys.modules["gym.utils.seeding"].np_random = lambda seed=None: (np.random.RandomState(seed), seed)
+    sys.modules["pybullet_data"].getDataPath = lambda: "/nonexistent"
 
 import rex_gym.model.gait_planner as gp                          # noqa: E402
 import rex_gym.util.bullet_client as bullet_client               # noqa: E402
-bullet_client.BulletClient = OraclePhysicsClient                 # the one substitution: the physics server
+if not REAL:
+    bullet_client.BulletClient = OraclePhysicsClient             # the one substitution: the physics server
 from rex_gym.envs.gym import gallop_env, poses_env, standup_env, turn_env, walk_env   # noqa: E402
 from rex_gym.agents.tools import wrappers                        # noqa: E402
 
@@ -214,7 +221,13 @@ def action_space(env):
 
 
 def body(client):
-    return client.st.tolist()
+    if not REAL:
+        return client.st.tolist()
+    rex = body.env.rex                                # the same 13 + 2 x motors words read back from the real engine
+    pos, orn = client.getBasePositionAndOrientation(rex.quadruped)
+    lin, ang = client.getBaseVelocity(rex.quadruped)
+    js = [client.getJointState(rex.quadruped, j) for j in rex._motor_id_list]
+    return list(pos) + list(orn) + list(lin) + list(ang) + [j[0] for j in js] + [j[1] for j in js]
 
 
 def run(name, cls, kwargs, steps, episodes, seed):
@@ -228,6 +241,7 @@ def run(name, cls, kwargs, steps, episodes, seed):
     rng = np.random.RandomState(seed)
     lo, hi = action_space(env)
     client, client_env = env._pybullet_client, env
+    body.env = env
     if wrap:                                          # playground/trainer.py:47-52
         env = wrappers.ConvertTo32Bit(wrappers.ClipAction(wrappers.RangeNormalize(wrappers.LimitDuration(env, wrap))))
         lo, hi = -1.5 * np.ones_like(lo), 1.5 * np.ones_like(hi)
@@ -252,7 +266,8 @@ def run(name, cls, kwargs, steps, episodes, seed):
 
 
 def main():
-    out = dict(description="reference env/robot code over the oracle's rigid-body step; see make_rollout_golden.py",
+    out = dict(description=("reference env/robot code on real pybullet" if REAL else
+                            "reference env/robot code over the oracle's rigid-body step") + "; see make_rollout_golden.py",
                scenarios=[])
     for i, (name, cls, kwargs, ocfg, steps, episodes) in enumerate(SCENARIOS):
         events = run(name, cls, kwargs, steps, episodes, seed=100 + i)
@@ -261,7 +276,7 @@ def main():
         print(f"{name}: {nstep} steps, {ndone} done, last x = {events[-1]['body'][0]:+.4f}")
         out["scenarios"].append(dict(name=name, env_class=cls.__name__, env_kwargs=kwargs, oracle_config=ocfg, events=events))
     print("client calls with nothing to do:", sorted(OraclePhysicsClient.unknown_calls))
-    path = os.path.join(HERE, "rollout_golden.json")
+    path = os.path.join(HERE, "pybullet_rollout_golden.json" if REAL else "rollout_golden.json")
     with open(path, "w") as f:
         json.dump(out, f)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")

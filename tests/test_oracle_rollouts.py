@@ -50,3 +50,34 @@ def test_oracle_reproduces_reference_rollout(sc):
         assert max(worst.values()) < 1e-3, f"event {k} ({ev['kind']}): {worst}"
     print(sc["name"], worst)
     assert max(worst.values()) < TOL, worst
+
+
+PYBULLET_GOLDEN = os.path.join(HERE, "golden", "pybullet_rollout_golden.json")
+
+
+@pytest.mark.skipif(not os.path.exists(PYBULLET_GOLDEN),
+                    reason="no pybullet rollouts committed (generate with make_rollout_golden.py --real-pybullet where pybullet "
+                           "is installed): the physics half stays 'parity unpinned'")
+def test_oracle_against_real_pybullet_rollouts():
+    """The fixture that would pin the physics: the same scenarios on the real engine.  Reports the joint-angle RMSE and
+    base-position error of the oracle over the first 200 control steps of every scenario (BASELINE.json's metric)."""
+    with open(PYBULLET_GOLDEN) as f:
+        scenarios = json.load(f)["scenarios"]
+    report = {}
+    for sc in scenarios:
+        kw = dict(sc["oracle_config"])
+        mark = "arm" if kw.get("mark", 0) == 1 else "base"
+        env = orclib.OracleEnv(orclib.default_config(kw.pop("task"), kw.pop("signal"), num_envs=1, auto_reset=0, **kw), np.float64, mark)
+        nm = env.o.num_motors
+        sq, n, pos = 0.0, 0, 0.0
+        for ev in sc["events"][:201]:
+            if ev["kind"] == "reset":
+                env.reset()
+            else:
+                env.step(np.asarray(ev["action"])[None, :])
+            st, ref = env.get_state()[:, 0], np.asarray(ev["body"])
+            sq += float(np.sum((st[13:13 + nm] - ref[13:13 + nm]) ** 2)); n += nm
+            pos = max(pos, float(np.max(np.abs(st[0:3] - ref[0:3]))))
+        report[sc["name"]] = dict(joint_rmse=(sq / n) ** 0.5, base_pos_err=pos)
+    print(json.dumps(report, indent=1))
+    assert max(r["joint_rmse"] for r in report.values()) < 1e-3, report     # BASELINE.json: joint-angle RMSE < 1e-3 rad
