@@ -846,3 +846,37 @@ def test_make_builds_the_registered_envs_with_their_step_limits(torch):
     dones = [bool(env.step(torch.zeros((4, 1), device="cuda"))[2].all()) for _ in range(3)]
     assert dones == [False, False, True]
     env.close()
+
+
+@pytest.mark.parametrize("n", [64, 8195])
+def test_latency_ring_survives_in_launch_auto_reset(torch, n):
+    """With a latency configured the observation ring is part of what reset() restores (the reference's deque holds the
+    last 100 observations of the reset motion, rex.py:309-323).  In-launch auto-reset must restore it exactly: with a
+    fixed target and direction and the same actions, the second episode repeats the first bit for bit, and both follow
+    the oracle."""
+    from rex_gym_amd import RexBatchEnv
+    kw = dict(task="walk", signal_type="ik", target_position=1.0, backwards=False, pd_latency=0.003, control_latency=0.0125,
+              auto_reset=True, max_episode_steps=12, seed=2)
+    env = RexBatchEnv(n, **kw)
+    cfg = orclib.default_config("walk", "ik", 4, target_position=1.0, backwards=0, pd_latency=0.003, control_latency=0.0125,
+                                auto_reset=1, max_episode_steps=12, seed=2)
+    orc = orclib.OracleEnv(cfg, np.float32)
+    first = env.reset().clone()
+    orc.reset()
+    rng = np.random.RandomState(11)
+    acts = rng.uniform(-0.4, 0.4, (12, 2)).astype(np.float32)
+    episodes = []
+    for ep in range(3):
+        seq = []
+        for k in range(12):
+            o, r, d, _ = env.step(torch.as_tensor(np.tile(acts[k], (n, 1)), device="cuda"))
+            assert bool(d.all()) == (k == 11)
+            seq.append(torch.cat([o, r[:, None]], dim=1).clone())
+            oo, orr, od, _ = orc.step(np.tile(acts[k], (4, 1)))
+            np.testing.assert_allclose(o[:4].cpu().numpy(), oo, atol=2e-3)
+            np.testing.assert_allclose(r[:4].cpu().numpy(), orr, atol=1e-4)
+        assert torch.equal(seq[-1][:, :first.shape[1]], first), "the observation after the auto-reset is the reset observation"
+        episodes.append(torch.stack(seq))
+    assert torch.equal(episodes[0], episodes[1]) and torch.equal(episodes[1], episodes[2])
+    assert bool((episodes[0] == episodes[0][:, :1]).all()), "identical envs stay identical across the lane groups of a wave"
+    env.close()
