@@ -3,7 +3,7 @@ SoA layout (include/rexsim.h) and the oracle's numeric layout, and lock-step rol
 import numpy as np
 
 import orclib
-from orclib import INT_WORDS, STATE_WORDS
+
 
 
 def product_state_to_numeric(state_tensor):

@@ -3,7 +3,6 @@
 import math
 
 import numpy as np
-import pytest
 import torch
 
 from rex_gym_amd.agents import PPOAgent, PPOConfig, StreamingNormalize, train
