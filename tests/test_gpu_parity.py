@@ -1,7 +1,6 @@
 """GPU parity tests proper: every call goes through the C ABI of librexsim_hip.so (via rex_gym_amd),
 and is checked against the CPU oracle / the golden vectors.  Tolerances are written next to each check.
 Run on the MI355X box: python -m pytest tests -m gpu"""
-import ctypes
 import os
 
 import numpy as np
