@@ -162,8 +162,16 @@ if not REAL:
     pb.getMatrixFromQuaternion = matrix_from_quaternion      # rex_gym_env.py:527 calls the module, not the client
     pb.GUI, pb.DIRECT, pb.SHARED_MEMORY = 1, 2, 3
     sys.modules["gym"].Env = type("Env", (), {})
-    sys.modules["gym.spaces"].Box = lambda low, high, dtype=None: types.SimpleNamespace(low=np.asarray(low), high=np.asarray(high),
-                                                                                         shape=np.asarray(low).shape)
+    class _Box:                                          # what rex_gym and its wrappers use of gym.spaces.Box
+        def __init__(self, low, high, dtype=None):
+            self.low, self.high = np.asarray(low), np.asarray(high)
+            self.shape = self.low.shape
+        def contains(self, x):
+            x = np.asarray(x)
+            return x.shape == self.shape and bool(np.all(x >= self.low)) and bool(np.all(x <= self.high))
+        def __eq__(self, other):
+            return np.array_equal(self.low, other.low) and np.array_equal(self.high, other.high)
+    sys.modules["gym.spaces"].Box = _Box
     sys.modules["gym"].spaces = sys.modules["gym.spaces"]
     sys.modules["gym"].utils = sys.modules["gym.utils"]
     sys.modules["gym.utils"].seeding = sys.modules["gym.utils.seeding"]
@@ -176,6 +184,7 @@ if not REAL:
     bullet_client.BulletClient = OraclePhysicsClient             # the one substitution: the physics server
 from rex_gym.envs.gym import gallop_env, poses_env, standup_env, turn_env, walk_env   # noqa: E402
 from rex_gym.agents.tools import wrappers                        # noqa: E402
+from rex_gym.agents.tools.batch_env import BatchEnv              # noqa: E402
 
 SCENARIOS = [
     # name, env class, constructor kwargs, oracle config kwargs, steps, episodes
@@ -205,6 +214,9 @@ SCENARIOS = [
     # a forward walk until the robot falls (is_fallen -> done, rex_gym_env.py:490-499), then the next episode
     ("walk_ik_until_fallen", walk_env.RexWalkEnv, dict(target_position=2.0, backwards=False, signal_type="ik"),
      dict(task="walk", signal="ik", target_position=2.0, backwards=0), 400, 2),
+    # three turn-IK envs behind the reference's BatchEnv, each inside the training stack; per-env actions, resets by index
+    ("turn_ik_batch", turn_env.RexTurnEnv, dict(target_orient=2.0, init_orient=0.5, signal_type="ik", wrap=15, batch=3),
+     dict(task="turn", signal="ik", target_orient=2.0, init_orient=0.5, orient_fixed=3, range_normalize=1, max_episode_steps=15), 50, 1),
     # the training stack of playground/trainer.py:47-52 around the env: LimitDuration, RangeNormalize, ClipAction,
     # ConvertTo32Bit; actions are drawn beyond [-1, 1] so that the clip is exercised
     ("walk_ik_wrapped", walk_env.RexWalkEnv, dict(target_position=1.0, backwards=False, signal_type="ik", wrap=25),
@@ -230,30 +242,91 @@ def body(client):
     return list(pos) + list(orn) + list(lin) + list(ang) + [j[0] for j in js] + [j[1] for j in js]
 
 
-def run(name, cls, kwargs, steps, episodes, seed):
-    gp_clock = types.SimpleNamespace(env=None)
-    gp.time.time = lambda: gp_clock.env.rex.GetTimeSinceReset() if gp_clock.env is not None and hasattr(gp_clock.env, "rex") else 0.0
-    random.seed(seed)
+ENV_OF_PLANNER = {}
+
+
+def planner_clock():
+    """time.time() as GaitPlanner.loop sees it: the simulation time of the env that owns the calling planner."""
+    planner = sys._getframe(1).f_locals.get("self")
+    env = ENV_OF_PLANNER.get(id(planner))
+    return env.rex.GetTimeSinceReset() if env is not None and hasattr(env, "rex") else 0.0
+
+
+def restart_phase(env):
+    """The reference's planner phase runs on the wall clock (gait_planner.py:108-110) and simply continues across
+    episodes; here the phase clock is simulation time since reset ("clock deviation"), so the phase
+    bookkeeping restarts with it.  The arc angle `_alpha` is NOT touched: it carries over, as in the reference."""
+    planner = getattr(env, "_gait_planner", None)
+    if planner is not None:
+        planner._phi, planner._last_time = 0.0, 0.0
+
+
+def build_env(cls, kwargs):
     kwargs = dict(kwargs)
     wrap = kwargs.pop("wrap", None)
+    kwargs.pop("batch", None)
     env = cls(render=False, terrain_id="plane", **kwargs)   # the reference's constructor (terrain_id as its CLI passes it): hard reset, drop, settle
-    gp_clock.env = env
-    rng = np.random.RandomState(seed)
-    lo, hi = action_space(env)
-    client, client_env = env._pybullet_client, env
-    body.env = env
+    if getattr(env, "_gait_planner", None) is not None:
+        ENV_OF_PLANNER[id(env._gait_planner)] = env
+    inner = env
     if wrap:                                          # playground/trainer.py:47-52
         env = wrappers.ConvertTo32Bit(wrappers.ClipAction(wrappers.RangeNormalize(wrappers.LimitDuration(env, wrap))))
+    return env, inner
+
+
+def run_batch(name, cls, kwargs, steps, seed):
+    """N envs behind the reference's BatchEnv (agents/tools/batch_env.py), stepped with per-env actions; finished envs are
+    reset by index the way simulate() does (agents/tools/simulate.py:70-81), and one env is reset early by index."""
+    gp.time.time = planner_clock
+    random.seed(seed)
+    n = kwargs["batch"]
+    pairs = [build_env(cls, kwargs) for _ in range(n)]
+    batch = BatchEnv([e for e, _ in pairs], blocking=True)
+    inners = [i for _, i in pairs]
+    rng = np.random.RandomState(seed)
+    events = []
+
+    def snapshot():
+        return [i._pybullet_client.st.tolist() for i in inners]
+
+    def reset(indices):
+        obs = batch.reset(None if indices is None else np.asarray(indices))
+        for k in (range(n) if indices is None else indices):
+            restart_phase(inners[k])
+        events.append(dict(kind="reset", indices=None if indices is None else [int(k) for k in indices],
+                           obs=np.asarray(obs, float).tolist(), body=snapshot()))
+
+    reset(None)
+    done = np.zeros(n, bool)
+    for k in range(steps):
+        if done.any():
+            reset(np.nonzero(done)[0].tolist())
+        if k == 7:
+            reset([1])                                 # an env taken out of its episode early
+        a = rng.uniform(-1.5, 1.5, (n, len(inners[0].action_space.low)))
+        obs, reward, done, info = batch.step(a)
+        events.append(dict(kind="step", action=a.tolist(), obs=np.asarray(obs, float).tolist(),
+                           reward=np.asarray(reward, float).tolist(), done=np.asarray(done, bool).tolist(),
+                           cmd=[np.asarray(i["action"], float).tolist() for i in info], body=snapshot()))
+    return events
+
+
+def run(name, cls, kwargs, steps, episodes, seed):
+    if "batch" in kwargs:
+        return run_batch(name, cls, kwargs, steps, seed)
+    gp.time.time = planner_clock
+    random.seed(seed)
+    env, client_env = build_env(cls, kwargs)
+    rng = np.random.RandomState(seed)
+    lo, hi = action_space(client_env)
+    client = client_env._pybullet_client
+    body.env = client_env
+    if "wrap" in kwargs:
         lo, hi = -1.5 * np.ones_like(lo), 1.5 * np.ones_like(hi)
     events = []
     for ep in range(episodes):
         obs = env.reset()                             # soft reset (hard_reset=False after the constructor)
-        # The reference's planner phase runs on the wall clock (gait_planner.py:108-110) and simply continues across
-        # episodes; here the phase clock is simulation time since reset ("clock deviation"), so the
-        # phase bookkeeping restarts with it.  The arc angle `_alpha` is NOT touched: it carries over, as in the reference.
-        planner = getattr(client_env, "_gait_planner", None)
-        if planner is not None:
-            planner._phi, planner._last_time = 0.0, 0.0
+        restart_phase(client_env)
         events.append(dict(kind="reset", obs=np.asarray(obs, float).tolist(), body=body(client)))
         for k in range(steps):
             a = rng.uniform(lo, hi)
@@ -272,8 +345,8 @@ def main():
     for i, (name, cls, kwargs, ocfg, steps, episodes) in enumerate(SCENARIOS):
         events = run(name, cls, kwargs, steps, episodes, seed=100 + i)
         nstep = sum(e["kind"] == "step" for e in events)
-        ndone = sum(e.get("done", False) for e in events)
-        print(f"{name}: {nstep} steps, {ndone} done, last x = {events[-1]['body'][0]:+.4f}")
+        ndone = sum(int(np.sum(e.get("done", False))) for e in events)
+        print(f"{name}: {nstep} steps, {ndone} done")
         out["scenarios"].append(dict(name=name, env_class=cls.__name__, env_kwargs=kwargs, oracle_config=ocfg, events=events))
     print("client calls with nothing to do:", sorted(OraclePhysicsClient.unknown_calls))
     path = os.path.join(HERE, "pybullet_rollout_golden.json" if REAL else "rollout_golden.json")

@@ -780,35 +780,42 @@ def test_hip_path_reproduces_reference_rollouts(torch, sc):
     trajectory: the command (no physics in it until the goal logic reads the base) must agree to float rounding, the
     rest to the single-step tolerances of this file accumulated over the episode."""
     from rex_gym_amd import RexBatchEnv
-    n = 8
     kw = dict(sc["env_kwargs"])
+    batch = kw.pop("batch", None)       # N different envs behind the reference's BatchEnv (per-env actions, resets by index)
+    n = batch or 8                      # otherwise 8 copies of the one env
     task = sc["oracle_config"]["task"]
     signal = kw.pop("signal_type", sc["oracle_config"]["signal"])
     if "wrap" in kw:    # the reference's training stack around the env (LimitDuration, RangeNormalize, ClipAction): folded into the launch
         kw.update(range_normalize=True, max_episode_steps=kw.pop("wrap"))
     env = RexBatchEnv(n, task=task, signal_type=signal, **kw)
     worst = dict(obs=0.0, rate=0.0, reward=0.0, cmd=0.0)
-    since_reset = 0
+    since_reset = np.zeros(n, int)
+    rows = (lambda x: np.asarray(x)) if batch else (lambda x: np.tile(np.asarray(x), (n, 1)) if np.ndim(x) else np.full(n, x))
     for k, ev in enumerate(sc["events"]):
         if ev["kind"] == "reset":
-            obs = env.reset().cpu().numpy()
-            since_reset = 0
+            idx = ev.get("indices")
+            if idx is None:
+                obs, ref, who = env.reset().cpu().numpy(), rows(ev["obs"]), np.arange(n)
+            else:
+                obs, ref, who = env.reset(idx).cpu().numpy(), np.asarray(ev["obs"]), np.asarray(idx)
+            since_reset[who] = 0
         else:
-            a = np.tile(np.asarray(ev["action"], np.float32), (n, 1))
-            o, r, d, info = env.step(torch.as_tensor(a, device="cuda"))
-            obs = o.cpu().numpy()
+            o, r, d, info = env.step(torch.as_tensor(rows(ev["action"]).astype(np.float32), device="cuda"))
+            obs, ref, who = o.cpu().numpy(), rows(ev["obs"]), np.arange(n)
             since_reset += 1
-            if since_reset > 25:     # fp32 vs fp64 along contacts: the comparison stops before rounding differences dominate
+            live = since_reset <= 25     # fp32 vs fp64 along contacts: the comparison stops before rounding differences dominate
+            if not live.any():
                 continue
-            assert d.cpu().numpy().astype(bool).tolist() == [ev["done"]] * n, f"event {k}: done"
-            worst["reward"] = max(worst["reward"], float(np.max(np.abs(r.cpu().numpy() - ev["reward"]))))
-            worst["cmd"] = max(worst["cmd"], float(np.max(np.abs(info["action"].cpu().numpy() - np.asarray(ev["cmd"])))))
-        ref = np.asarray(ev["obs"])
-        assert np.all(obs == obs[0]), "identical envs must stay identical"
-        err = np.abs(obs[0] - ref)
-        rates = np.zeros(len(ref), bool); rates[2:4] = True          # roll / pitch rate: O(1) rad/s signals
-        worst["obs"] = max(worst["obs"], float(err[~rates].max()))
-        worst["rate"] = max(worst["rate"], float(err[rates].max()))
+            assert (d.cpu().numpy().astype(bool) == rows(ev["done"]).astype(bool))[live].all(), f"event {k}: done"
+            worst["reward"] = max(worst["reward"], float(np.max(np.abs(r.cpu().numpy() - rows(ev["reward"]))[live])))
+            worst["cmd"] = max(worst["cmd"], float(np.max(np.abs(info["action"].cpu().numpy() - rows(ev["cmd"]))[live])))
+            obs, ref = obs[live], ref[live]
+        if not batch:
+            assert np.all(obs == obs[0]), "identical envs must stay identical"
+        err = np.abs(obs - ref)
+        rates = np.zeros(ref.shape[1], bool); rates[2:4] = True          # roll / pitch rate: O(1) rad/s signals
+        worst["obs"] = max(worst["obs"], float(err[:, ~rates].max()))
+        worst["rate"] = max(worst["rate"], float(err[:, rates].max()))
     print(sc["name"], worst)
     assert worst["cmd"] < 2e-5 and worst["obs"] < 2e-3 and worst["rate"] < 5e-2 and worst["reward"] < 2e-3, worst
     env.close()

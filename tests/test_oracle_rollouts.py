@@ -28,24 +28,33 @@ TOL = 2e-7
 def test_oracle_reproduces_reference_rollout(sc):
     kw = dict(sc["oracle_config"])
     mark = "arm" if kw.get("mark", 0) == 1 else "base"
-    cfg = orclib.default_config(kw.pop("task"), kw.pop("signal"), num_envs=1, auto_reset=0, **kw)
+    n = sc["env_kwargs"].get("batch", 1)        # batch scenarios: N envs behind the reference's BatchEnv, resets by index
+    cfg = orclib.default_config(kw.pop("task"), kw.pop("signal"), num_envs=n, auto_reset=0, **kw)
     env = orclib.OracleEnv(cfg, np.float64, mark)
     nm = env.o.num_motors
     worst = dict(obs=0.0, reward=0.0, cmd=0.0, body=0.0)
+    batched = "batch" in sc["env_kwargs"]
+    shape = (lambda x: np.asarray(x)) if batched else (lambda x: np.asarray(x)[None])
+    obs = np.zeros((n, env.obs_dim))
     for k, ev in enumerate(sc["events"]):
         if ev["kind"] == "reset":
-            obs = env.reset()[0]
+            idx = ev.get("indices")
+            if idx is None:
+                obs = env.reset()
+                ref_obs = shape(ev["obs"])
+            else:                                     # BatchEnv.reset(indices) returns the rows of those envs only
+                obs = env.reset(idx)
+                ref_obs = np.asarray(ev["obs"])
         else:
-            o, r, d, c = env.step(np.asarray(ev["action"])[None, :])
-            obs = o[0]
-            assert bool(d[0]) == ev["done"], f"event {k}: done"
-            worst["reward"] = max(worst["reward"], abs(float(r[0]) - ev["reward"]))
-            worst["cmd"] = max(worst["cmd"], float(np.max(np.abs(c[0] - np.asarray(ev["cmd"])))))
-        body = env.get_state()[:13 + 2 * nm, 0]
-        worst["obs"] = max(worst["obs"], float(np.max(np.abs(obs - np.asarray(ev["obs"])))))
-        # velocities are O(1..10): compare relative to their scale
-        ref = np.asarray(ev["body"])
-        scale = np.maximum(1.0, np.abs(ref))
+            obs, r, d, c = env.step(shape(ev["action"]))
+            ref_obs = shape(ev["obs"])
+            assert d.tolist() == np.atleast_1d(ev["done"]).tolist(), f"event {k}: done"
+            worst["reward"] = max(worst["reward"], float(np.max(np.abs(r - np.atleast_1d(ev["reward"])))))
+            worst["cmd"] = max(worst["cmd"], float(np.max(np.abs(c - shape(ev["cmd"])))))
+        body = env.get_state()[:13 + 2 * nm].T
+        worst["obs"] = max(worst["obs"], float(np.max(np.abs(obs - ref_obs))))
+        ref = shape(ev["body"])
+        scale = np.maximum(1.0, np.abs(ref))            # velocities are O(1..10): compare relative to their scale
         worst["body"] = max(worst["body"], float(np.max(np.abs(body - ref) / scale)))
         assert max(worst.values()) < 1e-3, f"event {k} ({ev['kind']}): {worst}"
     print(sc["name"], worst)
