@@ -211,6 +211,11 @@ SCENARIOS = [
      dict(task="poses", signal="ik", pose_index=3, pose_value=0.3), 60, 1),
     ("standup", standup_env.RexStandupEnv, dict(),
      dict(task="standup", signal="ol"), 60, 2),
+    # mark 'arm' under the other observation / reset shapes: gallop returns 4 + 18 motor angles, standup starts crouched
+    ("gallop_ik_arm", gallop_env.RexReactiveEnv, dict(target_position=2.0, signal_type="ik", mark="arm"),
+     dict(task="gallop", signal="ik", target_position=2.0, mark=1), 25, 1),
+    ("standup_arm", standup_env.RexStandupEnv, dict(mark="arm"),
+     dict(task="standup", signal="ol", mark=1), 25, 1),
     # a forward walk until the robot falls (is_fallen -> done, rex_gym_env.py:490-499), then the next episode
     ("walk_ik_until_fallen", walk_env.RexWalkEnv, dict(target_position=2.0, backwards=False, signal_type="ik"),
      dict(task="walk", signal="ik", target_position=2.0, backwards=0), 400, 2),
