@@ -175,7 +175,10 @@ REX_API int rex_set_body_params(RexSim* sim, const float* d_params);
 /* Observation-history ring for the latency model (Rex._observation_history, deque(maxlen=100) of 43-vectors:
  * q, qd, observed torque, base quaternion, base angular velocity; model/rex.py:122,717-763).  d_history: caller-owned
  * device buffer of REX_HISTORY_LEN * REX_HISTORY_WORDS * num_envs float32, laid out [slot][word][env].  Required only
- * when pd_latency or control_latency is non-zero. */
+ * when pd_latency or control_latency is non-zero (without a latency the delayed observation is the newest one and the
+ * buffer is not used).  The latency model also runs through the reset motion (rex.py:309-323): every reset, by call or
+ * in-launch, restores an env's ring to the 100 observations the reset motion leaves behind, so that an episode starts
+ * exactly as the reference's does. */
 #define REX_HISTORY_LEN 100
 #define REX_HISTORY_WORDS 43
 REX_API int rex_set_history(RexSim* sim, float* d_history);
