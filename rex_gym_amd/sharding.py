@@ -44,17 +44,18 @@ def shard_from_env(num_envs_total):
     return Shard(int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), num_envs_total)
 
 
-def gather_rollout(segment, group=None):
+def gather_rollout(segment, group=None, always=False):
     """All-gather one rollout segment to every rank (the learner hand-off).
 
     segment: dict name -> tensor [T, N_local, ...] (same T and dtypes on every rank).
     Returns dict name -> tensor [T, N_total, ...] in global env order.
     One all_gather per tensor per segment: at 29 B/env-step (walk-IK) a 25-step segment of 65 536
     envs is 47.5 MB in total, i.e. latency-bound on xGMI; never call this per step.
+    `always` issues the collectives even with one rank (exercises the backend's dtype support).
     """
     import torch
     import torch.distributed as dist
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_available() or not dist.is_initialized() or (dist.get_world_size(group) == 1 and not always):
         return dict(segment)
     world = dist.get_world_size(group)
     out = {}

@@ -886,3 +886,32 @@ def test_latency_ring_survives_in_launch_auto_reset(torch, n):
     assert torch.equal(episodes[0], episodes[1]) and torch.equal(episodes[1], episodes[2])
     assert bool((episodes[0] == episodes[0][:, :1]).all()), "identical envs stay identical across the lane groups of a wave"
     env.close()
+
+
+def test_rollout_gather_runs_on_rccl(torch):
+    """The learner hand-off (rex_gym_amd/sharding.py) on the real backend: backend "nccl" is RCCL on ROCm.  One rank is
+    all a 1-GPU box allows (RCCL refuses two ranks on one device); the collectives are still issued, for every dtype a
+    rollout segment carries (float32 observations / actions / rewards, bool done flags).  The multi-rank layout is
+    covered on CPU with gloo (tests/test_sharding_gloo.py)."""
+    import torch.distributed as dist
+    from rex_gym_amd import RexBatchEnv
+    from rex_gym_amd.sharding import Shard, gather_rollout
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29517")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        shard = Shard(0, 1, 64)
+        env = RexBatchEnv(task="walk", signal_type="ik", seed=5, **shard.env_kwargs())
+        env.reset()
+        seg = dict(obs=[], action=[], reward=[], done=[])
+        for k in range(5):
+            a = torch.zeros((64, 2), device="cuda")
+            o, r, d, _ = env.step(a)
+            seg["obs"].append(o.clone()); seg["action"].append(a); seg["reward"].append(r.clone()); seg["done"].append(d.clone())
+        seg = {k: torch.stack(v) for k, v in seg.items()}
+        out = gather_rollout(seg, always=True)
+        for k in seg:
+            assert out[k].dtype == seg[k].dtype and torch.equal(out[k], seg[k]), k
+        env.close()
+    finally:
+        dist.destroy_process_group()
