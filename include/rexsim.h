@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define REX_ABI_VERSION 2
+#define REX_ABI_VERSION 3
 #define REX_API __attribute__((visibility("default")))
 
 /* tasks (reference env classes) */
@@ -39,6 +39,9 @@ extern "C" {
 #define REX_TASK_TURN   2   /* envs/gym/turn_env.py   RexTurnEnv      */
 #define REX_TASK_POSES  3   /* envs/gym/poses_env.py  RexPosesEnv     */
 #define REX_TASK_STANDUP 4  /* envs/gym/standup_env.py RexStandupEnv  (the signal kwarg is unused by the env) */
+#define REX_TASK_MIXED  5   /* every env runs ONE of the tasks in RexConfig.task_mix, drawn per env from its global
+                               index (BASELINE.json configs[4]: the reference gets such a batch by handing BatchEnv a
+                               list of different env objects, agents/tools/batch_env.py:21-44) */
 /* signal_type kwarg of the reference envs */
 #define REX_SIGNAL_IK 0
 #define REX_SIGNAL_OL 1
@@ -137,6 +140,32 @@ typedef struct RexConfig {
      and overheat blocks grow to 18 motors, every other word keeps its order), d_motor_cmd rows are 18 wide and the
      gallop observation is 4 + 18; the latency model (43-word history records) is not offered. */
   int32_t mark;
+  /* ---- ABI 3 ---- */
+  /* GaitPlanner.loop reads WALL-CLOCK time (model/gait_planner.py:108-110: `time.time()`), so the reference's gait
+     runs at (wall seconds per simulated second) x the nominal rate of the host it runs on: rendered / real-time
+     playback = 1, a host that simulates faster than real time < 1, slower (GUI mode, many worker processes per core)
+     > 1.  The gait phase clock here is simulated time x gait_clock_scale.  0 means 1.0. */
+  float   gait_clock_scale;
+  /* 1: contact rows for the link collision boxes (base, chassis, shoulder, leg, foot boxes of rex.urdf) against the
+     ground, next to the toe rows; 0: toes only (the fast path; the boxes of a robot that satisfies its env's
+     termination test stay clear of the ground). */
+  int32_t body_contacts;
+  /* Rex(observation_noise_stdev=...) (model/rex.py:22,765-769): Gaussian noise added by the sensor getters --
+     [0] motor angles, [1] motor velocities, [2] motor torques, [3] base roll/pitch/yaw, [4] base angular rates.
+     Every getter call of the reference draws afresh; here every call site of a step draws from the env's Philox
+     stream (counter = episode, step, call site).  All 0 (the reference default): no draws. */
+  float   noise_stdev[5];
+  /* REX_TASK_MIXED: bit t set = task t is in the mix.  Env g runs task_of(g) = the (Philox(seed; g) mod count)-th set
+     bit for its whole life (a reference env object never changes class).  All envs use `signal`; the action row is
+     as wide as the widest task of the mix, the observation row likewise (narrower tasks leave the tail 0). */
+  int32_t task_mix;
+  /* Per-reset domain randomisation (the env_randomizer hook, rex_gym_env.py:345-346, turning the knobs of
+     Rex.SetBaseMasses / SetLegMasses, model/rex.py:659-692, plus the foot friction): on every reset env g draws
+     base-mass scale, leg-mass scale ~ U(mass_scale_lo, mass_scale_hi) and foot friction ~ U(friction_lo, friction_hi)
+     from its Philox stream (counter = episode).  lo == hi == 0: off (that quantity keeps its URDF value, or the
+     rex_set_body_params entry).  As with changeDynamics(mass=...), inertia tensors keep their load-time values, and
+     the reset motion is the nominal robot's (the reference randomises after Rex.Reset). */
+  float   mass_scale_lo, mass_scale_hi, friction_lo, friction_hi;
 } RexConfig;
 
 typedef struct RexSim RexSim;

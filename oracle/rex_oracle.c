@@ -94,11 +94,12 @@ static real m_com(int i, int k) {
 #endif
   return (real)REX_COM[i][k];
 }
+static real P_INERTIA_SCALE, P_LEG_INERTIA_ADD;
 static real m_inertia(int i, int k) {
 #ifdef REX_ARM
-  if (i >= REX_NB) return (real)REXA_INERTIA[i - REX_NB][k];
+  if (i >= REX_NB) return (real)REXA_INERTIA[i - REX_NB][k] * P_INERTIA_SCALE;
 #endif
-  return (real)REX_INERTIA[i][k];
+  return (real)REX_INERTIA[i][k] * P_INERTIA_SCALE + (i >= 1 && k < 3 ? P_LEG_INERTIA_ADD : 0);
 }
 static void m_joint_pos(int i, real r[3]) {
 #ifdef REX_ARM
@@ -147,6 +148,21 @@ static real FRICTION_MU = (real)0.5;      /* toe 0.5 x plane 1.0, 9.2-7 (variabl
 static long DBG_HIST[64] = {0};
 static long DBG_SWEEPS = 0, DBG_SUBSTEPS = 0; /* solver statistics (tests / tuning) */
 static real DBG_JOINT_FRICTION = 0, DBG_JOINT_VISC = 0; /* sensitivity probe only (off by default) */
+/* ---- sensitivity probes over the Bullet-behaviour assumptions of SURVEY.md 9.2 (tools/physics_sensitivity.py).
+ * Every probe defaults to the value the product kernels use; changing one changes the oracle only. ---- */
+static real DBG_GAIT_CLOCK = 1;          /* wall-clock seconds per simulated second seen by GaitPlanner.loop */
+static real P_ERP = CONTACT_ERP;          /* contact / joint-limit error reduction (btContactSolverInfo::m_erp2) */
+static real P_SLOP = 0;                   /* btContactSolverInfo::m_linearSlop: penetration = distance + slop */
+static real P_INERTIA_SCALE = 1;          /* rotational inertias of all links x this */
+static real P_LEG_INERTIA_ADD = 0;        /* kg m^2 added to every leg link's principal inertias (rotor / armature) */
+static int P_TOE_MODE = 2;                /* toe manifold stand-in: 2 = both cylinder ends, 1 = the lower end only,
+                                             4 = both ends + the arc points 0.3 rad before / behind the lowest line */
+static int P_LIMIT_EXACT = 0;             /* 1: joint-limit rows only once the bound is reached (Bullet's literal rule) */
+static real P_BREAKING = CONTACT_BREAKING;
+static real P_MARGIN = (real)REX_COLLISION_MARGIN;
+static int P_FRICTION_DIRS = 2;           /* 1: btPlaneSpace1's first tangent only (no SOLVER_USE_2_FRICTION_DIRECTIONS) */
+static int P_CONE = 0;                    /* 1: friction pair clamped to the cone instead of the pyramid */
+static real P_COVER_COM_Z = 0;            /* z of the 0.5 kg leg covers' centre of mass in the leg-link frame (URDF: 0) */
 static real clampr(real x, real lo, real hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
 /* =====================================================================================
@@ -645,7 +661,7 @@ static void impulse_response_at(const Aba* A, int kbody, const real fk[6], real 
 #define HF_N 256
 #define HF_CELL ((real)0.05)
 #define HF_INV_CELL ((real)20.0)    /* 1 / HF_CELL: written as a product on both sides (oracle and kernels) */
-typedef struct { const float* h; real mid; real base_mass_scale, leg_mass_scale, mu; int has_params; } Ground;
+typedef struct { const float* h; real mid; real base_mass_scale, leg_mass_scale, mu; int has_params; int body_contacts; } Ground;
 
 static void ground_query(const Ground* g, real x, real y, real* height, real n[3]) {
   n[0] = 0; n[1] = 0; n[2] = 1; *height = 0;
@@ -677,13 +693,15 @@ static void plane_space(const real n[3], real p[3], real q[3]) {
   }
 }
 
-#define MAX_POINTS 8
+#define MAX_TOE_POINTS 16
+#define MAX_POINTS (MAX_TOE_POINTS + 4 * REX_NBOX)   /* toe manifold points + the bottom face of every link box */
 #define MAX_ROWS (3 * MAX_POINTS + NJ)
 #define LIMIT_ACTIVATION ((real)0.15)  /* a limit row further away than this cannot act: |qd| dt <= 100 * 1e-3 */
 typedef struct {
   real J[NDOF], resp[NDOF];
   real rhs, invdiag, lo, hi, lambda;
   int normal_row; /* for friction rows: index of the normal row that bounds them; -1 for normals */
+  int pair_row;   /* friction rows: the other tangent row of the same point (cone probe), else -1 */
 } Row;
 
 /* Jacobian row of world direction d at world point P on body kbody, in (base body coords, joints) */
@@ -707,6 +725,15 @@ static void contact_jacobian(const Aba* A, int kbody, const real P[3], const rea
   for (int k = 0; k < 6; ++k) J[k] = phi[k];
 }
 
+/* body-vs-ground contact rows (config: RexConfig.body_contacts): the link collision boxes of rex.urdf:15-33,63-108,
+ * 119-124,151-156,170-175 against the ground.  Bullet's box-box detector clips the box face that looks at the ground
+ * and keeps at most four points per pair, PENETRATING ones only (a toe hull goes through GJK, which reports the
+ * closest points of separated shapes as well); here the candidates of a box are the four corners of its face most
+ * aligned with the ground normal under its centre, each against the ground under ITSELF, active once below it. */
+#define BODY_ACTIVATION ((real)0.0)
+static int BODY_CONTACTS = 0;
+static long DBG_BODY_POINTS = 0, DBG_BODY_SUBSTEPS = 0;   /* statistics (single-threaded census runs): active body points, substeps with any */
+
 /* one 1 ms world step: the restated stepSimulation */
 static void physics_substep(Phys* s, const real tau[NJ], real dt, int iterations, real residual_threshold, const Ground* ground) {
   static __thread Aba A;
@@ -728,13 +755,13 @@ static void physics_substep(Phys* s, const real tau[NJ], real dt, int iterations
   /* contact detection at the start-of-step pose: the two end points of each toe cylinder against the
    * ground.  Per end: ground normal n0 under the end centre -> the point of the end circle that is lowest
    * along n0 -> ground height / normal under THAT point -> signed distance to the local ground plane. */
-  Row rows[MAX_ROWS];
+  static __thread Row rows[MAX_ROWS];
   int nrow = 0, npoint = 0;
   int normal_of_point[MAX_POINTS];
   real PtP[MAX_POINTS][3], PtN[MAX_POINTS][3];
   int PtBody[MAX_POINTS];
   real PtDist[MAX_POINTS];
-  const real rad = (real)REX_TOE_RADIUS + (real)REX_COLLISION_MARGIN;
+  const real rad = (real)REX_TOE_RADIUS + P_MARGIN;
   for (int l = 0; l < REX_NLEG; ++l) {
     int kb = REX_TOE_BODY[l];
     real ctr[3] = {(real)REX_TOE_CENTER[l][0], (real)REX_TOE_CENTER[l][1], (real)REX_TOE_CENTER[l][2]};
@@ -743,6 +770,7 @@ static void physics_substep(Phys* s, const real tau[NJ], real dt, int iterations
     matvec3(A.Rw[kb], ctr, cw);
     matvec3(A.Rw[kb], axl, aw);
     for (int k = 0; k < 3; ++k) cw[k] += A.pw[kb][k];
+    int first = npoint;
     for (int e = 0; e < 2; ++e) {
       real sgn = e == 0 ? (real)-1 : (real)1;
       real ce[3], n0[3], h0;
@@ -752,18 +780,75 @@ static void physics_substep(Phys* s, const real tau[NJ], real dt, int iterations
       real dv[3] = {n0[0] - na * aw[0], n0[1] - na * aw[1], n0[2] - na * aw[2]};
       real dn = sqrt(dot3(dv, dv));
       real inv = dn > (real)1e-9 ? 1 / dn : 0;
-      real P[3], n[3], h;
-      for (int k = 0; k < 3; ++k) P[k] = ce[k] - rad * inv * dv[k];
-      ground_query(ground, P[0], P[1], &h, n);
-      real dist = (P[2] - h) * n[2];
-      if (dist < CONTACT_BREAKING) {
-        memcpy(PtP[npoint], P, sizeof(P));
-        memcpy(PtN[npoint], n, sizeof(n));
-        PtBody[npoint] = kb;
-        PtDist[npoint] = dist;
-        ++npoint;
+      int narc = P_TOE_MODE == 4 ? 3 : 1;
+      for (int a = 0; a < narc; ++a) {
+        /* probe: extra manifold points on the arc, 0.3 rad either side of the lowest line (rotation about the axis) */
+        real ang = a == 0 ? 0 : (a == 1 ? (real)0.3 : (real)-0.3);
+        real u[3] = {-inv * dv[0], -inv * dv[1], -inv * dv[2]}, t[3], dir[3];
+        cross3(aw, u, t);
+        for (int k = 0; k < 3; ++k) dir[k] = cos(ang) * u[k] + sin(ang) * t[k];
+        real P[3], n[3], h;
+        for (int k = 0; k < 3; ++k) P[k] = ce[k] + rad * dir[k];
+        ground_query(ground, P[0], P[1], &h, n);
+        real dist = (P[2] - h) * n[2];
+        if (dist < P_BREAKING) {
+          memcpy(PtP[npoint], P, sizeof(P));
+          memcpy(PtN[npoint], n, sizeof(n));
+          PtBody[npoint] = kb;
+          PtDist[npoint] = dist;
+          ++npoint;
+        }
       }
     }
+    if (P_TOE_MODE == 1 && npoint - first == 2) {   /* probe: a single manifold point, the lower end */
+      int keep = PtDist[first] <= PtDist[first + 1] ? first : first + 1;
+      if (keep != first) { memcpy(PtP[first], PtP[keep], sizeof(PtP[0])); memcpy(PtN[first], PtN[keep], sizeof(PtN[0])); PtDist[first] = PtDist[keep]; }
+      npoint = first + 1;
+    }
+  }
+  const int toe_points = npoint;
+  if (BODY_CONTACTS || (ground && ground->body_contacts)) {
+    for (int b = 0; b < REX_NBOX; ++b) {
+      int kb = REX_BOX_BODY[b];
+      real cl[3] = {(real)REX_BOX_CENTER[b][0], (real)REX_BOX_CENTER[b][1], (real)REX_BOX_CENTER[b][2]};
+      real cw[3];
+      matvec3(A.Rw[kb], cl, cw);
+      for (int k = 0; k < 3; ++k) cw[k] += A.pw[kb][k];
+      real n0[3], h0;
+      ground_query(ground, cw[0], cw[1], &h0, n0);
+      /* reach of the box along the ground normal, per box axis: the face axis is the largest */
+      real reach[3], sg[3];
+      for (int ax = 0; ax < 3; ++ax) {
+        real e_n = A.Rw[kb][0][ax] * n0[0] + A.Rw[kb][1][ax] * n0[1] + A.Rw[kb][2][ax] * n0[2];
+        reach[ax] = (real)REX_BOX_HALF[b][ax] * fabs(e_n);
+        sg[ax] = e_n > 0 ? (real)-1 : (real)1;      /* the side of the box that looks at the ground */
+      }
+      if ((cw[2] - h0) * n0[2] - (reach[0] + reach[1] + reach[2]) >= (real)0.05) continue;   /* far above */
+      int fa = 0;
+      if (reach[1] > reach[fa]) fa = 1;
+      if (reach[2] > reach[fa]) fa = 2;
+      int a1 = (fa + 1) % 3, a2 = (fa + 2) % 3;
+      for (int c = 0; c < 4; ++c) {
+        real loc[3];
+        loc[fa] = sg[fa] * (real)REX_BOX_HALF[b][fa];
+        loc[a1] = ((c & 1) ? (real)1 : (real)-1) * (real)REX_BOX_HALF[b][a1];
+        loc[a2] = ((c & 2) ? (real)1 : (real)-1) * (real)REX_BOX_HALF[b][a2];
+        real P[3], n[3], h;
+        matvec3(A.Rw[kb], loc, P);
+        for (int k = 0; k < 3; ++k) P[k] += cw[k];
+        ground_query(ground, P[0], P[1], &h, n);
+        real dist = (P[2] - h) * n[2];
+        if (dist < BODY_ACTIVATION) {
+          memcpy(PtP[npoint], P, sizeof(P));
+          memcpy(PtN[npoint], n, sizeof(n));
+          PtBody[npoint] = kb;
+          PtDist[npoint] = dist;
+          ++npoint;
+          ++DBG_BODY_POINTS;
+        }
+      }
+    }
+    if (npoint > toe_points) ++DBG_BODY_SUBSTEPS;
   }
   /* non-contact rows come first in every sweep (btMultiBodyConstraintSolver::solveSingleIteration): the URDF joint
    * limits (btMultiBodyJointLimitConstraint, one unilateral row per bound).  Bullet creates both rows for every joint;
@@ -774,6 +859,7 @@ static void physics_substep(Phys* s, const real tau[NJ], real dt, int iterations
     int lower = lo_gap < hi_gap;
     real gap = lower ? lo_gap : hi_gap;
     if (gap >= LIMIT_ACTIVATION) continue;
+    if (P_LIMIT_EXACT && gap > 0) continue;   /* probe: btMultiBodyJointLimitConstraint skips a row while its bound is not reached */
     Row* r = &rows[nrow++];
     real sgn = lower ? (real)1 : (real)-1;
     for (int k = 0; k < NDOF; ++k) r->J[k] = 0;
@@ -783,9 +869,9 @@ static void physics_substep(Phys* s, const real tau[NJ], real dt, int iterations
     real diag = r->resp[6 + j] * sgn, vel = sgn * nu[6 + j];
     r->invdiag = 1 / diag;
     real poserr = 0, velerr = -vel;
-    if (gap > 0) velerr -= gap / dt; else poserr = -gap * CONTACT_ERP / dt;
+    if (gap > 0) velerr -= gap / dt; else poserr = -gap * P_ERP / dt;
     r->rhs = (poserr + velerr) * r->invdiag;
-    r->lo = 0; r->hi = (real)1e10; r->lambda = 0; r->normal_row = -1;
+    r->lo = 0; r->hi = (real)1e10; r->lambda = 0; r->normal_row = -1; r->pair_row = -1;
   }
   /* then all contact normals, then the friction pairs (Bullet's per-iteration order) */
   for (int p = 0; p < npoint; ++p) {
@@ -796,15 +882,15 @@ static void physics_substep(Phys* s, const real tau[NJ], real dt, int iterations
     real diag = 0, vel = 0;
     for (int k = 0; k < NDOF; ++k) { diag += r->J[k] * r->resp[k]; vel += r->J[k] * nu[k]; }
     r->invdiag = 1 / diag;
-    real pen = PtDist[p];
+    real pen = PtDist[p] + P_SLOP;
     real poserr = 0, velerr = -vel;
-    if (pen > 0) velerr -= pen / dt; else poserr = -pen * CONTACT_ERP / dt;
+    if (pen > 0) velerr -= pen / dt; else poserr = -pen * P_ERP / dt;
     r->rhs = (poserr + velerr) * r->invdiag;
-    r->lo = 0; r->hi = (real)1e10; r->lambda = 0; r->normal_row = -1;
+    r->lo = 0; r->hi = (real)1e10; r->lambda = 0; r->normal_row = -1; r->pair_row = -1;
     normal_of_point[p] = nrow++;
   }
   for (int p = 0; p < npoint; ++p)
-    for (int d = 0; d < 2; ++d) {
+    for (int d = 0; d < P_FRICTION_DIRS; ++d) {
       Row* r = &rows[nrow];
       real fk[6], t1[3], t2[3];
       plane_space(PtN[p], t1, t2);
@@ -815,6 +901,7 @@ static void physics_substep(Phys* s, const real tau[NJ], real dt, int iterations
       r->invdiag = 1 / diag;
       r->rhs = -vel * r->invdiag;
       r->lambda = 0; r->normal_row = normal_of_point[p];
+      r->pair_row = P_FRICTION_DIRS == 2 ? (d == 0 ? nrow + 1 : nrow - 1) : -1;
       ++nrow;
     }
   /* projected Gauss-Seidel (btMultiBodyConstraintSolver::resolveSingleConstraintRowGeneric) */
@@ -832,6 +919,13 @@ static void physics_substep(Phys* s, const real tau[NJ], real dt, int iterations
       real sum = r->lambda + dl;
       if (sum < lo) { dl = lo - r->lambda; sum = lo; }
       else if (sum > hi) { dl = hi - r->lambda; sum = hi; }
+      if (P_CONE && r->normal_row >= 0 && r->pair_row >= 0) {   /* probe: implicit cone, |(l1, l2)| <= mu ln */
+        real other = rows[r->pair_row].lambda, lim = mu * rows[r->normal_row].lambda;
+        real un = r->lambda + (r->rhs - dvel * r->invdiag);
+        real mag = sqrt(un * un + other * other);
+        real want = mag > lim && mag > 0 ? un * lim / mag : un;
+        sum = want; dl = want - r->lambda;
+      }
       r->lambda = sum;
       for (int k = 0; k < NDOF; ++k) dv[k] += r->resp[k] * dl;
       real resid = dl / r->invdiag;
@@ -929,7 +1023,7 @@ static int terrain_index(const Orc* o, int idx, int episode) {
   return (int)(((uint32_t)(o->cfg.env_index_base + idx) + 977u * (uint32_t)episode) % (uint32_t)o->n_terrain);
 }
 static Ground env_ground(const Orc* o, int idx, int episode) {
-  Ground g = {0, 0, 1, 1, FRICTION_MU, 0};
+  Ground g = {0, 0, 1, 1, FRICTION_MU, 0, o->cfg.body_contacts};
   if (o->body_params) {
     int n = o->cfg.num_envs;
     g.has_params = 1; g.base_mass_scale = (real)o->body_params[idx]; g.leg_mass_scale = (real)o->body_params[n + idx];
@@ -1143,6 +1237,10 @@ static void env_reset(Orc* o, int idx) {
   }
 }
 
+/* the time GaitPlanner.loop reads: wall-clock seconds (gait_planner.py:108-110) = simulated time x the host's
+ * wall-seconds-per-simulated-second (RexConfig.gait_clock_scale; DBG_GAIT_CLOCK is the sensitivity tool's multiplier) */
+static real gait_now(const RexConfig* c, real t) { return t * (c->gait_clock_scale > 0 ? cfgf(c->gait_clock_scale) : (real)1) * DBG_GAIT_CLOCK; }
+
 /* walk_env.py:229-244 */
 static real walk_gait_coeff(real t, real a0) { real p = (real)0.8 + a0; return (0 <= t && t <= p) ? t : (real)1.0; }
 static real walk_brake_coeff(real t, real a1, real end_t) {
@@ -1179,7 +1277,7 @@ static void walk_command(const RexConfig* c, Env* e, const real* action, real cm
     }
     real direction = step_length < 0 ? (real)-1.0 : (real)1.0;
     real frames[12], ang[12];
-    gait_loop(&e->gait, 0, step_length, 0, 0, period, direction, t, frames);
+    gait_loop(&e->gait, 0, step_length, 0, 0, period, direction, gait_now(c, t), frames);
     ik_solve(orn, pos, frames, ang, 0);
     order_signal(ang, cmd);
   } else {                                                                              /* walk_env.py:292-315 */
@@ -1225,7 +1323,7 @@ static void gallop_command(const RexConfig* c, Env* e, const real* action, real 
     real step_length = (real)1.3 * gait_coeff;
     if (e->flags & REX_F_GOAL_REACHED) step_length *= gallop_brake_coeff(t, action[0], e->end_time);
     real frames[12], ang[12];
-    gait_loop(&e->gait, 1, step_length, 0, 0, (real)0.3, (real)1.0, t, frames);
+    gait_loop(&e->gait, 1, step_length, 0, 0, (real)0.3, (real)1.0, gait_now(c, t), frames);
     ik_solve(orn, pos, frames, ang, 0);
     order_signal(ang, cmd);
   } else {                                                                              /* gallop_env.py:287-304 */
@@ -1280,7 +1378,7 @@ static void turn_command(const RexConfig* c, Env* e, const real* action, real cm
     if (clockwise) dirv = -dirv;
     real pos[3] = {(real)0.009, 0, 0}, orn[3] = {0, 0, 0};
     real frames[12], ang[12];
-    gait_loop(&e->gait, 0, (real)0.02, 0, dirv + action[0], (real)0.75 + action[1], (real)1.0, t, frames);
+    gait_loop(&e->gait, 0, (real)0.02, 0, dirv + action[0], (real)0.75 + action[1], (real)1.0, gait_now(c, t), frames);
     ik_solve(orn, pos, frames, ang, 0);
     order_signal(ang, cmd);
   } else {
@@ -1441,7 +1539,8 @@ ORC_API void* orc_create(const RexConfig* cfg) {
   o->envs = (Env*)calloc((size_t)cfg->num_envs, sizeof(Env));
   if (cfg->pd_latency > 0 || cfg->control_latency > 0)
     for (int i = 0; i < cfg->num_envs; ++i) o->envs[i].hist = calloc(REX_HISTORY_LEN, sizeof(real[HIST_WORDS]));
-  settle(o, &o->snapshot, 0);
+  Ground g0 = {0, 0, 1, 1, FRICTION_MU, 0, cfg->body_contacts};
+  settle(o, &o->snapshot, &g0);
   return o;
 }
 ORC_API void orc_set_body_params(void* h, const float* params) {
@@ -1470,7 +1569,7 @@ ORC_API void orc_set_terrain(void* h, const float* heights, const float* mids, i
 #pragma omp parallel for schedule(dynamic)
 #endif
   for (int t = 0; t < k; ++t) {
-    Ground g = {o->heights + (size_t)t * HF_N * HF_N, (real)o->mids[t], 1, 1, FRICTION_MU, 0};
+    Ground g = {o->heights + (size_t)t * HF_N * HF_N, (real)o->mids[t], 1, 1, FRICTION_MU, 0, o->cfg.body_contacts};
     settle(o, &o->terrain_snapshot[t], &g);
   }
 }
@@ -1555,6 +1654,32 @@ ORC_API void orc_set_joint_friction(real f, real visc) { DBG_JOINT_FRICTION = f;
 ORC_API void orc_solver_hist(long* h) { for (int i = 0; i < 64; ++i) { h[i] = DBG_HIST[i]; DBG_HIST[i] = 0; } }
 ORC_API void orc_solver_stats(long* sweeps, long* substeps, int reset) { *sweeps = DBG_SWEEPS; *substeps = DBG_SUBSTEPS; if (reset) { DBG_SWEEPS = 0; DBG_SUBSTEPS = 0; } }
 ORC_API void orc_set_friction(real mu) { FRICTION_MU = mu; }
+ORC_API void orc_set_gait_clock(real s) { DBG_GAIT_CLOCK = s; }
+ORC_API void orc_set_body_contacts(int on) { BODY_CONTACTS = on; }
+ORC_API long orc_body_points(int reset) { long v = DBG_BODY_POINTS; if (reset) DBG_BODY_POINTS = 0; return v; }
+ORC_API long orc_substeps_with_body_points(int reset) { long v = DBG_BODY_SUBSTEPS; if (reset) DBG_BODY_SUBSTEPS = 0; return v; }
+/* sensitivity probes by name (tools/physics_sensitivity.py); returns 0 when the name is known */
+ORC_API int orc_set_probe(const char* name, double v) {
+  if (!strcmp(name, "erp")) P_ERP = (real)v;
+  else if (!strcmp(name, "slop")) P_SLOP = (real)v;
+  else if (!strcmp(name, "inertia_scale")) P_INERTIA_SCALE = (real)v;
+  else if (!strcmp(name, "leg_inertia_add")) P_LEG_INERTIA_ADD = (real)v;
+  else if (!strcmp(name, "toe_mode")) P_TOE_MODE = (int)v;
+  else if (!strcmp(name, "limit_exact")) P_LIMIT_EXACT = (int)v;
+  else if (!strcmp(name, "breaking")) P_BREAKING = (real)v;
+  else if (!strcmp(name, "margin")) P_MARGIN = (real)v;
+  else if (!strcmp(name, "friction_dirs")) P_FRICTION_DIRS = (int)v;
+  else if (!strcmp(name, "cone")) P_CONE = (int)v;
+  else if (!strcmp(name, "cover_com_z")) P_COVER_COM_Z = (real)v;
+  else if (!strcmp(name, "gait_clock")) DBG_GAIT_CLOCK = (real)v;
+  else if (!strcmp(name, "mu")) FRICTION_MU = (real)v;
+  else if (!strcmp(name, "lin_damping")) MB_LINEAR_DAMPING = (real)v;
+  else if (!strcmp(name, "ang_damping")) MB_ANGULAR_DAMPING = (real)v;
+  else if (!strcmp(name, "joint_friction")) { DBG_JOINT_FRICTION = (real)v; DBG_JOINT_VISC = (real)1e3; }
+  else if (!strcmp(name, "body_contacts")) BODY_CONTACTS = (int)v;
+  else return -1;
+  return 0;
+}
 ORC_API void orc_set_damping(real lin, real ang) { MB_LINEAR_DAMPING = lin; MB_ANGULAR_DAMPING = ang; }
 
 /* ---- physics-only probes used by the oracle's own unit tests (tests/test_oracle_physics.py) ---- */

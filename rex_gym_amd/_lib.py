@@ -7,12 +7,12 @@ import os
 
 from . import build as _build
 
-TASKS = {"walk": 0, "gallop": 1, "turn": 2, "poses": 3, "standup": 4}
+TASKS = {"walk": 0, "gallop": 1, "turn": 2, "poses": 3, "standup": 4, "mixed": 5}
 SIGNALS = {"ik": 0, "ol": 1}
 MARKS = {"base": 0, "arm": 1}
 STATE_WORDS = 54      # mark 'base'; rex_state_words(cfg) for the others
 NUM_MOTORS = 12       # mark 'base'; rex_num_motors(cfg) for the others
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class RexConfig(ctypes.Structure):
@@ -29,6 +29,9 @@ class RexConfig(ctypes.Structure):
         ("init_orient", ctypes.c_float), ("orient_fixed", ctypes.c_int32), ("pose_index", ctypes.c_int32),
         ("pose_value", ctypes.c_float), ("range_normalize", ctypes.c_int32), ("pd_latency", ctypes.c_float), ("control_latency", ctypes.c_float),
         ("mark", ctypes.c_int32),
+        ("gait_clock_scale", ctypes.c_float), ("body_contacts", ctypes.c_int32), ("noise_stdev", ctypes.c_float * 5),
+        ("task_mix", ctypes.c_int32), ("mass_scale_lo", ctypes.c_float), ("mass_scale_hi", ctypes.c_float),
+        ("friction_lo", ctypes.c_float), ("friction_hi", ctypes.c_float),
     ]
 
 

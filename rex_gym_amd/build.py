@@ -7,7 +7,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "librexsim_hip.so")
 SOURCES = ["rexsim.hip"]
-HEADERS = ["rex_device.h", "rex_controller.h", "rex_model_gen.h"]
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h"))   # every header rexsim.hip can include
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-fvisibility=hidden"]
 
 

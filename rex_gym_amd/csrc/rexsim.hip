@@ -167,6 +167,7 @@ struct DevCfg {
   int32_t reset_substeps;    // int(0.5 / time_step), rex.py:319 (the float quotient 0.5f / 0.001f truncates to 499)
   const float* body_params;  // [3][n] word-major: base mass scale, leg mass scale, foot friction (nullptr: 1, 1, 0.5)
   float act_lo, act_hi;      // Box bounds of the env's action space (host: rex_create)
+  float gait_clock;          // wall-clock seconds per simulated second seen by GaitPlanner.loop (gait_planner.py:108-110)
   float obs_hi_ang, obs_hi_rate;
 };
 
@@ -408,7 +409,7 @@ __device__ __forceinline__ void walk_command(const DevCfg& c, EnvState& e, const
     }
     const float direction = step_length < 0.0f ? -1.0f : 1.0f;
     float frames[12], ang[12];
-    gait_loop(e.gait, 0, step_length, 0.0f, 0.0f, period, direction, t, frames);
+    gait_loop(e.gait, 0, step_length, 0.0f, 0.0f, period, direction, t * c.gait_clock, frames);
     ik_solve(orn, pos, frames, ang);
     order_signal(ang, cmd);
   } else {                                                                       // walk_env.py:292-315
@@ -455,7 +456,7 @@ __device__ __forceinline__ void gallop_command(const DevCfg& c, EnvState& e, con
       step_length *= (e.end_time <= t && t <= pb + e.end_time) ? 1.0f - (t - e.end_time) : 0.0f;
     }
     float frames[12], ang[12];
-    gait_loop(e.gait, 1, step_length, 0.0f, 0.0f, 0.3f, 1.0f, t, frames);
+    gait_loop(e.gait, 1, step_length, 0.0f, 0.0f, 0.3f, 1.0f, t * c.gait_clock, frames);
     ik_solve(orn, pos, frames, ang);
     order_signal(ang, cmd);
   } else {                                                                       // gallop_env.py:287-304
@@ -520,7 +521,7 @@ __device__ __forceinline__ void turn_command(const DevCfg& c, EnvState& e, const
     if (clockwise) dirv = -dirv;
     const float pos[3] = {0.009f, 0.0f, 0.0f}, orn[3] = {0.0f, 0.0f, 0.0f};
     float frames[12], ang[12];
-    gait_loop(e.gait, 0, 0.02f, 0.0f, dirv + action[0], 0.75f + action[1], 1.0f, t, frames);
+    gait_loop(e.gait, 0, 0.02f, 0.0f, dirv + action[0], 0.75f + action[1], 1.0f, t * c.gait_clock, frames);
     ik_solve(orn, pos, frames, ang);
     order_signal(ang, cmd);
   } else {
@@ -928,6 +929,12 @@ static int validate(const RexConfig* c) {
   if ((long long)c->num_envs * 128 >= (1ll << 30)) return fail(REX_EINVAL, "num_envs too large for 32-bit state offsets%s", "");
   if (c->mark == REX_MARK_ARM && (c->pd_latency > 0.0f || c->control_latency > 0.0f))
     return fail(REX_EINVAL, "the latency model is not available with mark 'arm'%s", "");
+  if (c->gait_clock_scale < 0.0f) return fail(REX_EINVAL, "gait_clock_scale must be >= 0%s", "");
+  if (c->body_contacts) return fail(REX_EINVAL, "body_contacts: not built into this library yet%s", "");
+  for (int k = 0; k < 5; ++k) if (c->noise_stdev[k] != 0.0f) return fail(REX_EINVAL, "noise_stdev: not built into this library yet%s", "");
+  if (c->task == REX_TASK_MIXED) return fail(REX_EINVAL, "REX_TASK_MIXED: not built into this library yet%s", "");
+  if (c->mass_scale_lo != 0.0f || c->mass_scale_hi != 0.0f || c->friction_lo != 0.0f || c->friction_hi != 0.0f)
+    return fail(REX_EINVAL, "per-reset randomisation: not built into this library yet%s", "");
   return REX_OK;
 }
 
@@ -983,6 +990,7 @@ int rex_create(const RexConfig* cfg, int device, float* d_state, void* stream, R
     d.obs_hi_rate = (float)(2.0 * M_PI) / cfg->sim_time_step + 0.01f;
   }
   d.target_orient = cfg->target_orient; d.init_orient = cfg->init_orient; d.orient_fixed = cfg->orient_fixed;
+  d.gait_clock = cfg->gait_clock_scale > 0.0f ? cfg->gait_clock_scale : 1.0f;
   hipError_t e = hipMalloc(&s->d_snap, sizeof(float) * snapshot_floats(s, 1));
   if (e != hipSuccess) { delete s; return fail(REX_ENOMEM, "hipMalloc(snapshot): %s", hipGetErrorString(e)); }
   (void)hipEventCreate(&s->ev0);

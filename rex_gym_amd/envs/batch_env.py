@@ -67,8 +67,20 @@ class RexBatchEnv:
                  pd_latency=0.0,
                  solver_iterations=None, solver_residual_threshold=None,
                  range_normalize=False, check_actions=False, terrain_type="plane", terrain_pool=64, terrain_seed=10,
-                 mark="base", render=False, stream=None, **unused):
+                 mark="base", render=False, stream=None, gait_clock_scale=1.0,
+                 distance_weight=None, energy_weight=None, drift_weight=None, shake_weight=None, **ignored):
         import torch
+        # Reference constructor keywords that only touch the GUI, logging or debugging are accepted and ignored; anything
+        # else that would change what the env computes is an error here, not a silent no-op.
+        harmless = {"debug", "urdf_version", "num_steps_to_log", "log_path", "terrain_id", "urdf_root", "reflection",
+                    "draw_foot_path", "hard_reset", "forward_reward_cap"}
+        unknown = sorted(set(ignored) - harmless)
+        if ignored.get("on_rack") or ignored.get("env_randomizer"):
+            raise NotImplementedError("on_rack / env_randomizer objects are not supported: use mass_scale_range / "
+                                      "friction_range (per-reset draws) or set_body_params()")
+        unknown = [k for k in unknown if k not in ("on_rack", "env_randomizer")]
+        if unknown:
+            raise TypeError(f"RexBatchEnv: unsupported keyword(s) {unknown}")
         if terrain_type not in ("plane", "random") or mark not in _lib.MARKS or render:
             raise NotImplementedError("this round covers terrain_type in ('plane', 'random'), mark in ('base', 'arm'), "
                                       "render=False")
@@ -94,6 +106,11 @@ class RexBatchEnv:
         if solver_residual_threshold is not None:
             cfg.solver_residual_threshold = float(solver_residual_threshold)
         cfg.motor_kp, cfg.motor_kd = float(motor_kp), float(motor_kd)
+        cfg.gait_clock_scale = float(gait_clock_scale)     # wall-clock seconds per simulated second (gait_planner.py:108-110)
+        for name, v in (("distance_weight", distance_weight), ("energy_weight", energy_weight),
+                        ("drift_weight", drift_weight), ("shake_weight", shake_weight)):   # rex_gym_env.py:56-59
+            if v is not None:
+                setattr(cfg, name, float(v))
         cfg.backwards = -1 if backwards is None else int(bool(backwards))
         cfg.target_position = 0.0 if not target_position else float(target_position)
         if target_orient:                      # `if not self._target_orient` -> drawn (turn_env.py:137)

@@ -13,5 +13,5 @@ class RexReactiveEnv(_SingleEnv):
             raise NotImplementedError("on_rack / env_randomizer / angle-less observation are not covered")
         super().__init__(signal_type=signal_type, control_time_step=control_time_step, action_repeat=action_repeat,
                          motor_kp=motor_kp, motor_kd=motor_kd, control_latency=control_latency, pd_latency=pd_latency,
-                         render=render, target_position=target_position,
+                         render=render, target_position=target_position, energy_weight=energy_weight,
                          terrain_type=terrain_type, mark=mark, **kw)

@@ -39,17 +39,20 @@ class RexConfig(ctypes.Structure):
         ("init_orient", ctypes.c_float), ("orient_fixed", ctypes.c_int32), ("pose_index", ctypes.c_int32),
         ("pose_value", ctypes.c_float), ("range_normalize", ctypes.c_int32), ("pd_latency", ctypes.c_float), ("control_latency", ctypes.c_float),
         ("mark", ctypes.c_int32),
+        ("gait_clock_scale", ctypes.c_float), ("body_contacts", ctypes.c_int32), ("noise_stdev", ctypes.c_float * 5),
+        ("task_mix", ctypes.c_int32), ("mass_scale_lo", ctypes.c_float), ("mass_scale_hi", ctypes.c_float),
+        ("friction_lo", ctypes.c_float), ("friction_hi", ctypes.c_float),
     ]
 
 
-TASKS = {"walk": 0, "gallop": 1, "turn": 2, "poses": 3, "standup": 4}
+TASKS = {"walk": 0, "gallop": 1, "turn": 2, "poses": 3, "standup": 4, "mixed": 5}
 SIGNALS = {"ik": 0, "ol": 1}
 
 
 def default_config(task="walk", signal="ik", num_envs=1, **kw):
     """Reference defaults."""
     repeat = 6 if task in ("gallop", "poses") else 5
-    c = RexConfig(abi_version=2, num_envs=num_envs, env_index_base=0, task=TASKS[task], signal=SIGNALS[signal],
+    c = RexConfig(abi_version=3, num_envs=num_envs, env_index_base=0, task=TASKS[task], signal=SIGNALS[signal],
                   action_repeat=repeat, solver_iterations=300 // repeat, sim_time_step=0.001,
                   motor_kp=1.0, motor_kd=0.02, backwards=-1, target_position=0.0, seed=0, auto_reset=0,
                   max_episode_steps=0, distance_weight=1.0, energy_weight=0.005 if task == "gallop" else 0.0005, drift_weight=2.0,

@@ -428,6 +428,30 @@ def main():
         w("  {" + ", ".join(fmt(v if abs(v) > 1e-15 else 0.0) for v in t[2]) + "},")
     w("};")
     w("")
+    # collision boxes of every link (rex.urdf:15-33,63-108,119-124,151-156,170-175), expressed in the frame of the
+    # merged body they ride on: the candidates of the body-vs-ground contact rows.  All <collision> origins in rex.urdf
+    # are pure translations, so every box is axis-aligned with its body frame.
+    boxes = []
+    for bi, b in enumerate(bodies):
+        for ln, xyz, R in sorted(b["members"], key=lambda m: m[0] != b["name"]):
+            for kind, prm, cx, crpy in links[ln].collisions:
+                if kind != "box":
+                    continue
+                assert not crpy.any() and np.allclose(R, np.eye(3)), "rotated collision box"
+                boxes.append((bi, xyz + cx, np.asarray(prm) / 2.0, ln))
+    w("/* link collision boxes in body frames: body index, centre [m], half extents [m] (Bullet keeps a box's margin")
+    w("   inside its extents, so these are the contact surfaces) */")
+    w(f"#define REX_NBOX {len(boxes)}")
+    w("REX_CONST int REX_BOX_BODY[REX_NBOX] = {" + ", ".join(str(bx[0]) for bx in boxes) + "};")
+    w("REX_CONST double REX_BOX_CENTER[REX_NBOX][3] = {")
+    for bx in boxes:
+        w("  {" + ", ".join(fmt(v) for v in bx[1]) + "},  /* " + bx[3] + " */")
+    w("};")
+    w("REX_CONST double REX_BOX_HALF[REX_NBOX][3] = {")
+    for bx in boxes:
+        w("  {" + ", ".join(fmt(v) for v in bx[2]) + "},")
+    w("};")
+    w("")
     # leg-structured scalar view (the four legs are mirror images); used by the HIP kernels, which
     # unroll the star topology statically instead of walking the generic table.
     def leg_bodies(l):

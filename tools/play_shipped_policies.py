@@ -75,10 +75,13 @@ def main():
     p.add_argument("--policies-root", required=True)
     p.add_argument("--num-envs", type=int, default=256)
     p.add_argument("--max-steps", type=int, default=2500)
+    p.add_argument("--gait-clock-scale", type=float, default=1.0,
+                   help="wall-clock seconds per simulated second seen by GaitPlanner.loop (gait_planner.py:108-110)")
     a = p.parse_args()
     for task, signal, rel in POLICIES:
-        row = dict(env=task, signal=signal, checkpoint=rel, num_envs=a.num_envs, max_steps=a.max_steps)
-        env = RexBatchEnv(a.num_envs, task=task, signal_type=signal, seed=1)
+        row = dict(env=task, signal=signal, checkpoint=rel, num_envs=a.num_envs, max_steps=a.max_steps,
+                   gait_clock_scale=a.gait_clock_scale)
+        env = RexBatchEnv(a.num_envs, task=task, signal_type=signal, seed=1, gait_clock_scale=a.gait_clock_scale)
         try:
             pol = SimplePPOPolicy(env, os.path.join(a.policies_root, rel))
         except (CheckpointError, FileNotFoundError) as e:
