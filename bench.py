@@ -22,10 +22,22 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ENVS_PER_GPU = 4096
-# algorithmic bytes per env-step, walk-IK base mark (state r+w, action, obs, reward, done)
-ALGO_BYTES_PER_ENV_STEP = 541
-# this implementation's own layout: 54 state words read + written, action 8 B, obs 16 B, reward 4 B, done 1 B
-LAYOUT_BYTES_PER_ENV_STEP = 2 * 54 * 4 + 8 + 16 + 4 + 1
+PREROLL_STEPS = 1500             # untimed: episodes fall / time out at different steps, so after this many steps the batch
+                                 # holds a stationary mix of episode phases whatever --warmup the caller asks for
+
+
+def algorithmic_bytes(task, signal, terrain, mark, action_dim, obs_dim):
+    """ALGORITHMIC bytes per env-step = persistent state words read + written (64 walk / poses / standup,
+    62 gallop: no gait phase words, 66 turn: start and target yaw; + 15 for the 6 arm motors of mark 'arm'), the action
+    row in, the observation row + reward + done out, and on a heightfield 4 feet x 4 height samples.  Gives the
+    survey's 541 (walk-IK), 581 (gallop-OL), 621 (turn-IK on the heightfield pool), 661 (arm walk-IK)."""
+    words = {"walk": 64, "gallop": 62, "turn": 66, "poses": 64, "standup": 64, "mixed": 66}[task] + (15 if mark == "arm" else 0)
+    return 2 * 4 * words + 4 * action_dim + 4 * obs_dim + 4 + 1 + (64 if terrain != "plane" else 0)
+
+
+def layout_bytes(state_words, action_dim, obs_dim):
+    """this implementation's own traffic: its state words read + written, action, obs, reward, done"""
+    return 2 * 4 * state_words + 4 * action_dim + 4 * obs_dim + 4 + 1
 ALGO_FLOP_PER_ENV_STEP = 3.0e5   # SURVEY.md 8(d) estimate
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
 FP32_PEAK_TFLOPS = 157.3
@@ -53,20 +65,21 @@ def usable_cores():
     return cores
 
 
-def cpu_baseline(max_seconds=20.0):
+def cpu_baseline(task="walk", signal="ik", mark="base", n=ENVS_PER_GPU, cores=None, max_seconds=20.0):
     """Time the CPU oracle (a restatement, NOT PyBullet) on the host cores: bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
     import orclib
-    cores = usable_cores()
-    n = ENVS_PER_GPU            # the GPU line's own batch
-    cfg = orclib.default_config("walk", "ik", n, seed=0, auto_reset=1, max_episode_steps=2000)
-    env = orclib.OracleEnv(cfg, np.float32)
+    cores = cores or usable_cores()
+    cfg = orclib.default_config(task, signal, n, seed=0, auto_reset=1, max_episode_steps=2000, mark=orclib_mark(mark))
+    env = orclib.OracleEnv(cfg, np.float32, mark=mark)
     threads = int(env.o.lib.orc_set_threads(cores))
     env.reset()
     rng = np.random.RandomState(0)
-    acts = rng.uniform(-0.4, 0.4, (8, n, 2)).astype(np.float32)
-    env.step(acts[0])
+    b = {"walk": {"ik": 0.4, "ol": 0.01}, "gallop": {"ik": 0.4, "ol": 0.3}, "turn": {"ik": 0.01, "ol": 0.01}}.get(task, {}).get(signal, 0.1)
+    acts = rng.uniform(-b, b, (8, n, env.action_dim)).astype(np.float32)
+    for k in range(3):
+        env.step(acts[k])
     t0 = time.perf_counter()
     steps = 0
     while True:
@@ -77,9 +90,52 @@ def cpu_baseline(max_seconds=20.0):
             break
     env.close()
     return {"value": n * steps / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
-            "sample": f"{n} envs x {steps} steps walk-IK, oracle/rex_oracle.c fp32 build, OpenMP over envs on "
-                      f"{threads} threads = the CPUs this container is granted "
+            "sample": f"{n} envs x {steps} steps {task}-{signal.upper()} ({mark} mark), oracle/rex_oracle.c fp32 build, OpenMP "
+                      f"over envs on {threads} thread(s) of the {usable_cores()} CPUs this container is granted "
                       f"({dt:.1f} s); CPU restatement, not PyBullet (pybullet is not installable here)"}
+
+
+def orclib_mark(mark):
+    return 1 if mark == "arm" else 0
+
+
+def joint_rmse_vs_oracle(task, signal, mark, n=256, steps=200, seed=11):
+    """Half of BASELINE.json's metric ("joint RMSE vs PyBullet"): PyBullet cannot run here, so this is the HIP path
+    against the fp64 oracle -- the same `n` envs from reset, the same random actions, `steps` control steps (1 s of
+    robot time); per env the RMSE over time and joints of (q_hip - q_oracle), reported as median and max over envs,
+    and the base-position error at the end of the window."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orclib
+    from helpers import product_state_to_numeric
+    from rex_gym_amd import RexBatchEnv
+    env = RexBatchEnv(n, task=task, signal_type=signal, device=torch.cuda.current_device(), seed=seed, mark=mark)
+    orc = orclib.OracleEnv(orclib.default_config(task, signal, n, seed=seed, mark=orclib_mark(mark)), np.float64, mark=mark)
+    orc.o.lib.orc_set_threads(usable_cores())
+    env.reset(); orc.reset()
+    nm = env.num_motors
+    lo = np.minimum(env.action_space.low, env.action_space.high); hi = np.maximum(env.action_space.low, env.action_space.high)
+    rng = np.random.RandomState(seed)
+    sq = np.zeros(n)
+    alive = np.ones(n, bool)
+    cnt = np.zeros(n)
+    for _ in range(steps):
+        a = rng.uniform(lo, hi, (n, env.action_dim)).astype(np.float32)
+        _, _, d, _ = env.step(torch.as_tensor(a, device=env.device))
+        _, _, od, _ = orc.step(a)
+        ps, os_ = product_state_to_numeric(env.state), orc.get_state()
+        e = ps[orclib.S_Q:orclib.S_Q + nm] - os_[orclib.S_Q:orclib.S_Q + nm]
+        sq += np.where(alive, (e * e).mean(0), 0.0)
+        cnt += alive
+        alive &= ~(d.cpu().numpy().astype(bool) | od)      # an episode that ended (fall) leaves the comparison
+    rmse = np.sqrt(sq / np.maximum(cnt, 1))
+    pos = np.abs(ps[0:3] - os_[0:3]).max(0)
+    env.close(); orc.close()
+    return {"window_steps": steps, "envs": n, "median_rad": float(np.median(rmse)), "max_rad": float(rmse.max()),
+            "p99_rad": float(np.percentile(rmse, 99)), "base_pos_err_max_m": float(pos[alive].max()) if alive.any() else None,
+            "envs_compared_to_the_end": int(alive.sum()), "against": "oracle/rex_oracle.c fp64 (restatement; PyBullet is not installable)"}
+
 
 
 def main():
@@ -138,6 +194,10 @@ def main():
     hi = torch.as_tensor(env.action_space.low, device=dev).maximum(torch.as_tensor(env.action_space.high, device=dev))
     pool = [(torch.rand((n, env.action_dim), device=dev, generator=gen) * (hi - lo) + lo).contiguous() for _ in range(16)]
     env.reset()
+    # pre-roll (untimed, outside --warmup): right after a synchronous reset every env is in the same episode phase and
+    # the solver converges quickly; the number reported is the steady state a training run sees
+    for k in range(PREROLL_STEPS):
+        env.step(pool[k % 16])
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -159,16 +219,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # per-launch duration of the dominant kernel: HIP events recorded around each launch on the launch stream
+    # per-launch duration of the dominant kernel: a ring of HIP event pairs recorded around each launch on the launch
+    # stream, with no host synchronisation between the launches (the queue stays full, as in the timed region above)
     timed = env.envs[0] if args.mixed else env    # mixed: the kernel of the first sub-batch
-    timed.set_timing(True)
-    m = min(200, max(20, args.steps // 10))
-    kms = []
+    timed.set_timing(2)
+    m = min(256, max(20, args.steps // 8))
     for k in range(m):
         env.step(pool[k % 16])
-        kms.append(timed.last_step_ms())
+    kms = sorted(timed.step_times_ms(m))
     timed.set_timing(False)
-    kms.sort()
     kernel_ms = sum(kms) / len(kms)
 
     # HBM bytes per launch as measured with rocprofv3 PMC passes of this same command (cannot be collected from inside
@@ -186,10 +245,33 @@ def main():
     finite = bool(torch.isfinite(obs).all().item())
     env.close()
 
+    # the same workload with the gait phase clock of a host that runs 1.5 wall-seconds per simulated second (the regime in
+    # which the reference's gait -- driven by time.time(), gait_planner.py:108-110 -- walks instead of falling after ~240
+    # steps): reported next to the headline, never instead of it
+    walking = None
+    if world == 1 and not args.mixed and args.signal == "ik" and args.task in ("walk", "turn", "gallop"):
+        env2 = RexBatchEnv(n, task=args.task, signal_type=args.signal, device=local_rank, seed=0, env_index_base=rank * n,
+                           auto_reset=True, max_episode_steps=2000, terrain_type=args.terrain, mark=args.mark, gait_clock_scale=1.5)
+        env2.reset()
+        for k in range(PREROLL_STEPS + args.warmup):
+            env2.step(pool[k % 16])
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for k in range(args.steps):
+            env2.step(pool[k % 16])
+        torch.cuda.synchronize(dev)
+        e2 = time.perf_counter() - t1
+        walking = {"gait_clock_scale": 1.5, "value": n * args.steps / e2, "unit": "env-steps/s", "ms_per_step": e2 / args.steps * 1e3}
+        env2.close()
+
+    task_name = "mixed" if args.mixed else args.task
+    act_dim, obs_dim = env.action_dim, env.obs_dim
+    state_words = (env.envs[0] if args.mixed else env).state_words
     if rank == 0:
         total_envs = n * world
         value = total_envs * args.steps / elapsed
-        achieved_gbs = ALGO_BYTES_PER_ENV_STEP * n / (kernel_ms * 1e-3) / 1e9
+        algo_bytes = algorithmic_bytes(task_name, args.signal, args.terrain, args.mark, act_dim, obs_dim)
+        achieved_gbs = algo_bytes * n / (kernel_ms * 1e-3) / 1e9
         out = {
             "metric": "env-steps/sec (all envs) Rex " + ("mixed walk/gallop/turn-IK" if args.mixed else f"{args.task}-{args.signal.upper()}"),
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -200,25 +282,34 @@ def main():
                                    f"{'flat plane' if args.terrain == 'plane' else 'random heightfield pool'}, {args.mark} mark, "
                                    f"dt 1 ms x {env.config.action_repeat} substeps, <= {env.config.solver_iterations} PGS sweeps "
                                    "(Bullet residual threshold 1e-7), auto-reset, episode cap 2000, uniform random actions "
-                                   "over the env's action Box",
+                                   f"over the env's action Box; {PREROLL_STEPS} untimed pre-roll steps before --warmup (steady "
+                                   "episode-phase mix)",
                        "envs_total": total_envs, "parallelism": f"env-shards x{world} (no data-path collective)"},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "rex_step_kernel", "kernel_ms": kernel_ms, "kernel_ms_min": kms[0],
-                         "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP,
-                         "layout_bytes_per_env_step": LAYOUT_BYTES_PER_ENV_STEP,
+                         "algorithmic_bytes_per_env_step": algo_bytes,
+                         "layout_bytes_per_env_step": layout_bytes(state_words, act_dim, obs_dim),
                          "note": "the fused step is bound by the VALU issue rate of one wave per SIMD through the sequential "
                                  "contact solver (about 550 flop/B, SURVEY.md 8d; DESIGN.md 5-6), not by HBM: see valu_frac",
                          "valu_tflops_est": ALGO_FLOP_PER_ENV_STEP * n / (kernel_ms * 1e-3) / 1e12,
                          "valu_frac": ALGO_FLOP_PER_ENV_STEP * n / (kernel_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS},
             "finite": finite,
         }
-        if not args.no_cpu_baseline and world == 1:
-            try:
-                out["cpu_baseline"] = cpu_baseline()
+        if walking:
+            out["walking_gait_workload"] = walking
+        if not args.no_cpu_baseline and world == 1 and not args.mixed:
+            try:   # SURVEY.md 8(d) baseline (ii): the CPU restatement on all granted threads and on one
+                out["cpu_baseline"] = cpu_baseline(args.task, args.signal, args.mark, n)
+                out["cpu_baseline_1thread"] = cpu_baseline(args.task, args.signal, args.mark, min(n, 256), cores=1, max_seconds=8.0)
             except Exception as e:  # the baseline is reporting only; never fail the GPU line for it
                 out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": 0, "kind": "port",
                                        "sample": f"failed: {e}"}
+            if args.terrain == "plane":
+                try:   # the other half of BASELINE.json's metric
+                    out["joint_rmse_vs_oracle"] = joint_rmse_vs_oracle(args.task, args.signal, args.mark)
+                except Exception as e:
+                    out["joint_rmse_vs_oracle"] = {"failed": str(e)}
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -227,9 +227,14 @@ REX_API int rex_reset(RexSim* sim, const int32_t* d_indices, int n, float* d_obs
 REX_API int rex_step(RexSim* sim, const float* d_action, float* d_obs, float* d_reward,
              uint8_t* d_done, float* d_motor_cmd, void* stream);
 
-/* HIP event timing of the last rex_step launch on its own stream (ms); needs rex_set_timing(1). */
+/* HIP event timing of rex_step launches on their own stream (ms).  rex_set_timing(1): one event pair, read with
+ * rex_last_step_ms (synchronises on the launch).  rex_set_timing(2): a ring of event pairs around the last 256 launches,
+ * recorded without any host synchronisation between launches (the stream stays full, so a duration is that of the kernel
+ * itself, not of an idle queue being refilled); rex_step_times_ms waits for the newest one and returns the last
+ * min(max_count, recorded, 256) durations, oldest first -- the return value is their number (< 0: error). */
 REX_API int rex_set_timing(RexSim* sim, int enable);
 REX_API int rex_last_step_ms(RexSim* sim, float* ms);
+REX_API int rex_step_times_ms(RexSim* sim, float* ms, int max_count);
 
 /* ---- controller-only entry points (parity tests of the controller half) ----
  * n independent problems, row-major device arrays, all float32. */
@@ -246,6 +251,10 @@ REX_API int rex_motor_torque(int n, const float* d_cmd, const float* d_q, const 
  * (v, angle_deg, w_rot, period, direction, now); frames_out[n,4,3] (FR,FL,RR,RL). */
 REX_API int rex_gait_loop(int n, int mode, float* d_planner, const float* d_params,
                   float* d_frames_out, void* stream);
+
+/* Envs per wavefront of the step kernel this sim launches (4, 8, 16: lane groups; 64: one env per lane).  Chosen from
+ * the batch size; the environment variable REX_ENVS_PER_WAVE overrides (tests run every variant through it). */
+REX_API int rex_envs_per_wave(const RexSim* sim);
 
 REX_API const char* rex_last_error(void);
 REX_API int rex_abi_version(void);

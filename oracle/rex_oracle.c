@@ -1193,8 +1193,8 @@ static void env_reset(Orc* o, int idx) {
   e->episode = episode + 1;
   e->hist = hist;
   e->gait.phi = 0; e->gait.last_time = 0; e->gait.alpha = alpha;
-  uint32_t ctr[4] = {(uint32_t)e->episode, 0, 0, 0};
-  philox4x32(ctr, (uint32_t)c->seed ^ (uint32_t)(c->env_index_base + idx), (uint32_t)(c->seed >> 32));
+  uint32_t ctr[4] = {(uint32_t)e->episode, (uint32_t)(c->env_index_base + idx), 0, 0};   /* key = seed, counter = (episode, global env) */
+  philox4x32(ctr, (uint32_t)c->seed, (uint32_t)(c->seed >> 32));
   e->flags = 0;
   if (c->task == REX_TASK_WALK) {
     int backwards = c->backwards < 0 ? (int)(ctr[0] >> 31) : c->backwards;     /* walk_env.py:133-136 */

@@ -10,8 +10,11 @@ What is restated, piece by piece:
   PPOAgent               agents/ppo/algorithm.py:26-531   (episode buffers, memory of `update_every` episodes, policy /
                                                            value updates, KL penalty adaptation)
   train                  agents/tools/simulate.py:15-131  (reset done envs, act, step, hand transitions to the agent)
-Defaults are agents/scripts/configs.py:24-52.  Multi-GPU: each rank trains on its own shard's episodes and the
-gradients are averaged (torch.distributed all-reduce = RCCL over xGMI), see PPOAgent(sync_gradients=True).
+Defaults are agents/scripts/configs.py:24-52.  Multi-GPU (PPOAgent(sync_gradients=True)): every rank keeps the
+episodes of its own shard in its own memory; the update is collective -- decided by an all-reduce once every rank's
+memory is full, gradients and the KL statistic averaged over the ranks, the observation / reward filters merged
+(torch.distributed = RCCL over xGMI).  `sharding.gather_rollout` is the hand-off for a CENTRAL learner (one rank
+training on everybody's rollouts) and is not used by this gradient-averaged loop.
 """
 import math
 from dataclasses import dataclass
@@ -73,6 +76,36 @@ class StreamingNormalize:
         self.var_sum = self.var_sum + ((value - self.mean) * (value - new_mean)).sum(0)
         self.mean = new_mean
         return first
+
+    def merge_ranks(self):
+        """Multi-rank learner: replace this rank's statistics by those of the union of what all ranks have seen since the
+        last merge plus the common statistics of that merge (Chan's parallel mean / variance combination, one all-reduce).
+        After the call every rank holds the same filter."""
+        import torch.distributed as dist
+        base = getattr(self, "_base", None)
+        if base is None:
+            base = (0, torch.zeros_like(self.mean), torch.zeros_like(self.var_sum))
+        n0, m0, v0 = base
+        # this rank's own samples since the last merge: (count, mean, var_sum) "minus" the common base
+        n1 = self.count - n0
+        if n1 > 0:
+            m1 = (self.mean * self.count - m0 * n0) / n1
+            v1 = self.var_sum - v0 - (m0 - self.mean) ** 2 * n0 - (m1 - self.mean) ** 2 * n1
+        else:
+            m1, v1 = torch.zeros_like(self.mean), torch.zeros_like(self.var_sum)
+        pack = torch.cat([torch.tensor([float(n1)], device=self.mean.device, dtype=torch.float64),
+                          (m1.double() * n1).reshape(-1), (v1.double() + m1.double() ** 2 * n1).reshape(-1)])
+        dist.all_reduce(pack)
+        k = self.mean.numel()
+        n = float(pack[0]) + n0
+        s1 = pack[1:1 + k].reshape(self.mean.shape) + m0.double() * n0
+        s2 = pack[1 + k:].reshape(self.mean.shape) + v0.double() + m0.double() ** 2 * n0
+        if n > 0:
+            mean = s1 / n
+            self.mean = mean.to(self.mean.dtype)
+            self.var_sum = (s2 - mean ** 2 * n).clamp_min(0).to(self.var_sum.dtype)
+            self.count = int(round(n))
+        self._base = (self.count, self.mean.clone(), self.var_sum.clone())
 
 
 # ---- utility.py:71-143 on [B, T] sequences with a length per row -------------------------------------------------
@@ -229,9 +262,28 @@ class PPOAgent:
                 mem[dst] = epi[use]
             self.memory_length[dst] = self.episode_length[use].clamp(max=self.cfg.max_length)
             self.memory_index += k
-        if self.memory_index >= self.cfg.update_every:
+        if self.memory_index >= self.cfg.update_every and not self._distributed():
             return self._training()
         return None
+
+    def _distributed(self):
+        return self.sync_gradients and torch.distributed.is_available() and torch.distributed.is_initialized() \
+            and torch.distributed.get_world_size() > 1
+
+    def train_if_all_full(self):
+        """Multi-rank learner: episodes end at different steps on different ranks, and an update is a sequence of
+        blocking gradient all-reduces, so the decision to update is itself collective -- every rank calls this at the
+        same loop positions (train() does, every `sync_poll` steps); the update runs, on every rank at once, as soon as
+        every rank's memory is full (a full memory ignores further episodes, as in the reference, algorithm.py:196-199)."""
+        if not self._distributed():
+            return None
+        full = torch.tensor([1.0 if self.memory_index >= self.cfg.update_every else 0.0], device=self.device)
+        torch.distributed.all_reduce(full, op=torch.distributed.ReduceOp.MIN)
+        if float(full) < 1.0:
+            return None
+        self.observ_filter.merge_ranks()      # the ranks' filters have seen different envs: one filter from here on
+        self.reward_filter.merge_ranks()
+        return self._training()
 
     # ---- learning (algorithm.py:214-470) ----
     def _training(self):
@@ -263,7 +315,7 @@ class PPOAgent:
         return_ = discounted_return(reward, length, self.cfg.discount)
         losses = []
         for _ in range(self.cfg.update_epochs_value):
-            value = self.net(observ)[2]
+            value = self.net(observ)[2] * mask                                      # dynamic_rnn: zero beyond the length
             loss = (0.5 * mask * (return_ - value) ** 2).mean()                     # :289-301
             self.value_opt.zero_grad(set_to_none=True)
             loss.backward()
@@ -276,7 +328,10 @@ class PPOAgent:
         cfg = self.cfg
         with torch.no_grad():
             return_ = discounted_return(reward, length, cfg.discount)
-            value = self.net(observ)[2]
+            # the reference runs the network through tf.nn.dynamic_rnn(cell, observ, length) (algorithm.py:521), which
+            # returns ZERO outputs beyond an episode's length: the value (and with it the advantage) of a padded step is
+            # 0 there, so padding never enters advantage.mean() / var() nor the TD-lambda bootstrap of the last valid step
+            value = self.net(observ)[2] * _mask(length, reward.shape[1])
             if cfg.gae_lambda:
                 advantage = lambda_return(reward, value, length, cfg.discount, cfg.gae_lambda)   # :336-338
             else:
@@ -303,7 +358,11 @@ class PPOAgent:
     def _adjust_penalty(self, observ, old_mean, old_logstd, length):
         """algorithm.py:436-474: x1.5 when the policy moved more than 1.3 kl_target, /1.5 below 0.7 kl_target."""
         mean, logstd, _ = self.net(observ)
-        kl_change = float((_mask(length, observ.shape[1]) * diag_normal_kl(old_mean, old_logstd, mean, logstd)).mean())
+        kl = (_mask(length, observ.shape[1]) * diag_normal_kl(old_mean, old_logstd, mean, logstd)).mean()
+        if self._distributed():               # one penalty for all ranks: the mean KL over every rank's memory
+            torch.distributed.all_reduce(kl)
+            kl = kl / torch.distributed.get_world_size()
+        kl_change = float(kl)
         if kl_change > 1.3 * self.cfg.kl_target:
             self.penalty *= 1.5
         if kl_change < 0.7 * self.cfg.kl_target:
@@ -311,7 +370,7 @@ class PPOAgent:
         return {"kl_change": kl_change, "penalty": self.penalty}
 
 
-def train(env, agent, steps, training=True):
+def train(env, agent, steps, training=True, sync_poll=8):
     """agents/tools/simulate.py:15-131 for an env with the RexBatchEnv surface (reset(indices), step(actions) on device
     tensors; auto_reset must be off: finished envs are reset here, by index, as simulate() does).
     Returns the mean score (undiscounted episode reward) and length of the episodes that ended."""
@@ -322,7 +381,7 @@ def train(env, agent, steps, training=True):
     length = torch.zeros(agent.n, dtype=torch.long, device=dev)
     done = torch.zeros(agent.n, dtype=torch.bool, device=dev)
     scores, lengths = [], []
-    for _ in range(int(steps)):
+    for it in range(int(steps)):   # every rank of a multi-rank job runs the same number of iterations
         idx = done.nonzero()[:, 0]
         if idx.numel():
             observ[idx] = env.reset(idx.to(torch.int32)).to(dev)
@@ -343,6 +402,8 @@ def train(env, agent, steps, training=True):
             scores.append(score[idx].clone()); lengths.append(length[idx].clone())
             if training:
                 agent.end_episode(idx)
+        if training and (it + 1) % sync_poll == 0:
+            agent.train_if_all_full()         # no-op for a single-rank learner
         observ = nobs.clone()
     if not scores:
         return float("nan"), float("nan")

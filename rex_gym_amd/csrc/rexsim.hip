@@ -344,8 +344,10 @@ __device__ __forceinline__ void env_reset(const DevCfg& c, const float* snap, in
   for (int k = 0; k < 3; ++k) seen[4 + k] = e.ph.ang[k];
   e.episode = episode;
   e.gait.phi = 0.0f; e.gait.last_time = 0.0f; e.gait.alpha = alpha;
-  uint32_t ctr[4] = {(uint32_t)episode, 0u, 0u, 0u};
-  philox4x32(ctr, c.seed_lo ^ (uint32_t)gidx, c.seed_hi);
+  // key = the 64-bit seed, counter = (episode, global env index): distinct seeds give independent streams for every env
+  // (a key of seed ^ index would hand (seed 0, env 1) and (seed 1, env 0) the same stream)
+  uint32_t ctr[4] = {(uint32_t)episode, (uint32_t)gidx, 0u, 0u};
+  philox4x32(ctr, c.seed_lo, c.seed_hi);
   e.flags = 0;
   const float u = u01(ctr[1]);
   if (c.task == REX_TASK_WALK) {
@@ -812,6 +814,7 @@ __global__ void rex_gait_kernel(int n, int mode, float* __restrict__ planner, co
 // =================================================================================================
 //                                          host side: C ABI
 // =================================================================================================
+#define REX_TIMING_RING 256
 struct RexSim {
   RexConfig cfg;
   rex::DevCfg dev;
@@ -822,6 +825,9 @@ struct RexSim {
   hipEvent_t ev0, ev1;
   int timing;
   int have_timing;
+  // ring of event pairs around the last REX_TIMING_RING launches: per-launch durations without a host sync in between
+  hipEvent_t ring0[REX_TIMING_RING], ring1[REX_TIMING_RING];
+  long long timed_steps;
   int words;   // per-env state words of the config's mark
 };
 
@@ -995,6 +1001,8 @@ int rex_create(const RexConfig* cfg, int device, float* d_state, void* stream, R
   if (e != hipSuccess) { delete s; return fail(REX_ENOMEM, "hipMalloc(snapshot): %s", hipGetErrorString(e)); }
   (void)hipEventCreate(&s->ev0);
   (void)hipEventCreate(&s->ev1);
+  for (int k = 0; k < REX_TIMING_RING; ++k) { s->ring0[k] = nullptr; s->ring1[k] = nullptr; }
+  s->timed_steps = 0;
   hipStream_t st = (hipStream_t)stream;
   launch_settle(s, 1, st, s->d_snap);
   e = hipGetLastError();
@@ -1049,6 +1057,7 @@ int rex_destroy(RexSim* s) {
   (void)hipFree(s->d_snap);
   (void)hipEventDestroy(s->ev0);
   (void)hipEventDestroy(s->ev1);
+  for (int k = 0; k < REX_TIMING_RING; ++k) if (s->ring0[k]) { (void)hipEventDestroy(s->ring0[k]); (void)hipEventDestroy(s->ring1[k]); }
   delete s;
   return REX_OK;
 }
@@ -1076,18 +1085,40 @@ int rex_step(RexSim* s, const float* d_action, float* d_obs, float* d_reward, ui
   HIPCHK(hipSetDevice(s->device));
   hipStream_t st = (hipStream_t)stream;
   const int blocks = (s->cfg.num_envs + s->epw - 1) / s->epw;
-  if (s->timing) HIPCHK(hipEventRecord(s->ev0, st));
+  hipEvent_t e0 = s->ev0, e1 = s->ev1;
+  if (s->timing == 2) {
+    const int k = (int)(s->timed_steps % REX_TIMING_RING);
+    if (!s->ring0[k]) { HIPCHK(hipEventCreate(&s->ring0[k])); HIPCHK(hipEventCreate(&s->ring1[k])); }
+    e0 = s->ring0[k]; e1 = s->ring1[k];
+  }
+  if (s->timing) HIPCHK(hipEventRecord(e0, st));
   launch_step(s, blocks, st, d_action, d_obs, d_reward, d_done, d_motor_cmd);
   HIPCHK(hipGetLastError());
-  if (s->timing) { HIPCHK(hipEventRecord(s->ev1, st)); s->have_timing = 1; }
+  if (s->timing) { HIPCHK(hipEventRecord(e1, st)); s->have_timing = 1; if (s->timing == 2) s->timed_steps++; }
   return REX_OK;
 }
 
+int rex_envs_per_wave(const RexSim* s) { return s ? s->epw : REX_EINVAL; }
+
 int rex_set_timing(RexSim* s, int enable) {
   if (!s) return fail(REX_EINVAL, "rex_set_timing: null sim%s", "");
-  s->timing = enable ? 1 : 0;
+  s->timing = enable == 2 ? 2 : (enable ? 1 : 0);
   s->have_timing = 0;
+  s->timed_steps = 0;
   return REX_OK;
+}
+
+int rex_step_times_ms(RexSim* s, float* ms, int max_count) {
+  if (!s || !ms || max_count <= 0) return fail(REX_EINVAL, "rex_step_times_ms: bad arguments%s", "");
+  if (s->timing != 2 || s->timed_steps == 0) return 0;
+  long long have = s->timed_steps < REX_TIMING_RING ? s->timed_steps : REX_TIMING_RING;
+  int n = (int)(have < max_count ? have : max_count);
+  HIPCHK(hipEventSynchronize(s->ring1[(int)((s->timed_steps - 1) % REX_TIMING_RING)]));
+  for (int j = 0; j < n; ++j) {   // oldest of the last n first
+    const int k = (int)((s->timed_steps - n + j) % REX_TIMING_RING);
+    HIPCHK(hipEventElapsedTime(&ms[j], s->ring0[k], s->ring1[k]));
+  }
+  return n;
 }
 
 int rex_last_step_ms(RexSim* s, float* ms) {

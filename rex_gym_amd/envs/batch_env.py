@@ -173,6 +173,12 @@ class RexBatchEnv:
         s = self._stream if self._stream is not None else self._torch.cuda.current_stream(self.device)
         return ctypes.c_void_p(s.cuda_stream)
 
+    def _on_stream(self):
+        """Context in which host-side staging (dtype / device conversion of actions and indices) is issued: the stream the
+        kernels are launched on, so that a RexBatchEnv(stream=...) orders its copies with its launches by itself."""
+        import contextlib
+        return self._torch.cuda.stream(self._stream) if self._stream is not None else contextlib.nullcontext()
+
     def __len__(self):
         return self.num_envs
 
@@ -195,7 +201,14 @@ class RexBatchEnv:
             pass
 
     def set_timing(self, enable=True):
+        """True / 1: time the last launch (last_step_ms); 2: a ring of the last 256 launches, no sync in between (step_times_ms)."""
         _lib.check(self._L.rex_set_timing(self._h, int(enable)), "rex_set_timing")
+
+    def step_times_ms(self, count=256):
+        buf = (ctypes.c_float * int(count))()
+        n = self._L.rex_step_times_ms(self._h, buf, int(count))
+        _lib.check(min(n, 0), "rex_step_times_ms")
+        return list(buf[:n])
 
     def last_step_ms(self):
         ms = ctypes.c_float()
@@ -223,11 +236,12 @@ class RexBatchEnv:
             _lib.check(self._L.rex_reset(self._h, None, 0, self._obs.data_ptr(), self._stream_ptr()), "rex_reset")
             self._needs_reset = False
             return self._obs.clone()
-        idx = torch.as_tensor(indices, dtype=torch.int32, device=self.device).contiguous()
-        obs = torch.empty((idx.numel(), self.obs_dim), dtype=torch.float32, device=self.device)
-        if idx.numel():
-            _lib.check(self._L.rex_reset(self._h, idx.data_ptr(), idx.numel(), obs.data_ptr(), self._stream_ptr()),
-                       "rex_reset")
+        with self._on_stream():
+            idx = torch.as_tensor(indices, dtype=torch.int32, device=self.device).contiguous()
+            obs = torch.empty((idx.numel(), self.obs_dim), dtype=torch.float32, device=self.device)
+            if idx.numel():
+                _lib.check(self._L.rex_reset(self._h, idx.data_ptr(), idx.numel(), obs.data_ptr(), self._stream_ptr()),
+                           "rex_reset")
         return obs
 
     def step(self, actions):
@@ -236,10 +250,11 @@ class RexBatchEnv:
         torch = self._torch
         if self._needs_reset:
             raise RuntimeError("Must reset environment.")   # wrappers.py:286-288 semantics
-        a = torch.as_tensor(actions, dtype=torch.float32, device=self.device)
-        if a.shape != (self.num_envs, self.action_dim):
-            raise ValueError(f"actions must have shape {(self.num_envs, self.action_dim)}, got {tuple(a.shape)}")
-        a = a.contiguous()
+        with self._on_stream():
+            a = torch.as_tensor(actions, dtype=torch.float32, device=self.device)
+            if a.shape != (self.num_envs, self.action_dim):
+                raise ValueError(f"actions must have shape {(self.num_envs, self.action_dim)}, got {tuple(a.shape)}")
+            a = a.contiguous()
         if self.check_actions:   # batch_env.py:76-79
             lo = torch.as_tensor(np.minimum(self.action_space.low, self.action_space.high), device=self.device)
             hi = torch.as_tensor(np.maximum(self.action_space.low, self.action_space.high), device=self.device)

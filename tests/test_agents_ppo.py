@@ -76,10 +76,12 @@ def test_network_shapes_and_initialisers():
 
 
 class _PointEnv:
-    """N points on a line; action moves the point, reward = -|x|; episodes of fixed length."""
-    def __init__(self, n, seed=0):
+    """N points on a line; action moves the point, reward = -|x|; episodes of fixed length -- or, with `fall` > 0, ending
+    at random (each step with that probability), like robots that fall at different times."""
+    def __init__(self, n, seed=0, fall=0.0):
         self.n, self.g = n, torch.Generator().manual_seed(seed)
         self.x = torch.zeros(n, 1)
+        self.fall = fall
     def reset(self, indices=None):
         if indices is None:
             self.x = torch.rand((self.n, 1), generator=self.g) * 4 - 2
@@ -89,7 +91,8 @@ class _PointEnv:
         return self.x[idx].clone()
     def step(self, a):
         self.x = self.x + 0.5 * a.clamp(-1, 1)
-        return self.x.clone(), -self.x[:, 0].abs(), torch.zeros(self.n, dtype=torch.bool), {}
+        done = torch.rand(self.n, generator=self.g) < self.fall
+        return self.x.clone(), -self.x[:, 0].abs(), done, {}
 
 
 def test_ppo_learns_a_toy_task_and_adapts_its_penalty():
@@ -122,3 +125,32 @@ def test_memory_takes_only_the_episodes_it_has_room_for():
     assert list(agent.memory_length[:2]) == [3, 3]
     stats = agent.end_episode(torch.tensor([1, 3, 4, 5]))         # room for two more: trains, then the memory is empty
     assert stats is not None and agent.memory_index == 0 and agent.updates == 1
+
+
+def test_padding_beyond_an_episode_never_enters_the_advantage():
+    """The reference evaluates the network with tf.nn.dynamic_rnn(cell, observ, length) (algorithm.py:521): outputs
+    beyond an episode's length are zero.  With short episodes and stale observations in the padding, the advantage
+    statistics and the TD-lambda bootstrap must be those of the valid steps alone."""
+    torch.manual_seed(1)
+    for lam in (None, 0.8):
+        cfg = PPOConfig(policy_layers=(8,), value_layers=(8,), update_every=4, update_epochs_policy=1, update_epochs_value=1,
+                        max_length=6, gae_lambda=lam, policy_lr=0.0, value_lr=0.0)
+        results = []
+        for pad in (0.0, 50.0):                                   # same episodes, different garbage in the padding
+            agent = PPOAgent(4, 2, 1, cfg, device="cpu", seed=5)
+            g = torch.Generator().manual_seed(9)
+            length = torch.tensor([6, 2, 3, 1])
+            obs = torch.randn((4, 6, 2), generator=g)
+            act = torch.randn((4, 6, 1), generator=g)
+            rew = torch.randn((4, 6), generator=g)
+            m = ppo._mask(length, 6)
+            obs = obs * m[..., None] + pad * (1 - m[..., None])
+            rew = rew * m + pad * (1 - m)
+            mean, logstd, _ = agent.net(obs)
+            agent.memory = [obs, act, mean.detach(), logstd.detach(), rew]
+            agent.memory_length = length
+            captured = {}
+            orig = ppo.diag_normal_logpdf
+            stats = agent._update_policy(obs, act, mean.detach(), logstd.detach(), rew, length)
+            results.append(stats["policy_loss"])
+        assert abs(results[0] - results[1]) < 1e-6, (lam, results)

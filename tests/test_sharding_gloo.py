@@ -76,16 +76,19 @@ def _ppo_worker(rank, world, port, q):
     cfg = PPOConfig(policy_layers=(16,), value_layers=(16,), update_every=n, update_epochs_policy=3, update_epochs_value=3,
                     policy_lr=1e-3, value_lr=1e-3, max_length=8)
     agent = PPOAgent(n, 1, 1, cfg, device="cpu", seed=2, sync_gradients=True)   # same initial weights on every rank
-    train(_PointEnv(n, seed=100 + rank), agent, 8 * 3)                           # different data on every rank
+    # different data on every rank, and episodes that end at different steps on different ranks: the update decision
+    # itself has to be collective (PPOAgent.train_if_all_full), or the gradient all-reduces of the ranks mis-pair
+    train(_PointEnv(n, seed=100 + rank, fall=0.15), agent, 8 * 6, sync_poll=4)
     flat = torch.cat([p.detach().reshape(-1) for p in agent.net.parameters()])
-    q.put((rank, flat.numpy(), agent.updates))
+    q.put((rank, torch.cat([flat, agent.observ_filter.mean.reshape(-1), torch.tensor([agent.penalty])]).numpy(), agent.updates))
     dist.barrier()
     dist.destroy_process_group()
 
 
 def test_ppo_ranks_stay_in_step_when_gradients_are_averaged():
     """The learner's multi-rank mode: every rank trains on its own shard's episodes, gradients are all-reduced, so the
-    weights stay identical on all ranks (and differ from a run on one rank's data alone)."""
+    weights, the KL penalty and the observation filter stay identical on all ranks, although the ranks' episodes end at
+    different times."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29810 + (os.getpid() % 150)
