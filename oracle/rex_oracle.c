@@ -755,7 +755,7 @@ static void physics_substep(Phys* s, const real tau[NJ], real dt, int iterations
   /* contact detection at the start-of-step pose: the two end points of each toe cylinder against the
    * ground.  Per end: ground normal n0 under the end centre -> the point of the end circle that is lowest
    * along n0 -> ground height / normal under THAT point -> signed distance to the local ground plane. */
-  static __thread Row rows[MAX_ROWS];
+  Row rows[MAX_ROWS];
   int nrow = 0, npoint = 0;
   int normal_of_point[MAX_POINTS];
   real PtP[MAX_POINTS][3], PtN[MAX_POINTS][3];
@@ -1007,7 +1007,8 @@ typedef struct {
 typedef struct {
   RexConfig cfg;
   Env* envs;
-  Env snapshot; /* settled reset state (rex.py:296-324) */
+  Env snapshot[5]; /* settled reset state (rex.py:296-324), one per task of a REX_TASK_MIXED batch */
+  int n_mix, mix_task[5];
   /* terrain pool (terrain_type='random'): K heightfields, one settled snapshot per terrain */
   int n_terrain;
   float* heights; /* [K][256*256] */
@@ -1015,6 +1016,25 @@ typedef struct {
   Env* terrain_snapshot;
   float* body_params; /* [3][N] or NULL */
 } Orc;
+
+/* ---- REX_TASK_MIXED: env g runs one task of the mix for its whole life, drawn from its own Philox stream ---- */
+static int task_action_repeat(int task) { return (task == REX_TASK_GALLOP || task == REX_TASK_POSES) ? 6 : 5; }
+static int mixed_task_of(const Orc* o, int idx) {
+  uint32_t ctr[4] = {0xFFFFFFFFu, (uint32_t)(o->cfg.env_index_base + idx), 2u, 0u};
+  philox4x32(ctr, (uint32_t)o->cfg.seed, (uint32_t)(o->cfg.seed >> 32));
+  return o->mix_task[ctr[0] % (uint32_t)o->n_mix];
+}
+static RexConfig task_cfg(const Orc* o, int task) {   /* the per-task constants of the reference env classes */
+  RexConfig c = o->cfg;
+  if (o->cfg.task != REX_TASK_MIXED) return c;
+  c.task = task;
+  c.action_repeat = task_action_repeat(task);
+  c.solver_iterations = 300 / c.action_repeat;
+  c.energy_weight = task == REX_TASK_GALLOP ? 0.005f : 0.0005f;
+  return c;
+}
+static RexConfig env_cfg(const Orc* o, int idx) { return o->cfg.task == REX_TASK_MIXED ? task_cfg(o, mixed_task_of(o, idx)) : o->cfg; }
+static int mix_slot(const Orc* o, int task) { for (int k = 0; k < o->n_mix; ++k) if (o->mix_task[k] == task) return k; return 0; }
 
 /* terrain of (global env index, episode): the reference regenerates the field on every reset
  * (rex_gym_env.py:347-348); here each episode picks one of the K pool entries */
@@ -1029,15 +1049,33 @@ static Ground env_ground(const Orc* o, int idx, int episode) {
     g.has_params = 1; g.base_mass_scale = (real)o->body_params[idx]; g.leg_mass_scale = (real)o->body_params[n + idx];
     g.mu = (real)o->body_params[2 * n + idx];
   }
+  if (o->cfg.mass_scale_hi > 0 || o->cfg.friction_hi > 0) {   /* per-reset draws (env_randomizer hook, rex_gym_env.py:345-346) */
+    uint32_t ctr[4] = {(uint32_t)episode, (uint32_t)(o->cfg.env_index_base + idx), 1u, 0u};
+    philox4x32(ctr, (uint32_t)o->cfg.seed, (uint32_t)(o->cfg.seed >> 32));
+    g.has_params = 1;
+    if (o->cfg.mass_scale_hi > 0) {
+      g.base_mass_scale = (real)fmaf(o->cfg.mass_scale_hi - o->cfg.mass_scale_lo, u01(ctr[0]), o->cfg.mass_scale_lo);
+      g.leg_mass_scale = (real)fmaf(o->cfg.mass_scale_hi - o->cfg.mass_scale_lo, u01(ctr[1]), o->cfg.mass_scale_lo);
+    }
+    if (o->cfg.friction_hi > 0) g.mu = (real)fmaf(o->cfg.friction_hi - o->cfg.friction_lo, u01(ctr[2]), o->cfg.friction_lo);
+  }
   int t = terrain_index(o, idx, episode);
   if (t >= 0) { g.h = o->heights + (size_t)t * HF_N * HF_N; g.mid = (real)o->mids[t]; }
   return g;
 }
 
-ORC_API int orc_obs_dim(const RexConfig* c) { return c->task == REX_TASK_GALLOP ? 4 + NJ : 4; }
+ORC_API int orc_obs_dim(const RexConfig* c) {
+  if (c->task == REX_TASK_MIXED) return ((c->task_mix >> REX_TASK_GALLOP) & 1) ? 4 + NJ : 4;
+  return c->task == REX_TASK_GALLOP ? 4 + NJ : 4;
+}
 ORC_API int orc_num_motors(void) { return NJ; }
 ORC_API int orc_state_words(void) { return SW_WORDS; }
 ORC_API int orc_action_dim(const RexConfig* c) {
+  if (c->task == REX_TASK_MIXED) {
+    int best = 0;
+    for (int t = 0; t < 5; ++t) if ((c->task_mix >> t) & 1) { RexConfig one = *c; one.task = t; int d = orc_action_dim(&one); if (d > best) best = d; }
+    return best;
+  }
   if (c->task == REX_TASK_WALK) return c->signal == REX_SIGNAL_IK ? 2 : 8;
   if (c->task == REX_TASK_GALLOP) return c->signal == REX_SIGNAL_IK ? 2 : 4;
   if (c->task == REX_TASK_POSES || c->task == REX_TASK_STANDUP) return 1;         /* standup_env.py:99-101 */
@@ -1136,10 +1174,11 @@ static void rex_substep(const RexConfig* c, Env* e, const real cmd[NJ], const Gr
   receive_observation(c, e);
 }
 
-static void settle(Orc* o, Env* e, const Ground* ground) {
+static void settle(Orc* o, Env* e, const Ground* ground, const RexConfig* cfgp) {
+  (void)o;
   real (*hist)[HIST_WORDS] = e->hist;     /* the snapshot keeps its own ring when a latency is configured */
   memset(e, 0, sizeof(*e));
-  if (!hist && (o->cfg.pd_latency > 0 || o->cfg.control_latency > 0)) hist = calloc(REX_HISTORY_LEN, sizeof(real[HIST_WORDS]));
+  if (!hist && (cfgp->pd_latency > 0 || cfgp->control_latency > 0)) hist = calloc(REX_HISTORY_LEN, sizeof(real[HIST_WORDS]));
   e->hist = hist;
   e->ph.pos[2] = ROBOT_INIT_Z;
   e->ph.quat[3] = 1;
@@ -1150,15 +1189,15 @@ static void settle(Orc* o, Env* e, const Ground* ground) {
   /* Rex.Reset: `_observation_history.clear()` (rex.py:309), then -- only when a reset motion follows -- one
    * ReceiveObservation of the dropped robot (rex.py:314) */
   e->hist_head = REX_HISTORY_LEN - 1; e->hist_len = 0;
-  if (o->cfg.task == REX_TASK_POSES) { receive_observation(&o->cfg, e); return; }   /* rex.py:323 alone */
-  receive_observation(&o->cfg, e);
+  if (cfgp->task == REX_TASK_POSES) { receive_observation(cfgp, e); return; }   /* rex.py:323 alone */
+  receive_observation(cfgp, e);
   real cmd[NJ];
   full_command(POSE_STAND, cmd);
-  for (int k = 0; k < 100; ++k) rex_substep(&o->cfg, e, cmd, ground);      /* rex.py:315-318 */
-  int nreset = whole_steps(0.5f, o->cfg.sim_time_step);             /* rex.py:319 */
-  full_command(init_pose(&o->cfg), cmd);
-  for (int k = 0; k < nreset; ++k) rex_substep(&o->cfg, e, cmd, ground);
-  receive_observation(&o->cfg, e);                                          /* rex.py:323: the last state once more */
+  for (int k = 0; k < 100; ++k) rex_substep(cfgp, e, cmd, ground);      /* rex.py:315-318 */
+  int nreset = whole_steps(0.5f, cfgp->sim_time_step);             /* rex.py:319 */
+  full_command(init_pose(cfgp), cmd);
+  for (int k = 0; k < nreset; ++k) rex_substep(cfgp, e, cmd, ground);
+  receive_observation(cfgp, e);                                          /* rex.py:323: the last state once more */
 }
 
 /* the observation the controller-facing getters read (Rex._control_observation): delayed when a latency is set */
@@ -1179,7 +1218,9 @@ static void env_observation(const RexConfig* c, const Env* e, real* obs) {
 }
 
 static void env_reset(Orc* o, int idx) {
-  const RexConfig* c = &o->cfg;
+  const RexConfig cfg_env = env_cfg(o, idx);
+  const RexConfig* c = &cfg_env;
+  const int slot = mix_slot(o, c->task);
   Env* e = &o->envs[idx];
   int32_t episode = e->episode;
   real (*hist)[HIST_WORDS] = e->hist;
@@ -1188,7 +1229,7 @@ static void env_reset(Orc* o, int idx) {
   real alpha = e->gait.alpha;
   {
     int t = terrain_index(o, idx, episode + 1);
-    *e = t >= 0 ? o->terrain_snapshot[t] : o->snapshot;   /* settled on this episode's terrain */
+    *e = t >= 0 ? o->terrain_snapshot[t * o->n_mix + slot] : o->snapshot[slot];   /* settled on this episode's terrain (under this env's task) */
   }
   e->episode = episode + 1;
   e->hist = hist;
@@ -1232,7 +1273,7 @@ static void env_reset(Orc* o, int idx) {
    * motion (the newest twice, rex.py:323), and the turn env's teleport (turn_env.py:158-159) happens behind its back --
    * the observation reset() returns and the first step's yaw reading are those of the settled, not yet turned robot */
   if (e->hist) {
-    const Env* snap = o->n_terrain ? &o->terrain_snapshot[terrain_index(o, idx, e->episode)] : &o->snapshot;
+    const Env* snap = o->n_terrain ? &o->terrain_snapshot[terrain_index(o, idx, e->episode) * o->n_mix + slot] : &o->snapshot[slot];
     memcpy(e->hist, snap->hist, sizeof(real[HIST_WORDS]) * REX_HISTORY_LEN);
   }
 }
@@ -1481,12 +1522,13 @@ static void env_command(const RexConfig* c, Env* e, const real* action, real* le
 }
 
 static void env_step(Orc* o, int idx, const real* action_in, real* obs, real* reward, uint8_t* done, real* motor_cmd) {
-  const RexConfig* c = &o->cfg;
+  const RexConfig cfg_env = env_cfg(o, idx);
+  const RexConfig* c = &cfg_env;
   Env* e = &o->envs[idx];
   real cmd[NJ], leg_cmd[12];
   real action[8];
   {
-    int ad = orc_action_dim(c);
+    int ad = orc_action_dim(c);   /* this env's own task; the batch's rows may be wider (REX_TASK_MIXED) */
     real lo, hi;
     action_bounds(c, &lo, &hi);
     for (int k = 0; k < ad; ++k) {
@@ -1518,8 +1560,9 @@ static void env_step(Orc* o, int idx, const real* action_in, real* obs, real* re
   if (motor_cmd) memcpy(motor_cmd, cmd, sizeof(real) * NJ);
   if (d) e->flags |= REX_F_DONE;
   if (d && c->auto_reset) env_reset(o, idx);
+  for (int k = 4; k < orc_obs_dim(&o->cfg); ++k) obs[k] = 0;   /* a narrower task leaves the tail of a mixed batch's row 0 */
   env_observation(c, e, obs);
-  if (c->range_normalize) normalize_obs(c, obs, orc_obs_dim(c));
+  if (c->range_normalize) normalize_obs(c, obs, orc_obs_dim(&o->cfg));
 }
 
 /* ---------------------------------- batch API (mirrors include/rexsim.h) ---------------------------------- */
@@ -1539,8 +1582,13 @@ ORC_API void* orc_create(const RexConfig* cfg) {
   o->envs = (Env*)calloc((size_t)cfg->num_envs, sizeof(Env));
   if (cfg->pd_latency > 0 || cfg->control_latency > 0)
     for (int i = 0; i < cfg->num_envs; ++i) o->envs[i].hist = calloc(REX_HISTORY_LEN, sizeof(real[HIST_WORDS]));
+  o->n_mix = 1; o->mix_task[0] = cfg->task;
+  if (cfg->task == REX_TASK_MIXED) {
+    o->n_mix = 0;
+    for (int t = 0; t < 5; ++t) if ((cfg->task_mix >> t) & 1) o->mix_task[o->n_mix++] = t;
+  }
   Ground g0 = {0, 0, 1, 1, FRICTION_MU, 0, cfg->body_contacts};
-  settle(o, &o->snapshot, &g0);
+  for (int k = 0; k < o->n_mix; ++k) { RexConfig ct = task_cfg(o, o->mix_task[k]); settle(o, &o->snapshot[k], &g0, &ct); }
   return o;
 }
 ORC_API void orc_set_body_params(void* h, const float* params) {
@@ -1551,26 +1599,28 @@ ORC_API void orc_set_body_params(void* h, const float* params) {
     memcpy(o->body_params, params, sizeof(float) * 3 * (size_t)o->cfg.num_envs);
   }
 }
-ORC_API void orc_destroy(void* h) { Orc* o = (Orc*)h; for (int i = 0; i < o->cfg.num_envs; ++i) free(o->envs[i].hist); free(o->snapshot.hist); for (int t = 0; t < o->n_terrain; ++t) free(o->terrain_snapshot[t].hist); free(o->body_params); free(o->envs); free(o->heights); free(o->mids); free(o->terrain_snapshot); free(o); }
+ORC_API void orc_destroy(void* h) { Orc* o = (Orc*)h; for (int i = 0; i < o->cfg.num_envs; ++i) free(o->envs[i].hist); for (int k = 0; k < o->n_mix; ++k) free(o->snapshot[k].hist); for (int t = 0; t < o->n_terrain * o->n_mix; ++t) free(o->terrain_snapshot[t].hist); free(o->body_params); free(o->envs); free(o->heights); free(o->mids); free(o->terrain_snapshot); free(o); }
 
 /* terrain pool: heights [k][256*256] raw vertex heights (terrain.py:36-43 layout: data[i + j*rows], i along x),
  * mids [k] = (min+max)/2 of each field */
 ORC_API void orc_set_terrain(void* h, const float* heights, const float* mids, int k) {
   Orc* o = (Orc*)h;
-  for (int t = 0; t < o->n_terrain; ++t) free(o->terrain_snapshot[t].hist);
+  for (int t = 0; t < o->n_terrain * o->n_mix; ++t) free(o->terrain_snapshot[t].hist);
   free(o->heights); free(o->mids); free(o->terrain_snapshot);
   o->n_terrain = k;
   o->heights = (float*)malloc(sizeof(float) * (size_t)k * HF_N * HF_N);
   o->mids = (float*)malloc(sizeof(float) * (size_t)k);
-  o->terrain_snapshot = (Env*)calloc((size_t)k, sizeof(Env));
+  o->terrain_snapshot = (Env*)calloc((size_t)k * o->n_mix, sizeof(Env));
   memcpy(o->heights, heights, sizeof(float) * (size_t)k * HF_N * HF_N);
   memcpy(o->mids, mids, sizeof(float) * (size_t)k);
 #ifdef _OPENMP
 #pragma omp parallel for schedule(dynamic)
 #endif
-  for (int t = 0; t < k; ++t) {
+  for (int r = 0; r < k * o->n_mix; ++r) {
+    int t = r / o->n_mix;
     Ground g = {o->heights + (size_t)t * HF_N * HF_N, (real)o->mids[t], 1, 1, FRICTION_MU, 0, o->cfg.body_contacts};
-    settle(o, &o->terrain_snapshot[t], &g);
+    RexConfig ct = task_cfg(o, o->mix_task[r % o->n_mix]);
+    settle(o, &o->terrain_snapshot[r], &g, &ct);
   }
 }
 
@@ -1581,7 +1631,9 @@ ORC_API void orc_reset(void* h, const int32_t* indices, int n, real* obs) {
   for (int r = 0; r < cnt; ++r) {
     int idx = indices ? indices[r] : r;
     env_reset(o, idx);
-    env_observation(&o->cfg, &o->envs[idx], obs + (size_t)r * od);
+    RexConfig ce = env_cfg(o, idx);
+    for (int k = 4; k < od; ++k) obs[(size_t)r * od + k] = 0;
+    env_observation(&ce, &o->envs[idx], obs + (size_t)r * od);
     if (o->cfg.range_normalize) normalize_obs(&o->cfg, obs + (size_t)r * od, od);
   }
 }
@@ -1603,7 +1655,8 @@ ORC_API void orc_step(void* h, const real* action, real* obs, real* reward, uint
 ORC_API void orc_env_command(void* h, int idx, const real* action, real* cmd_out) {
   Orc* o = (Orc*)h;
   real leg_cmd[12];
-  env_command(&o->cfg, &o->envs[idx], action, leg_cmd);
+  RexConfig ce = env_cfg(o, idx);
+  env_command(&ce, &o->envs[idx], action, leg_cmd);
   full_command(leg_cmd, cmd_out);
 }
 

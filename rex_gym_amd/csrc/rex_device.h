@@ -728,7 +728,7 @@ struct DvLane {
 
 template <int LPE, class SM, class ARMP>
 __device__ __forceinline__ void pgs_dv(const SM& sm, ARMP& armp, PgsX& x, int p, const bool (&lim)[4], bool any_contact,
-                                       float mu, int iterations, float thr, int& nsweeps) {
+                                       float mu, int iterations, int lane_iterations, float thr, int& nsweeps) {
   constexpr int EPW = SM::kEpw, NY = (6 + LPE - 1) / LPE;
   constexpr int kRow = REX_ROW_F4 * EPW * 16;   // bytes from a row to the next
   DvLane<NY, EPW> ln;
@@ -839,7 +839,7 @@ __device__ __forceinline__ void pgs_dv(const SM& sm, ARMP& armp, PgsX& x, int p,
           zs[L] = fmaf(Jz[r], dl, zs[L]);
         }
       }
-      running = worst > 0.0f;
+      running = worst > 0.0f && it + 1 < lane_iterations;
     }
     if (__builtin_amdgcn_ballot_w64(running) == 0) break;
   }
@@ -875,8 +875,10 @@ __device__ long long g_prof[10 * 1024];  // per block: cycle counters of the sec
 #define REX_STAMP(var)
 #endif
 template <class SM, class ARMP>
-__device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float dt, int iterations,
+__device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float dt, int iterations, int lane_iterations,
                                                 float sqrt_res_thr, const SM& sm, const Ground& ground, ARMP& armp) {
+  // `iterations`: wave-uniform sweep cap; `lane_iterations` <= iterations: this env's own cap (they differ only in a batch
+  // that mixes tasks with different numSolverIterations, REX_TASK_MIXED)
   REX_STAMP(t_begin);
   // base rotation (btMatrix3x3::setRotation)
   BaseKin bk;
@@ -1049,7 +1051,7 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
     if (pl == 0) sm.parkf(REX_PARK_CPL, 0) = 0.0f;
     mirror_sync();
     const bool lim[4] = {lim0, lim1, lim2, lim3};
-    pgs_dv<LPE>(sm, armp, x, pl, lim, any0 || any1 || any2 || any3, ground.mu, iterations, sqrt_res_thr, nsweeps);
+    pgs_dv<LPE>(sm, armp, x, pl, lim, any0 || any1 || any2 || any3, ground.mu, iterations, lane_iterations, sqrt_res_thr, nsweeps);
   } else {
     // one env per lane (EPW = 64): every lane carries the whole of x, row by row from LDS
     bool running = true;
@@ -1070,7 +1072,7 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
         if (any1) pgs_leg_friction<1>(sm, x, lam, worst, ground.mu);
         if (any2) pgs_leg_friction<2>(sm, x, lam, worst, ground.mu);
         if (any3) pgs_leg_friction<3>(sm, x, lam, worst, ground.mu);
-        running = worst > sqrt_res_thr;
+        running = worst > sqrt_res_thr && it + 1 < lane_iterations;
       }
       if (__builtin_amdgcn_ballot_w64(running) == 0) break;
     }

@@ -168,8 +168,50 @@ struct DevCfg {
   const float* body_params;  // [3][n] word-major: base mass scale, leg mass scale, foot friction (nullptr: 1, 1, 0.5)
   float act_lo, act_hi;      // Box bounds of the env's action space (host: rex_create)
   float gait_clock;          // wall-clock seconds per simulated second seen by GaitPlanner.loop (gait_planner.py:108-110)
+  // REX_TASK_MIXED: the tasks of the mix (task_mix bits, ascending), their number, and the largest action_repeat /
+  // solver sweep cap among them (wave-uniform loop bounds; every env stops at its own)
+  int32_t mix_task[5], n_mix, max_repeat, max_iterations;
+  float mass_lo, mass_hi, mu_lo, mu_hi;   // per-reset randomisation ranges (lo == hi == 0: off)
   float obs_hi_ang, obs_hi_rate;
 };
+
+// per-task constants of the reference env classes (walk_env.py:34-40,104-114, gallop_env.py:45-53,
+// 119-130, turn_env.py:33-39,100-110, poses_env.py:38-44,115-117, standup_env.py:32-38,99-101)
+__host__ __device__ __forceinline__ int task_action_repeat(int task) { return (task == REX_TASK_GALLOP || task == REX_TASK_POSES) ? 6 : 5; }
+__host__ __device__ __forceinline__ float task_action_bound(int task, int signal) {   // Box(low = -b, high = +b); gallop's is inverted
+  if (task == REX_TASK_WALK) return signal == REX_SIGNAL_IK ? 0.4f : 0.01f;
+  if (task == REX_TASK_GALLOP) return signal == REX_SIGNAL_IK ? -0.4f : -0.3f;
+  if (task == REX_TASK_TURN) return 0.01f;
+  return 0.1f;
+}
+__host__ __device__ __forceinline__ float task_energy_weight(int task) { return task == REX_TASK_GALLOP ? 0.005f : 0.0005f; }
+
+// the task env `gidx` runs for its whole life in a REX_TASK_MIXED batch: a draw from its own Philox stream
+__device__ __forceinline__ int mixed_task_of(const DevCfg& c, int gidx) {
+  uint32_t ctr[4] = {0xFFFFFFFFu, (uint32_t)gidx, 2u, 0u};
+  philox4x32(ctr, c.seed_lo, c.seed_hi);
+  const int k = (int)(ctr[0] % (uint32_t)c.n_mix);
+  return k == 0 ? c.mix_task[0] : (k == 1 ? c.mix_task[1] : (k == 2 ? c.mix_task[2] : (k == 3 ? c.mix_task[3] : c.mix_task[4])));
+}
+
+// this env's view of the config in a REX_TASK_MIXED batch: its task and the per-task constants that go with it
+__device__ __forceinline__ void mixed_config(const DevCfg& c, int gidx, DevCfg& cm) {
+  cm = c;
+  cm.task = mixed_task_of(c, gidx);
+  cm.action_repeat = task_action_repeat(cm.task);
+  cm.iterations = 300 / cm.action_repeat;                       // rex_gym_env.py:25,184
+  const float b = task_action_bound(cm.task, c.signal);
+  cm.act_lo = -b; cm.act_hi = b;
+  cm.w_energy = task_energy_weight(cm.task);
+}
+// snapshot record of (terrain, task): one settled robot per terrain and -- in a mixed batch -- per task of the mix
+// (the reset motion runs under the task's own numSolverIterations)
+__device__ __forceinline__ int mix_slot(const DevCfg& c, int task) {
+  int sl = 0;
+#pragma unroll
+  for (int k = 1; k < 5; ++k) if (k < c.n_mix && c.mix_task[k] == task) sl = k;
+  return sl;
+}
 
 // INIT_POSES['rest_position'] (rex_constants.py:41-46): the foot target 6 rad lies beyond the URDF bound 2.59
 __device__ __forceinline__ float pose_rest(int j) {
@@ -211,6 +253,17 @@ __device__ __forceinline__ Ground env_ground(const DevCfg& c, int i, int gidx, i
   Ground g{nullptr, 0.0f, 1.0f, 1.0f, kMu};
   if (c.body_params) {
     g.base_mass_scale = c.body_params[i]; g.leg_mass_scale = c.body_params[(size_t)c.n + i]; g.mu = c.body_params[2 * (size_t)c.n + i];
+  }
+  if (c.mass_hi > 0.0f || c.mu_hi > 0.0f) {
+    // per-reset draws of the env_randomizer hook (rex_gym_env.py:345-346): a pure function of (seed, env, episode), so
+    // nothing has to be stored -- every step of the episode recomputes the same three numbers
+    uint32_t ctr[4] = {(uint32_t)episode, (uint32_t)gidx, 1u, 0u};
+    philox4x32(ctr, c.seed_lo, c.seed_hi);
+    if (c.mass_hi > 0.0f) {
+      g.base_mass_scale = fmaf(c.mass_hi - c.mass_lo, u01(ctr[0]), c.mass_lo);
+      g.leg_mass_scale = fmaf(c.mass_hi - c.mass_lo, u01(ctr[1]), c.mass_lo);
+    }
+    if (c.mu_hi > 0.0f) g.mu = fmaf(c.mu_hi - c.mu_lo, u01(ctr[2]), c.mu_lo);
   }
   if (c.n_terrain > 0) {
     const int t = terrain_index(c, gidx, episode);
@@ -265,7 +318,7 @@ __device__ __forceinline__ void rex_substep(const DevCfg& c, EnvState& e, int i,
     tau_obs[j] = obs;
     tau[j] = ((e.motor_en >> j) & 1u) ? act : 0.0f;                             // rex.py:617-623
   }
-  physics_substep(e.ph, tau, c.dt, c.iterations, c.res_thr, sm, ground, armp);
+  physics_substep(e.ph, tau, c.dt, c.max_iterations, c.iterations, c.res_thr, sm, ground, armp);
   receive_observation(c, e, i, live, tau_obs);
 }
 
@@ -327,9 +380,9 @@ template <int NM>
 __device__ __forceinline__ void env_reset(const DevCfg& c, const float* snap, int i, bool live, int gidx, EnvState& e, float* seen) {
   const int32_t episode = e.episode + 1;
   const float alpha = e.gait.alpha;   // the env keeps one GaitPlanner for life: its arc angle survives reset() (gait_planner.py:76-85)
-  const int nrec = c.n_terrain > 0 ? c.n_terrain : 1;
-  const int rec = c.n_terrain > 0 ? terrain_index(c, gidx, episode) : 0;
-  load_env<NM>(snap, nrec, rec, e);   // settled on this episode's terrain
+  const int nrec = (c.n_terrain > 0 ? c.n_terrain : 1) * c.n_mix;
+  const int rec = (c.n_terrain > 0 ? terrain_index(c, gidx, episode) : 0) * c.n_mix + (c.n_mix > 1 ? mix_slot(c, c.task) : 0);
+  load_env<NM>(snap, nrec, rec, e);   // settled on this episode's terrain (under this env's task)
   if (c.hist) {   // the deque as the reset motion left it: its last 100 observations, ring position included (e.hist)
     if (live) {
       const float* ring = snap + (size_t)Lay<NM>::WORDS * nrec;
@@ -547,7 +600,7 @@ __device__ __forceinline__ void standup_command(const DevCfg& c, const EnvState&
 }
 
 // ------------------------------------------------------------------------------------------
-template <int EPW, bool ARM>
+template <int EPW, bool ARM, bool MIXED>
 __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __restrict__ state, const float* __restrict__ snap,
                                                             const float* __restrict__ action, float* __restrict__ obs_out,
                                                             float* __restrict__ reward_out, uint8_t* __restrict__ done_out,
@@ -558,6 +611,7 @@ __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __r
   // wave.  With EPW <= 16 every env owns a group of LPE = 8 (EPW <= 8) or 4 (EPW = 16) adjacent lanes (for EPW = 4 the
   // upper 32 lanes repeat the lower 32): the lanes of a group run the same arithmetic on the same state, split the
   // per-leg and per-row work of a substep between them (rex_device.h) and only lane 0 of the group stores.
+  // MIXED (REX_TASK_MIXED): the envs of a wave may run different tasks -- c_ below is the lane's own view of the config.
   constexpr int NM = ARM ? 18 : 12;   // mark='arm': 6 more motors held at ARM_POSES['rest'] (rex_gym_env.py:347-353)
   constexpr int kLegF4 = REX_LEG_F4_OF(EPW, ARM);
   constexpr int kRowsF4 = ARM ? REX_LDS_F4_PER_ENV_ARM_OF(EPW) : REX_ROWS_F4_OF(kLegF4);
@@ -572,6 +626,10 @@ __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __r
   const Lds<EPW, kLegF4> sm{lds, slot, EPW <= 16 ? lds + kRowsF4 * EPW : nullptr};
   typename ArmHook<EPW, ARM>::type armp = ArmHook<EPW, ARM>::make(lds, slot);
 
+  DevCfg cmix;                          // MIXED only
+  if constexpr (MIXED) mixed_config(c, c.env_index_base + i, cmix);
+  const DevCfg& c_ = MIXED ? cmix : c;
+
   EnvState e;
   load_env<NM>(state, c.n, i, e);
   float act[8];
@@ -580,7 +638,7 @@ __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __r
     float a = k < c.action_dim ? action[(size_t)i * c.action_dim + k] : 0.0f;
     if (c.range_normalize) {                       // ClipAction + RangeNormalize (wrappers.py:229-234,261-265)
       a = fminf(fmaxf(a, -1.0f), 1.0f);
-      a = (a + 1.0f) / 2.0f * (c.act_hi - c.act_lo) + c.act_lo;
+      a = (a + 1.0f) / 2.0f * (c_.act_hi - c_.act_lo) + c_.act_lo;
     }
     act[k] = a;
   }
@@ -590,8 +648,8 @@ __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __r
 #pragma unroll
     for (int j = 12; j < NM; ++j) cmd[j] = (float)REXA_REST[j - 12];
   }
-  if (c.task == REX_TASK_GALLOP) gallop_command(c, e, act, cmd);
-  else if (c.task == REX_TASK_TURN) {
+  if (c_.task == REX_TASK_GALLOP) gallop_command(c_, e, act, cmd);
+  else if (c_.task == REX_TASK_TURN) {
     float cq[4] = {e.ph.quat[0], e.ph.quat[1], e.ph.quat[2], e.ph.quat[3]};
     if (c.hist) {
       int s0, s1; float alpha;
@@ -599,16 +657,17 @@ __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __r
 #pragma unroll
       for (int k = 0; k < 4; ++k) cq[k] = delayed_word(c, i, s0, s1, alpha, 36 + k);
     }
-    turn_command(c, e, cq, act, cmd);
+    turn_command(c_, e, cq, act, cmd);
   }
-  else if (c.task == REX_TASK_POSES) poses_command(c, e, act, cmd);
-  else if (c.task == REX_TASK_STANDUP) standup_command(c, e, act, cmd);
-  else walk_command(c, e, act, cmd);
+  else if (c_.task == REX_TASK_POSES) poses_command(c_, e, act, cmd);
+  else if (c_.task == REX_TASK_STANDUP) standup_command(c_, e, act, cmd);
+  else walk_command(c_, e, act, cmd);
 
   float tau_obs[NM];
   const Ground ground = env_ground(c, i, c.env_index_base + i, e.episode);
-  for (int k = 0; k < c.action_repeat; ++k) rex_substep(c, e, i, live, cmd, tau_obs, sm, ground, armp);   // Rex.Step
 
+  // everything of env.step() after Rex.Step: reward, termination, in-launch reset, observation, stores
+  auto epilogue = [&](bool commit) {
   // ---- reward (rex_gym_env.py:501-542) ----
   CtrlObs co;
   control_observation<NM>(c, e, i, tau_obs, co);
@@ -630,10 +689,10 @@ __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __r
 #pragma unroll
   for (int j = 0; j < NM; ++j) dp += co.tau[j] * co.qd[j];   // GetMotorTorques . GetMotorVelocities
   const float energy = -fabsf(dp) * c.dt;
-  float reward = c.w_dist * fwd + c.w_energy * energy + c.w_drift * drift + c.w_shake * shake;
-  if (c.task == REX_TASK_TURN) reward = 0.035f - fabsf(e.ph.pos[0]) - fabsf(e.ph.pos[1]);   // turn_env.py:362-367
-  if (c.task == REX_TASK_POSES) reward = 1.0f;                                                // poses_env.py:267-269
-  if (c.task == REX_TASK_STANDUP) {                                                           // standup_env.py:150-166
+  float reward = c.w_dist * fwd + c_.w_energy * energy + c.w_drift * drift + c.w_shake * shake;
+  if (c_.task == REX_TASK_TURN) reward = 0.035f - fabsf(e.ph.pos[0]) - fabsf(e.ph.pos[1]);   // turn_env.py:362-367
+  if (c_.task == REX_TASK_POSES) reward = 1.0f;                                                // poses_env.py:267-269
+  if (c_.task == REX_TASK_STANDUP) {                                                           // standup_env.py:150-166
     float pr = fabsf(e.ph.pos[0]) + fabsf(e.ph.pos[1]) + fabsf(0.21f - e.ph.pos[2]);
     pr = pr < 0.1f ? 1.0f - pr : -pr;
     if (e.ph.pos[2] > 0.21f) pr = -1.0f - pr;
@@ -642,19 +701,19 @@ __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __r
 
   // ---- termination (rex_gym_env.py:490-499, walk_env.py:326-338, gallop_env.py:315-329) ----
   bool done;
-  if (c.task == REX_TASK_GALLOP || c.task == REX_TASK_STANDUP) {   // GetTrueBaseRollPitchYaw: never delayed (gallop_env.py:319-329)
+  if (c_.task == REX_TASK_GALLOP || c_.task == REX_TASK_STANDUP) {   // GetTrueBaseRollPitchYaw: never delayed (gallop_env.py:319-329)
     float trpy[3];
     quat_to_euler(e.ph.quat, trpy);
-    done = fabsf(trpy[0]) > 0.3f || fabsf(trpy[1]) > 0.5f || (c.task == REX_TASK_GALLOP && e.ph.pos[1] > 0.3f);
+    done = fabsf(trpy[0]) > 0.3f || fabsf(trpy[1]) > 0.5f || (c_.task == REX_TASK_GALLOP && e.ph.pos[1] > 0.3f);
   } else done = r22 < 0.85f;
-  if ((e.flags & REX_F_ENV_GOAL) && c.task != REX_TASK_STANDUP) done = true;     // rex_gym_env.py:495; standup overrides _termination
-  if (c.task == REX_TASK_POSES) done = false;                                    // is_fallen() returns False, poses_env.py:265
+  if ((e.flags & REX_F_ENV_GOAL) && c_.task != REX_TASK_STANDUP) done = true;     // rex_gym_env.py:495; standup overrides _termination
+  if (c_.task == REX_TASK_POSES) done = false;                                    // is_fallen() returns False, poses_env.py:265
   e.steps += 1;
   if (c.max_steps > 0 && e.steps >= c.max_steps) done = true;
   if (done) e.flags |= REX_F_DONE;
   if (done && c.auto_reset) {
     float seen[7];
-    env_reset<NM>(c, snap, i, live, c.env_index_base + i, e, seen);
+    env_reset<NM>(c_, snap, i, commit, c.env_index_base + i, e, seen);
 #pragma unroll
     for (int j = 0; j < NM; ++j) tau_obs[j] = 0.0f;
     control_observation<NM>(c, e, i, tau_obs, co);
@@ -667,9 +726,13 @@ __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __r
   }
 
   float obs[22];
-  env_observation<NM>(c, co, obs);
+  if constexpr (MIXED) {
+#pragma unroll
+    for (int k = 4; k < 22; ++k) obs[k] = 0.0f;    // a task with a narrower observation leaves the tail of its row 0
+  }
+  env_observation<NM>(c_, co, obs);
   if (c.range_normalize) normalize_obs(c, obs);
-  if (live) {
+  if (commit) {
     // an opaque copy of the env index: the store addresses are rebuilt here instead of 54 address pairs being carried
     // (in AGPRs and scratch) from load_env across the whole kernel
     int is = i;
@@ -681,6 +744,20 @@ __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __r
     if (cmd_out) {
 #pragma unroll
       for (int j = 0; j < NM; ++j) cmd_out[(size_t)is * NM + j] = cmd[j];
+    }
+  }
+  };
+
+  if constexpr (!MIXED) {
+    for (int k = 0; k < c.action_repeat; ++k) rex_substep(c, e, i, live, cmd, tau_obs, sm, ground, armp);   // Rex.Step
+    epilogue(live);
+  } else {
+    // Rex.Step of tasks with different action_repeat in one wave: every lane runs max_repeat substeps (the substep is
+    // full of wave-level operations), an env whose own count is reached finishes its env.step() -- epilogue, stores --
+    // before the extra substeps, whose results it never stores
+    for (int k = 0; k <= c.max_repeat; ++k) {
+      if (k == c_.action_repeat) epilogue(live);
+      if (k < c.max_repeat) rex_substep(c_, e, i, live && k < c_.action_repeat, cmd, tau_obs, sm, ground, armp);
     }
   }
 #ifdef REX_PROF
@@ -701,12 +778,13 @@ __global__ __launch_bounds__(REX_WAVE) void rex_settle_kernel(DevCfg c, float* _
   const int lane = (int)(threadIdx.x / LPE) & (EPW - 1);
   const Lds<EPW, kLegF4> sm{lds, lane, EPW <= 16 ? lds + kRowsF4 * EPW : nullptr};
   typename ArmHook<EPW, ARM>::type armp = ArmHook<EPW, ARM>::make(lds, lane);
-  const int nrec = c.n_terrain > 0 ? c.n_terrain : 1;
-  const int first = (int)blockIdx.x * EPW + lane;                       // the terrain record this lane group settles on
+  const int nrec = (c.n_terrain > 0 ? c.n_terrain : 1) * c.n_mix;
+  const int first = (int)blockIdx.x * EPW + lane;                       // the (terrain, task) record this lane group settles
   const int rec = (threadIdx.x & (LPE - 1)) == 0 ? first : nrec;        // one lane of the group stores it
   const int t = first < nrec ? first : nrec - 1;
+  const int terr = t / c.n_mix, slot = t % c.n_mix;
   Ground ground{nullptr, 0.0f, 1.0f, 1.0f, kMu};
-  if (c.n_terrain > 0) { ground.h = c.terrain + (size_t)t * 65536; ground.mid = c.terrain_mid[t]; }
+  if (c.n_terrain > 0) { ground.h = c.terrain + (size_t)terr * 65536; ground.mid = c.terrain_mid[terr]; }
   EnvState e;
   memset(&e, 0, sizeof(e));
   e.ph.pos[2] = kInitZ;
@@ -724,6 +802,10 @@ __global__ __launch_bounds__(REX_WAVE) void rex_settle_kernel(DevCfg c, float* _
   DevCfg cs = c;
   cs.hist = (c.pd_latency > 0.0f || c.control_latency > 0.0f) ? snap + (size_t)Lay<NM>::WORDS * nrec : nullptr;
   cs.n = nrec;
+  if (c.n_mix > 1) {   // the reset motion of this record's task: its own sweep cap (rex_gym_env.py:184)
+    const int task = slot == 0 ? c.mix_task[0] : (slot == 1 ? c.mix_task[1] : (slot == 2 ? c.mix_task[2] : (slot == 3 ? c.mix_task[3] : c.mix_task[4])));
+    cs.iterations = 300 / task_action_repeat(task);
+  }
   const bool keeps = rec < nrec;
   e.hist = (uint32_t)(REX_HISTORY_LEN - 1);
   float tau_obs[NM];
@@ -759,7 +841,10 @@ __global__ void rex_reset_kernel(DevCfg c, float* __restrict__ state, const floa
   e.episode = (int32_t)ldi(state, c.n, Lay<NM>::EPISODE, i);
   e.gait.alpha = state[(size_t)Lay<NM>::ALPHA * c.n + i];
   float seen[7];
-  env_reset<NM>(c, snap, i, true, c.env_index_base + i, e, seen);
+  DevCfg cmix;
+  if (c.task == REX_TASK_MIXED) mixed_config(c, c.env_index_base + i, cmix);
+  const DevCfg& c_ = c.task == REX_TASK_MIXED ? cmix : c;
+  env_reset<NM>(c_, snap, i, true, c.env_index_base + i, e, seen);
   store_env<NM>(state, c.n, i, e);
   float obs[22], tz[NM];
 #pragma unroll
@@ -770,7 +855,8 @@ __global__ void rex_reset_kernel(DevCfg c, float* __restrict__ state, const floa
     for (int k = 0; k < 4; ++k) co.quat[k] = seen[k];
     for (int k = 0; k < 3; ++k) co.w[k] = seen[4 + k];
   }
-  env_observation<NM>(c, co, obs);
+  for (int k = 4; k < 22; ++k) obs[k] = 0.0f;
+  env_observation<NM>(c_, co, obs);
   if (c.range_normalize) normalize_obs(c, obs);
   if (obs_out) for (int k = 0; k < c.obs_dim; ++k) obs_out[(size_t)r * c.obs_dim + k] = obs[k];
 }
@@ -849,7 +935,8 @@ int rex_abi_version(void) { return REX_ABI_VERSION; }
 
 int rex_default_config(int task, int signal, int num_envs, RexConfig* cfg) {
   if (!cfg || num_envs <= 0) return fail(REX_EINVAL, "rex_default_config: bad arguments%s", "");
-  if (task != REX_TASK_WALK && task != REX_TASK_GALLOP && task != REX_TASK_TURN && task != REX_TASK_POSES && task != REX_TASK_STANDUP) return fail(REX_EINVAL, "rex_default_config: unsupported task%s", "");
+  if (task != REX_TASK_WALK && task != REX_TASK_GALLOP && task != REX_TASK_TURN && task != REX_TASK_POSES && task != REX_TASK_STANDUP &&
+      task != REX_TASK_MIXED) return fail(REX_EINVAL, "rex_default_config: unsupported task%s", "");
   if (signal != REX_SIGNAL_IK && signal != REX_SIGNAL_OL) return fail(REX_EINVAL, "rex_default_config: unsupported signal%s", "");
   memset(cfg, 0, sizeof(*cfg));
   cfg->abi_version = REX_ABI_VERSION;
@@ -872,11 +959,27 @@ int rex_default_config(int task, int signal, int num_envs, RexConfig* cfg) {
   cfg->shake_weight = 0.005f;
   cfg->pose_index = -1;
   cfg->solver_residual_threshold = 1e-7f;                        /* PyBullet default solverResidualThreshold */
+  if (task == REX_TASK_MIXED) {   /* BASELINE.json configs[4]: walk, gallop and turn; per-task repeat / sweeps / weights apply per env */
+    cfg->task_mix = (1 << REX_TASK_WALK) | (1 << REX_TASK_GALLOP) | (1 << REX_TASK_TURN);
+    cfg->action_repeat = 6; cfg->solver_iterations = 60;         /* the largest of the mix (loop bounds only) */
+  }
   return REX_OK;
+}
+
+static int mix_tasks(const RexConfig* c, int* out) {   // tasks of a REX_TASK_MIXED config, ascending
+  int n = 0;
+  for (int t = 0; t < 5; ++t) if ((c->task_mix >> t) & 1) out[n++] = t;
+  return n;
 }
 
 int rex_action_dim(const RexConfig* c) {
   if (!c) return REX_EINVAL;
+  if (c->task == REX_TASK_MIXED) {          /* as wide as the widest task of the mix */
+    int ts[5], best = REX_EINVAL;
+    RexConfig one = *c;
+    for (int k = 0, n = mix_tasks(c, ts); k < n; ++k) { one.task = ts[k]; int d = rex_action_dim(&one); if (d > best) best = d; }
+    return best;
+  }
   if (c->task == REX_TASK_WALK) return c->signal == REX_SIGNAL_IK ? 2 : 8;      /* walk_env.py:104-112 */
   if (c->task == REX_TASK_GALLOP) return c->signal == REX_SIGNAL_IK ? 2 : 4;    /* gallop_env.py:119-130 */
   if (c->task == REX_TASK_TURN) return 2;                                       /* turn_env.py:100-110 */
@@ -893,6 +996,7 @@ int rex_state_words(const RexConfig* c) {
 }
 int rex_obs_dim(const RexConfig* c) {
   if (!c) return REX_EINVAL;
+  if (c->task == REX_TASK_MIXED) return ((c->task_mix >> REX_TASK_GALLOP) & 1) ? 4 + rex_num_motors(c) : 4;
   return c->task == REX_TASK_GALLOP ? 4 + rex_num_motors(c) : 4;                 /* gallop_env.py:349-356 */
 }
 
@@ -938,9 +1042,12 @@ static int validate(const RexConfig* c) {
   if (c->gait_clock_scale < 0.0f) return fail(REX_EINVAL, "gait_clock_scale must be >= 0%s", "");
   if (c->body_contacts) return fail(REX_EINVAL, "body_contacts: not built into this library yet%s", "");
   for (int k = 0; k < 5; ++k) if (c->noise_stdev[k] != 0.0f) return fail(REX_EINVAL, "noise_stdev: not built into this library yet%s", "");
-  if (c->task == REX_TASK_MIXED) return fail(REX_EINVAL, "REX_TASK_MIXED: not built into this library yet%s", "");
-  if (c->mass_scale_lo != 0.0f || c->mass_scale_hi != 0.0f || c->friction_lo != 0.0f || c->friction_hi != 0.0f)
-    return fail(REX_EINVAL, "per-reset randomisation: not built into this library yet%s", "");
+  if (c->task == REX_TASK_MIXED) {
+    const int allowed = (1 << REX_TASK_WALK) | (1 << REX_TASK_GALLOP) | (1 << REX_TASK_TURN);   // tasks that share one reset pose per signal
+    if (c->task_mix == 0 || (c->task_mix & ~allowed)) return fail(REX_EINVAL, "task_mix must be a non-empty subset of {walk, gallop, turn}%s", "");
+  }
+  if (c->mass_scale_lo < 0.0f || c->mass_scale_hi < c->mass_scale_lo || c->friction_lo < 0.0f || c->friction_hi < c->friction_lo)
+    return fail(REX_EINVAL, "randomisation ranges must satisfy 0 <= lo <= hi%s", "");
   return REX_OK;
 }
 
@@ -973,7 +1080,19 @@ int rex_create(const RexConfig* cfg, int device, float* d_state, void* stream, R
   d.w_dist = cfg->distance_weight; d.w_energy = cfg->energy_weight; d.w_drift = cfg->drift_weight; d.w_shake = cfg->shake_weight;
   d.action_dim = rex_action_dim(cfg); d.obs_dim = rex_obs_dim(cfg);
   s->epw = pick_envs_per_wave(cfg->num_envs);
-  if (cfg->mark == REX_MARK_ARM && s->epw > 16) s->epw = 16;
+  if ((cfg->mark == REX_MARK_ARM || cfg->task == REX_TASK_MIXED) && s->epw > 16) s->epw = 16;
+  d.n_mix = 1; d.mix_task[0] = cfg->task; d.max_repeat = cfg->action_repeat; d.max_iterations = cfg->solver_iterations;
+  for (int k = 1; k < 5; ++k) d.mix_task[k] = cfg->task;
+  if (cfg->task == REX_TASK_MIXED) {
+    int ts[5];
+    d.n_mix = mix_tasks(cfg, ts);
+    d.max_repeat = 0;
+    for (int k = 0; k < d.n_mix; ++k) { d.mix_task[k] = ts[k]; const int r = rex::task_action_repeat(ts[k]); if (r > d.max_repeat) d.max_repeat = r; }
+    for (int k = d.n_mix; k < 5; ++k) d.mix_task[k] = ts[0];
+    d.action_repeat = d.max_repeat;          // per-env values replace these inside the mixed kernel
+    d.iterations = d.max_iterations = 60;
+  }
+  d.mass_lo = cfg->mass_scale_lo; d.mass_hi = cfg->mass_scale_hi; d.mu_lo = cfg->friction_lo; d.mu_hi = cfg->friction_hi;
   s->words = rex_state_words(cfg);
   d.pose_index = cfg->pose_index; d.pose_value = cfg->pose_value;
   d.range_normalize = cfg->range_normalize;
@@ -997,14 +1116,14 @@ int rex_create(const RexConfig* cfg, int device, float* d_state, void* stream, R
   }
   d.target_orient = cfg->target_orient; d.init_orient = cfg->init_orient; d.orient_fixed = cfg->orient_fixed;
   d.gait_clock = cfg->gait_clock_scale > 0.0f ? cfg->gait_clock_scale : 1.0f;
-  hipError_t e = hipMalloc(&s->d_snap, sizeof(float) * snapshot_floats(s, 1));
+  hipError_t e = hipMalloc(&s->d_snap, sizeof(float) * snapshot_floats(s, d.n_mix));
   if (e != hipSuccess) { delete s; return fail(REX_ENOMEM, "hipMalloc(snapshot): %s", hipGetErrorString(e)); }
   (void)hipEventCreate(&s->ev0);
   (void)hipEventCreate(&s->ev1);
   for (int k = 0; k < REX_TIMING_RING; ++k) { s->ring0[k] = nullptr; s->ring1[k] = nullptr; }
   s->timed_steps = 0;
   hipStream_t st = (hipStream_t)stream;
-  launch_settle(s, 1, st, s->d_snap);
+  launch_settle(s, d.n_mix, st, s->d_snap);
   e = hipGetLastError();
   if (e == hipSuccess) e = hipMemsetAsync(d_state, 0, sizeof(float) * (size_t)s->words * cfg->num_envs, st);
   if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -1022,7 +1141,7 @@ int rex_set_terrain(RexSim* s, const float* d_heights, const float* d_mids, int 
   HIPCHK(hipSetDevice(s->device));
   hipStream_t st = (hipStream_t)stream;
   float* snap = nullptr;
-  const int nrec = k > 0 ? k : 1;
+  const int nrec = (k > 0 ? k : 1) * s->dev.n_mix;
   HIPCHK(hipMalloc(&snap, sizeof(float) * snapshot_floats(s, nrec)));
   HIPCHK(hipStreamSynchronize(st));
   (void)hipFree(s->d_snap);
@@ -1161,19 +1280,23 @@ REX_API int rex_debug_prof(long long* out, int reset) {
 #endif
 }  // extern "C"
 
-#define REX_LAUNCH_STEP(EPW, ARM)                                                                                        \
-  hipLaunchKernelGGL((rex::rex_step_kernel<EPW, ARM>), dim3(blocks), dim3(REX_WAVE), 0, st, s->dev, s->d_state, s->d_snap, a, o, \
+#define REX_LAUNCH_STEP(EPW, ARM, MIXED)                                                                                        \
+  hipLaunchKernelGGL((rex::rex_step_kernel<EPW, ARM, MIXED>), dim3(blocks), dim3(REX_WAVE), 0, st, s->dev, s->d_state, s->d_snap, a, o, \
                      r, d, m)
 static void launch_step(RexSim* s, int blocks, hipStream_t st, const float* a, float* o, float* r, uint8_t* d, float* m) {
-  if (s->cfg.mark == REX_MARK_ARM) {
-    if (s->epw == 4) REX_LAUNCH_STEP(4, true);
-    else if (s->epw == 8) REX_LAUNCH_STEP(8, true);
-    else REX_LAUNCH_STEP(16, true);
+  const bool arm = s->cfg.mark == REX_MARK_ARM;
+  if (s->cfg.task == REX_TASK_MIXED) {   // lane groups only (rex_create caps the envs per wave at 16)
+    if (arm) { if (s->epw == 4) REX_LAUNCH_STEP(4, true, true); else if (s->epw == 8) REX_LAUNCH_STEP(8, true, true); else REX_LAUNCH_STEP(16, true, true); }
+    else { if (s->epw == 4) REX_LAUNCH_STEP(4, false, true); else if (s->epw == 8) REX_LAUNCH_STEP(8, false, true); else REX_LAUNCH_STEP(16, false, true); }
+  } else if (arm) {
+    if (s->epw == 4) REX_LAUNCH_STEP(4, true, false);
+    else if (s->epw == 8) REX_LAUNCH_STEP(8, true, false);
+    else REX_LAUNCH_STEP(16, true, false);
   } else {
-    if (s->epw == 4) REX_LAUNCH_STEP(4, false);
-    else if (s->epw == 8) REX_LAUNCH_STEP(8, false);
-    else if (s->epw == 16) REX_LAUNCH_STEP(16, false);
-    else REX_LAUNCH_STEP(64, false);
+    if (s->epw == 4) REX_LAUNCH_STEP(4, false, false);
+    else if (s->epw == 8) REX_LAUNCH_STEP(8, false, false);
+    else if (s->epw == 16) REX_LAUNCH_STEP(16, false, false);
+    else REX_LAUNCH_STEP(64, false, false);
   }
 }
 static void launch_settle(RexSim* s, int nrec, hipStream_t st, float* snap) {

@@ -68,7 +68,8 @@ class RexBatchEnv:
                  solver_iterations=None, solver_residual_threshold=None,
                  range_normalize=False, check_actions=False, terrain_type="plane", terrain_pool=64, terrain_seed=10,
                  mark="base", render=False, stream=None, gait_clock_scale=1.0,
-                 distance_weight=None, energy_weight=None, drift_weight=None, shake_weight=None, **ignored):
+                 distance_weight=None, energy_weight=None, drift_weight=None, shake_weight=None,
+                 tasks=None, mass_scale_range=None, friction_range=None, **ignored):
         import torch
         # Reference constructor keywords that only touch the GUI, logging or debugging are accepted and ignored; anything
         # else that would change what the env computes is an error here, not a silent no-op.
@@ -86,6 +87,8 @@ class RexBatchEnv:
                                       "render=False")
         if task not in _lib.TASKS or signal_type not in _lib.SIGNALS:
             raise ValueError(f"unsupported task/signal {task}/{signal_type}")
+        if tasks is not None and task != "mixed":
+            raise ValueError("`tasks` goes with task='mixed'")
         self._torch = torch
         self._L = _lib.lib()   # raises if the HIP library is absent: no fallback
         if not torch.cuda.is_available():
@@ -105,6 +108,15 @@ class RexBatchEnv:
             cfg.solver_iterations = int(solver_iterations)
         if solver_residual_threshold is not None:
             cfg.solver_residual_threshold = float(solver_residual_threshold)
+        if task == "mixed":   # BASELINE.json configs[4]: every env runs one task of the mix, drawn per env (REX_TASK_MIXED)
+            names = ("walk", "gallop", "turn") if tasks is None else tuple(tasks)
+            if not names or any(t not in ("walk", "gallop", "turn") for t in names):
+                raise ValueError("tasks must be a non-empty subset of ('walk', 'gallop', 'turn')")
+            cfg.task_mix = sum(1 << _lib.TASKS[t] for t in set(names))
+            self.tasks = tuple(t for t in ("walk", "gallop", "turn") if t in names)
+        for rng, lo_name, hi_name in ((mass_scale_range, "mass_scale_lo", "mass_scale_hi"), (friction_range, "friction_lo", "friction_hi")):
+            if rng is not None:   # per-reset draws of the env_randomizer hook (rex_gym_env.py:345-346)
+                setattr(cfg, lo_name, float(rng[0])); setattr(cfg, hi_name, float(rng[1]))
         cfg.motor_kp, cfg.motor_kd = float(motor_kp), float(motor_kd)
         cfg.gait_clock_scale = float(gait_clock_scale)     # wall-clock seconds per simulated second (gait_planner.py:108-110)
         for name, v in (("distance_weight", distance_weight), ("energy_weight", energy_weight),
@@ -135,7 +147,15 @@ class RexBatchEnv:
         self.state_words = self._L.rex_state_words(ctypes.byref(cfg))
         self.action_dim = self._L.rex_action_dim(ctypes.byref(cfg))
         self.obs_dim = self._L.rex_obs_dim(ctypes.byref(cfg))
-        self.action_space, self.observation_space = _spaces(task, signal_type, cfg.sim_time_step, self.num_motors)
+        if task == "mixed":   # the widest task of the mix; narrower tasks ignore / zero the tail of their rows
+            per = {t: _spaces(t, signal_type, cfg.sim_time_step, self.num_motors) for t in self.tasks}
+            self.task_action_spaces = {t: sp[0] for t, sp in per.items()}
+            wide_a = max(per.values(), key=lambda sp: sp[0].shape[0])[0]
+            wide_o = max(per.values(), key=lambda sp: sp[1].shape[0])[1]
+            tight = min(float(np.abs(sp[0].high).min()) for sp in per.values())     # inside every task's Box
+            self.action_space, self.observation_space = Box(-np.full(wide_a.shape, tight), np.full(wide_a.shape, tight)), wide_o
+        else:
+            self.action_space, self.observation_space = _spaces(task, signal_type, cfg.sim_time_step, self.num_motors)
         if range_normalize:   # RangeNormalize / ClipAction expose [-1, 1] boxes (wrappers.py:205-219)
             self.inner_action_space, self.inner_observation_space = self.action_space, self.observation_space
             self.action_space = Box(-np.ones(self.action_space.shape), np.ones(self.action_space.shape))
@@ -172,6 +192,19 @@ class RexBatchEnv:
     def _stream_ptr(self):
         s = self._stream if self._stream is not None else self._torch.cuda.current_stream(self.device)
         return ctypes.c_void_p(s.cuda_stream)
+
+    def task_ids(self):
+        """task='mixed': the task every env runs, as a device int32 tensor of REX_TASK_* ids (drawn per env from its global
+        index, fixed for the env's life -- the same draw the kernels make)."""
+        torch = self._torch
+        if self.task != "mixed":
+            return torch.full((self.num_envs,), _lib.TASKS[self.task], dtype=torch.int32, device=self.device)
+        from .philox import philox4x32
+        g = np.arange(self.num_envs, dtype=np.uint32) + np.uint32(self.config.env_index_base)
+        ctr = np.stack([np.full_like(g, 0xFFFFFFFF), g, np.full_like(g, 2), np.zeros_like(g)])
+        out = philox4x32(ctr, np.uint32(self.config.seed & 0xFFFFFFFF), np.uint32(self.config.seed >> 32))
+        ids = np.array([_lib.TASKS[t] for t in self.tasks], dtype=np.int32)
+        return torch.from_numpy(ids[(out[0] % np.uint32(len(ids))).astype(np.int64)]).to(self.device)
 
     def _on_stream(self):
         """Context in which host-side staging (dtype / device conversion of actions and indices) is issued: the stream the

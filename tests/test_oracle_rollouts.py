@@ -90,3 +90,35 @@ def test_oracle_against_real_pybullet_rollouts():
         report[sc["name"]] = dict(joint_rmse=(sq / n) ** 0.5, base_pos_err=pos)
     print(json.dumps(report, indent=1))
     assert max(r["joint_rmse"] for r in report.values()) < 1e-3, report     # BASELINE.json: joint-angle RMSE < 1e-3 rad
+
+
+def test_oracle_mixed_task_batch_equals_single_task_batches():
+    """REX_TASK_MIXED in the oracle: env g of a mixed batch (task drawn per env, mass / friction drawn per reset) is
+    bit-identical to env g of the single-task batch of its task -- the property the HIP path is tested for on the GPU."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from rex_gym_amd.envs.philox import philox4x32
+    n, steps = 24, 70
+    kw = dict(seed=5, auto_reset=1, max_episode_steps=30, mass_scale_lo=0.8, mass_scale_hi=1.2, friction_lo=0.25, friction_hi=0.625)
+    mix = orclib.OracleEnv(orclib.default_config("mixed", "ik", n, task_mix=0b111, action_repeat=6, solver_iterations=60, **kw), np.float64)
+    g = np.arange(n, dtype=np.uint32)
+    ids = philox4x32(np.stack([np.full_like(g, 0xFFFFFFFF), g, np.full_like(g, 2), np.zeros_like(g)]), 5, 0)[0] % 3
+    assert set(ids) == {0, 1, 2}
+    rng = np.random.RandomState(1)
+    acts = rng.uniform(-0.01, 0.01, (steps, n, 2))
+    o0 = mix.reset()
+    outs = [mix.step(a) for a in acts]
+    assert sum(int(o[2].sum()) for o in outs) >= n
+    for tid, name in enumerate(("walk", "gallop", "turn")):
+        sel = ids == tid
+        ref = orclib.OracleEnv(orclib.default_config(name, "ik", n, **kw), np.float64)
+        r0 = ref.reset()
+        np.testing.assert_array_equal(r0[sel], o0[sel][:, :ref.obs_dim])
+        for k, a in enumerate(acts):
+            o, r, d, c = ref.step(a)
+            np.testing.assert_array_equal(o[sel], outs[k][0][sel][:, :ref.obs_dim])
+            np.testing.assert_array_equal(r[sel], outs[k][1][sel])
+            np.testing.assert_array_equal(d[sel], outs[k][2][sel])
+            np.testing.assert_array_equal(c[sel], outs[k][3][sel])
+        ref.close()
+    mix.close()
