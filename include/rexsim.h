@@ -138,7 +138,7 @@ typedef struct RexConfig {
   float   pd_latency, control_latency;
   /* REX_MARK_BASE / REX_MARK_ARM.  With REX_MARK_ARM the per-env state has rex_state_words() = 69 words (the q, qd
      and overheat blocks grow to 18 motors, every other word keeps its order), d_motor_cmd rows are 18 wide and the
-     gallop observation is 4 + 18; the latency model (43-word history records) is not offered. */
+     gallop observation is 4 + 18; the history records of the latency model are 61 words (REX_HISTORY_WORDS_ARM). */
   int32_t mark;
   /* ---- ABI 3 ---- */
   /* GaitPlanner.loop reads WALL-CLOCK time (model/gait_planner.py:108-110: `time.time()`), so the reference's gait
@@ -166,6 +166,9 @@ typedef struct RexConfig {
      rex_set_body_params entry).  As with changeDynamics(mass=...), inertia tensors keep their load-time values, and
      the reset motion is the nominal robot's (the reference randomises after Rex.Reset). */
   float   mass_scale_lo, mass_scale_hi, friction_lo, friction_hi;
+  /* Height the robot is dropped from at reset (ROBOT_INIT_POSITION[terrain_id][2], model/terrain.py:14-20: 0.21 on
+     plane / random / maze, 0.85 on mounts, 1.98 on hills).  0 means 0.21. */
+  float   init_height;
 } RexConfig;
 
 typedef struct RexSim RexSim;
@@ -194,6 +197,16 @@ REX_API int rex_destroy(RexSim* sim);
  * field (one settled snapshot each).  k = 0 returns to the flat plane.  Call before rex_reset. */
 REX_API int rex_set_terrain(RexSim* sim, const float* d_heights, const float* d_mids, int k, void* stream);
 
+/* Any other heightfield terrain (the reference's 'hills' csv and 'mounts' / 'maze' png fields, model/terrain.py:55-78,
+ * whose files live in the pip package pybullet_data and are not part of rex-gym): a pool of k fields of nx x ny vertex
+ * heights IN METRES (meshScale z already applied), laid out like rex_set_terrain's (data[ix + iy*nx], ix along x),
+ * vertex spacing cell_x / cell_y (meshScale x / y), the grid centred on (origin_x, origin_y).  d_mids[k] = the raw
+ * height that ends up at world z = 0: Bullet centres a heightfield shape on the middle of its height range and the
+ * reference then places the body at some z0 (terrain.py:64,75), so d_mids[i] = (min_i + max_i) / 2 - z0.  The z = 0
+ * ground box of plane.urdf stays underneath, as in the reference.  Everything else as rex_set_terrain. */
+REX_API int rex_set_heightfield(RexSim* sim, const float* d_heights, const float* d_mids, int k, int nx, int ny,
+                                float cell_x, float cell_y, float origin_x, float origin_y, void* stream);
+
 /* Domain randomisation hooks (the knobs an env_randomizer turns: Rex.SetBaseMasses / SetLegMasses, model/rex.py:659-692;
  * the reference has no friction setter).  d_params: caller-owned device array [3][num_envs], word-major:
  * base-link mass scale, leg-link mass scale, foot friction coefficient; read on every step (so the caller may rewrite
@@ -203,13 +216,15 @@ REX_API int rex_set_body_params(RexSim* sim, const float* d_params);
 
 /* Observation-history ring for the latency model (Rex._observation_history, deque(maxlen=100) of 43-vectors:
  * q, qd, observed torque, base quaternion, base angular velocity; model/rex.py:122,717-763).  d_history: caller-owned
- * device buffer of REX_HISTORY_LEN * REX_HISTORY_WORDS * num_envs float32, laid out [slot][word][env].  Required only
+ * device buffer of REX_HISTORY_LEN * REX_HISTORY_WORDS (_ARM for mark 'arm': 61-vectors) * num_envs float32, laid out
+ * [slot][word][env].  Required only
  * when pd_latency or control_latency is non-zero (without a latency the delayed observation is the newest one and the
  * buffer is not used).  The latency model also runs through the reset motion (rex.py:309-323): every reset, by call or
  * in-launch, restores an env's ring to the 100 observations the reset motion leaves behind, so that an episode starts
  * exactly as the reference's does. */
 #define REX_HISTORY_LEN 100
-#define REX_HISTORY_WORDS 43
+#define REX_HISTORY_WORDS 43       /* mark 'base': 3 x 12 + 7 */
+#define REX_HISTORY_WORDS_ARM 61   /* mark 'arm':  3 x 18 + 7 */
 REX_API int rex_set_history(RexSim* sim, float* d_history);
 
 /* Reset envs. d_indices == NULL: all envs. Else n int32 env indices (device).  Writes the first

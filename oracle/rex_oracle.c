@@ -661,19 +661,22 @@ static void impulse_response_at(const Aba* A, int kbody, const real fk[6], real 
 #define HF_N 256
 #define HF_CELL ((real)0.05)
 #define HF_INV_CELL ((real)20.0)    /* 1 / HF_CELL: written as a product on both sides (oracle and kernels) */
-typedef struct { const float* h; real mid; real base_mass_scale, leg_mass_scale, mu; int has_params; int body_contacts; } Ground;
+typedef struct { int nx, ny; real inv_cx, inv_cy, off_x, off_y, max_x, max_y; } HfGeom;   /* grid geometry of a heightfield pool */
+static const HfGeom HF_RANDOM = {HF_N, HF_N, (real)20.0, (real)20.0, (real)127.5, (real)127.5, (real)254.999, (real)254.999};   /* model/terrain.py:32-54 */
+typedef struct { const float* h; real mid; real base_mass_scale, leg_mass_scale, mu; int has_params; int body_contacts; HfGeom geo; } Ground;
 
 static void ground_query(const Ground* g, real x, real y, real* height, real n[3]) {
   n[0] = 0; n[1] = 0; n[2] = 1; *height = 0;
   if (!g || !g->h) return;
-  real fx = x * HF_INV_CELL + (real)127.5, fy = y * HF_INV_CELL + (real)127.5;
-  fx = clampr(fx, 0, (real)254.999); fy = clampr(fy, 0, (real)254.999);
+  const HfGeom* q = &g->geo;
+  real fx = x * q->inv_cx + q->off_x, fy = y * q->inv_cy + q->off_y;
+  fx = clampr(fx, 0, q->max_x); fy = clampr(fy, 0, q->max_y);
   int i = (int)fx, j = (int)fy;
   real u = fx - i, v = fy - j;
-  real h00 = g->h[j * HF_N + i], h10 = g->h[j * HF_N + i + 1], h01 = g->h[(j + 1) * HF_N + i], h11 = g->h[(j + 1) * HF_N + i + 1];
+  real h00 = g->h[j * q->nx + i], h10 = g->h[j * q->nx + i + 1], h01 = g->h[(j + 1) * q->nx + i], h11 = g->h[(j + 1) * q->nx + i + 1];
   real hh, gx, gy;
-  if (u + v <= 1) { hh = h00 + u * (h10 - h00) + v * (h01 - h00); gx = (h10 - h00) * HF_INV_CELL; gy = (h01 - h00) * HF_INV_CELL; }
-  else { hh = h11 + (1 - u) * (h01 - h11) + (1 - v) * (h10 - h11); gx = (h11 - h01) * HF_INV_CELL; gy = (h11 - h10) * HF_INV_CELL; }
+  if (u + v <= 1) { hh = h00 + u * (h10 - h00) + v * (h01 - h00); gx = (h10 - h00) * q->inv_cx; gy = (h01 - h00) * q->inv_cy; }
+  else { hh = h11 + (1 - u) * (h01 - h11) + (1 - v) * (h10 - h11); gx = (h11 - h01) * q->inv_cx; gy = (h11 - h10) * q->inv_cy; }
   hh -= g->mid;
   if (hh <= 0) return;                      /* the plane is on top here */
   real inv = 1 / sqrt(gx * gx + gy * gy + 1);
@@ -981,6 +984,20 @@ static float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
 
 ORC_API void orc_philox(uint32_t* ctr4, uint32_t k0, uint32_t k1) { philox4x32(ctr4, k0, k1); }
 
+/* sensor noise (Rex._AddSensorNoise, model/rex.py:765-769): four standard normals per Philox block, keyed by
+ * (seed; episode, global env, 16 + block, step); block numbering as in csrc/rexsim.hip */
+enum { NZ_GOAL = 0, NZ_REWARD_RPY = 1, NZ_FALLEN_RPY = 2, NZ_OBS_RPY = 3, NZ_OBS_RATE = 4, NZ_TORQUE = 8, NZ_VELOCITY = 16, NZ_ANGLE = 24 };
+static void gauss4(const RexConfig* c, int gidx, int episode, int step, int block, real* z) {
+  uint32_t ctr[4] = {(uint32_t)episode, (uint32_t)gidx, 16u + (uint32_t)block, (uint32_t)step};
+  philox4x32(ctr, (uint32_t)c->seed, (uint32_t)(c->seed >> 32));
+  for (int p = 0; p < 2; ++p) {
+    float u1 = (float)((ctr[2 * p] >> 8) + 1u) * (1.0f / 16777216.0f), u2 = u01(ctr[2 * p + 1]);
+    real r = sqrt(-2 * log((real)u1)), a = (real)6.28318530717958648 * (real)u2;
+    z[2 * p] = r * cos(a); z[2 * p + 1] = r * sin(a);
+  }
+}
+static int noise_on(const RexConfig* c) { for (int k = 0; k < 5; ++k) if (c->noise_stdev[k] > 0) return 1; return 0; }
+
 /* =====================================================================================
  *                                   environments
  * ===================================================================================== */
@@ -1002,6 +1019,7 @@ typedef struct {
   int hist_head, hist_len;
   real (*hist)[HIST_WORDS];   /* [REX_HISTORY_LEN][43], allocated only when a latency is configured */
   real ctrl_obs[HIST_WORDS];  /* Rex._control_observation */
+  int nz_gidx, nz_episode, nz_step; /* keys of the current step's sensor-noise draws (transient) */
 } Env;
 
 typedef struct {
@@ -1011,7 +1029,8 @@ typedef struct {
   int n_mix, mix_task[5];
   /* terrain pool (terrain_type='random'): K heightfields, one settled snapshot per terrain */
   int n_terrain;
-  float* heights; /* [K][256*256] */
+  float* heights; /* [K][nx*ny] */
+  HfGeom geo;
   float* mids;    /* [K] */
   Env* terrain_snapshot;
   float* body_params; /* [3][N] or NULL */
@@ -1043,7 +1062,7 @@ static int terrain_index(const Orc* o, int idx, int episode) {
   return (int)(((uint32_t)(o->cfg.env_index_base + idx) + 977u * (uint32_t)episode) % (uint32_t)o->n_terrain);
 }
 static Ground env_ground(const Orc* o, int idx, int episode) {
-  Ground g = {0, 0, 1, 1, FRICTION_MU, 0, o->cfg.body_contacts};
+  Ground g = {0, 0, 1, 1, FRICTION_MU, 0, o->cfg.body_contacts, o->geo};
   if (o->body_params) {
     int n = o->cfg.num_envs;
     g.has_params = 1; g.base_mass_scale = (real)o->body_params[idx]; g.leg_mass_scale = (real)o->body_params[n + idx];
@@ -1060,7 +1079,7 @@ static Ground env_ground(const Orc* o, int idx, int episode) {
     if (o->cfg.friction_hi > 0) g.mu = (real)fmaf(o->cfg.friction_hi - o->cfg.friction_lo, u01(ctr[2]), o->cfg.friction_lo);
   }
   int t = terrain_index(o, idx, episode);
-  if (t >= 0) { g.h = o->heights + (size_t)t * HF_N * HF_N; g.mid = (real)o->mids[t]; }
+  if (t >= 0) { g.h = o->heights + (size_t)t * o->geo.nx * o->geo.ny; g.mid = (real)o->mids[t]; }
   return g;
 }
 
@@ -1180,7 +1199,7 @@ static void settle(Orc* o, Env* e, const Ground* ground, const RexConfig* cfgp) 
   memset(e, 0, sizeof(*e));
   if (!hist && (cfgp->pd_latency > 0 || cfgp->control_latency > 0)) hist = calloc(REX_HISTORY_LEN, sizeof(real[HIST_WORDS]));
   e->hist = hist;
-  e->ph.pos[2] = ROBOT_INIT_Z;
+  e->ph.pos[2] = cfgp->init_height > 0 ? cfgf(cfgp->init_height) : ROBOT_INIT_Z;
   e->ph.quat[3] = 1;
   full_command(POSE_STAND, e->ph.q); /* ResetPose: INIT_POSES[pose_id='stand'] (+ _ResetArmMotors: ARM_POSES['rest'], rex.py:395-400) */
   e->motor_enabled = (1u << NJ) - 1;
@@ -1204,13 +1223,18 @@ static void settle(Orc* o, Env* e, const Ground* ground, const RexConfig* cfgp) 
 static void control_observation(const Env* e, real o[HIST_WORDS]) { memcpy(o, e->ctrl_obs, sizeof(real) * HIST_WORDS); }
 
 static void env_observation(const RexConfig* c, const Env* e, real* obs) {
-  real co[HIST_WORDS], rpy[3];
+  real co[HIST_WORDS], rpy[3], z[4];
   control_observation(e, co);
   quat_to_euler(co + 3 * NJ, rpy);
-  obs[0] = rpy[0]; obs[1] = rpy[1]; obs[2] = co[3 * NJ + 4]; obs[3] = co[3 * NJ + 5];
+  real wx = co[3 * NJ + 4], wy = co[3 * NJ + 5];
+  if (c->noise_stdev[3] > 0) { gauss4(c, e->nz_gidx, e->nz_episode, e->nz_step, NZ_OBS_RPY, z); rpy[0] += cfgf(c->noise_stdev[3]) * z[0]; rpy[1] += cfgf(c->noise_stdev[3]) * z[1]; }
+  if (c->noise_stdev[4] > 0) { gauss4(c, e->nz_gidx, e->nz_episode, e->nz_step, NZ_OBS_RATE, z); wx += cfgf(c->noise_stdev[4]) * z[0]; wy += cfgf(c->noise_stdev[4]) * z[1]; }
+  obs[0] = rpy[0]; obs[1] = rpy[1]; obs[2] = wx; obs[3] = wy;
   if (c->task == REX_TASK_GALLOP) {
-    for (int j = 0; j < NJ; ++j) { /* MapToMinusPiToPi, rex.py:26-41 */
-      real a = fmod(co[j], (real)(2 * M_PI));
+    real nz[20] = {0};
+    if (c->noise_stdev[0] > 0) for (int b = 0; b < (NJ + 3) / 4; ++b) gauss4(c, e->nz_gidx, e->nz_episode, e->nz_step, NZ_ANGLE + b, nz + 4 * b);
+    for (int j = 0; j < NJ; ++j) { /* GetMotorAngles: noise, then MapToMinusPiToPi (rex.py:26-41,457-468) */
+      real a = fmod(co[j] + cfgf(c->noise_stdev[0]) * nz[j], (real)(2 * M_PI));
       if (a >= (real)M_PI) a -= (real)(2 * M_PI); else if (a < -(real)M_PI) a += (real)(2 * M_PI);
       obs[4 + j] = a;
     }
@@ -1267,7 +1291,7 @@ static void env_reset(Orc* o, int idx) {
     e->target = tgt; e->aux = ini;
     real rpy[3] = {0, 0, ini};
     euler_to_quat(rpy, e->ph.quat);                                             /* resetBasePositionAndOrientation */
-    e->ph.pos[0] = 0; e->ph.pos[1] = 0; e->ph.pos[2] = ROBOT_INIT_Z;
+    e->ph.pos[0] = 0; e->ph.pos[1] = 0; e->ph.pos[2] = c->init_height > 0 ? cfgf(c->init_height) : ROBOT_INIT_Z;
   }
   /* the reference's deque is not touched by reset() after Rex.Reset: it holds the last 100 observations of the reset
    * motion (the newest twice, rex.py:323), and the turn env's teleport (turn_env.py:158-159) happens behind its back --
@@ -1404,6 +1428,13 @@ static void turn_command(const RexConfig* c, Env* e, const real* action, real cm
     real rpy[3], co[HIST_WORDS];
     control_observation(e, co);
     quat_to_euler(co + 3 * NJ, rpy);
+    if (c->noise_stdev[3] > 0) {   /* GetBaseOrientation = quaternion of the NOISY roll / pitch / yaw (rex.py:430-442,530-537) */
+      real z[4], qq[4];
+      gauss4(c, e->nz_gidx, e->nz_episode, e->nz_step, NZ_GOAL, z);
+      for (int k = 0; k < 3; ++k) rpy[k] += cfgf(c->noise_stdev[3]) * z[k];
+      euler_to_quat(rpy, qq);
+      quat_to_euler(qq, rpy);
+    }
     real cz = rpy[2];
     if (cz < 0) cz += (real)6.28;
     if (fabs(e->target - cz) <= (real)0.01) {
@@ -1465,6 +1496,15 @@ static real base_reward(const RexConfig* c, Env* e) {
   real co[HIST_WORDS], rpy[3], qq[4], R[3][3];
   control_observation(e, co);
   quat_to_euler(co + 3 * NJ, rpy);  /* GetBaseOrientation: delayed quat -> RPY -> quat (rex.py:530-537) */
+  if (noise_on(c)) {
+    real z[4], nt[20], nv[20];
+    if (c->noise_stdev[3] > 0) { gauss4(c, e->nz_gidx, e->nz_episode, e->nz_step, NZ_REWARD_RPY, z); for (int k = 0; k < 3; ++k) rpy[k] += cfgf(c->noise_stdev[3]) * z[k]; }
+    for (int b = 0; b < (NJ + 3) / 4; ++b) {
+      gauss4(c, e->nz_gidx, e->nz_episode, e->nz_step, NZ_TORQUE + b, nt + 4 * b);
+      gauss4(c, e->nz_gidx, e->nz_episode, e->nz_step, NZ_VELOCITY + b, nv + 4 * b);
+    }
+    for (int j = 0; j < NJ; ++j) { co[2 * NJ + j] += cfgf(c->noise_stdev[2]) * nt[j]; co[NJ + j] += cfgf(c->noise_stdev[1]) * nv[j]; }
+  }
   euler_to_quat(rpy, qq);
   quat_to_mat(qq, R);
   real shake = -fabs(R[2][0] + R[2][1]);
@@ -1482,6 +1522,7 @@ static int env_fallen(const RexConfig* c, const Env* e) {
   real co[HIST_WORDS];
   control_observation(e, co);
   quat_to_euler(co + 3 * NJ, rpy);                                      /* GetBaseOrientation (delayed) */
+  if (c->noise_stdev[3] > 0) { real z[4]; gauss4(c, e->nz_gidx, e->nz_episode, e->nz_step, NZ_FALLEN_RPY, z); for (int k = 0; k < 3; ++k) rpy[k] += cfgf(c->noise_stdev[3]) * z[k]; }
   real qq[4], R[3][3];                                                  /* walk_env.py:326-338 */
   euler_to_quat(rpy, qq);
   quat_to_mat(qq, R);
@@ -1525,6 +1566,7 @@ static void env_step(Orc* o, int idx, const real* action_in, real* obs, real* re
   const RexConfig cfg_env = env_cfg(o, idx);
   const RexConfig* c = &cfg_env;
   Env* e = &o->envs[idx];
+  e->nz_gidx = c->env_index_base + idx; e->nz_episode = e->episode; e->nz_step = e->steps;
   real cmd[NJ], leg_cmd[12];
   real action[8];
   {
@@ -1559,7 +1601,7 @@ static void env_step(Orc* o, int idx, const real* action_in, real* obs, real* re
   *done = (uint8_t)d;
   if (motor_cmd) memcpy(motor_cmd, cmd, sizeof(real) * NJ);
   if (d) e->flags |= REX_F_DONE;
-  if (d && c->auto_reset) env_reset(o, idx);
+  if (d && c->auto_reset) { int g = e->nz_gidx, ep = e->nz_episode, st = e->nz_step; env_reset(o, idx); e->nz_gidx = g; e->nz_episode = ep; e->nz_step = st; }
   for (int k = 4; k < orc_obs_dim(&o->cfg); ++k) obs[k] = 0;   /* a narrower task leaves the tail of a mixed batch's row 0 */
   env_observation(c, e, obs);
   if (c->range_normalize) normalize_obs(c, obs, orc_obs_dim(&o->cfg));
@@ -1587,7 +1629,8 @@ ORC_API void* orc_create(const RexConfig* cfg) {
     o->n_mix = 0;
     for (int t = 0; t < 5; ++t) if ((cfg->task_mix >> t) & 1) o->mix_task[o->n_mix++] = t;
   }
-  Ground g0 = {0, 0, 1, 1, FRICTION_MU, 0, cfg->body_contacts};
+  o->geo = HF_RANDOM;
+  Ground g0 = {0, 0, 1, 1, FRICTION_MU, 0, cfg->body_contacts, HF_RANDOM};
   for (int k = 0; k < o->n_mix; ++k) { RexConfig ct = task_cfg(o, o->mix_task[k]); settle(o, &o->snapshot[k], &g0, &ct); }
   return o;
 }
@@ -1603,25 +1646,41 @@ ORC_API void orc_destroy(void* h) { Orc* o = (Orc*)h; for (int i = 0; i < o->cfg
 
 /* terrain pool: heights [k][256*256] raw vertex heights (terrain.py:36-43 layout: data[i + j*rows], i along x),
  * mids [k] = (min+max)/2 of each field */
-ORC_API void orc_set_terrain(void* h, const float* heights, const float* mids, int k) {
-  Orc* o = (Orc*)h;
+static void install_terrain(Orc* o, const float* heights, const float* mids, int k) {
   for (int t = 0; t < o->n_terrain * o->n_mix; ++t) free(o->terrain_snapshot[t].hist);
   free(o->heights); free(o->mids); free(o->terrain_snapshot);
+  size_t per = (size_t)o->geo.nx * o->geo.ny;
   o->n_terrain = k;
-  o->heights = (float*)malloc(sizeof(float) * (size_t)k * HF_N * HF_N);
+  o->heights = (float*)malloc(sizeof(float) * (size_t)k * per);
   o->mids = (float*)malloc(sizeof(float) * (size_t)k);
   o->terrain_snapshot = (Env*)calloc((size_t)k * o->n_mix, sizeof(Env));
-  memcpy(o->heights, heights, sizeof(float) * (size_t)k * HF_N * HF_N);
+  memcpy(o->heights, heights, sizeof(float) * (size_t)k * per);
   memcpy(o->mids, mids, sizeof(float) * (size_t)k);
 #ifdef _OPENMP
 #pragma omp parallel for schedule(dynamic)
 #endif
   for (int r = 0; r < k * o->n_mix; ++r) {
     int t = r / o->n_mix;
-    Ground g = {o->heights + (size_t)t * HF_N * HF_N, (real)o->mids[t], 1, 1, FRICTION_MU, 0, o->cfg.body_contacts};
+    Ground g = {o->heights + (size_t)t * per, (real)o->mids[t], 1, 1, FRICTION_MU, 0, o->cfg.body_contacts, o->geo};
     RexConfig ct = task_cfg(o, o->mix_task[r % o->n_mix]);
     settle(o, &o->terrain_snapshot[r], &g, &ct);
   }
+}
+ORC_API void orc_set_terrain(void* h, const float* heights, const float* mids, int k) {
+  Orc* o = (Orc*)h;
+  o->geo = HF_RANDOM;
+  install_terrain(o, heights, mids, k);
+}
+/* any other heightfield pool (rex_set_heightfield in include/rexsim.h): heights in metres, [k][ny][nx] */
+ORC_API void orc_set_heightfield(void* h, const float* heights, const float* mids, int k, int nx, int ny, float cell_x, float cell_y,
+                                 float origin_x, float origin_y) {
+  Orc* o = (Orc*)h;
+  /* the same float32 arithmetic as the product's host code, so that both sides hold identical grid constants */
+  float icx = 1.0f / cell_x, icy = 1.0f / cell_y;
+  HfGeom g = {nx, ny, (real)icx, (real)icy, (real)(0.5f * (float)(nx - 1) - origin_x * icx), (real)(0.5f * (float)(ny - 1) - origin_y * icy),
+              (real)((float)(nx - 1) - 0.001f), (real)((float)(ny - 1) - 0.001f)};
+  o->geo = g;
+  install_terrain(o, heights, mids, k);
 }
 
 ORC_API void orc_reset(void* h, const int32_t* indices, int n, real* obs) {
@@ -1632,6 +1691,7 @@ ORC_API void orc_reset(void* h, const int32_t* indices, int n, real* obs) {
     int idx = indices ? indices[r] : r;
     env_reset(o, idx);
     RexConfig ce = env_cfg(o, idx);
+    o->envs[idx].nz_gidx = ce.env_index_base + idx; o->envs[idx].nz_episode = o->envs[idx].episode; o->envs[idx].nz_step = -1;
     for (int k = 4; k < od; ++k) obs[(size_t)r * od + k] = 0;
     env_observation(&ce, &o->envs[idx], obs + (size_t)r * od);
     if (o->cfg.range_normalize) normalize_obs(&o->cfg, obs + (size_t)r * od, od);

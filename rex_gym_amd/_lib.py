@@ -31,7 +31,7 @@ class RexConfig(ctypes.Structure):
         ("mark", ctypes.c_int32),
         ("gait_clock_scale", ctypes.c_float), ("body_contacts", ctypes.c_int32), ("noise_stdev", ctypes.c_float * 5),
         ("task_mix", ctypes.c_int32), ("mass_scale_lo", ctypes.c_float), ("mass_scale_hi", ctypes.c_float),
-        ("friction_lo", ctypes.c_float), ("friction_hi", ctypes.c_float),
+        ("friction_lo", ctypes.c_float), ("friction_hi", ctypes.c_float), ("init_height", ctypes.c_float),
     ]
 
 
@@ -53,6 +53,8 @@ _SIGS = {
     "rex_set_body_params": ([ctypes.c_void_p, ctypes.c_void_p], ctypes.c_int),
     "rex_set_history": ([ctypes.c_void_p, ctypes.c_void_p], ctypes.c_int),
     "rex_set_terrain": ([ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p], ctypes.c_int),
+    "rex_set_heightfield": ([ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                             ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_void_p], ctypes.c_int),
     "rex_reset": ([ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p], ctypes.c_int),
     "rex_step": ([ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                   ctypes.c_void_p, ctypes.c_void_p], ctypes.c_int),

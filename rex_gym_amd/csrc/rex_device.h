@@ -55,7 +55,7 @@ constexpr float kErp = 0.2f;               // btContactSolverInfo::m_erp2
 constexpr float kBreaking = 0.02f;         // contact breaking threshold
 constexpr float kLimitActivation = 0.15f;  // a joint bound further away cannot act within one step (|qd| dt <= 0.1)
 constexpr float kMu = 0.5f;                // toe 0.5 x plane 1.0
-constexpr float kInitZ = 0.21f;            // terrain.py:14-20
+constexpr float kInitZ = 0.21f;            // terrain.py:14-20 (default drop height; RexConfig.init_height overrides)
 constexpr float kToeRad = (float)(REX_TOE_RADIUS + REX_COLLISION_MARGIN);
 constexpr float kToeHalf = (float)REX_TOE_HALFLEN;
 
@@ -177,22 +177,27 @@ struct BaseKin {
 // 256 x 256 vertex heights, 5 cm cells, centred on the origin, shifted down by `mid` (Bullet centres a
 // heightfield on the middle of its height range) -- the plane shows wherever the field is
 // below 0.  Triangulation: Bullet's default diagonal (i,j+1)-(i+1,j).  h == nullptr: plane only.
+// Grid geometry of the heightfield pool (wave-uniform): nx vertices per row, index scale and offset per axis
+// (vertex coordinate = x * inv_cx + off_x, clamped to [0, max_x]).  The reference's random terrain: 256, 20, 127.5, 254.999.
+struct HfGeom { int nx; float inv_cx, inv_cy, off_x, off_y, max_x, max_y; };
 struct Ground {
   const float* h; float mid;
   // per-env domain randomisation (Rex.SetBaseMasses / SetLegMasses, rex.py:659-692: masses only -- Bullet keeps the
   // inertia tensors computed at load time; plus the foot friction coefficient)
   float base_mass_scale, leg_mass_scale, mu;
+  HfGeom geo;
 };
-// (cell size 0.05 m: every division by it is a multiplication by 20, here and in the oracle)
+// (every division by the cell size is a multiplication by its inverse, here and in the oracle)
 __device__ __forceinline__ void ground_query(const Ground& g, float x, float y, float& height, f3& n) {
   n = f3{0.f, 0.f, 1.f}; height = 0.0f;
-  float fx = fminf(fmaxf(x * 20.0f + 127.5f, 0.0f), 254.999f), fy = fminf(fmaxf(y * 20.0f + 127.5f, 0.0f), 254.999f);
+  const HfGeom& q = g.geo;
+  float fx = fminf(fmaxf(x * q.inv_cx + q.off_x, 0.0f), q.max_x), fy = fminf(fmaxf(y * q.inv_cy + q.off_y, 0.0f), q.max_y);
   const int i = (int)fx, j = (int)fy;
   const float u = fx - (float)i, v = fy - (float)j;
-  const float h00 = g.h[j * 256 + i], h10 = g.h[j * 256 + i + 1], h01 = g.h[(j + 1) * 256 + i], h11 = g.h[(j + 1) * 256 + i + 1];
+  const float h00 = g.h[j * q.nx + i], h10 = g.h[j * q.nx + i + 1], h01 = g.h[(j + 1) * q.nx + i], h11 = g.h[(j + 1) * q.nx + i + 1];
   float hh, gx, gy;
-  if (u + v <= 1.0f) { hh = h00 + u * (h10 - h00) + v * (h01 - h00); gx = (h10 - h00) * 20.0f; gy = (h01 - h00) * 20.0f; }
-  else { hh = h11 + (1.0f - u) * (h01 - h11) + (1.0f - v) * (h10 - h11); gx = (h11 - h01) * 20.0f; gy = (h11 - h10) * 20.0f; }
+  if (u + v <= 1.0f) { hh = h00 + u * (h10 - h00) + v * (h01 - h00); gx = (h10 - h00) * q.inv_cx; gy = (h01 - h00) * q.inv_cy; }
+  else { hh = h11 + (1.0f - u) * (h01 - h11) + (1.0f - v) * (h10 - h11); gx = (h11 - h01) * q.inv_cx; gy = (h11 - h10) * q.inv_cy; }
   hh -= g.mid;
   if (hh > 0.0f) {
     const float inv = rsqrtf(gx * gx + gy * gy + 1.0f);

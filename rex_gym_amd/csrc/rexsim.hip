@@ -140,6 +140,25 @@ __device__ __forceinline__ void philox4x32(uint32_t* c, uint32_t k0, uint32_t k1
   }
 }
 __device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+// Four standard normal draws (Box-Muller on one Philox block) for the sensor-noise model: Rex._AddSensorNoise
+// (model/rex.py:765-769) draws np.random.normal afresh in every getter call; here a getter call site of a step is one or
+// more Philox blocks keyed by (seed; episode, global env, 16 + block, step).
+__device__ __forceinline__ void gauss4(uint32_t seed_lo, uint32_t seed_hi, int gidx, int episode, int step, int block, float* z) {
+  uint32_t ctr[4] = {(uint32_t)episode, (uint32_t)gidx, 16u + (uint32_t)block, (uint32_t)step};
+  philox4x32(ctr, seed_lo, seed_hi);
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const float u1 = (float)((ctr[2 * p] >> 8) + 1u) * (1.0f / 16777216.0f), u2 = u01(ctr[2 * p + 1]);
+    const float r = sqrtf(-2.0f * __logf(u1));
+    float sn, cs;
+    sincos_fast(6.28318530717958648f * u2, sn, cs);
+    z[2 * p] = r * cs; z[2 * p + 1] = r * sn;
+  }
+}
+// call sites of a step (blocks): orientation read by the turn env's goal test, by the reward, by is_fallen, by the
+// observation; angular rates of the observation; then NM-wide reads (5 blocks each): reward torques, reward velocities,
+// observed motor angles
+enum { kNzGoal = 0, kNzRewardRpy = 1, kNzFallenRpy = 2, kNzObsRpy = 3, kNzObsRate = 4, kNzTorque = 8, kNzVelocity = 16, kNzAngle = 24 };
 
 struct DevCfg {
   int32_t n, env_index_base, task, signal, action_repeat, iterations;
@@ -158,7 +177,8 @@ struct DevCfg {
   const float* terrain;      // [n_terrain][256*256] raw vertex heights (nullptr: plane only)
   const float* terrain_mid;  // [n_terrain]
   int32_t n_terrain;
-  float* hist;               // [100][43][n] observation history (nullptr: no latency model)
+  float* hist;               // [100][hist_words][n] observation history (nullptr: no latency model)
+  int32_t hist_words;        // 3 NM + 7 words per record: q, qd, observed torque, base quaternion, base angular velocity
   float pd_latency, control_latency;
   // int(latency / time_step) and the blend weight of the older slot (rex.py:747-751), taken on the host in double on
   // the decimal values the caller wrote: the float quotient 0.02f / 0.001f is 19.999998
@@ -172,6 +192,11 @@ struct DevCfg {
   // solver sweep cap among them (wave-uniform loop bounds; every env stops at its own)
   int32_t mix_task[5], n_mix, max_repeat, max_iterations;
   float mass_lo, mass_hi, mu_lo, mu_hi;   // per-reset randomisation ranges (lo == hi == 0: off)
+  float noise[5];            // observation_noise_stdev (rex.py:22,765-769): angles, velocities, torques, rpy, rpy rates
+  int32_t noise_on;          // any of them > 0
+  HfGeom geo;                // heightfield grid geometry
+  int32_t hf_stride;         // floats per field of the pool
+  float init_z;              // drop height of the reset (terrain.py:14-20)
   float obs_hi_ang, obs_hi_rate;
 };
 
@@ -224,7 +249,7 @@ __device__ __forceinline__ float reset_pose(const DevCfg& c, int j) { return c.t
 
 // ---- latency model: Rex._observation_history / _GetDelayedObservation (model/rex.py:122,717-763) ----
 __device__ __forceinline__ float& hist_at(const DevCfg& c, int i, int slot, int w) {
-  return c.hist[((size_t)slot * REX_HISTORY_WORDS + w) * c.n + i];
+  return c.hist[((size_t)slot * c.hist_words + w) * c.n + i];   // hist_words = 3 NM + 7: 43 (mark 'base') or 61 ('arm')
 }
 // which two ring slots to blend, and with which weight, for an observation `latency` seconds old
 __device__ __forceinline__ void delay_slots(uint32_t hist, float latency, int n, float blend, int& s0, int& s1, float& alpha) {
@@ -250,7 +275,7 @@ __device__ __forceinline__ int terrain_index(const DevCfg& c, int gidx, int epis
   return (int)(((uint32_t)gidx + 977u * (uint32_t)episode) % (uint32_t)c.n_terrain);
 }
 __device__ __forceinline__ Ground env_ground(const DevCfg& c, int i, int gidx, int episode) {
-  Ground g{nullptr, 0.0f, 1.0f, 1.0f, kMu};
+  Ground g{nullptr, 0.0f, 1.0f, 1.0f, kMu, c.geo};
   if (c.body_params) {
     g.base_mass_scale = c.body_params[i]; g.leg_mass_scale = c.body_params[(size_t)c.n + i]; g.mu = c.body_params[2 * (size_t)c.n + i];
   }
@@ -267,13 +292,14 @@ __device__ __forceinline__ Ground env_ground(const DevCfg& c, int i, int gidx, i
   }
   if (c.n_terrain > 0) {
     const int t = terrain_index(c, gidx, episode);
-    g.h = c.terrain + (size_t)t * 65536;
+    g.h = c.terrain + (size_t)t * c.hf_stride;
     g.mid = c.terrain_mid[t];
   }
   return g;
 }
 
 // Rex.ReceiveObservation (rex.py:726-733): the true observation goes to the front of the history ring
+template <int NM>
 __device__ __forceinline__ void receive_observation(const DevCfg& c, EnvState& e, int i, bool live, const float* tau_obs) {
   if (!c.hist) return;
   const int head = ((int)(e.hist & 0xFFu) + 1) % REX_HISTORY_LEN;
@@ -281,16 +307,15 @@ __device__ __forceinline__ void receive_observation(const DevCfg& c, EnvState& e
   e.hist = (uint32_t)head | ((uint32_t)len << 8);
   if (live) {
 #pragma unroll
-    for (int j = 0; j < 12; ++j) { hist_at(c, i, head, j) = e.ph.q[j]; hist_at(c, i, head, 12 + j) = e.ph.qd[j]; hist_at(c, i, head, 24 + j) = tau_obs[j]; }
+    for (int j = 0; j < NM; ++j) { hist_at(c, i, head, j) = e.ph.q[j]; hist_at(c, i, head, NM + j) = e.ph.qd[j]; hist_at(c, i, head, 2 * NM + j) = tau_obs[j]; }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) hist_at(c, i, head, 36 + k) = e.ph.quat[k];
+    for (int k = 0; k < 4; ++k) hist_at(c, i, head, 3 * NM + k) = e.ph.quat[k];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) hist_at(c, i, head, 40 + k) = e.ph.ang[k];
+    for (int k = 0; k < 3; ++k) hist_at(c, i, head, 3 * NM + 4 + k) = e.ph.ang[k];
   }
 }
 
-// Rex.ApplyAction + stepSimulation + ReceiveObservation (rex.py:158-163, 568-641).  The latency model (c.hist) is
-// only offered for mark 'base' (43-word history records); rex_create rejects it for mark 'arm'.
+// Rex.ApplyAction + stepSimulation + ReceiveObservation (rex.py:158-163, 568-641).
 template <class SM, class ARMP>
 __device__ __forceinline__ void rex_substep(const DevCfg& c, EnvState& e, int i, bool live, const float* cmd, float* tau_obs,
                                             const SM& sm, const Ground& ground, ARMP& armp) {
@@ -305,7 +330,7 @@ __device__ __forceinline__ void rex_substep(const DevCfg& c, EnvState& e, int i,
     float alpha;
     delay_slots(e.hist, c.pd_latency, c.pd_slots, c.pd_alpha, s0, s1, alpha);
 #pragma unroll
-    for (int j = 0; j < 12; ++j) { qo[j] = delayed_word(c, i, s0, s1, alpha, j); qdo[j] = delayed_word(c, i, s0, s1, alpha, 12 + j); }
+    for (int j = 0; j < NM; ++j) { qo[j] = delayed_word(c, i, s0, s1, alpha, j); qdo[j] = delayed_word(c, i, s0, s1, alpha, NM + j); }
   }
 #pragma unroll
   for (int j = 0; j < NM; ++j) {
@@ -319,7 +344,7 @@ __device__ __forceinline__ void rex_substep(const DevCfg& c, EnvState& e, int i,
     tau[j] = ((e.motor_en >> j) & 1u) ? act : 0.0f;                             // rex.py:617-623
   }
   physics_substep(e.ph, tau, c.dt, c.max_iterations, c.iterations, c.res_thr, sm, ground, armp);
-  receive_observation(c, e, i, live, tau_obs);
+  receive_observation<NM>(c, e, i, live, tau_obs);
 }
 
 // Rex._control_observation as the env-level getters see it (delayed by control_latency when the model is on)
@@ -329,14 +354,14 @@ __device__ __forceinline__ void control_observation(const DevCfg& c, const EnvSt
     int s0, s1; float alpha;
     delay_slots(e.hist, c.control_latency, c.control_slots, c.control_alpha, s0, s1, alpha);
 #pragma unroll
-    for (int j = 0; j < 12; ++j) {
-      o.q[j] = delayed_word(c, i, s0, s1, alpha, j); o.qd[j] = delayed_word(c, i, s0, s1, alpha, 12 + j);
-      o.tau[j] = delayed_word(c, i, s0, s1, alpha, 24 + j);
+    for (int j = 0; j < NM; ++j) {
+      o.q[j] = delayed_word(c, i, s0, s1, alpha, j); o.qd[j] = delayed_word(c, i, s0, s1, alpha, NM + j);
+      o.tau[j] = delayed_word(c, i, s0, s1, alpha, 2 * NM + j);
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) o.quat[k] = delayed_word(c, i, s0, s1, alpha, 36 + k);
+    for (int k = 0; k < 4; ++k) o.quat[k] = delayed_word(c, i, s0, s1, alpha, 3 * NM + k);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) o.w[k] = delayed_word(c, i, s0, s1, alpha, 40 + k);
+    for (int k = 0; k < 3; ++k) o.w[k] = delayed_word(c, i, s0, s1, alpha, 3 * NM + 4 + k);
   } else {
 #pragma unroll
     for (int j = 0; j < NM; ++j) { o.q[j] = e.ph.q[j]; o.qd[j] = e.ph.qd[j]; o.tau[j] = tau_obs[j]; }
@@ -359,14 +384,26 @@ __device__ __forceinline__ void normalize_obs(const DevCfg& c, float* obs) {
 }
 
 template <int NM>
-__device__ __forceinline__ void env_observation(const DevCfg& c, const CtrlObs& co, float* obs) {
+__device__ __forceinline__ void env_observation(const DevCfg& c, const CtrlObs& co, float* obs, int gidx = 0, int episode = 0, int step = 0) {
   float rpy[3];
   quat_to_euler(co.quat, rpy);
-  obs[0] = rpy[0]; obs[1] = rpy[1]; obs[2] = co.w[0]; obs[3] = co.w[1];           // walk_env.py:356-362
+  float wx = co.w[0], wy = co.w[1];
+  if (c.noise_on) {                                                               // GetBaseRollPitchYaw / ...Rate: rex.py:430-442,548-558
+    float z[4];
+    if (c.noise[3] > 0.0f) { gauss4(c.seed_lo, c.seed_hi, gidx, episode, step, kNzObsRpy, z); rpy[0] += c.noise[3] * z[0]; rpy[1] += c.noise[3] * z[1]; }
+    if (c.noise[4] > 0.0f) { gauss4(c.seed_lo, c.seed_hi, gidx, episode, step, kNzObsRate, z); wx += c.noise[4] * z[0]; wy += c.noise[4] * z[1]; }
+  }
+  obs[0] = rpy[0]; obs[1] = rpy[1]; obs[2] = wx; obs[3] = wy;                       // walk_env.py:356-362
   if (c.task == REX_TASK_GALLOP) {
+    float nz[20];
+    const bool noisy = c.noise_on && c.noise[0] > 0.0f;                           // GetMotorAngles: noise, then MapToMinusPiToPi (rex.py:457-468)
+    if (noisy) {
+#pragma unroll
+      for (int b = 0; b < (NM + 3) / 4; ++b) gauss4(c.seed_lo, c.seed_hi, gidx, episode, step, kNzAngle + b, nz + 4 * b);
+    }
 #pragma unroll
     for (int j = 0; j < NM; ++j) {                                                // MapToMinusPiToPi, rex.py:26-41
-      float a = fmodf(co.q[j], 2.0f * kPi);
+      float a = fmodf(co.q[j] + (noisy ? c.noise[0] * nz[j] : 0.0f), 2.0f * kPi);
       if (a >= kPi) a -= 2.0f * kPi; else if (a < -kPi) a += 2.0f * kPi;
       obs[4 + j] = a;
     }
@@ -387,7 +424,7 @@ __device__ __forceinline__ void env_reset(const DevCfg& c, const float* snap, in
     if (live) {
       const float* ring = snap + (size_t)Lay<NM>::WORDS * nrec;
 #pragma unroll 8
-      for (int k = 0; k < REX_HISTORY_LEN * REX_HISTORY_WORDS; ++k) c.hist[(size_t)k * c.n + i] = ring[(size_t)k * nrec + rec];
+      for (int k = 0; k < REX_HISTORY_LEN * (3 * NM + 7); ++k) c.hist[(size_t)k * c.n + i] = ring[(size_t)k * nrec + rec];
     }
     mirror_sync();
   } else e.hist = 0u;
@@ -428,7 +465,7 @@ __device__ __forceinline__ void env_reset(const DevCfg& c, const float* snap, in
     sincos_fast(0.5f * ini, sh, ch);                                             // getQuaternionFromEuler([0, 0, yaw])
     const float nn = rsqrtf(sh * sh + ch * ch);
     e.ph.quat[0] = 0.0f; e.ph.quat[1] = 0.0f; e.ph.quat[2] = sh * nn; e.ph.quat[3] = ch * nn;
-    e.ph.pos[0] = 0.0f; e.ph.pos[1] = 0.0f; e.ph.pos[2] = kInitZ;                // resetBasePositionAndOrientation
+    e.ph.pos[0] = 0.0f; e.ph.pos[1] = 0.0f; e.ph.pos[2] = c.init_z;              // resetBasePositionAndOrientation
   }
 }
 
@@ -549,7 +586,7 @@ __device__ __forceinline__ void poses_command(const DevCfg& c, EnvState& e, cons
 }
 
 // RexTurnEnv._transform_action_to_motor_command (turn_env.py:239-347)
-__device__ __forceinline__ void turn_command(const DevCfg& c, EnvState& e, const float* ctrl_quat, const float* action, float* cmd) {
+__device__ __forceinline__ void turn_command(const DevCfg& c, EnvState& e, const float* ctrl_quat, const float* action, float* cmd, int gidx) {
   const float t = (float)(e.steps * c.action_repeat) * c.dt;
   if (e.flags & REX_F_STAY_STILL) {
     if (t - e.end_time >= 1.0f) e.flags |= REX_F_ENV_GOAL;                       // _terminate_with_delay
@@ -560,6 +597,19 @@ __device__ __forceinline__ void turn_command(const DevCfg& c, EnvState& e, const
   {                                                                              // _check_target_position
     float rpy[3];
     quat_to_euler(ctrl_quat, rpy);                                               // GetBaseOrientation (delayed when latency is on)
+    if (c.noise_on && c.noise[3] > 0.0f) {                                       // ... through GetBaseRollPitchYaw's sensor noise (rex.py:430-442)
+      float z[4];
+      gauss4(c.seed_lo, c.seed_hi, gidx, e.episode, e.steps, kNzGoal, z);
+      rpy[0] += c.noise[3] * z[0]; rpy[1] += c.noise[3] * z[1]; rpy[2] += c.noise[3] * z[2];
+      float q[4], r2[3];                                                         // rpy -> quaternion -> rpy, as the reference does
+      {
+        float sr, cr, sp, cp, sy, cy;
+        sincos_fast(rpy[0] * 0.5f, sr, cr); sincos_fast(rpy[1] * 0.5f, sp, cp); sincos_fast(rpy[2] * 0.5f, sy, cy);
+        q[0] = sr * cp * cy - cr * sp * sy; q[1] = cr * sp * cy + sr * cp * sy; q[2] = cr * cp * sy - sr * sp * cy; q[3] = cr * cp * cy + sr * sp * sy;
+      }
+      quat_to_euler(q, r2);
+      rpy[2] = r2[2];
+    }
     float cz = rpy[2];
     if (cz < 0.0f) cz += 6.28f;
     if (fabsf(e.target - cz) <= 0.01f) {
@@ -655,9 +705,9 @@ __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __r
       int s0, s1; float alpha;
       delay_slots(e.hist, c.control_latency, c.control_slots, c.control_alpha, s0, s1, alpha);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) cq[k] = delayed_word(c, i, s0, s1, alpha, 36 + k);
+      for (int k = 0; k < 4; ++k) cq[k] = delayed_word(c, i, s0, s1, alpha, 3 * NM + k);
     }
-    turn_command(c_, e, cq, act, cmd);
+    turn_command(c_, e, cq, act, cmd, c.env_index_base + i);
   }
   else if (c_.task == REX_TASK_POSES) poses_command(c_, e, act, cmd);
   else if (c_.task == REX_TASK_STANDUP) standup_command(c_, e, act, cmd);
@@ -665,6 +715,7 @@ __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __r
 
   float tau_obs[NM];
   const Ground ground = env_ground(c, i, c.env_index_base + i, e.episode);
+  const int step0 = e.steps, episode0 = e.episode;   // keys of this step's sensor-noise draws
 
   // everything of env.step() after Rex.Step: reward, termination, in-launch reset, observation, stores
   auto epilogue = [&](bool commit) {
@@ -673,6 +724,26 @@ __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __r
   control_observation<NM>(c, e, i, tau_obs, co);
   float rpy[3], r20, r21, r22;
   quat_to_euler(co.quat, rpy);       // GetBaseOrientation: (delayed) quat -> RPY -> quat, rex.py:530-537
+  if (c.noise_on) {                  // sensor noise: the reward's and is_fallen's orientation reads draw separately
+    const int gx = c.env_index_base + i;
+    float z[4], rp[3], d0, d1;
+    if (c.noise[3] > 0.0f) {
+      gauss4(c.seed_lo, c.seed_hi, gx, episode0, step0, kNzFallenRpy, z);
+      rp[0] = rpy[0] + c.noise[3] * z[0]; rp[1] = rpy[1] + c.noise[3] * z[1]; rp[2] = rpy[2] + c.noise[3] * z[2];
+      euler_to_row2(rp, d0, d1, r22);
+      gauss4(c.seed_lo, c.seed_hi, gx, episode0, step0, kNzRewardRpy, z);
+      rp[0] = rpy[0] + c.noise[3] * z[0]; rp[1] = rpy[1] + c.noise[3] * z[1]; rp[2] = rpy[2] + c.noise[3] * z[2];
+      euler_to_row2(rp, r20, r21, d0);
+    } else euler_to_row2(rpy, r20, r21, r22);
+    float nt[20], nv[20];
+#pragma unroll
+    for (int b = 0; b < (NM + 3) / 4; ++b) {
+      gauss4(c.seed_lo, c.seed_hi, gx, episode0, step0, kNzTorque + b, nt + 4 * b);
+      gauss4(c.seed_lo, c.seed_hi, gx, episode0, step0, kNzVelocity + b, nv + 4 * b);
+    }
+#pragma unroll
+    for (int j = 0; j < NM; ++j) { co.tau[j] += c.noise[2] * nt[j]; co.qd[j] += c.noise[1] * nv[j]; }   // GetMotorTorques / Velocities
+  } else
   euler_to_row2(rpy, r20, r21, r22);
   float x = -e.ph.pos[0];
   if (c.backwards > 0) x = -x;      // `if self._backwards:` is the constructor argument, not the draw
@@ -730,7 +801,7 @@ __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __r
 #pragma unroll
     for (int k = 4; k < 22; ++k) obs[k] = 0.0f;    // a task with a narrower observation leaves the tail of its row 0
   }
-  env_observation<NM>(c_, co, obs);
+  env_observation<NM>(c_, co, obs, c.env_index_base + i, episode0, step0);
   if (c.range_normalize) normalize_obs(c, obs);
   if (commit) {
     // an opaque copy of the env index: the store addresses are rebuilt here instead of 54 address pairs being carried
@@ -783,11 +854,11 @@ __global__ __launch_bounds__(REX_WAVE) void rex_settle_kernel(DevCfg c, float* _
   const int rec = (threadIdx.x & (LPE - 1)) == 0 ? first : nrec;        // one lane of the group stores it
   const int t = first < nrec ? first : nrec - 1;
   const int terr = t / c.n_mix, slot = t % c.n_mix;
-  Ground ground{nullptr, 0.0f, 1.0f, 1.0f, kMu};
-  if (c.n_terrain > 0) { ground.h = c.terrain + (size_t)terr * 65536; ground.mid = c.terrain_mid[terr]; }
+  Ground ground{nullptr, 0.0f, 1.0f, 1.0f, kMu, c.geo};
+  if (c.n_terrain > 0) { ground.h = c.terrain + (size_t)terr * c.hf_stride; ground.mid = c.terrain_mid[terr]; }
   EnvState e;
   memset(&e, 0, sizeof(e));
-  e.ph.pos[2] = kInitZ;
+  e.ph.pos[2] = c.init_z;
   e.ph.quat[3] = 1.0f;
 #pragma unroll
   for (int j = 0; j < 12; ++j) e.ph.q[j] = pose_stand(j);       // ResetPose: INIT_POSES[pose_id = 'stand']
@@ -812,7 +883,7 @@ __global__ __launch_bounds__(REX_WAVE) void rex_settle_kernel(DevCfg c, float* _
 #pragma unroll
   for (int j = 0; j < NM; ++j) tau_obs[j] = 0.0f;
   if (c.task != REX_TASK_POSES) {   // RexPosesEnv: base reset() with initial_motor_angles=None skips the motion (rex.py:308)
-    receive_observation(cs, e, t, keeps, tau_obs);
+    receive_observation<NM>(cs, e, t, keeps, tau_obs);
     float cmd[NM];
     if (ARM) {
 #pragma unroll
@@ -825,7 +896,7 @@ __global__ __launch_bounds__(REX_WAVE) void rex_settle_kernel(DevCfg c, float* _
     for (int j = 0; j < 12; ++j) cmd[j] = reset_pose(c, j);
     for (int k = 0; k < c.reset_substeps; ++k) rex_substep(cs, e, t, keeps, cmd, tau_obs, sm, ground, armp);   // rex.py:319-322
   }
-  receive_observation(cs, e, t, keeps, tau_obs);                                                               // rex.py:323
+  receive_observation<NM>(cs, e, t, keeps, tau_obs);                                                           // rex.py:323
   if (!cs.hist) e.hist = 0u;
   if (keeps) store_env<NM>(snap, nrec, rec, e);
 }
@@ -856,7 +927,7 @@ __global__ void rex_reset_kernel(DevCfg c, float* __restrict__ state, const floa
     for (int k = 0; k < 3; ++k) co.w[k] = seen[4 + k];
   }
   for (int k = 4; k < 22; ++k) obs[k] = 0.0f;
-  env_observation<NM>(c_, co, obs);
+  env_observation<NM>(c_, co, obs, c.env_index_base + i, e.episode, -1);   // reset()'s own reading: its own noise draws
   if (c.range_normalize) normalize_obs(c, obs);
   if (obs_out) for (int k = 0; k < c.obs_dim; ++k) obs_out[(size_t)r * c.obs_dim + k] = obs[k];
 }
@@ -1037,11 +1108,9 @@ static int validate(const RexConfig* c) {
     return fail(REX_EINVAL, "action_repeat, solver_iterations and sim_time_step must be positive%s", "");
   if (c->mark != REX_MARK_BASE && c->mark != REX_MARK_ARM) return fail(REX_EINVAL, "unknown mark%s", "");
   if ((long long)c->num_envs * 128 >= (1ll << 30)) return fail(REX_EINVAL, "num_envs too large for 32-bit state offsets%s", "");
-  if (c->mark == REX_MARK_ARM && (c->pd_latency > 0.0f || c->control_latency > 0.0f))
-    return fail(REX_EINVAL, "the latency model is not available with mark 'arm'%s", "");
   if (c->gait_clock_scale < 0.0f) return fail(REX_EINVAL, "gait_clock_scale must be >= 0%s", "");
   if (c->body_contacts) return fail(REX_EINVAL, "body_contacts: not built into this library yet%s", "");
-  for (int k = 0; k < 5; ++k) if (c->noise_stdev[k] != 0.0f) return fail(REX_EINVAL, "noise_stdev: not built into this library yet%s", "");
+  for (int k = 0; k < 5; ++k) if (c->noise_stdev[k] < 0.0f) return fail(REX_EINVAL, "noise_stdev must be >= 0%s", "");
   if (c->task == REX_TASK_MIXED) {
     const int allowed = (1 << REX_TASK_WALK) | (1 << REX_TASK_GALLOP) | (1 << REX_TASK_TURN);   // tasks that share one reset pose per signal
     if (c->task_mix == 0 || (c->task_mix & ~allowed)) return fail(REX_EINVAL, "task_mix must be a non-empty subset of {walk, gallop, turn}%s", "");
@@ -1054,7 +1123,7 @@ static int validate(const RexConfig* c) {
 // a snapshot record: the state words, and behind all records the observation rings the reset motion leaves behind
 static size_t snapshot_floats(const RexSim* s, int nrec) {
   const bool ring = s->cfg.pd_latency > 0.0f || s->cfg.control_latency > 0.0f;
-  return (size_t)nrec * ((size_t)s->words + (ring ? (size_t)REX_HISTORY_LEN * REX_HISTORY_WORDS : 0));
+  return (size_t)nrec * ((size_t)s->words + (ring ? (size_t)REX_HISTORY_LEN * (size_t)s->dev.hist_words : 0));
 }
 
 int rex_create(const RexConfig* cfg, int device, float* d_state, void* stream, RexSim** out) {
@@ -1097,7 +1166,12 @@ int rex_create(const RexConfig* cfg, int device, float* d_state, void* stream, R
   d.pose_index = cfg->pose_index; d.pose_value = cfg->pose_value;
   d.range_normalize = cfg->range_normalize;
   d.terrain = nullptr; d.terrain_mid = nullptr; d.n_terrain = 0; d.body_params = nullptr;
+  d.geo = rex::HfGeom{256, 20.0f, 20.0f, 127.5f, 127.5f, 254.999f, 254.999f}; d.hf_stride = 65536;   /* model/terrain.py:32-54 */
+  d.init_z = cfg->init_height > 0.0f ? cfg->init_height : rex::kInitZ;
+  d.noise_on = 0;
+  for (int k = 0; k < 5; ++k) { d.noise[k] = cfg->noise_stdev[k]; if (cfg->noise_stdev[k] > 0.0f) d.noise_on = 1; }
   d.hist = nullptr; d.pd_latency = cfg->pd_latency; d.control_latency = cfg->control_latency;
+  d.hist_words = 3 * rex_num_motors(cfg) + 7;
   {
     const double dt = as_written(cfg->sim_time_step), pl = as_written(cfg->pd_latency), cl = as_written(cfg->control_latency);
     d.pd_slots = (int)(pl / dt); d.pd_alpha = (float)((pl - d.pd_slots * dt) / dt);
@@ -1136,8 +1210,7 @@ int rex_create(const RexConfig* cfg, int device, float* d_state, void* stream, R
   return REX_OK;
 }
 
-int rex_set_terrain(RexSim* s, const float* d_heights, const float* d_mids, int k, void* stream) {
-  if (!s || k < 0 || (k > 0 && (!d_heights || !d_mids))) return fail(REX_EINVAL, "rex_set_terrain: bad arguments%s", "");
+static int install_terrain(RexSim* s, const float* d_heights, const float* d_mids, int k, void* stream) {
   HIPCHK(hipSetDevice(s->device));
   hipStream_t st = (hipStream_t)stream;
   float* snap = nullptr;
@@ -1155,9 +1228,28 @@ int rex_set_terrain(RexSim* s, const float* d_heights, const float* d_mids, int 
   return REX_OK;
 }
 
+int rex_set_terrain(RexSim* s, const float* d_heights, const float* d_mids, int k, void* stream) {
+  if (!s || k < 0 || (k > 0 && (!d_heights || !d_mids))) return fail(REX_EINVAL, "rex_set_terrain: bad arguments%s", "");
+  s->dev.geo = rex::HfGeom{256, 20.0f, 20.0f, 127.5f, 127.5f, 254.999f, 254.999f};   /* 256 x 256 vertices, 5 cm cells, centred */
+  s->dev.hf_stride = 65536;
+  return install_terrain(s, d_heights, d_mids, k, stream);
+}
+
+int rex_set_heightfield(RexSim* s, const float* d_heights, const float* d_mids, int k, int nx, int ny, float cell_x, float cell_y,
+                        float origin_x, float origin_y, void* stream) {
+  if (!s || k <= 0 || !d_heights || !d_mids || nx < 2 || ny < 2 || !(cell_x > 0.0f) || !(cell_y > 0.0f) || (long long)nx * ny > (1ll << 26))
+    return fail(REX_EINVAL, "rex_set_heightfield: bad arguments%s", "");
+  rex::HfGeom g;
+  g.nx = nx; g.inv_cx = 1.0f / cell_x; g.inv_cy = 1.0f / cell_y;
+  g.off_x = 0.5f * (float)(nx - 1) - origin_x * g.inv_cx; g.off_y = 0.5f * (float)(ny - 1) - origin_y * g.inv_cy;
+  g.max_x = (float)(nx - 1) - 0.001f; g.max_y = (float)(ny - 1) - 0.001f;
+  s->dev.geo = g;
+  s->dev.hf_stride = nx * ny;
+  return install_terrain(s, d_heights, d_mids, k, stream);
+}
+
 int rex_set_history(RexSim* s, float* d_history) {
   if (!s) return fail(REX_EINVAL, "rex_set_history: null sim%s", "");
-  if (s->cfg.mark == REX_MARK_ARM && d_history) return fail(REX_EINVAL, "rex_set_history: not available with mark 'arm'%s", "");
   // without a latency the delayed observation IS the newest one (rex.py:744-745): the ring is not needed, and the
   // snapshot holds none to restore from
   s->dev.hist = (s->cfg.pd_latency > 0.0f || s->cfg.control_latency > 0.0f) ? d_history : nullptr;

@@ -69,7 +69,8 @@ class RexBatchEnv:
                  range_normalize=False, check_actions=False, terrain_type="plane", terrain_pool=64, terrain_seed=10,
                  mark="base", render=False, stream=None, gait_clock_scale=1.0,
                  distance_weight=None, energy_weight=None, drift_weight=None, shake_weight=None,
-                 tasks=None, mass_scale_range=None, friction_range=None, **ignored):
+                 tasks=None, mass_scale_range=None, friction_range=None, observation_noise_stdev=None,
+                 heightfield=None, heightfield_cell=None, heightfield_origin=(0.0, 0.0, 0.0), init_height=None, **ignored):
         import torch
         # Reference constructor keywords that only touch the GUI, logging or debugging are accepted and ignored; anything
         # else that would change what the env computes is an error here, not a silent no-op.
@@ -82,9 +83,17 @@ class RexBatchEnv:
         unknown = [k for k in unknown if k not in ("on_rack", "env_randomizer")]
         if unknown:
             raise TypeError(f"RexBatchEnv: unsupported keyword(s) {unknown}")
-        if terrain_type not in ("plane", "random") or mark not in _lib.MARKS or render:
-            raise NotImplementedError("this round covers terrain_type in ('plane', 'random'), mark in ('base', 'arm'), "
-                                      "render=False")
+        if terrain_type in ("hills", "mounts", "maze") and heightfield is None:
+            raise NotImplementedError(
+                f"terrain_type={terrain_type!r}: the reference loads this field from the pip package pybullet_data "
+                "(model/terrain.py:55-78), which is not part of rex-gym; pass its heights as heightfield=<array [ny, nx] in "
+                "metres>, heightfield_cell=(cx, cy), heightfield_origin=(x, y, z) -- e.g. mounts: cell (0.1, 0.1), z scale 24 "
+                "folded into the array, origin z = 2, init_height 0.85")
+        if terrain_type not in ("plane", "random", "hills", "mounts", "maze", "custom") or mark not in _lib.MARKS or render:
+            raise NotImplementedError("terrain_type must be 'plane', 'random' or a heightfield ('hills', 'mounts', 'maze', "
+                                      "'custom' with heightfield=...); mark 'base' or 'arm'; render=False")
+        if heightfield is not None and terrain_type in ("plane", "random"):
+            raise ValueError("heightfield=... goes with terrain_type 'custom' / 'hills' / 'mounts' / 'maze'")
         if task not in _lib.TASKS or signal_type not in _lib.SIGNALS:
             raise ValueError(f"unsupported task/signal {task}/{signal_type}")
         if tasks is not None and task != "mixed":
@@ -117,6 +126,15 @@ class RexBatchEnv:
         for rng, lo_name, hi_name in ((mass_scale_range, "mass_scale_lo", "mass_scale_hi"), (friction_range, "friction_lo", "friction_hi")):
             if rng is not None:   # per-reset draws of the env_randomizer hook (rex_gym_env.py:345-346)
                 setattr(cfg, lo_name, float(rng[0])); setattr(cfg, hi_name, float(rng[1]))
+        if observation_noise_stdev is not None:   # Rex(observation_noise_stdev=...), rex.py:22: angle, velocity, torque, rpy, rpy rate
+            if len(observation_noise_stdev) != 5:
+                raise ValueError("observation_noise_stdev has 5 entries (motor angle, velocity, torque, base rpy, base rpy rate)")
+            for k, v in enumerate(observation_noise_stdev):
+                cfg.noise_stdev[k] = float(v)
+        if init_height is None and terrain_type in ("hills", "mounts"):
+            init_height = {"hills": 1.98, "mounts": 0.85}[terrain_type]     # ROBOT_INIT_POSITION, terrain.py:14-20
+        if init_height is not None:
+            cfg.init_height = float(init_height)
         cfg.motor_kp, cfg.motor_kd = float(motor_kp), float(motor_kd)
         cfg.gait_clock_scale = float(gait_clock_scale)     # wall-clock seconds per simulated second (gait_planner.py:108-110)
         for name, v in (("distance_weight", distance_weight), ("energy_weight", energy_weight),
@@ -176,9 +194,23 @@ class RexBatchEnv:
         self._needs_reset = True
         if cfg.pd_latency > 0 or cfg.control_latency > 0:   # observation-history ring of the latency model (rex.py:122)
             with torch.cuda.device(self.device):
-                self.history = torch.zeros((100 * 43, self.num_envs), dtype=torch.float32, device=self.device)
+                self.history = torch.zeros((100 * (3 * self.num_motors + 7), self.num_envs), dtype=torch.float32, device=self.device)
             _lib.check(self._L.rex_set_history(self._h, self.history.data_ptr()), "rex_set_history")
         self.terrain_type = terrain_type
+        if heightfield is not None:    # model/terrain.py:55-78 style fields, supplied by the caller
+            h = np.asarray(heightfield, dtype=np.float32)
+            if h.ndim == 2:
+                h = h[None]
+            if h.ndim != 3 or heightfield_cell is None:
+                raise ValueError("heightfield must be [ny, nx] or [k, ny, nx] (metres) and heightfield_cell=(cx, cy) given")
+            ox, oy, oz = (float(v) for v in heightfield_origin)
+            mids = np.array([0.5 * (float(f.min()) + float(f.max())) - oz for f in h], dtype=np.float32)   # Bullet centres the shape, then places it at z0
+            with torch.cuda.device(self.device):
+                self.terrain_heights = torch.from_numpy(np.ascontiguousarray(h)).to(self.device)
+                self.terrain_mids = torch.from_numpy(mids).to(self.device)
+                _lib.check(self._L.rex_set_heightfield(self._h, self.terrain_heights.data_ptr(), self.terrain_mids.data_ptr(),
+                                                       int(h.shape[0]), int(h.shape[2]), int(h.shape[1]), float(heightfield_cell[0]),
+                                                       float(heightfield_cell[1]), ox, oy, self._stream_ptr()), "rex_set_heightfield")
         if terrain_type == "random":   # model/terrain.py:32-54 -- a pool of fields instead of one per env
             from ..terrain import random_terrain_pool
             h, m = random_terrain_pool(int(terrain_pool), int(terrain_seed))

@@ -41,7 +41,7 @@ class RexConfig(ctypes.Structure):
         ("mark", ctypes.c_int32),
         ("gait_clock_scale", ctypes.c_float), ("body_contacts", ctypes.c_int32), ("noise_stdev", ctypes.c_float * 5),
         ("task_mix", ctypes.c_int32), ("mass_scale_lo", ctypes.c_float), ("mass_scale_hi", ctypes.c_float),
-        ("friction_lo", ctypes.c_float), ("friction_hi", ctypes.c_float),
+        ("friction_lo", ctypes.c_float), ("friction_hi", ctypes.c_float), ("init_height", ctypes.c_float),
     ]
 
 
@@ -198,6 +198,14 @@ class OracleEnv:
         mids = np.ascontiguousarray(mids, np.float32)
         self.o.lib.orc_set_terrain(self.h, heights.ctypes.data_as(ctypes.c_void_p), mids.ctypes.data_as(ctypes.c_void_p),
                                    int(heights.shape[0]))
+
+    def set_heightfield(self, heights, mids, cell, origin_xy=(0.0, 0.0)):
+        heights = np.ascontiguousarray(heights, np.float32)
+        mids = np.ascontiguousarray(mids, np.float32)
+        k, ny, nx = heights.shape
+        self.o.lib.orc_set_heightfield(self.h, heights.ctypes.data_as(ctypes.c_void_p), mids.ctypes.data_as(ctypes.c_void_p),
+                                       int(k), int(nx), int(ny), ctypes.c_float(cell[0]), ctypes.c_float(cell[1]),
+                                       ctypes.c_float(origin_xy[0]), ctypes.c_float(origin_xy[1]))
 
     def get_state(self):
         out = np.zeros((self.o.state_words, self.n), np.float64)

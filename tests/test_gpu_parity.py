@@ -259,10 +259,28 @@ def test_arm_mark_trajectory_and_auto_reset(torch):
     env.close()
 
 
-def test_arm_mark_rejects_latency_model(torch):
-    from rex_gym_amd import RexBatchEnv, _lib
-    with pytest.raises(_lib.RexSimError):
-        RexBatchEnv(4, task="walk", signal_type="ik", mark="arm", pd_latency=0.003)
+def test_arm_mark_latency_model_parity(torch):
+    """The latency model for mark 'arm' (61-word history records: 18 q, 18 qd, 18 observed torques, quaternion, angular
+    velocity; rex.py:717-763): PD latency 3.5 ms + control latency 20 ms, lock step with the fp32 arm oracle through a
+    reset by index."""
+    n = 16
+    env, orc = make_pair("walk", "ik", n, np.float32, seed=3, mark="arm", pd_latency=0.0035, control_latency=0.02)
+    assert env.history.shape[0] == 100 * 61
+    np.testing.assert_allclose(env.reset().cpu().numpy(), orc.reset(), atol=2e-3)
+    rng = np.random.RandomState(1)
+    for k in range(40):
+        if k == 20:
+            idx = np.array([1, 5, 9], np.int32)
+            np.testing.assert_allclose(env.reset(idx).cpu().numpy(), orc.reset(idx), atol=2e-3)
+        a = rng.uniform(-0.4, 0.4, (n, 2)).astype(np.float32)
+        o, r, d, info = env.step(torch.as_tensor(a, device="cuda"))
+        oo, orr, od, ocmd = orc.step(a)
+        np.testing.assert_allclose(info["action"].cpu().numpy(), ocmd, atol=5e-5)
+        np.testing.assert_allclose(o.cpu().numpy(), oo, atol=2e-2)
+        np.testing.assert_allclose(r.cpu().numpy(), orr, atol=5e-3)
+    ps, os_ = product_state_to_numeric(env.state), orc.get_state()
+    np.testing.assert_allclose(ps[13:31], os_[13:31], atol=5e-3)
+    env.close()
 
 
 def test_turn_env_reset_and_goal_logic(torch):
@@ -1032,3 +1050,77 @@ def test_every_kernel_variant_against_the_oracle_at_baseline_sizes(torch, task, 
     assert rec["median_rad"] <= 1e-3
     assert rec["p99_rad"] <= 2e-2 and rec["max_rad"] <= 0.3, rec
     env.close()
+
+
+def test_sensor_noise_model(torch):
+    """Rex(observation_noise_stdev=...) (rex.py:22,765-769): Gaussian noise in the sensor getters.  Every getter call
+    site of a step draws from the env's Philox stream, in the kernels as in the oracle, so the two agree sample for
+    sample; and the noise has the configured standard deviation, is independent across envs and steps, and leaves the
+    physics untouched."""
+    from rex_gym_amd import RexBatchEnv
+    n = 512
+    stdev = (0.01, 0.3, 0.2, 0.02, 0.5)
+    env = RexBatchEnv(n, task="gallop", signal_type="ol", seed=8, observation_noise_stdev=stdev)
+    clean = RexBatchEnv(n, task="gallop", signal_type="ol", seed=8)
+    cfg = orclib.default_config("gallop", "ol", n, seed=8)
+    for k, v in enumerate(stdev):
+        cfg.noise_stdev[k] = v
+    orc = orclib.OracleEnv(cfg, np.float32)
+    o0, c0, oo0 = env.reset().cpu().numpy(), clean.reset().cpu().numpy(), orc.reset()
+    np.testing.assert_allclose(o0, oo0, atol=3e-3)
+    assert 0.015 < (o0[:, 0] - c0[:, 0]).std() < 0.025 and 0.4 < (o0[:, 2] - c0[:, 2]).std() < 0.6
+    rng = np.random.RandomState(2)
+    d_obs, d_rew = [], []
+    for k in range(12):
+        a = rng.uniform(-0.3, 0.3, (n, 4)).astype(np.float32)
+        o, r, d, _ = env.step(torch.as_tensor(a, device="cuda"))
+        co, cr, cd, _ = clean.step(torch.as_tensor(a, device="cuda"))
+        oo, orr, od, _ = orc.step(a)
+        np.testing.assert_allclose(o.cpu().numpy(), oo, atol=3e-2)
+        np.testing.assert_allclose(r.cpu().numpy(), orr, atol=5e-3)
+        d_obs.append((o - co).cpu().numpy()); d_rew.append((r - cr).cpu().numpy())
+    np.testing.assert_array_equal(env.state[:37].cpu().numpy(), clean.state[:37].cpu().numpy())    # the physics never sees the noise
+    d_obs = np.stack(d_obs)
+    for col, sd in ((0, 0.02), (1, 0.02), (2, 0.5), (3, 0.5), (4, 0.01), (15, 0.01)):
+        x = d_obs[:, :, col].ravel()
+        assert abs(x.mean()) < 4 * sd / np.sqrt(x.size) + 1e-4 and 0.93 * sd < x.std() < 1.07 * sd, (col, x.mean(), x.std())
+    assert abs(np.corrcoef(d_obs[0, :, 0], d_obs[1, :, 0])[0, 1]) < 0.15 and abs(np.corrcoef(d_obs[0, :-1, 0], d_obs[0, 1:, 0])[0, 1]) < 0.15
+    assert np.std(np.stack(d_rew)) > 0           # energy term: noisy torques . noisy velocities
+    env.close(); clean.close()
+
+
+def test_caller_supplied_heightfield_terrain(torch):
+    """Heightfields other than the reference's random one (model/terrain.py:55-78 'hills' / 'mounts' / 'maze', whose data
+    files are not part of rex-gym): any nx x ny grid, cell size, placement and drop height through rex_set_heightfield.
+    A synthetic field of rolling bumps (96 x 64 vertices, 8 x 6 cm cells, off-centre, raised by 0.5 m): the robots settle ON
+    it, and the HIP path follows the fp32 oracle on the same field."""
+    from rex_gym_amd import RexBatchEnv
+    ny, nx, cell = 64, 96, (0.08, 0.06)
+    yy, xx = np.meshgrid(np.arange(ny), np.arange(nx), indexing="ij")
+    field = (0.03 * np.sin(0.35 * xx) * np.cos(0.3 * yy) + 0.03).astype(np.float32)        # 0 .. 0.06 m
+    fields = np.stack([field, field[::-1].copy()])
+    origin = (0.3, -0.2, 0.5)
+    n = 32
+    env = RexBatchEnv(n, task="turn", signal_type="ik", seed=2, terrain_type="custom", heightfield=fields, heightfield_cell=cell,
+                      heightfield_origin=origin, init_height=0.75)
+    cfg = orclib.default_config("turn", "ik", n, seed=2, init_height=0.75)
+    orc = orclib.OracleEnv(cfg, np.float32)
+    mids = np.array([0.5 * (f.min() + f.max()) - origin[2] for f in fields], np.float32)
+    orc.set_heightfield(fields, mids, cell, origin[:2])
+    np.testing.assert_allclose(env.reset().cpu().numpy(), orc.reset(), atol=3e-3)
+    ps, os_ = product_state_to_numeric(env.state), orc.get_state()
+    # shape centred on (min + max) / 2 = 0.03 and placed at z = 0.5: the surface spans 0.47 .. 0.53, the base stands ~0.2 above it
+    assert np.all(ps[2] > 0.62) and np.all(ps[2] < 0.76)
+    np.testing.assert_allclose(ps[:7], os_[:7], atol=3e-4)
+    rng = np.random.RandomState(4)
+    for k in range(25):
+        a = rng.uniform(-0.01, 0.01, (n, 2)).astype(np.float32)
+        o, r, d, info = env.step(torch.as_tensor(a, device="cuda"))
+        oo, orr, od, ocmd = orc.step(a)
+        np.testing.assert_allclose(info["action"].cpu().numpy(), ocmd, atol=5e-5)
+    ps, os_ = product_state_to_numeric(env.state), orc.get_state()
+    err = np.abs(ps[13:25] - os_[13:25]).max(0)
+    assert np.median(err) < 1e-3 and (err < 2e-2).mean() > 0.9
+    env.close()
+    with pytest.raises(NotImplementedError, match="pybullet_data"):
+        RexBatchEnv(4, task="walk", terrain_type="mounts")
