@@ -697,7 +697,7 @@ static void plane_space(const real n[3], real p[3], real q[3]) {
 }
 
 #define MAX_TOE_POINTS 16
-#define MAX_POINTS (MAX_TOE_POINTS + 4 * REX_NBOX)   /* toe manifold points + the bottom face of every link box */
+#define MAX_POINTS (MAX_TOE_POINTS + 4 + 2 * REX_NLEG)   /* toe manifold points + the kept link-box points (4 base, 2 per leg) */
 #define MAX_ROWS (3 * MAX_POINTS + NJ)
 #define LIMIT_ACTIVATION ((real)0.15)  /* a limit row further away than this cannot act: |qd| dt <= 100 * 1e-3 */
 typedef struct {
@@ -811,44 +811,62 @@ static void physics_substep(Phys* s, const real tau[NJ], real dt, int iterations
   }
   const int toe_points = npoint;
   if (BODY_CONTACTS || (ground && ground->body_contacts)) {
-    for (int b = 0; b < REX_NBOX; ++b) {
-      int kb = REX_BOX_BODY[b];
-      real cl[3] = {(real)REX_BOX_CENTER[b][0], (real)REX_BOX_CENTER[b][1], (real)REX_BOX_CENTER[b][2]};
-      real cw[3];
-      matvec3(A.Rw[kb], cl, cw);
-      for (int k = 0; k < 3; ++k) cw[k] += A.pw[kb][k];
-      real n0[3], h0;
-      ground_query(ground, cw[0], cw[1], &h0, n0);
-      /* reach of the box along the ground normal, per box axis: the face axis is the largest */
-      real reach[3], sg[3];
-      for (int ax = 0; ax < 3; ++ax) {
-        real e_n = A.Rw[kb][0][ax] * n0[0] + A.Rw[kb][1][ax] * n0[1] + A.Rw[kb][2][ax] * n0[2];
-        reach[ax] = (real)REX_BOX_HALF[b][ax] * fabs(e_n);
-        sg[ax] = e_n > 0 ? (real)-1 : (real)1;      /* the side of the box that looks at the ground */
-      }
-      if ((cw[2] - h0) * n0[2] - (reach[0] + reach[1] + reach[2]) >= (real)0.05) continue;   /* far above */
-      int fa = 0;
-      if (reach[1] > reach[fa]) fa = 1;
-      if (reach[2] > reach[fa]) fa = 2;
-      int a1 = (fa + 1) % 3, a2 = (fa + 2) % 3;
-      for (int c = 0; c < 4; ++c) {
-        real loc[3];
-        loc[fa] = sg[fa] * (real)REX_BOX_HALF[b][fa];
-        loc[a1] = ((c & 1) ? (real)1 : (real)-1) * (real)REX_BOX_HALF[b][a1];
-        loc[a2] = ((c & 2) ? (real)1 : (real)-1) * (real)REX_BOX_HALF[b][a2];
-        real P[3], n[3], h;
-        matvec3(A.Rw[kb], loc, P);
-        for (int k = 0; k < 3; ++k) P[k] += cw[k];
-        ground_query(ground, P[0], P[1], &h, n);
-        real dist = (P[2] - h) * n[2];
-        if (dist < BODY_ACTIVATION) {
-          memcpy(PtP[npoint], P, sizeof(P));
-          memcpy(PtN[npoint], n, sizeof(n));
-          PtBody[npoint] = kb;
-          PtDist[npoint] = dist;
-          ++npoint;
-          ++DBG_BODY_POINTS;
+    /* candidates: the ground-facing face of every link box.  Kept: per GROUP of boxes -- the base with its two chassis
+     * boxes, and each leg with its shoulder / leg / foot boxes -- the REX_BODY_SLOTS deepest penetrating corners (4 for the
+     * base group, 2 per leg; Bullet keeps at most 4 points per box pair, deepest first).  Ties go to the earlier
+     * candidate (box order of rex_model_gen.h, corner order below). */
+    for (int grp = 0; grp < 1 + REX_NLEG; ++grp) {
+      const int slots = grp == 0 ? 4 : 2;
+      real bestD[4]; real bestP[4][3], bestN[4][3]; int bestB[4]; int nbest = 0;
+      for (int b = 0; b < REX_NBOX; ++b) {
+        int kb = REX_BOX_BODY[b];
+        int g_of = kb == 0 ? 0 : 1 + (kb - 1) / 3;
+        if (g_of != grp) continue;
+        real cl[3] = {(real)REX_BOX_CENTER[b][0], (real)REX_BOX_CENTER[b][1], (real)REX_BOX_CENTER[b][2]};
+        real cw[3];
+        matvec3(A.Rw[kb], cl, cw);
+        for (int k = 0; k < 3; ++k) cw[k] += A.pw[kb][k];
+        real n0[3], h0;
+        ground_query(ground, cw[0], cw[1], &h0, n0);
+        /* reach of the box along the ground normal, per box axis: the face axis is the largest */
+        real reach[3], sg[3];
+        for (int ax = 0; ax < 3; ++ax) {
+          real e_n = A.Rw[kb][0][ax] * n0[0] + A.Rw[kb][1][ax] * n0[1] + A.Rw[kb][2][ax] * n0[2];
+          reach[ax] = (real)REX_BOX_HALF[b][ax] * fabs(e_n);
+          sg[ax] = e_n > 0 ? (real)-1 : (real)1;      /* the side of the box that looks at the ground */
         }
+        int fa = 0;
+        if (reach[1] > reach[fa]) fa = 1;
+        if (reach[2] > reach[fa]) fa = 2;
+        int a1 = (fa + 1) % 3, a2 = (fa + 2) % 3;
+        for (int c = 0; c < 4; ++c) {
+          real loc[3];
+          loc[fa] = sg[fa] * (real)REX_BOX_HALF[b][fa];
+          loc[a1] = ((c & 1) ? (real)1 : (real)-1) * (real)REX_BOX_HALF[b][a1];
+          loc[a2] = ((c & 2) ? (real)1 : (real)-1) * (real)REX_BOX_HALF[b][a2];
+          real P[3], n[3], h;
+          matvec3(A.Rw[kb], loc, P);
+          for (int k = 0; k < 3; ++k) P[k] += cw[k];
+          ground_query(ground, P[0], P[1], &h, n);
+          real dist = (P[2] - h) * n[2];
+          if (!(dist < BODY_ACTIVATION)) continue;
+          /* insertion into the group's deepest-first list */
+          int pos = nbest;
+          while (pos > 0 && dist < bestD[pos - 1]) --pos;
+          if (pos >= slots) continue;
+          int last = nbest < slots ? nbest : slots - 1;
+          for (int k = last; k > pos; --k) { bestD[k] = bestD[k - 1]; bestB[k] = bestB[k - 1]; memcpy(bestP[k], bestP[k - 1], sizeof(bestP[0])); memcpy(bestN[k], bestN[k - 1], sizeof(bestN[0])); }
+          bestD[pos] = dist; bestB[pos] = kb; memcpy(bestP[pos], P, sizeof(P)); memcpy(bestN[pos], n, sizeof(n));
+          if (nbest < slots) ++nbest;
+        }
+      }
+      for (int k = 0; k < nbest; ++k) {
+        memcpy(PtP[npoint], bestP[k], sizeof(bestP[0]));
+        memcpy(PtN[npoint], bestN[k], sizeof(bestN[0]));
+        PtBody[npoint] = bestB[k];
+        PtDist[npoint] = bestD[k];
+        ++npoint;
+        ++DBG_BODY_POINTS;
       }
     }
     if (npoint > toe_points) ++DBG_BODY_SUBSTEPS;
@@ -876,8 +894,14 @@ static void physics_substep(Phys* s, const real tau[NJ], real dt, int iterations
     r->rhs = (poserr + velerr) * r->invdiag;
     r->lo = 0; r->hi = (real)1e10; r->lambda = 0; r->normal_row = -1; r->pair_row = -1;
   }
-  /* then all contact normals, then the friction pairs (Bullet's per-iteration order) */
-  for (int p = 0; p < npoint; ++p) {
+  /* then all contact normals, then the friction pairs (Bullet's per-iteration order).  Among the normals the link-box
+   * points come before the toe points, among the friction pairs after them (Bullet's own order among manifolds is that
+   * of its broadphase pairs, i.e. arbitrary; this one keeps the toe rows contiguous for the kernels' row pipeline). */
+  int order[MAX_POINTS], nord = 0;
+  for (int p = toe_points; p < npoint; ++p) order[nord++] = p;
+  for (int p = 0; p < toe_points; ++p) order[nord++] = p;
+  for (int q = 0; q < npoint; ++q) {
+    int p = order[q];
     Row* r = &rows[nrow];
     real fk[6];
     contact_jacobian(&A, PtBody[p], PtP[p], PtN[p], r->J, fk);
@@ -892,8 +916,12 @@ static void physics_substep(Phys* s, const real tau[NJ], real dt, int iterations
     r->lo = 0; r->hi = (real)1e10; r->lambda = 0; r->normal_row = -1; r->pair_row = -1;
     normal_of_point[p] = nrow++;
   }
-  for (int p = 0; p < npoint; ++p)
+  nord = 0;
+  for (int p = 0; p < toe_points; ++p) order[nord++] = p;
+  for (int p = toe_points; p < npoint; ++p) order[nord++] = p;
+  for (int q = 0; q < npoint; ++q)
     for (int d = 0; d < P_FRICTION_DIRS; ++d) {
+      int p = order[q];
       Row* r = &rows[nrow];
       real fk[6], t1[3], t2[3];
       plane_space(PtN[p], t1, t2);

@@ -41,6 +41,12 @@
 /* small-batch waves (EPW <= 16) only: chunks 0..1 the whitened base velocity y on its way to / from the lanes that own
    its components (pgs_dv), 2..7 the couplings A(r, r-1) of consecutive contact rows */
 #define REX_PARK_F4 8
+/* link-box contact rows (RexConfig.body_contacts): 12 point slots -- 0..3 the base group (base + chassis boxes), 4 + 2 L + k
+   leg L's boxes -- with a normal row (index slot) and two friction rows (12 + 2 slot + d) each, 3 chunks per row like the
+   toe rows, in their own LDS region behind the hand-over chunks; lane groups only */
+#define REX_NBSLOT 12
+#define REX_NBROW (3 * REX_NBSLOT)
+#define REX_BODY_F4 (REX_NBROW * REX_ROW_F4)
 #define REX_PARK_XY 0
 #define REX_PARK_CPL 2
 
@@ -62,11 +68,14 @@ constexpr float kToeHalf = (float)REX_TOE_HALFLEN;
 // LDS view of one workgroup.  EPW = envs per wave (compile-time power of two <= 64): lane l works on env
 // slot l & (EPW-1); lanes beyond EPW mirror a live lane (see rex_step_kernel).  Layout float4[chunk][slot]:
 // lanes of different slots hit consecutive 16 B -> conflict-free ds_read_b128.
-template <int EPW, int LEGF4 = REX_LEG_F4>
+template <int EPW, int LEGF4 = REX_LEG_F4, bool BODY = false>
 struct Lds {
   static constexpr int kEpw = EPW;
+  static constexpr bool kBody = BODY;
   float4* p; int slot;
   float4* pk;   // hand-over region of pgs_dv (REX_PARK_F4 chunks per env, behind the rows of all marks); null when EPW = 64
+  float4* pb;   // link-box contact rows (BODY only): REX_BODY_F4 chunks per env behind the hand-over region
+  __device__ __forceinline__ float4& brow(int r, int c) const { return pb[(r * REX_ROW_F4 + c) * EPW + slot]; }
   __device__ __forceinline__ float4& park(int c) const { return pk[c * EPW + slot]; }
   // scalar views for the lanes that own single components (pgs_dv): float f of a chunk sequence starting at chunk c0
   __device__ __forceinline__ float& parkf(int c0, int f) const { return reinterpret_cast<float*>(&pk[(c0 + (f >> 2)) * EPW + slot])[f & 3]; }
@@ -483,6 +492,105 @@ __device__ __forceinline__ void leg_pass(int leg, const BaseKin& bk, const float
     }
   }
 
+  // --- link-box contact rows of this leg (RexConfig.body_contacts): shoulder, leg and foot boxes of rex.urdf:119-124,
+  //     151-156,170-175 against the ground.  Candidates: the four corners of each box's ground-facing face; kept: the two
+  //     deepest penetrating ones (Bullet's box-box detector reports penetrating points only, deepest first).  Same
+  //     selection as oracle/rex_oracle.c.  A point on the shoulder moves with joint 1 only, on the leg link with joints
+  //     1-2, on the foot link with all three.
+  if constexpr (SM::kBody) {
+    constexpr int B0 = 3;   // boxes 3..5 of rex_model_gen.h: the first leg's (all legs carry identical boxes)
+    static_assert(REX_BOX_BODY[B0] == 1 && REX_BOX_BODY[B0 + 1] == 2 && REX_BOX_BODY[B0 + 2] == 3, "leg box table");
+    const f3 bo[3] = {o1, o2, o3};
+    const f3 bx[3] = {x1, x2, x3}, bz[3] = {z1, z2, z3};
+    float lowest = 1e9f;
+    float rch[3][3], sgn[3][3];
+    f3 ctr[3], nb[3];
+    float hb[3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      ctr[b] = bo[b] + (float)REX_BOX_CENTER[B0 + b][2] * bz[b];
+      nb[b] = mk(0.f, 0.f, 1.f); hb[b] = 0.0f;
+      if (ground.h != nullptr) ground_query(ground, bk.px + ctr[b].x, bk.py + ctr[b].y, hb[b], nb[b]);
+      const float en[3] = {dot(bx[b], nb[b]), dot(y1, nb[b]), dot(bz[b], nb[b])};
+      float sum = 0.0f;
+#pragma unroll
+      for (int ax = 0; ax < 3; ++ax) {
+        rch[b][ax] = (float)REX_BOX_HALF[B0 + b][ax] * fabsf(en[ax]);
+        sgn[b][ax] = en[ax] > 0.0f ? -1.0f : 1.0f;
+        sum += rch[b][ax];
+      }
+      lowest = fminf(lowest, (bk.height + ctr[b].z - hb[b]) * nb[b].z - sum);
+    }
+    // a box corner can only be below the ground if the box's lowest point along the normal under its centre is (on the
+    // heightfield the ground under a corner may stand up to the field's roughness above that under the centre)
+    const bool near = lowest < (ground.h != nullptr ? 0.06f : 0.0f);
+    if (__builtin_amdgcn_ballot_w64(near) != 0) {
+      active_mask |= 1u << (21 + leg);
+      float bestD[2] = {0.0f, 0.0f};
+      f3 bestP[2] = {mk(0.f, 0.f, 0.f), mk(0.f, 0.f, 0.f)}, bestN[2] = {mk(0.f, 0.f, 1.f), mk(0.f, 0.f, 1.f)};
+      int bestL[2] = {0, 0};   // 0 = empty slot, else 1 + box (= number of joints that move the point)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        int fa = 0;
+        if (rch[b][1] > rch[b][fa]) fa = 1;
+        if (rch[b][2] > rch[b][fa]) fa = 2;
+        const f3 ax3[3] = {bx[b], y1, bz[b]};
+        const float hx = (float)REX_BOX_HALF[B0 + b][0], hy = (float)REX_BOX_HALF[B0 + b][1], hz = (float)REX_BOX_HALF[B0 + b][2];
+#pragma unroll
+        for (int cnr = 0; cnr < 4; ++cnr) {
+          const float s1 = (cnr & 1) ? 1.0f : -1.0f, s2 = (cnr & 2) ? 1.0f : -1.0f;
+          // local corner: face axis at its ground side, the other two axes (cyclic order) at +-1
+          const float lx = fa == 0 ? sgn[b][0] : (fa == 1 ? s2 : s1);
+          const float ly = fa == 1 ? sgn[b][1] : (fa == 2 ? s2 : s1);
+          const float lz = fa == 2 ? sgn[b][2] : (fa == 0 ? s2 : s1);
+          const f3 P = ctr[b] + (lx * hx) * ax3[0] + (ly * hy) * ax3[1] + (lz * hz) * ax3[2];
+          f3 n = mk(0.f, 0.f, 1.f);
+          float h = 0.0f;
+          if (ground.h != nullptr) ground_query(ground, bk.px + P.x, bk.py + P.y, h, n);
+          const float dist = (bk.height + P.z - h) * n.z;
+          if (dist < 0.0f) {   // deepest-first list of two; ties keep the earlier candidate
+            if (bestL[0] == 0 || dist < bestD[0]) {
+              bestD[1] = bestD[0]; bestP[1] = bestP[0]; bestN[1] = bestN[0]; bestL[1] = bestL[0];
+              bestD[0] = dist; bestP[0] = P; bestN[0] = n; bestL[0] = 1 + b;
+            } else if (bestL[1] == 0 || dist < bestD[1]) {
+              bestD[1] = dist; bestP[1] = P; bestN[1] = n; bestL[1] = 1 + b;
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        if (esel >= 0 && k != esel) continue;   // 8 lanes per env: the two lanes of a leg take one slot each
+        const int slot = 4 + 2 * leg + k;
+        const bool act = bestL[k] != 0;
+        const f3 P = bestP[k], nrm = bestN[k];
+        f3 t1 = mk(0.f, -1.f, 0.f), t2 = mk(1.f, 0.f, 0.f);
+        if (ground.h != nullptr) plane_space(nrm, t1, t2);
+        const f3 r1v = P - o1, r2v = P - o2, r3v = P - o3;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          const f3 dir = d == 0 ? nrm : (d == 1 ? t1 : t2);
+          const f3 Jw = cross(P, dir);
+          const float Jq1 = dot(a1, cross(r1v, dir));
+          const float Jq2 = bestL[k] >= 2 ? dot(a2, cross(r2v, dir)) : 0.0f;
+          const float Jq3 = bestL[k] >= 3 ? dot(a2, cross(r3v, dir)) : 0.0f;
+          const float j1 = Jq1 * gi1;
+          const float j2 = (Jq2 - g21 * j1) * gi2;
+          const float j3 = (Jq3 - g31 * j1 - g32 * j2) * gi3;
+          const float Jb[6] = {Jw.x, Jw.y, Jw.z, dir.x, dir.y, dir.z};
+          float g[6];
+#pragma unroll
+          for (int m = 0; m < 6; ++m) g[m] = act ? Jb[m] - (L.Bw[0][m] * j1 + L.Bw[1][m] * j2 + L.Bw[2][m] * j3) : 0.0f;
+          const float target = d == 0 ? -bestD[k] * (kErp / dt) : 0.0f;   // penetrating: position error through ERP
+          const int r = d == 0 ? slot : (REX_NBSLOT + 2 * slot + (d - 1));
+          sm.brow(r, 0) = make_float4(g[0], g[1], g[2], g[3]);
+          sm.brow(r, 1) = make_float4(g[4], g[5], act ? j1 : 0.0f, act ? j2 : 0.0f);
+          sm.brow(r, 2) = make_float4(act ? j3 : 0.0f, act ? target : 0.0f, act ? 1.0f : 0.0f, 0.0f);
+        }
+      }
+    }
+  }
+
   // --- joint-limit rows (btMultiBodyJointLimitConstraint): the near bound of each joint, active within
   //     kLimitActivation; J = +-e_k on the leg's joints, so the whitened row is a column of G^-1 ---
   const float qv[3] = {q1, q2, q3};
@@ -731,9 +839,34 @@ struct DvLane {
   }
 };
 
+// one Gauss-Seidel step of a link-box contact row, straight from LDS (like the joint-limit rows): row r of the body
+// region; leg < 0: a base-group row (no leg part)
+template <int LPE, int NY, class SM, class LN>
+__device__ __forceinline__ void body_row(const SM& sm, const LN& ln, int bodyoff, int r, int leg, float* ys, float* zs, float& lam, float lim,
+                                         bool friction, float& worst, float thr) {
+  constexpr int kRow = REX_ROW_F4 * SM::kEpw * 16;
+  float jy[NY];
+#pragma unroll
+  for (int i = 0; i < NY; ++i) jy[i] = ln.ld(sm, bodyoff + r * kRow + ln.oy[i]);
+  const float jz = leg >= 0 ? ln.ld(sm, bodyoff + r * kRow + ln.oz) : 0.0f;
+  const float4 c2 = sm.brow(r, 2);
+  float part = leg >= 0 ? jz * zs[leg] : 0.0f;
+#pragma unroll
+  for (int i = 0; i < NY; ++i) part = fmaf(jy[i], ys[i], part);
+  const float vel = group_sum<LPE>(part);
+  float nl = fmaf(-c2.z, vel, lam + c2.y);
+  nl = friction ? __builtin_amdgcn_fmed3f(nl, -lim, lim) : fmaxf(nl, 0.0f);
+  const float dl = nl - lam;
+  lam = nl;
+  worst = fmaxf(worst, fmaf(-thr, c2.z, fabsf(dl)));
+#pragma unroll
+  for (int i = 0; i < NY; ++i) ys[i] = fmaf(jy[i], dl, ys[i]);
+  if (leg >= 0) zs[leg] = fmaf(jz, dl, zs[leg]);
+}
+
 template <int LPE, class SM, class ARMP>
 __device__ __forceinline__ void pgs_dv(const SM& sm, ARMP& armp, PgsX& x, int p, const bool (&lim)[4], bool any_contact,
-                                       float mu, int iterations, int lane_iterations, float thr, int& nsweeps) {
+                                       unsigned bgroups, float mu, int iterations, int lane_iterations, float thr, int& nsweeps) {
   constexpr int EPW = SM::kEpw, NY = (6 + LPE - 1) / LPE;
   constexpr int kRow = REX_ROW_F4 * EPW * 16;   // bytes from a row to the next
   DvLane<NY, EPW> ln;
@@ -765,6 +898,13 @@ __device__ __forceinline__ void pgs_dv(const SM& sm, ARMP& armp, PgsX& x, int p,
   float lam[REX_NROW];
 #pragma unroll
   for (int r = 0; r < REX_NROW; ++r) lam[r] = 0.0f;
+  float lamb[SM::kBody ? REX_NBROW : 1];
+  int bodyoff = 0;
+  if constexpr (SM::kBody) {
+#pragma unroll
+    for (int r = 0; r < REX_NBROW; ++r) lamb[r] = 0.0f;
+    bodyoff = (int)(reinterpret_cast<const char*>(sm.pb) - reinterpret_cast<const char*>(sm.p));
+  }
   // this lane's slice of the 24 contact rows, read once per substep: its components of J~, invd, and -target in lane 0
   // of the group (0 elsewhere): the addend of the lane's first product, so that the group sum is vel - target and the
   // impulse step is one fma, nl = lam - invd (vel - target)
@@ -810,6 +950,17 @@ __device__ __forceinline__ void pgs_dv(const SM& sm, ARMP& armp, PgsX& x, int p,
         }
       }
       armp.template dv_sweep<LPE, NY>(ys, worst, thr);
+      if constexpr (SM::kBody) {
+        // link-box normals (among the normals they come before the toe points: the toe rows stay one pipelined block)
+        if (bgroups != 0) {
+#pragma unroll
+          for (int sl = 0; sl < REX_NBSLOT; ++sl) {
+            const int g = sl < 4 ? 0 : 1 + ((sl - 4) >> 1);
+            if (!((bgroups >> g) & 1u)) continue;      // wave-uniform
+            body_row<LPE, NY>(sm, ln, bodyoff, sl, sl < 4 ? -1 : (sl - 4) >> 1, ys, zs, lamb[sl], 0.0f, false, worst, thr);
+          }
+        }
+      }
       if (any_contact) {
         // contact rows, pipelined; this lane's slice of the rows sits in registers (Jy, Jz, Kc, Ki)
         float S, dlp = 0.0f;
@@ -842,6 +993,18 @@ __device__ __forceinline__ void pgs_dv(const SM& sm, ARMP& armp, PgsX& x, int p,
 #pragma unroll
           for (int i = 0; i < NY; ++i) ys[i] = fmaf(Jy[r][i], dl, ys[i]);
           zs[L] = fmaf(Jz[r], dl, zs[L]);
+        }
+      }
+      if constexpr (SM::kBody) {
+        if (bgroups != 0) {       // link-box friction pairs: after the toe friction rows
+#pragma unroll
+          for (int sl = 0; sl < REX_NBSLOT; ++sl) {
+            const int g = sl < 4 ? 0 : 1 + ((sl - 4) >> 1);
+            if (!((bgroups >> g) & 1u)) continue;
+            const float lm = mu * lamb[sl];
+            body_row<LPE, NY>(sm, ln, bodyoff, REX_NBSLOT + 2 * sl, sl < 4 ? -1 : (sl - 4) >> 1, ys, zs, lamb[REX_NBSLOT + 2 * sl], lm, true, worst, thr);
+            body_row<LPE, NY>(sm, ln, bodyoff, REX_NBSLOT + 2 * sl + 1, sl < 4 ? -1 : (sl - 4) >> 1, ys, zs, lamb[REX_NBSLOT + 2 * sl + 1], lm, true, worst, thr);
+          }
         }
       }
       running = worst > 0.0f && it + 1 < lane_iterations;
@@ -970,6 +1133,85 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
     x.z01[k] = v2{zc.x, zc.y}; x.z2[k] = zc.z;
   }
   REX_STAMP(t_legs);
+  if constexpr (SM::kBody) {
+    // link-box contact rows of the base group: base_link and the two chassis boxes (rex.urdf:15-33,63-108), the four
+    // deepest penetrating corners of their ground-facing faces.  Every lane of the group computes (and writes) the same rows.
+    static_assert(kSplitLegs, "link-box contact rows need the lane-group layout (their rows do not fit 64 envs per workgroup in LDS)");
+    static_assert(REX_BOX_BODY[0] == 0 && REX_BOX_BODY[1] == 0 && REX_BOX_BODY[2] == 0 && REX_BOX_BODY[3] == 1, "base box table");
+    float lowest = 1e9f;
+    float rch[3][3], sgn[3][3];
+    f3 ctr[3], nb[3];
+    float hb[3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      ctr[b] = (float)REX_BOX_CENTER[b][0] * bk.ex + (float)REX_BOX_CENTER[b][1] * bk.ey + (float)REX_BOX_CENTER[b][2] * bk.ez;
+      nb[b] = mk(0.f, 0.f, 1.f); hb[b] = 0.0f;
+      if (ground.h != nullptr) ground_query(ground, bk.px + ctr[b].x, bk.py + ctr[b].y, hb[b], nb[b]);
+      const float en[3] = {dot(bk.ex, nb[b]), dot(bk.ey, nb[b]), dot(bk.ez, nb[b])};
+      float sum = 0.0f;
+#pragma unroll
+      for (int ax = 0; ax < 3; ++ax) {
+        rch[b][ax] = (float)REX_BOX_HALF[b][ax] * fabsf(en[ax]);
+        sgn[b][ax] = en[ax] > 0.0f ? -1.0f : 1.0f;
+        sum += rch[b][ax];
+      }
+      lowest = fminf(lowest, (bk.height + ctr[b].z - hb[b]) * nb[b].z - sum);
+    }
+    const bool near = lowest < (ground.h != nullptr ? 0.06f : 0.0f);
+    if (__builtin_amdgcn_ballot_w64(near) != 0) {
+      active |= 1u << 20;
+      float bestD[4] = {0.f, 0.f, 0.f, 0.f};
+      f3 bestP[4], bestN[4];
+      bool bestA[4] = {false, false, false, false};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { bestP[k] = mk(0.f, 0.f, 0.f); bestN[k] = mk(0.f, 0.f, 1.f); }
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        int fa = 0;
+        if (rch[b][1] > rch[b][fa]) fa = 1;
+        if (rch[b][2] > rch[b][fa]) fa = 2;
+        const float hx = (float)REX_BOX_HALF[b][0], hy = (float)REX_BOX_HALF[b][1], hz = (float)REX_BOX_HALF[b][2];
+#pragma unroll
+        for (int cnr = 0; cnr < 4; ++cnr) {
+          const float s1 = (cnr & 1) ? 1.0f : -1.0f, s2 = (cnr & 2) ? 1.0f : -1.0f;
+          const float lx = fa == 0 ? sgn[b][0] : (fa == 1 ? s2 : s1);
+          const float ly = fa == 1 ? sgn[b][1] : (fa == 2 ? s2 : s1);
+          const float lz = fa == 2 ? sgn[b][2] : (fa == 0 ? s2 : s1);
+          const f3 P = ctr[b] + (lx * hx) * bk.ex + (ly * hy) * bk.ey + (lz * hz) * bk.ez;
+          f3 n = mk(0.f, 0.f, 1.f);
+          float h = 0.0f;
+          if (ground.h != nullptr) ground_query(ground, bk.px + P.x, bk.py + P.y, h, n);
+          const float dist = (bk.height + P.z - h) * n.z;
+          if (dist < 0.0f) {   // insertion into the deepest-first list of four (ties keep the earlier candidate)
+            float dcur = dist; f3 pcur = P, ncur = n; bool acur = true;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const bool take = acur && (!bestA[k] || dcur < bestD[k]);
+              const float dt_ = bestD[k]; const f3 pt = bestP[k], nt = bestN[k]; const bool at = bestA[k];
+              if (take) { bestD[k] = dcur; bestP[k] = pcur; bestN[k] = ncur; bestA[k] = true; dcur = dt_; pcur = pt; ncur = nt; acur = at; }
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const bool act = bestA[k];
+        const f3 P = bestP[k], nrm = bestN[k];
+        f3 t1 = mk(0.f, -1.f, 0.f), t2 = mk(1.f, 0.f, 0.f);
+        if (ground.h != nullptr) plane_space(nrm, t1, t2);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          const f3 dir = d == 0 ? nrm : (d == 1 ? t1 : t2);
+          const f3 Jw = cross(P, dir);
+          const float target = d == 0 ? -bestD[k] * (kErp / dt) : 0.0f;
+          const int r = d == 0 ? k : (REX_NBSLOT + 2 * k + (d - 1));
+          sm.brow(r, 0) = act ? make_float4(Jw.x, Jw.y, Jw.z, dir.x) : make_float4(0.f, 0.f, 0.f, 0.f);
+          sm.brow(r, 1) = act ? make_float4(dir.y, dir.z, 0.0f, 0.0f) : make_float4(0.f, 0.f, 0.f, 0.f);
+          sm.brow(r, 2) = make_float4(0.0f, act ? target : 0.0f, act ? 1.0f : 0.0f, 0.0f);
+        }
+      }
+    }
+  }
   armp.pass(bk, s, tau, dt, acc, ground);   // extra branch on the base (mark='arm'), no-op otherwise
 
   // base articulated inertia A = [[Io, hx],[hx^T, m]] - S, then A = Lc Lc^T
@@ -1021,6 +1263,29 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
     sm.row(r, 2) = make_float4(c2.x, c2.y * invd, invd, kSplitLegs ? 0.0f : diag);   // .w = 0: see pgs_dv
   }
 
+  unsigned bgroups = 0;   // bit g: link-box group g (0 base, 1 + leg) has rows in reach of some env of the wave
+  if constexpr (SM::kBody) {
+#pragma unroll
+    for (int g = 0; g < 5; ++g) if (__builtin_amdgcn_ballot_w64((active >> (20 + g)) & 1u) != 0) bgroups |= 1u << g;
+    if (bgroups != 0) {
+      mirror_sync();
+      for (int r = pl; r < REX_NBROW; r += LPE) {   // lane p: rows p, p + LPE, ...
+        const int slot = r < REX_NBSLOT ? r : (r - REX_NBSLOT) >> 1;
+        const int g = slot < 4 ? 0 : 1 + ((slot - 4) >> 1);
+        if (!((bgroups >> g) & 1u)) continue;
+        float4 c0 = sm.brow(r, 0), c1 = sm.brow(r, 1), c2 = sm.brow(r, 2);
+        const float gq[6] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y};
+        float gw[6];
+        fwd6(Lc, gq, gw);
+        const float diag = gw[0] * gw[0] + gw[1] * gw[1] + gw[2] * gw[2] + gw[3] * gw[3] + gw[4] * gw[4] + gw[5] * gw[5] +
+                           c1.z * c1.z + c1.w * c1.w + c2.x * c2.x;
+        const float invd = c2.z != 0.0f ? __builtin_amdgcn_rcpf(diag) : 0.0f;
+        sm.brow(r, 0) = make_float4(gw[0], gw[1], gw[2], gw[3]);
+        sm.brow(r, 1) = make_float4(gw[4], gw[5], c1.z, c1.w);
+        sm.brow(r, 2) = make_float4(c2.x, c2.y * invd, invd, 0.0f);
+      }
+    }
+  }
   if constexpr (kSplitLegs) mirror_sync();
   // projected Gauss-Seidel in Bullet's order: all normals, then all friction rows; a point that no
   // lane of the wavefront has within the breaking distance is skipped for the whole wavefront
@@ -1056,7 +1321,7 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
     if (pl == 0) sm.parkf(REX_PARK_CPL, 0) = 0.0f;
     mirror_sync();
     const bool lim[4] = {lim0, lim1, lim2, lim3};
-    pgs_dv<LPE>(sm, armp, x, pl, lim, any0 || any1 || any2 || any3, ground.mu, iterations, lane_iterations, sqrt_res_thr, nsweeps);
+    pgs_dv<LPE>(sm, armp, x, pl, lim, any0 || any1 || any2 || any3, bgroups, ground.mu, iterations, lane_iterations, sqrt_res_thr, nsweeps);
   } else {
     // one env per lane (EPW = 64): every lane carries the whole of x, row by row from LDS
     bool running = true;

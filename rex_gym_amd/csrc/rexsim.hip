@@ -650,7 +650,7 @@ __device__ __forceinline__ void standup_command(const DevCfg& c, const EnvState&
 }
 
 // ------------------------------------------------------------------------------------------
-template <int EPW, bool ARM, bool MIXED>
+template <int EPW, bool ARM, bool MIXED, bool BODY>
 __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __restrict__ state, const float* __restrict__ snap,
                                                             const float* __restrict__ action, float* __restrict__ obs_out,
                                                             float* __restrict__ reward_out, uint8_t* __restrict__ done_out,
@@ -665,7 +665,8 @@ __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __r
   constexpr int NM = ARM ? 18 : 12;   // mark='arm': 6 more motors held at ARM_POSES['rest'] (rex_gym_env.py:347-353)
   constexpr int kLegF4 = REX_LEG_F4_OF(EPW, ARM);
   constexpr int kRowsF4 = ARM ? REX_LDS_F4_PER_ENV_ARM_OF(EPW) : REX_ROWS_F4_OF(kLegF4);
-  __shared__ float4 lds[(kRowsF4 + (EPW <= 16 ? REX_PARK_F4 : 0)) * EPW];
+  static_assert(!BODY || EPW <= 16, "link-box contact rows: lane-group kernels only");
+  __shared__ float4 lds[(kRowsF4 + (EPW <= 16 ? REX_PARK_F4 : 0) + (BODY ? REX_BODY_F4 : 0)) * EPW];
   REX_STAMP(t_kernel);
   const int lane = threadIdx.x;
   constexpr int LPE = EPW < 64 ? lanes_per_env(EPW) : 1;     // EPW <= 16: lane = LPE * slot + p (rex_device.h, group layout)
@@ -673,7 +674,7 @@ __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __r
   const int gi = blockIdx.x * EPW + slot;
   const bool live = lane < LPE * EPW && (lane & (LPE - 1)) == 0 && gi < c.n;
   const int i = gi < c.n ? gi : c.n - 1;   // tail slots shadow the last env (keeps the wave convergent)
-  const Lds<EPW, kLegF4> sm{lds, slot, EPW <= 16 ? lds + kRowsF4 * EPW : nullptr};
+  const Lds<EPW, kLegF4, BODY> sm{lds, slot, EPW <= 16 ? lds + kRowsF4 * EPW : nullptr, BODY ? lds + (kRowsF4 + REX_PARK_F4) * EPW : nullptr};
   typename ArmHook<EPW, ARM>::type armp = ArmHook<EPW, ARM>::make(lds, slot);
 
   DevCfg cmix;                          // MIXED only
@@ -838,16 +839,16 @@ __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __r
 
 // The reset motion of Rex.Reset (rex.py:296-324).  Plane: ONE robot, lane 0 writes the snapshot.  Terrain pool:
 // lane t settles on terrain t and writes snapshot record t (word-major [53][n_terrain]).
-template <bool ARM>
+template <bool ARM, bool BODY>
 __global__ __launch_bounds__(REX_WAVE) void rex_settle_kernel(DevCfg c, float* __restrict__ snap) {
   constexpr int NM = ARM ? 18 : 12;
-  constexpr int EPW = ARM ? 16 : REX_WAVE;   // the arm rows do not fit 64 envs per workgroup in LDS
+  constexpr int EPW = (ARM || BODY) ? 16 : REX_WAVE;   // the arm rows / link-box rows do not fit 64 envs per workgroup in LDS
   constexpr int kLegF4 = REX_LEG_F4_OF(EPW, ARM);
   constexpr int kRowsF4 = ARM ? REX_LDS_F4_PER_ENV_ARM_OF(EPW) : REX_ROWS_F4_OF(kLegF4);
-  __shared__ float4 lds[(kRowsF4 + (EPW <= 16 ? REX_PARK_F4 : 0)) * EPW];
+  __shared__ float4 lds[(kRowsF4 + (EPW <= 16 ? REX_PARK_F4 : 0) + (BODY ? REX_BODY_F4 : 0)) * EPW];
   constexpr int LPE = EPW < 64 ? lanes_per_env(EPW) : 1;
   const int lane = (int)(threadIdx.x / LPE) & (EPW - 1);
-  const Lds<EPW, kLegF4> sm{lds, lane, EPW <= 16 ? lds + kRowsF4 * EPW : nullptr};
+  const Lds<EPW, kLegF4, BODY> sm{lds, lane, EPW <= 16 ? lds + kRowsF4 * EPW : nullptr, BODY ? lds + (kRowsF4 + REX_PARK_F4) * EPW : nullptr};
   typename ArmHook<EPW, ARM>::type armp = ArmHook<EPW, ARM>::make(lds, lane);
   const int nrec = (c.n_terrain > 0 ? c.n_terrain : 1) * c.n_mix;
   const int first = (int)blockIdx.x * EPW + lane;                       // the (terrain, task) record this lane group settles
@@ -1109,7 +1110,7 @@ static int validate(const RexConfig* c) {
   if (c->mark != REX_MARK_BASE && c->mark != REX_MARK_ARM) return fail(REX_EINVAL, "unknown mark%s", "");
   if ((long long)c->num_envs * 128 >= (1ll << 30)) return fail(REX_EINVAL, "num_envs too large for 32-bit state offsets%s", "");
   if (c->gait_clock_scale < 0.0f) return fail(REX_EINVAL, "gait_clock_scale must be >= 0%s", "");
-  if (c->body_contacts) return fail(REX_EINVAL, "body_contacts: not built into this library yet%s", "");
+  if (c->body_contacts && c->task == REX_TASK_MIXED) return fail(REX_EINVAL, "body_contacts is not offered together with REX_TASK_MIXED%s", "");
   for (int k = 0; k < 5; ++k) if (c->noise_stdev[k] < 0.0f) return fail(REX_EINVAL, "noise_stdev must be >= 0%s", "");
   if (c->task == REX_TASK_MIXED) {
     const int allowed = (1 << REX_TASK_WALK) | (1 << REX_TASK_GALLOP) | (1 << REX_TASK_TURN);   // tasks that share one reset pose per signal
@@ -1149,7 +1150,7 @@ int rex_create(const RexConfig* cfg, int device, float* d_state, void* stream, R
   d.w_dist = cfg->distance_weight; d.w_energy = cfg->energy_weight; d.w_drift = cfg->drift_weight; d.w_shake = cfg->shake_weight;
   d.action_dim = rex_action_dim(cfg); d.obs_dim = rex_obs_dim(cfg);
   s->epw = pick_envs_per_wave(cfg->num_envs);
-  if ((cfg->mark == REX_MARK_ARM || cfg->task == REX_TASK_MIXED) && s->epw > 16) s->epw = 16;
+  if ((cfg->mark == REX_MARK_ARM || cfg->task == REX_TASK_MIXED || cfg->body_contacts) && s->epw > 16) s->epw = 16;
   d.n_mix = 1; d.mix_task[0] = cfg->task; d.max_repeat = cfg->action_repeat; d.max_iterations = cfg->solver_iterations;
   for (int k = 1; k < 5; ++k) d.mix_task[k] = cfg->task;
   if (cfg->task == REX_TASK_MIXED) {
@@ -1372,28 +1373,32 @@ REX_API int rex_debug_prof(long long* out, int reset) {
 #endif
 }  // extern "C"
 
-#define REX_LAUNCH_STEP(EPW, ARM, MIXED)                                                                                        \
-  hipLaunchKernelGGL((rex::rex_step_kernel<EPW, ARM, MIXED>), dim3(blocks), dim3(REX_WAVE), 0, st, s->dev, s->d_state, s->d_snap, a, o, \
-                     r, d, m)
+#define REX_LAUNCH_STEP(EPW, ARM, MIXED, BODY)                                                                                  \
+  hipLaunchKernelGGL((rex::rex_step_kernel<EPW, ARM, MIXED, BODY>), dim3(blocks), dim3(REX_WAVE), 0, st, s->dev, s->d_state, s->d_snap, \
+                     a, o, r, d, m)
+#define REX_LAUNCH_BY_EPW(ARM, MIXED, BODY)                                           \
+  do {                                                                                \
+    if (s->epw == 4) REX_LAUNCH_STEP(4, ARM, MIXED, BODY);                            \
+    else if (s->epw == 8) REX_LAUNCH_STEP(8, ARM, MIXED, BODY);                       \
+    else REX_LAUNCH_STEP(16, ARM, MIXED, BODY);                                       \
+  } while (0)
 static void launch_step(RexSim* s, int blocks, hipStream_t st, const float* a, float* o, float* r, uint8_t* d, float* m) {
   const bool arm = s->cfg.mark == REX_MARK_ARM;
   if (s->cfg.task == REX_TASK_MIXED) {   // lane groups only (rex_create caps the envs per wave at 16)
-    if (arm) { if (s->epw == 4) REX_LAUNCH_STEP(4, true, true); else if (s->epw == 8) REX_LAUNCH_STEP(8, true, true); else REX_LAUNCH_STEP(16, true, true); }
-    else { if (s->epw == 4) REX_LAUNCH_STEP(4, false, true); else if (s->epw == 8) REX_LAUNCH_STEP(8, false, true); else REX_LAUNCH_STEP(16, false, true); }
+    if (arm) REX_LAUNCH_BY_EPW(true, true, false); else REX_LAUNCH_BY_EPW(false, true, false);
+  } else if (s->cfg.body_contacts) {     // link-box contact rows: lane groups only
+    if (arm) REX_LAUNCH_BY_EPW(true, false, true); else REX_LAUNCH_BY_EPW(false, false, true);
   } else if (arm) {
-    if (s->epw == 4) REX_LAUNCH_STEP(4, true, false);
-    else if (s->epw == 8) REX_LAUNCH_STEP(8, true, false);
-    else REX_LAUNCH_STEP(16, true, false);
+    REX_LAUNCH_BY_EPW(true, false, false);
   } else {
-    if (s->epw == 4) REX_LAUNCH_STEP(4, false, false);
-    else if (s->epw == 8) REX_LAUNCH_STEP(8, false, false);
-    else if (s->epw == 16) REX_LAUNCH_STEP(16, false, false);
-    else REX_LAUNCH_STEP(64, false, false);
+    if (s->epw == 64) REX_LAUNCH_STEP(64, false, false, false);
+    else REX_LAUNCH_BY_EPW(false, false, false);
   }
 }
 static void launch_settle(RexSim* s, int nrec, hipStream_t st, float* snap) {
-  if (s->cfg.mark == REX_MARK_ARM)
-    hipLaunchKernelGGL(rex::rex_settle_kernel<true>, dim3((nrec + 15) / 16), dim3(REX_WAVE), 0, st, s->dev, snap);
-  else
-    hipLaunchKernelGGL(rex::rex_settle_kernel<false>, dim3((nrec + REX_WAVE - 1) / REX_WAVE), dim3(REX_WAVE), 0, st, s->dev, snap);
+  const bool arm = s->cfg.mark == REX_MARK_ARM, body = s->cfg.body_contacts != 0;
+  if (arm && body) hipLaunchKernelGGL((rex::rex_settle_kernel<true, true>), dim3((nrec + 15) / 16), dim3(REX_WAVE), 0, st, s->dev, snap);
+  else if (arm) hipLaunchKernelGGL((rex::rex_settle_kernel<true, false>), dim3((nrec + 15) / 16), dim3(REX_WAVE), 0, st, s->dev, snap);
+  else if (body) hipLaunchKernelGGL((rex::rex_settle_kernel<false, true>), dim3((nrec + 15) / 16), dim3(REX_WAVE), 0, st, s->dev, snap);
+  else hipLaunchKernelGGL((rex::rex_settle_kernel<false, false>), dim3((nrec + REX_WAVE - 1) / REX_WAVE), dim3(REX_WAVE), 0, st, s->dev, snap);
 }

@@ -70,7 +70,8 @@ class RexBatchEnv:
                  mark="base", render=False, stream=None, gait_clock_scale=1.0,
                  distance_weight=None, energy_weight=None, drift_weight=None, shake_weight=None,
                  tasks=None, mass_scale_range=None, friction_range=None, observation_noise_stdev=None,
-                 heightfield=None, heightfield_cell=None, heightfield_origin=(0.0, 0.0, 0.0), init_height=None, **ignored):
+                 heightfield=None, heightfield_cell=None, heightfield_origin=(0.0, 0.0, 0.0), init_height=None,
+                 body_contacts=False, **ignored):
         import torch
         # Reference constructor keywords that only touch the GUI, logging or debugging are accepted and ignored; anything
         # else that would change what the env computes is an error here, not a silent no-op.
@@ -135,6 +136,7 @@ class RexBatchEnv:
             init_height = {"hills": 1.98, "mounts": 0.85}[terrain_type]     # ROBOT_INIT_POSITION, terrain.py:14-20
         if init_height is not None:
             cfg.init_height = float(init_height)
+        cfg.body_contacts = int(bool(body_contacts))   # link collision boxes vs ground, next to the toe rows (include/rexsim.h)
         cfg.motor_kp, cfg.motor_kd = float(motor_kp), float(motor_kd)
         cfg.gait_clock_scale = float(gait_clock_scale)     # wall-clock seconds per simulated second (gait_planner.py:108-110)
         for name, v in (("distance_weight", distance_weight), ("energy_weight", energy_weight),
