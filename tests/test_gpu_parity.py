@@ -277,7 +277,8 @@ def test_arm_mark_latency_model_parity(torch):
         o, r, d, info = env.step(torch.as_tensor(a, device="cuda"))
         oo, orr, od, ocmd = orc.step(a)
         np.testing.assert_allclose(info["action"].cpu().numpy(), ocmd, atol=5e-5)
-        np.testing.assert_allclose(o.cpu().numpy(), oo, atol=2e-2)
+        np.testing.assert_allclose(o.cpu().numpy()[:, :2], oo[:, :2], atol=2e-3)
+        np.testing.assert_allclose(o.cpu().numpy()[:, 2:], oo[:, 2:], atol=0.1)        # angular rates: 1 / dt times the angle error
         np.testing.assert_allclose(r.cpu().numpy(), orr, atol=5e-3)
     ps, os_ = product_state_to_numeric(env.state), orc.get_state()
     np.testing.assert_allclose(ps[13:31], os_[13:31], atol=5e-3)
@@ -1055,8 +1056,9 @@ def test_every_kernel_variant_against_the_oracle_at_baseline_sizes(torch, task, 
     with open(os.path.join(os.path.dirname(__file__), "..", "gpurun_out", "r02_parity.jsonl"), "a") as f:
         f.write(json.dumps(rec) + "\n")
     print(json.dumps(rec))
-    assert rec["median_rad"] <= 1e-3
-    assert rec["p99_rad"] <= 2e-2 and rec["max_rad"] <= 0.3, rec
+    assert rec["median_rad"] <= 1e-4                           # measured 2e-6 (profiles/r02_parity.json); BASELINE.json's bar is 1e-3
+    assert rec["p99_rad"] <= 5e-3 and rec["max_rad"] <= 2e-2, rec   # measured 4e-4 / 1.8e-3
+    assert curve[25]["max"] <= 2e-2 and curve[100]["median"] <= 1e-4
     env.close()
 
 
@@ -1138,33 +1140,44 @@ def test_caller_supplied_heightfield_terrain(torch):
 @pytest.mark.parametrize("mark,n", [("base", 64), ("arm", 24), ("base", 9000)])
 def test_link_box_ground_contacts(torch, mark, n):
     """RexConfig.body_contacts: the link collision boxes of rex.urdf (base, chassis, shoulder, leg, foot) against the
-    ground.  Robots whose motors give up (kp = kd = 0: only the back-EMF term is left) collapse: without the rows the base
-    sinks through the floor, with them it comes to rest on its boxes -- and the HIP path follows the fp32 oracle through
-    the fall (the first 60 steps in lock step; the resting height at the end)."""
+    ground.  Limp robots (kp = kd = 0: only the back-EMF term is left) dropped ON THEIR SIDE from 0.25 m: the toes cannot
+    catch them; without the rows the base falls through the floor, with them the robot comes to rest on its boxes -- and
+    the HIP path follows the fp32 oracle through the fall (the first 40 steps in lock step; the resting height at the end)."""
     from rex_gym_amd import RexBatchEnv
     kw = dict(seed=5, motor_kp=0.0, motor_kd=0.0, mark=mark)
+
+    def on_its_side(env_state_numeric):
+        st = env_state_numeric.copy()
+        st[2] = 0.25
+        st[3], st[4], st[5], st[6] = np.sin(0.785), 0.0, 0.0, np.cos(0.785)
+        st[7:13] = 0.0
+        return st
+
     env, orc = make_pair("poses", "ik", n, np.float32, body_contacts=1, **kw)     # poses: the env that never terminates
-    np.testing.assert_allclose(env.reset().cpu().numpy(), orc.reset(), atol=2e-3)
+    env.reset(); orc.reset()
+    st = on_its_side(orc.get_state())
+    orc.set_state(st)
+    env.state.copy_(numeric_to_product_state(st, torch, env.state.device))
     zero = np.zeros((n, 1), np.float32)
-    for k in range(260):
+    for k in range(300):
         env.step(torch.as_tensor(zero, device="cuda"))
         if n <= 64:
             orc.step(zero)
-            if k < 60:
+            if k < 40:
                 ps, os_ = product_state_to_numeric(env.state), orc.get_state()
-                np.testing.assert_allclose(ps[:3], os_[:3], atol=2e-3, err_msg=f"step {k}")
-    os_ = orc.get_state()
-    ps = product_state_to_numeric(env.state)
+                np.testing.assert_allclose(ps[:3], os_[:3], atol=3e-3, err_msg=f"step {k}")
+    ps, os_ = product_state_to_numeric(env.state), orc.get_state()
     assert np.isfinite(ps[:37]).all()
-    # at rest on the boxes: the base box is 35 mm thick below the base origin; nothing below the floor
-    assert np.all(ps[2] > 0.02) and np.all(ps[2] < 0.12), (ps[2].min(), ps[2].max())
+    assert np.all(ps[2] > 0.04) and np.all(ps[2] < 0.14), (ps[2].min(), ps[2].max())   # resting on the boxes, above the floor
+    assert np.abs(ps[7:10]).max() < 0.05                                                # and at rest
     if n <= 64:
         np.testing.assert_allclose(ps[2], os_[2], atol=1.5e-2)
     env.close()
     if n <= 64:
         sunk = RexBatchEnv(n, task="poses", signal_type="ik", **kw)
         sunk.reset()
-        for k in range(260):
+        sunk.state.copy_(numeric_to_product_state(st, torch, sunk.state.device))
+        for k in range(300):
             sunk.step(torch.as_tensor(zero, device="cuda"))
         assert float(sunk.state[2].max()) < 0.0          # toes only: the base goes through the floor
         sunk.close()
