@@ -866,7 +866,7 @@ __device__ __forceinline__ void body_row(const SM& sm, const LN& ln, int bodyoff
 
 template <int LPE, class SM, class ARMP>
 __device__ __forceinline__ void pgs_dv(const SM& sm, ARMP& armp, PgsX& x, int p, const bool (&lim)[4], bool any_contact,
-                                       unsigned bgroups, float mu, int iterations, int lane_iterations, float thr, int& nsweeps) {
+                                       unsigned bgroups, float mu, int iterations, int lane_iterations, float thr, int& nsweeps, int& lane_sweeps) {
   constexpr int EPW = SM::kEpw, NY = (6 + LPE - 1) / LPE;
   constexpr int kRow = REX_ROW_F4 * EPW * 16;   // bytes from a row to the next
   DvLane<NY, EPW> ln;
@@ -923,6 +923,7 @@ __device__ __forceinline__ void pgs_dv(const SM& sm, ARMP& armp, PgsX& x, int p,
   for (int it = 0; it < iterations; ++it) {
     ++nsweeps;
     if (running) {
+      ++lane_sweeps;
       float worst = 0.0f;
       // joint-limit rows (non-contact rows come first in Bullet's sweep): plain Gauss-Seidel steps
 #pragma unroll
@@ -1044,7 +1045,8 @@ __device__ long long g_prof[10 * 1024];  // per block: cycle counters of the sec
 #endif
 template <class SM, class ARMP>
 __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float dt, int iterations, int lane_iterations,
-                                                float sqrt_res_thr, const SM& sm, const Ground& ground, ARMP& armp) {
+                                                float sqrt_res_thr, const SM& sm, const Ground& ground, ARMP& armp, int& lane_sweeps) {
+  // lane_sweeps: += the solver sweeps THIS env ran (the host regroups large batches by it, rex_regroup_kernel)
   // `iterations`: wave-uniform sweep cap; `lane_iterations` <= iterations: this env's own cap (they differ only in a batch
   // that mixes tasks with different numSolverIterations, REX_TASK_MIXED)
   REX_STAMP(t_begin);
@@ -1321,13 +1323,14 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
     if (pl == 0) sm.parkf(REX_PARK_CPL, 0) = 0.0f;
     mirror_sync();
     const bool lim[4] = {lim0, lim1, lim2, lim3};
-    pgs_dv<LPE>(sm, armp, x, pl, lim, any0 || any1 || any2 || any3, bgroups, ground.mu, iterations, lane_iterations, sqrt_res_thr, nsweeps);
+    pgs_dv<LPE>(sm, armp, x, pl, lim, any0 || any1 || any2 || any3, bgroups, ground.mu, iterations, lane_iterations, sqrt_res_thr, nsweeps, lane_sweeps);
   } else {
     // one env per lane (EPW = 64): every lane carries the whole of x, row by row from LDS
     bool running = true;
     for (int it = 0; it < iterations; ++it) {
       ++nsweeps;
       if (running) {
+        ++lane_sweeps;
         float worst = 0.0f;
         if (lim0) pgs_leg_limits<0>(sm, x, lam, worst);   // non-contact rows first (Bullet's sweep order)
         if (lim1) pgs_leg_limits<1>(sm, x, lam, worst);

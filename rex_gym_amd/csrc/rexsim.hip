@@ -41,6 +41,7 @@ struct EnvState {
   uint32_t motor_en;
   uint32_t overheat[18]; // one counter per motor in registers; packed 2 x u16 per state word in HBM
   uint32_t hist;         // observation-history ring: bits 0-7 newest slot, bits 8-15 fill
+  int sweeps;            // solver sweeps this env ran in this launch (transient: regrouping key)
 };
 
 // Persistent-state word layout for NM motors (include/rexsim.h spells out NM = 12 as enum RexStateWord; mark='arm'
@@ -192,6 +193,9 @@ struct DevCfg {
   // solver sweep cap among them (wave-uniform loop bounds; every env stops at its own)
   int32_t mix_task[5], n_mix, max_repeat, max_iterations;
   float mass_lo, mass_hi, mu_lo, mu_hi;   // per-reset randomisation ranges (lo == hi == 0: off)
+  // large batches: envs are regrouped into waves by the solver sweeps they needed in the previous step (a wave sweeps
+  // until the slowest of its envs has converged): wave slot k works on env perm[k]; sweeps[i] = this step's count of env i
+  const int32_t* perm; int32_t* sweeps;
   float noise[5];            // observation_noise_stdev (rex.py:22,765-769): angles, velocities, torques, rpy, rpy rates
   int32_t noise_on;          // any of them > 0
   HfGeom geo;                // heightfield grid geometry
@@ -343,7 +347,7 @@ __device__ __forceinline__ void rex_substep(const DevCfg& c, EnvState& e, int i,
     tau_obs[j] = obs;
     tau[j] = ((e.motor_en >> j) & 1u) ? act : 0.0f;                             // rex.py:617-623
   }
-  physics_substep(e.ph, tau, c.dt, c.max_iterations, c.iterations, c.res_thr, sm, ground, armp);
+  physics_substep(e.ph, tau, c.dt, c.max_iterations, c.iterations, c.res_thr, sm, ground, armp, e.sweeps);
   receive_observation<NM>(c, e, i, live, tau_obs);
 }
 
@@ -673,7 +677,8 @@ __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __r
   const int slot = (lane / LPE) & (EPW - 1);
   const int gi = blockIdx.x * EPW + slot;
   const bool live = lane < LPE * EPW && (lane & (LPE - 1)) == 0 && gi < c.n;
-  const int i = gi < c.n ? gi : c.n - 1;   // tail slots shadow the last env (keeps the wave convergent)
+  const int gj = gi < c.n ? gi : c.n - 1;   // tail slots shadow the last env (keeps the wave convergent)
+  const int i = c.perm ? c.perm[gj] : gj;   // regrouped batches: the env this slot works on
   const Lds<EPW, kLegF4, BODY> sm{lds, slot, EPW <= 16 ? lds + kRowsF4 * EPW : nullptr, BODY ? lds + (kRowsF4 + REX_PARK_F4) * EPW : nullptr};
   typename ArmHook<EPW, ARM>::type armp = ArmHook<EPW, ARM>::make(lds, slot);
 
@@ -683,6 +688,7 @@ __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __r
 
   EnvState e;
   load_env<NM>(state, c.n, i, e);
+  e.sweeps = 0;
   float act[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
@@ -813,6 +819,7 @@ __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __r
     for (int k = 0; k < c.obs_dim; ++k) obs_out[(size_t)is * c.obs_dim + k] = obs[k];
     reward_out[is] = reward;
     done_out[is] = done ? 1 : 0;
+    if (c.sweeps) c.sweeps[is] = e.sweeps;
     if (cmd_out) {
 #pragma unroll
       for (int j = 0; j < NM; ++j) cmd_out[(size_t)is * NM + j] = cmd[j];
@@ -933,6 +940,25 @@ __global__ void rex_reset_kernel(DevCfg c, float* __restrict__ state, const floa
   if (obs_out) for (int k = 0; k < c.obs_dim; ++k) obs_out[(size_t)r * c.obs_dim + k] = obs[k];
 }
 
+// Regrouping of a large batch (one workgroup): counting sort of the env indices by the solver sweeps of the last step,
+// most sweeps first (the long waves start first), 64 bins.  perm[k] = env of wave slot k.  The order inside a bin does
+// not matter: an env's result does not depend on its wave-mates.
+__global__ __launch_bounds__(1024) void rex_regroup_kernel(int n, int bin_width, const int32_t* __restrict__ sweeps, int32_t* __restrict__ perm) {
+  __shared__ int hist[64], base[64];
+  const int t = threadIdx.x;
+  if (t < 64) hist[t] = 0;
+  __syncthreads();
+  for (int i = t; i < n; i += 1024) atomicAdd(&hist[63 - min(sweeps[i] / bin_width, 63)], 1);
+  __syncthreads();
+  if (t == 0) { int acc = 0; for (int b = 0; b < 64; ++b) { base[b] = acc; acc += hist[b]; } }
+  __syncthreads();
+  for (int i = t; i < n; i += 1024) perm[atomicAdd(&base[63 - min(sweeps[i] / bin_width, 63)], 1)] = i;
+}
+__global__ void rex_iota_kernel(int n, int32_t* __restrict__ perm, int32_t* __restrict__ sweeps) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { perm[i] = i; sweeps[i] = 0; }
+}
+
 // ---- controller-only kernels ----
 __global__ void rex_ik_kernel(int n, const float* __restrict__ orn, const float* __restrict__ pos,
                               const float* __restrict__ frames, float* __restrict__ angles) {
@@ -984,6 +1010,8 @@ struct RexSim {
   int timing;
   int have_timing;
   // ring of event pairs around the last REX_TIMING_RING launches: per-launch durations without a host sync in between
+  int32_t* d_perm;   // regrouping (large batches only): wave slot -> env, and the per-env sweep counts it is sorted by
+  int32_t* d_sweeps;
   hipEvent_t ring0[REX_TIMING_RING], ring1[REX_TIMING_RING];
   long long timed_steps;
   int words;   // per-env state words of the config's mark
@@ -1167,6 +1195,7 @@ int rex_create(const RexConfig* cfg, int device, float* d_state, void* stream, R
   d.pose_index = cfg->pose_index; d.pose_value = cfg->pose_value;
   d.range_normalize = cfg->range_normalize;
   d.terrain = nullptr; d.terrain_mid = nullptr; d.n_terrain = 0; d.body_params = nullptr;
+  d.perm = nullptr; d.sweeps = nullptr; s->d_perm = nullptr; s->d_sweeps = nullptr;
   d.geo = rex::HfGeom{256, 20.0f, 20.0f, 127.5f, 127.5f, 254.999f, 254.999f}; d.hf_stride = 65536;   /* model/terrain.py:32-54 */
   d.init_z = cfg->init_height > 0.0f ? cfg->init_height : rex::kInitZ;
   d.noise_on = 0;
@@ -1191,6 +1220,19 @@ int rex_create(const RexConfig* cfg, int device, float* d_state, void* stream, R
   }
   d.target_orient = cfg->target_orient; d.init_orient = cfg->init_orient; d.orient_fixed = cfg->orient_fixed;
   d.gait_clock = cfg->gait_clock_scale > 0.0f ? cfg->gait_clock_scale : 1.0f;
+  {
+    // Regrouping pays once a SIMD runs several waves one after the other (below that the launch ends with its slowest
+    // wave whatever the grouping).  REX_REGROUP=0 / 1 overrides.
+    const char* ov = getenv("REX_REGROUP");
+    const bool want = ov ? atoi(ov) != 0 : cfg->num_envs >= 32768;
+    if (want) {
+      hipError_t e2 = hipMalloc(&s->d_perm, sizeof(int32_t) * (size_t)cfg->num_envs);
+      if (e2 == hipSuccess) e2 = hipMalloc(&s->d_sweeps, sizeof(int32_t) * (size_t)cfg->num_envs);
+      if (e2 != hipSuccess) { delete s; return fail(REX_ENOMEM, "hipMalloc(regroup): %s", hipGetErrorString(e2)); }
+      hipLaunchKernelGGL(rex::rex_iota_kernel, dim3((cfg->num_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, cfg->num_envs, s->d_perm, s->d_sweeps);
+      d.perm = s->d_perm; d.sweeps = s->d_sweeps;
+    }
+  }
   hipError_t e = hipMalloc(&s->d_snap, sizeof(float) * snapshot_floats(s, d.n_mix));
   if (e != hipSuccess) { delete s; return fail(REX_ENOMEM, "hipMalloc(snapshot): %s", hipGetErrorString(e)); }
   (void)hipEventCreate(&s->ev0);
@@ -1267,6 +1309,8 @@ int rex_destroy(RexSim* s) {
   if (!s) return REX_OK;
   (void)hipSetDevice(s->device);
   (void)hipFree(s->d_snap);
+  if (s->d_perm) (void)hipFree(s->d_perm);
+  if (s->d_sweeps) (void)hipFree(s->d_sweeps);
   (void)hipEventDestroy(s->ev0);
   (void)hipEventDestroy(s->ev1);
   for (int k = 0; k < REX_TIMING_RING; ++k) if (s->ring0[k]) { (void)hipEventDestroy(s->ring0[k]); (void)hipEventDestroy(s->ring1[k]); }
@@ -1306,6 +1350,9 @@ int rex_step(RexSim* s, const float* d_action, float* d_obs, float* d_reward, ui
   if (s->timing) HIPCHK(hipEventRecord(e0, st));
   launch_step(s, blocks, st, d_action, d_obs, d_reward, d_done, d_motor_cmd);
   HIPCHK(hipGetLastError());
+  if (s->d_perm)   // next step's grouping from this step's sweep counts (stream-ordered behind the step)
+    hipLaunchKernelGGL(rex::rex_regroup_kernel, dim3(1), dim3(1024), 0, st, s->cfg.num_envs, (s->dev.max_repeat * s->dev.max_iterations + 63) / 64,
+                       s->d_sweeps, s->d_perm);
   if (s->timing) { HIPCHK(hipEventRecord(e1, st)); s->have_timing = 1; if (s->timing == 2) s->timed_steps++; }
   return REX_OK;
 }

@@ -1201,3 +1201,27 @@ def test_link_box_rows_change_nothing_while_no_box_touches_the_ground(torch):
         np.testing.assert_allclose(xa.cpu().numpy()[:, :2], xb.cpu().numpy()[:, :2], atol=2e-4)
     np.testing.assert_allclose(a.state[13:25].cpu().numpy(), b.state[13:25].cpu().numpy(), atol=2e-3)
     a.close(); b.close()
+
+
+def test_regrouped_batch_is_bit_identical(torch, monkeypatch):
+    """Large batches regroup their envs into waves by the solver sweeps of the previous step (REX_REGROUP; on from 32 768
+    envs): the wave slot -> env permutation changes every step, an env's results must not."""
+    from rex_gym_amd import RexBatchEnv
+    n = 3000
+    outs = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("REX_REGROUP", flag)
+        monkeypatch.setenv("REX_ENVS_PER_WAVE", "16")
+        env = RexBatchEnv(n, task="walk", signal_type="ik", seed=9, auto_reset=True, max_episode_steps=40)
+        env.reset()
+        g = torch.Generator(device="cuda"); g.manual_seed(5)
+        rec = []
+        for k in range(60):
+            a = torch.rand((n, 2), device="cuda", generator=g) * 0.8 - 0.4
+            o, r, d, info = env.step(a)
+            rec.append((o.clone(), r.clone(), d.clone(), info["action"].clone()))
+        outs[flag] = (rec, env.state.clone())
+        env.close()
+    for (o0, r0, d0, c0), (o1, r1, d1, c1) in zip(outs["0"][0], outs["1"][0]):
+        assert torch.equal(o0, o1) and torch.equal(r0, r1) and torch.equal(d0, d1) and torch.equal(c0, c1)
+    assert torch.equal(outs["0"][1], outs["1"][1])
