@@ -271,6 +271,10 @@ REX_API int rex_gait_loop(int n, int mode, float* d_planner, const float* d_para
  * the batch size; the environment variable REX_ENVS_PER_WAVE overrides (tests run every variant through it). */
 REX_API int rex_envs_per_wave(const RexSim* sim);
 
+/* Solver sweeps every env ran in the last rex_step (summed over its substeps), int32 [num_envs] copied to the caller's
+ * device buffer -- the key a batch created under REX_REGROUP=1 is regrouped into waves by (opt-in). */
+REX_API int rex_get_sweeps(RexSim* sim, int32_t* d_out, void* stream);
+
 REX_API const char* rex_last_error(void);
 REX_API int rex_abi_version(void);
 

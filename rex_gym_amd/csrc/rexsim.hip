@@ -675,7 +675,16 @@ __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __r
   const int lane = threadIdx.x;
   constexpr int LPE = EPW < 64 ? lanes_per_env(EPW) : 1;     // EPW <= 16: lane = LPE * slot + p (rex_device.h, group layout)
   const int slot = (lane / LPE) & (EPW - 1);
-  const int gi = blockIdx.x * EPW + slot;
+  // Block b runs on XCD b % 8 (observed placement; speed only).  A 64-byte sector of a state word holds 16 envs = 16 / EPW
+  // blocks' worth: hand the blocks of one sector to the same XCD, so that one L2 fetches (and writes back) the sector
+  // instead of 16 / EPW of them.  A bijection on the full groups of 8 x (16 / EPW) blocks; the tail keeps its order.
+  int blk = (int)blockIdx.x;
+  if constexpr (EPW < 16) {
+    constexpr int G = 16 / EPW;
+    const int full = ((int)gridDim.x / (8 * G)) * (8 * G);
+    if (blk < full) { const int xcd = blk & 7, q = blk >> 3; blk = ((q / G) * 8 + xcd) * G + (q % G); }
+  }
+  const int gi = blk * EPW + slot;
   const bool live = lane < LPE * EPW && (lane & (LPE - 1)) == 0 && gi < c.n;
   const int gj = gi < c.n ? gi : c.n - 1;   // tail slots shadow the last env (keeps the wave convergent)
   const int i = c.perm ? c.perm[gj] : gj;   // regrouped batches: the env this slot works on
@@ -1221,10 +1230,12 @@ int rex_create(const RexConfig* cfg, int device, float* d_state, void* stream, R
   d.target_orient = cfg->target_orient; d.init_orient = cfg->init_orient; d.orient_fixed = cfg->orient_fixed;
   d.gait_clock = cfg->gait_clock_scale > 0.0f ? cfg->gait_clock_scale : 1.0f;
   {
-    // Regrouping pays once a SIMD runs several waves one after the other (below that the launch ends with its slowest
-    // wave whatever the grouping).  REX_REGROUP=0 / 1 overrides.
+    // Regrouping (opt-in: REX_REGROUP=1) can pay once a SIMD runs several waves one after the other -- below that the launch
+    // ends with its slowest wave whatever the grouping.  Measured on MI355X (profiles/r02_regroup.md): +10 % on the walking
+    // workload (gait clock 1.5, sweep counts 0.96 correlated from step to step), -11 % on the falling one (0.52), where the
+    // scattered state access and the sort cost more than the 18 % of sweeps the grouping can save.
     const char* ov = getenv("REX_REGROUP");
-    const bool want = ov ? atoi(ov) != 0 : cfg->num_envs >= 32768;
+    const bool want = ov ? atoi(ov) != 0 : false;
     if (want) {
       hipError_t e2 = hipMalloc(&s->d_perm, sizeof(int32_t) * (size_t)cfg->num_envs);
       if (e2 == hipSuccess) e2 = hipMalloc(&s->d_sweeps, sizeof(int32_t) * (size_t)cfg->num_envs);
@@ -1358,6 +1369,13 @@ int rex_step(RexSim* s, const float* d_action, float* d_obs, float* d_reward, ui
 }
 
 int rex_envs_per_wave(const RexSim* s) { return s ? s->epw : REX_EINVAL; }
+
+int rex_get_sweeps(RexSim* s, int32_t* d_out, void* stream) {
+  if (!s || !d_out) return fail(REX_EINVAL, "rex_get_sweeps: null pointer%s", "");
+  if (!s->d_sweeps) return fail(REX_EINVAL, "rex_get_sweeps: this sim does not regroup (REX_REGROUP=1 was not set when it was created)%s", "");
+  HIPCHK(hipMemcpyAsync(d_out, s->d_sweeps, sizeof(int32_t) * (size_t)s->cfg.num_envs, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return REX_OK;
+}
 
 int rex_set_timing(RexSim* s, int enable) {
   if (!s) return fail(REX_EINVAL, "rex_set_timing: null sim%s", "");

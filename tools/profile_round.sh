@@ -1,13 +1,15 @@
 #!/bin/bash
-# run on the GPU box: full GPU tests, default bench, rocprofv3 kernel stats, two PMC passes (HBM read / write bytes)
-TAG=${1:-r01}
-cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
+# Run on the GPU box (gpurun): rocprofv3 kernel stats + two PMC passes (HBM read / write bytes) of bench.py for one
+# workload.  usage: tools/profile_round.sh TAG [bench.py workload flags ...]   -> gpurun_out/TAG_*
+TAG=$1; shift
+cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests -m gpu -q > gpurun_out/tests_$TAG.log 2>&1; tail -3 gpurun_out/tests_$TAG.log
-python bench.py > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err; cat gpurun_out/bench_$TAG.json
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -o prof -- python bench.py --steps 300 --warmup 1500 --no-cpu-baseline > gpurun_out/bench_prof_$TAG.log 2>&1
+cd /tmp
+rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_prof -- python $GRAFT_REPO_ROOT/bench.py --steps 400 --warmup 50 --no-cpu-baseline "$@" > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_bench_under_rocprof.json 2>/dev/null
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_$C -o pmc -- python bench.py --steps 100 --warmup 1500 --no-cpu-baseline > gpurun_out/pmc_${TAG}_$C.log 2>&1
+  rocprofv3 --pmc $C --kernel-trace -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_$C -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 50 --no-cpu-baseline "$@" > /dev/null 2>&1
 done
-find gpurun_out/prof_$TAG -name "*stats*" | head; 
+cd $GRAFT_REPO_ROOT
+python tools/rocprof_stats.py $(find gpurun_out/${TAG}_prof -name "*_results.db" | head -1) --skip 1550 | head -4
+python tools/rocprof_pmc.py $(find gpurun_out/${TAG}_pmc_FETCH_SIZE -name "*_results.db" | head -1) $(find gpurun_out/${TAG}_pmc_WRITE_SIZE -name "*_results.db" | head -1)
