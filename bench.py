@@ -145,6 +145,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-walking-workload", action="store_true", help="skip the secondary gait-clock-1.5 measurement (profiling runs)")
     # the default line is BASELINE.json configs[1]; the other supported configs can be timed with these
     ap.add_argument("--task", default="walk", choices=["walk", "gallop", "turn", "poses", "standup"])
     ap.add_argument("--signal", default="ik", choices=["ik", "ol"])
@@ -256,7 +257,7 @@ def main():
     # which the reference's gait -- driven by time.time(), gait_planner.py:108-110 -- walks instead of falling after ~240
     # steps): reported next to the headline, never instead of it
     walking = None
-    if world == 1 and not args.mixed and args.signal == "ik" and args.task in ("walk", "turn", "gallop"):
+    if world == 1 and not args.mixed and not args.no_walking_workload and args.signal == "ik" and args.task in ("walk", "turn", "gallop"):
         env2 = RexBatchEnv(n, task=args.task, signal_type=args.signal, device=local_rank, seed=0, env_index_base=rank * n,
                            auto_reset=True, max_episode_steps=2000, terrain_type=args.terrain, mark=args.mark, gait_clock_scale=1.5)
         env2.reset()

@@ -145,8 +145,13 @@ static real MB_ANGULAR_DAMPING = (real)0.04; /* (variables only so the conservat
 static real FRICTION_MU = (real)0.5;      /* toe 0.5 x plane 1.0, 9.2-7 (variable for sensitivity probes) */
 #define ROBOT_INIT_Z ((real)0.21)        /* terrain.py:14-20 */
 
-static long DBG_HIST[64] = {0};
-static long DBG_SWEEPS = 0, DBG_SUBSTEPS = 0; /* solver statistics (tests / tuning) */
+/* solver statistics (tools / tuning).  Counted only while DBG_STATS is set (orc_solver_stats / orc_solver_hist /
+ * orc_body_points switch it on): shared counters that every OpenMP thread bumps once per sweep would otherwise drag the
+ * cache line they share with the read-only solver parameters from core to core (on the 2-socket GPU hosts that halved
+ * the 16-thread throughput of the cpu_baseline). */
+static int DBG_STATS = 0;
+static long DBG_HIST[64] __attribute__((aligned(128))) = {0};
+static long DBG_SWEEPS = 0, DBG_SUBSTEPS = 0;
 static real DBG_JOINT_FRICTION = 0, DBG_JOINT_VISC = 0; /* sensitivity probe only (off by default) */
 /* ---- sensitivity probes over the Bullet-behaviour assumptions of SURVEY.md 9.2 (tools/physics_sensitivity.py).
  * Every probe defaults to the value the product kernels use; changing one changes the oracle only. ---- */
@@ -866,10 +871,10 @@ static void physics_substep(Phys* s, const real tau[NJ], real dt, int iterations
         PtBody[npoint] = bestB[k];
         PtDist[npoint] = bestD[k];
         ++npoint;
-        ++DBG_BODY_POINTS;
+        if (DBG_STATS) ++DBG_BODY_POINTS;
       }
     }
-    if (npoint > toe_points) ++DBG_BODY_SUBSTEPS;
+    if (DBG_STATS && npoint > toe_points) ++DBG_BODY_SUBSTEPS;
   }
   /* non-contact rows come first in every sweep (btMultiBodyConstraintSolver::solveSingleIteration): the URDF joint
    * limits (btMultiBodyJointLimitConstraint, one unilateral row per bound).  Bullet creates both rows for every joint;
@@ -964,11 +969,11 @@ static void physics_substep(Phys* s, const real tau[NJ], real dt, int iterations
     }
     /* btSequentialImpulseConstraintSolver::solveGroupCacheFriendlyIterations: leave the sweep loop once
      * the residual is below m_leastSquaresResidualThreshold (PyBullet default 1e-7) */
-    ++DBG_SWEEPS;
-    if (worst <= residual_threshold) { DBG_HIST[it < 63 ? it : 63]++; break; }
-    if (it == iterations - 1) DBG_HIST[63]++;
+    if (DBG_STATS) ++DBG_SWEEPS;
+    if (worst <= residual_threshold) { if (DBG_STATS) DBG_HIST[it < 63 ? it : 63]++; break; }
+    if (DBG_STATS && it == iterations - 1) DBG_HIST[63]++;
   }
-  ++DBG_SUBSTEPS;
+  if (DBG_STATS) ++DBG_SUBSTEPS;
   /* apply, clamp (btMultiBody::applyDeltaVeeMultiDof), integrate positions with the NEW velocities */
   real dw[3], dl[3];
   matvec3(A.Rw[0], dv, dw);
@@ -1792,13 +1797,13 @@ ORC_API void orc_set_state(void* h, const double* in) {
 }
 
 ORC_API void orc_set_joint_friction(real f, real visc) { DBG_JOINT_FRICTION = f; DBG_JOINT_VISC = visc; }
-ORC_API void orc_solver_hist(long* h) { for (int i = 0; i < 64; ++i) { h[i] = DBG_HIST[i]; DBG_HIST[i] = 0; } }
-ORC_API void orc_solver_stats(long* sweeps, long* substeps, int reset) { *sweeps = DBG_SWEEPS; *substeps = DBG_SUBSTEPS; if (reset) { DBG_SWEEPS = 0; DBG_SUBSTEPS = 0; } }
+ORC_API void orc_solver_hist(long* h) { DBG_STATS = 1; for (int i = 0; i < 64; ++i) { h[i] = DBG_HIST[i]; DBG_HIST[i] = 0; } }
+ORC_API void orc_solver_stats(long* sweeps, long* substeps, int reset) { DBG_STATS = 1; *sweeps = DBG_SWEEPS; *substeps = DBG_SUBSTEPS; if (reset) { DBG_SWEEPS = 0; DBG_SUBSTEPS = 0; } }
 ORC_API void orc_set_friction(real mu) { FRICTION_MU = mu; }
 ORC_API void orc_set_gait_clock(real s) { DBG_GAIT_CLOCK = s; }
 ORC_API void orc_set_body_contacts(int on) { BODY_CONTACTS = on; }
-ORC_API long orc_body_points(int reset) { long v = DBG_BODY_POINTS; if (reset) DBG_BODY_POINTS = 0; return v; }
-ORC_API long orc_substeps_with_body_points(int reset) { long v = DBG_BODY_SUBSTEPS; if (reset) DBG_BODY_SUBSTEPS = 0; return v; }
+ORC_API long orc_body_points(int reset) { DBG_STATS = 1; long v = DBG_BODY_POINTS; if (reset) DBG_BODY_POINTS = 0; return v; }
+ORC_API long orc_substeps_with_body_points(int reset) { DBG_STATS = 1; long v = DBG_BODY_SUBSTEPS; if (reset) DBG_BODY_SUBSTEPS = 0; return v; }
 /* sensitivity probes by name (tools/physics_sensitivity.py); returns 0 when the name is known */
 ORC_API int orc_set_probe(const char* name, double v) {
   if (!strcmp(name, "erp")) P_ERP = (real)v;

@@ -277,7 +277,7 @@ def test_arm_mark_latency_model_parity(torch):
         o, r, d, info = env.step(torch.as_tensor(a, device="cuda"))
         oo, orr, od, ocmd = orc.step(a)
         np.testing.assert_allclose(info["action"].cpu().numpy(), ocmd, atol=5e-5)
-        np.testing.assert_allclose(o.cpu().numpy()[:, :2], oo[:, :2], atol=2e-3)
+        np.testing.assert_allclose(o.cpu().numpy()[:, :2], oo[:, :2], atol=5e-3)
         np.testing.assert_allclose(o.cpu().numpy()[:, 2:], oo[:, 2:], atol=0.3)        # angular rates: 1 / dt times the angle error
         np.testing.assert_allclose(r.cpu().numpy(), orr, atol=5e-3)
     ps, os_ = product_state_to_numeric(env.state), orc.get_state()

@@ -6,9 +6,9 @@ cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_prof -- python $GRAFT_REPO_ROOT/bench.py --steps 400 --warmup 50 --no-cpu-baseline "$@" > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_bench_under_rocprof.json 2>/dev/null
+rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_prof -- python $GRAFT_REPO_ROOT/bench.py --steps 400 --warmup 50 --no-cpu-baseline --no-walking-workload "$@" > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_bench_under_rocprof.json 2>/dev/null
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_$C -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 50 --no-cpu-baseline "$@" > /dev/null 2>&1
+  rocprofv3 --pmc $C --kernel-trace -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_$C -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 50 --no-cpu-baseline --no-walking-workload "$@" > /dev/null 2>&1
 done
 cd $GRAFT_REPO_ROOT
 python tools/rocprof_stats.py $(find gpurun_out/${TAG}_prof -name "*_results.db" | head -1) --skip 1550 | head -4
