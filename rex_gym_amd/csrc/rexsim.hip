@@ -1360,6 +1360,10 @@ int rex_step(RexSim* s, const float* d_action, float* d_obs, float* d_reward, ui
   }
   if (s->timing) HIPCHK(hipEventRecord(e0, st));
   launch_step(s, blocks, st, d_action, d_obs, d_reward, d_done, d_motor_cmd);
+  {   // developer probe (tools/launch_gap.py): REX_STEP_REPEAT=R issues the launch R times back to back from C
+    static const int repeat = getenv("REX_STEP_REPEAT") ? atoi(getenv("REX_STEP_REPEAT")) : 1;
+    for (int k = 1; k < repeat; ++k) launch_step(s, blocks, st, d_action, d_obs, d_reward, d_done, d_motor_cmd);
+  }
   HIPCHK(hipGetLastError());
   if (s->d_perm)   // next step's grouping from this step's sweep counts (stream-ordered behind the step)
     hipLaunchKernelGGL(rex::rex_regroup_kernel, dim3(1), dim3(1024), 0, st, s->cfg.num_envs, (s->dev.max_repeat * s->dev.max_iterations + 63) / 64,
