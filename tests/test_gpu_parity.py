@@ -826,6 +826,9 @@ def test_goal_brake_and_hold_sequence_on_the_gpu(torch, task, signal):
     env.close()
 
 
+REPLAY_WINDOW = 60
+
+
 def _rollout_scenarios():
     import json
     with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rollout_golden.json")) as f:
@@ -863,7 +866,10 @@ def test_hip_path_reproduces_reference_rollouts(torch, sc):
             o, r, d, info = env.step(torch.as_tensor(rows(ev["action"]).astype(np.float32), device="cuda"))
             obs, ref, who = o.cpu().numpy(), rows(ev["obs"]), np.arange(n)
             since_reset += 1
-            live = since_reset <= 25     # fp32 vs fp64 along contacts: the comparison stops before rounding differences dominate
+            # fp32 vs fp64 along contacts: the comparison stops before rounding differences dominate.  Measured divergence
+            # (profiles/r02_parity.json, 4 096 / 8 192 envs against the fp32 oracle): max |joint error| over all envs 3e-6 rad
+            # at step 25, 1e-5 at step 100 for walk-IK; 7e-3 at step 25 for gallop-OL (first landings) -- hence 60 steps.
+            live = since_reset <= REPLAY_WINDOW
             if not live.any():
                 continue
             assert (d.cpu().numpy().astype(bool) == rows(ev["done"]).astype(bool))[live].all(), f"event {k}: done"

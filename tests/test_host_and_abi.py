@@ -139,3 +139,17 @@ def test_registered_env_ids_mirror_the_reference():
         registry.make("RexGo-v0")
     with pytest.raises(KeyError):
         registry.make("RexFly-v0")
+
+
+def test_constructor_keywords_are_checked_before_anything_touches_the_gpu():
+    """A caller porting reference code must not get silently different behaviour: keywords that would change what the
+    env computes and are not supported raise; GUI / logging keywords of the reference are accepted."""
+    from rex_gym_amd import RexBatchEnv
+    with pytest.raises(TypeError, match="unsupported keyword"):
+        RexBatchEnv(4, task="walk", forward_reward=3.0)
+    with pytest.raises(NotImplementedError, match="env_randomizer"):
+        RexBatchEnv(4, task="walk", env_randomizer=object())
+    with pytest.raises(NotImplementedError, match="pybullet_data"):
+        RexBatchEnv(4, task="walk", terrain_type="mounts")
+    with pytest.raises(ValueError, match="tasks"):
+        RexBatchEnv(4, task="walk", tasks=("walk", "turn"))
