@@ -44,6 +44,11 @@
 /* link-box contact rows (RexConfig.body_contacts): 12 point slots -- 0..3 the base group (base + chassis boxes), 4 + 2 L + k
    leg L's boxes -- with a normal row (index slot) and two friction rows (12 + 2 slot + d) each, 3 chunks per row like the
    toe rows, in their own LDS region behind the hand-over chunks; lane groups only */
+/* mark 'arm' at <= 8 envs per wave: what the motor model keeps per env across a physics substep -- 18 commands, 18 observed
+   torques, 18 overheat counters, 11 scalars of the env state -- waits in LDS while the substep runs, instead of in
+   registers the 19-body substep then spills (ScratchSize 204 / 208 B per lane before) */
+#define REX_MOTOR_PARK_WORDS (3 * 18 + 11)
+#define REX_MOTOR_PARK_F4 ((REX_MOTOR_PARK_WORDS + 3) / 4)
 #define REX_NBSLOT 12
 #define REX_NBROW (3 * REX_NBSLOT)
 #define REX_BODY_F4 (REX_NBROW * REX_ROW_F4)
@@ -75,6 +80,8 @@ struct Lds {
   float4* p; int slot;
   float4* pk;   // hand-over region of pgs_dv (REX_PARK_F4 chunks per env, behind the rows of all marks); null when EPW = 64
   float4* pb;   // link-box contact rows (BODY only): REX_BODY_F4 chunks per env behind the hand-over region
+  float4* pm;   // motor-side state parked around the physics call (mark 'arm', <= 8 envs per wave; else null): REX_MOTOR_PARK_F4 chunks per env
+  __device__ __forceinline__ float& motorf(int f) const { return reinterpret_cast<float*>(&pm[(f >> 2) * EPW + slot])[f & 3]; }
   __device__ __forceinline__ float4& brow(int r, int c) const { return pb[(r * REX_ROW_F4 + c) * EPW + slot]; }
   __device__ __forceinline__ float4& park(int c) const { return pk[c * EPW + slot]; }
   // scalar views for the lanes that own single components (pgs_dv): float f of a chunk sequence starting at chunk c0

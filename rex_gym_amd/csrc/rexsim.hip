@@ -321,7 +321,7 @@ __device__ __forceinline__ void receive_observation(const DevCfg& c, EnvState& e
 
 // Rex.ApplyAction + stepSimulation + ReceiveObservation (rex.py:158-163, 568-641).
 template <class SM, class ARMP>
-__device__ __forceinline__ void rex_substep(const DevCfg& c, EnvState& e, int i, bool live, const float* cmd, float* tau_obs,
+__device__ __forceinline__ void rex_substep(const DevCfg& c, EnvState& e, int i, bool live, float* cmd, float* tau_obs,
                                             const SM& sm, const Ground& ground, ARMP& armp) {
   constexpr int NM = ARMP::NM;
   float tau[18];
@@ -347,7 +347,30 @@ __device__ __forceinline__ void rex_substep(const DevCfg& c, EnvState& e, int i,
     tau_obs[j] = obs;
     tau[j] = ((e.motor_en >> j) & 1u) ? act : 0.0f;                             // rex.py:617-623
   }
+  // mark 'arm', <= 8 envs per wave: the motor-side state of the env waits in LDS while the substep runs (rex_device.h,
+  // REX_MOTOR_PARK_WORDS); one lane of the group writes, all read back
+  constexpr bool kPark = NM == 18 && SM::kEpw <= 8;
+  if constexpr (kPark) {
+    if ((threadIdx.x & 7u) == 0u) {
+#pragma unroll
+      for (int j = 0; j < 18; ++j) { sm.motorf(j) = cmd[j]; sm.motorf(18 + j) = tau_obs[j]; sm.motorf(36 + j) = __uint_as_float(e.overheat[j]); }
+      sm.motorf(54) = e.gait.phi; sm.motorf(55) = e.gait.last_time; sm.motorf(56) = e.gait.alpha;
+      sm.motorf(57) = e.target; sm.motorf(58) = e.end_time; sm.motorf(59) = e.aux;
+      sm.motorf(60) = __uint_as_float(e.flags); sm.motorf(61) = __int_as_float(e.steps); sm.motorf(62) = __int_as_float(e.episode);
+      sm.motorf(63) = __uint_as_float(e.motor_en); sm.motorf(64) = __uint_as_float(e.hist);
+    }
+    asm volatile("" ::: "memory");
+  }
   physics_substep(e.ph, tau, c.dt, c.max_iterations, c.iterations, c.res_thr, sm, ground, armp, e.sweeps);
+  if constexpr (kPark) {
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < 18; ++j) { cmd[j] = sm.motorf(j); tau_obs[j] = sm.motorf(18 + j); e.overheat[j] = __float_as_uint(sm.motorf(36 + j)); }
+    e.gait.phi = sm.motorf(54); e.gait.last_time = sm.motorf(55); e.gait.alpha = sm.motorf(56);
+    e.target = sm.motorf(57); e.end_time = sm.motorf(58); e.aux = sm.motorf(59);
+    e.flags = __float_as_uint(sm.motorf(60)); e.steps = __float_as_int(sm.motorf(61)); e.episode = __float_as_int(sm.motorf(62));
+    e.motor_en = __float_as_uint(sm.motorf(63)); e.hist = __float_as_uint(sm.motorf(64));
+  }
   receive_observation<NM>(c, e, i, live, tau_obs);
 }
 
@@ -670,7 +693,8 @@ __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __r
   constexpr int kLegF4 = REX_LEG_F4_OF(EPW, ARM);
   constexpr int kRowsF4 = ARM ? REX_LDS_F4_PER_ENV_ARM_OF(EPW) : REX_ROWS_F4_OF(kLegF4);
   static_assert(!BODY || EPW <= 16, "link-box contact rows: lane-group kernels only");
-  __shared__ float4 lds[(kRowsF4 + (EPW <= 16 ? REX_PARK_F4 : 0) + (BODY ? REX_BODY_F4 : 0)) * EPW];
+  constexpr int kMotorF4 = (ARM && EPW <= 8) ? REX_MOTOR_PARK_F4 : 0;
+  __shared__ float4 lds[(kRowsF4 + (EPW <= 16 ? REX_PARK_F4 : 0) + (BODY ? REX_BODY_F4 : 0) + kMotorF4) * EPW];
   REX_STAMP(t_kernel);
   const int lane = threadIdx.x;
   constexpr int LPE = EPW < 64 ? lanes_per_env(EPW) : 1;     // EPW <= 16: lane = LPE * slot + p (rex_device.h, group layout)
@@ -688,7 +712,8 @@ __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __r
   const bool live = lane < LPE * EPW && (lane & (LPE - 1)) == 0 && gi < c.n;
   const int gj = gi < c.n ? gi : c.n - 1;   // tail slots shadow the last env (keeps the wave convergent)
   const int i = c.perm ? c.perm[gj] : gj;   // regrouped batches: the env this slot works on
-  const Lds<EPW, kLegF4, BODY> sm{lds, slot, EPW <= 16 ? lds + kRowsF4 * EPW : nullptr, BODY ? lds + (kRowsF4 + REX_PARK_F4) * EPW : nullptr};
+  const Lds<EPW, kLegF4, BODY> sm{lds, slot, EPW <= 16 ? lds + kRowsF4 * EPW : nullptr, BODY ? lds + (kRowsF4 + REX_PARK_F4) * EPW : nullptr,
+                                  kMotorF4 ? lds + (kRowsF4 + REX_PARK_F4 + (BODY ? REX_BODY_F4 : 0)) * EPW : nullptr};
   typename ArmHook<EPW, ARM>::type armp = ArmHook<EPW, ARM>::make(lds, slot);
 
   DevCfg cmix;                          // MIXED only
@@ -864,7 +889,7 @@ __global__ __launch_bounds__(REX_WAVE) void rex_settle_kernel(DevCfg c, float* _
   __shared__ float4 lds[(kRowsF4 + (EPW <= 16 ? REX_PARK_F4 : 0) + (BODY ? REX_BODY_F4 : 0)) * EPW];
   constexpr int LPE = EPW < 64 ? lanes_per_env(EPW) : 1;
   const int lane = (int)(threadIdx.x / LPE) & (EPW - 1);
-  const Lds<EPW, kLegF4, BODY> sm{lds, lane, EPW <= 16 ? lds + kRowsF4 * EPW : nullptr, BODY ? lds + (kRowsF4 + REX_PARK_F4) * EPW : nullptr};
+  const Lds<EPW, kLegF4, BODY> sm{lds, lane, EPW <= 16 ? lds + kRowsF4 * EPW : nullptr, BODY ? lds + (kRowsF4 + REX_PARK_F4) * EPW : nullptr, nullptr};
   typename ArmHook<EPW, ARM>::type armp = ArmHook<EPW, ARM>::make(lds, lane);
   const int nrec = (c.n_terrain > 0 ? c.n_terrain : 1) * c.n_mix;
   const int first = (int)blockIdx.x * EPW + lane;                       // the (terrain, task) record this lane group settles
