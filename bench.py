@@ -219,10 +219,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # average launch duration of the dominant kernel: two HIP events on the launch stream (RexBatchEnv launches on torch's
-    # current stream, so torch.cuda.Event records on that very stream) around m back-to-back launches -- the queue stays
-    # full, nothing else runs in between, so (t1 - t0) / m is the kernel's duration plus the few microseconds between two
-    # dependent launches.  The per-launch ring (rex_set_timing(2)) gives the spread (min).
+    # Launch duration of the dominant kernel, two ways, both on the launch stream and inside the timed regime:
+    #  * kernel_ms: device-side timestamps (rex_set_timing(3)): first-wave start to last-wave end of each of m back-to-back
+    #    launches, averaged -- the kernel alone, comparable with rocprofv3's kernel trace (profiles/);
+    #  * launch_ms: two HIP events around m back-to-back launches / m (RexBatchEnv launches on torch's current stream, so
+    #    torch.cuda.Event records on that very stream) -- the kernel plus the hand-over between two dependent dispatches.
     timed = env
     m = min(256, max(20, args.steps // 8))
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -231,12 +232,13 @@ def main():
         env.step(pool[k % 16])
     ev1.record(torch.cuda.current_stream(dev))
     ev1.synchronize()
-    kernel_ms = ev0.elapsed_time(ev1) / m
-    timed.set_timing(2)
+    launch_ms = ev0.elapsed_time(ev1) / m
+    timed.set_timing(3)
     for k in range(m):
         env.step(pool[k % 16])
     kms = sorted(timed.step_times_ms(m))
     timed.set_timing(False)
+    kernel_ms = sum(kms) / len(kms)
 
     # HBM bytes per launch as measured with rocprofv3 PMC passes of this same command (cannot be collected from inside
     # the process); null when no measurement of this workload is committed
@@ -295,7 +297,7 @@ def main():
                        "envs_total": total_envs, "parallelism": f"env-shards x{world} (no data-path collective)"},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "rex_step_kernel", "kernel_ms": kernel_ms, "kernel_ms_min": kms[0],
+                         "kernel": "rex_step_kernel", "kernel_ms": kernel_ms, "kernel_ms_min": kms[0], "launch_ms": launch_ms,
                          "algorithmic_bytes_per_env_step": algo_bytes,
                          "layout_bytes_per_env_step": layout_bytes(state_words, act_dim, obs_dim),
                          "note": "the fused step is bound by the VALU issue rate of one wave per SIMD through the sequential "

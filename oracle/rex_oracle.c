@@ -796,7 +796,7 @@ static void physics_substep(Phys* s, const real tau[NJ], real dt, int iterations
         cross3(aw, u, t);
         for (int k = 0; k < 3; ++k) dir[k] = cos(ang) * u[k] + sin(ang) * t[k];
         real P[3], n[3], h;
-        for (int k = 0; k < 3; ++k) P[k] = ce[k] + rad * dir[k];
+        for (int k = 0; k < 3; ++k) P[k] = a == 0 ? ce[k] - rad * inv * dv[k] : ce[k] + rad * dir[k];   /* a == 0: the lowest line itself */
         ground_query(ground, P[0], P[1], &h, n);
         real dist = (P[2] - h) * n[2];
         if (dist < P_BREAKING) {

@@ -196,6 +196,9 @@ struct DevCfg {
   // large batches: envs are regrouped into waves by the solver sweeps they needed in the previous step (a wave sweeps
   // until the slowest of its envs has converged): wave slot k works on env perm[k]; sweeps[i] = this step's count of env i
   const int32_t* perm; int32_t* sweeps;
+  // rex_set_timing(3): device-side launch duration -- every workgroup folds its start / end wall-clock tick (100 MHz
+  // constant clock, s_memrealtime) into clock[0] (min) / clock[1] (max); nullptr otherwise
+  unsigned long long* clock;
   float noise[5];            // observation_noise_stdev (rex.py:22,765-769): angles, velocities, torques, rpy, rpy rates
   int32_t noise_on;          // any of them > 0
   HfGeom geo;                // heightfield grid geometry
@@ -696,6 +699,7 @@ __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __r
   constexpr int kMotorF4 = (ARM && EPW <= 8) ? REX_MOTOR_PARK_F4 : 0;
   __shared__ float4 lds[(kRowsF4 + (EPW <= 16 ? REX_PARK_F4 : 0) + (BODY ? REX_BODY_F4 : 0) + kMotorF4) * EPW];
   REX_STAMP(t_kernel);
+  if (c.clock && threadIdx.x == 0) atomicMin(&c.clock[0], (unsigned long long)wall_clock64());
   const int lane = threadIdx.x;
   constexpr int LPE = EPW < 64 ? lanes_per_env(EPW) : 1;     // EPW <= 16: lane = LPE * slot + p (rex_device.h, group layout)
   const int slot = (lane / LPE) & (EPW - 1);
@@ -873,6 +877,7 @@ __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __r
       if (k < c.max_repeat) rex_substep(c_, e, i, live && k < c_.action_repeat, cmd, tau_obs, sm, ground, armp);
     }
   }
+  if (c.clock && threadIdx.x == 0) atomicMax(&c.clock[1], (unsigned long long)wall_clock64());
 #ifdef REX_PROF
   if (threadIdx.x == 0 && blockIdx.x < 1024) { g_prof[10 * blockIdx.x + 8] += clock64() - t_kernel; g_prof[10 * blockIdx.x + 9] += 1; }
 #endif
@@ -1044,6 +1049,7 @@ struct RexSim {
   int timing;
   int have_timing;
   // ring of event pairs around the last REX_TIMING_RING launches: per-launch durations without a host sync in between
+  unsigned long long* d_clock;   // [REX_TIMING_RING][2] device-side (min start, max end) ticks, rex_set_timing(3)
   int32_t* d_perm;   // regrouping (large batches only): wave slot -> env, and the per-env sweep counts it is sorted by
   int32_t* d_sweeps;
   hipEvent_t ring0[REX_TIMING_RING], ring1[REX_TIMING_RING];
@@ -1229,7 +1235,7 @@ int rex_create(const RexConfig* cfg, int device, float* d_state, void* stream, R
   d.pose_index = cfg->pose_index; d.pose_value = cfg->pose_value;
   d.range_normalize = cfg->range_normalize;
   d.terrain = nullptr; d.terrain_mid = nullptr; d.n_terrain = 0; d.body_params = nullptr;
-  d.perm = nullptr; d.sweeps = nullptr; s->d_perm = nullptr; s->d_sweeps = nullptr;
+  d.perm = nullptr; d.sweeps = nullptr; s->d_perm = nullptr; s->d_sweeps = nullptr; d.clock = nullptr; s->d_clock = nullptr;
   d.geo = rex::HfGeom{256, 20.0f, 20.0f, 127.5f, 127.5f, 254.999f, 254.999f}; d.hf_stride = 65536;   /* model/terrain.py:32-54 */
   d.init_z = cfg->init_height > 0.0f ? cfg->init_height : rex::kInitZ;
   d.noise_on = 0;
@@ -1345,6 +1351,7 @@ int rex_destroy(RexSim* s) {
   if (!s) return REX_OK;
   (void)hipSetDevice(s->device);
   (void)hipFree(s->d_snap);
+  if (s->d_clock) (void)hipFree(s->d_clock);
   if (s->d_perm) (void)hipFree(s->d_perm);
   if (s->d_sweeps) (void)hipFree(s->d_sweeps);
   (void)hipEventDestroy(s->ev0);
@@ -1383,7 +1390,14 @@ int rex_step(RexSim* s, const float* d_action, float* d_obs, float* d_reward, ui
     if (!s->ring0[k]) { HIPCHK(hipEventCreate(&s->ring0[k])); HIPCHK(hipEventCreate(&s->ring1[k])); }
     e0 = s->ring0[k]; e1 = s->ring1[k];
   }
-  if (s->timing) HIPCHK(hipEventRecord(e0, st));
+  if (s->timing == 3) {   // device-side timestamps: this launch's (min start, max end) slot, primed to (max, 0)
+    const int k = (int)(s->timed_steps % REX_TIMING_RING);
+    static const unsigned long long init[2] = {~0ull, 0ull};
+    HIPCHK(hipMemcpyAsync(s->d_clock + 2 * k, init, sizeof(init), hipMemcpyHostToDevice, st));
+    s->dev.clock = s->d_clock + 2 * k;
+    s->timed_steps++;
+  } else s->dev.clock = nullptr;
+  if (s->timing == 1 || s->timing == 2) HIPCHK(hipEventRecord(e0, st));
   launch_step(s, blocks, st, d_action, d_obs, d_reward, d_done, d_motor_cmd);
   {   // developer probe (tools/launch_gap.py): REX_STEP_REPEAT=R issues the launch R times back to back from C
     static const int repeat = getenv("REX_STEP_REPEAT") ? atoi(getenv("REX_STEP_REPEAT")) : 1;
@@ -1393,7 +1407,7 @@ int rex_step(RexSim* s, const float* d_action, float* d_obs, float* d_reward, ui
   if (s->d_perm)   // next step's grouping from this step's sweep counts (stream-ordered behind the step)
     hipLaunchKernelGGL(rex::rex_regroup_kernel, dim3(1), dim3(1024), 0, st, s->cfg.num_envs, (s->dev.max_repeat * s->dev.max_iterations + 63) / 64,
                        s->d_sweeps, s->d_perm);
-  if (s->timing) { HIPCHK(hipEventRecord(e1, st)); s->have_timing = 1; if (s->timing == 2) s->timed_steps++; }
+  if (s->timing == 1 || s->timing == 2) { HIPCHK(hipEventRecord(e1, st)); s->have_timing = 1; if (s->timing == 2) s->timed_steps++; }
   return REX_OK;
 }
 
@@ -1408,17 +1422,30 @@ int rex_get_sweeps(RexSim* s, int32_t* d_out, void* stream) {
 
 int rex_set_timing(RexSim* s, int enable) {
   if (!s) return fail(REX_EINVAL, "rex_set_timing: null sim%s", "");
-  s->timing = enable == 2 ? 2 : (enable ? 1 : 0);
+  s->timing = (enable == 2 || enable == 3) ? enable : (enable ? 1 : 0);
   s->have_timing = 0;
   s->timed_steps = 0;
+  if (s->timing == 3 && !s->d_clock) HIPCHK(hipMalloc(&s->d_clock, sizeof(unsigned long long) * 2 * REX_TIMING_RING));
   return REX_OK;
 }
 
 int rex_step_times_ms(RexSim* s, float* ms, int max_count) {
   if (!s || !ms || max_count <= 0) return fail(REX_EINVAL, "rex_step_times_ms: bad arguments%s", "");
-  if (s->timing != 2 || s->timed_steps == 0) return 0;
+  if ((s->timing != 2 && s->timing != 3) || s->timed_steps == 0) return 0;
   long long have = s->timed_steps < REX_TIMING_RING ? s->timed_steps : REX_TIMING_RING;
   int n = (int)(have < max_count ? have : max_count);
+  if (s->timing == 3) {
+    static unsigned long long ticks[2 * REX_TIMING_RING];
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(ticks, s->d_clock, sizeof(ticks), hipMemcpyDeviceToHost));
+    int khz = 100000;   // s_memrealtime: constant 100 MHz on gfx9
+    (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, s->device);
+    for (int j = 0; j < n; ++j) {
+      const int k = (int)((s->timed_steps - n + j) % REX_TIMING_RING);
+      ms[j] = (float)((double)(ticks[2 * k + 1] - ticks[2 * k]) / (double)khz);
+    }
+    return n;
+  }
   HIPCHK(hipEventSynchronize(s->ring1[(int)((s->timed_steps - 1) % REX_TIMING_RING)]));
   for (int j = 0; j < n; ++j) {   // oldest of the last n first
     const int k = (int)((s->timed_steps - n + j) % REX_TIMING_RING);

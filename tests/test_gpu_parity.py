@@ -167,7 +167,7 @@ def test_walk_ik_trajectory_rmse(torch):
         r = joint_rmse(product_state_to_numeric(env.state), orc.get_state())
         worst = np.maximum(worst, r)
     print("walk-ik 200-step joint RMSE vs f32 oracle: median %.3e max %.3e" % (np.median(worst), worst.max()))
-    assert np.median(worst) < 1e-3
+    assert np.median(worst) < 1e-4 and worst.max() < 5e-2      # measured 2e-6 / 1e-2 (profiles/r02_parity.json); BASELINE's bar: 1e-3
     env.close()
 
 
