@@ -13,6 +13,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("db")
     ap.add_argument("--skip", type=int, default=0)
+    ap.add_argument("--window", default=None, help="a:b -- steady-state columns over dispatches a..b-1 of every kernel instead of --skip")
     a = ap.parse_args()
     cur = sqlite3.connect(a.db).cursor()
     names = dict(cur.execute("select id, kernel_name from rocpd_info_kernel_symbol"))
@@ -24,7 +25,11 @@ def main():
     print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
     for kid, rows in sorted(per.items(), key=lambda kv: -sum(r[0] for r in kv[1])):
         d = [r[0] / 1e3 for r in rows]
-        st = d[a.skip:] if len(d) > a.skip else d
+        if a.window:
+            lo, hi = (int(v) for v in a.window.split(":"))
+            st = d[lo:hi] or d
+        else:
+            st = d[a.skip:] if len(d) > a.skip else d
         v, ag, sg, lds, scr = regs[kid]
         print(f"| `{names[kid][:90]}` | {len(d)} | {sum(d) / len(d):.1f} | {len(st)} | {sum(st) / len(st):.1f} | {min(st):.1f} | {max(st):.1f} | "
               f"{rows[-1][1]} | {rows[-1][2]} | {v} | {ag} | {sg} | {lds} | {scr} |")
