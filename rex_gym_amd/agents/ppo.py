@@ -417,9 +417,12 @@ if __name__ == "__main__":   # python -m rex_gym_amd.agents.ppo --task walk --en
     ap.add_argument("--task", default="walk"); ap.add_argument("--signal", default="ik")
     ap.add_argument("--envs", type=int, default=1024); ap.add_argument("--iterations", type=int, default=20)
     ap.add_argument("--max-length", type=int, default=500); ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--gait-clock-scale", type=float, default=1.0,
+                    help="wall-clock seconds per simulated second seen by GaitPlanner.loop (gait_planner.py:108-110)")
     a = ap.parse_args()
     # the reference trains through RangeNormalize + ClipAction (playground/trainer.py:48-52): actions in [-1, 1]
-    env = RexBatchEnv(a.envs, task=a.task, signal_type=a.signal, seed=a.seed, max_episode_steps=a.max_length, range_normalize=True)
+    env = RexBatchEnv(a.envs, task=a.task, signal_type=a.signal, seed=a.seed, max_episode_steps=a.max_length, range_normalize=True,
+                      gait_clock_scale=a.gait_clock_scale)
     agent = PPOAgent(a.envs, env.obs_dim, env.action_dim, PPOConfig(update_every=a.envs, max_length=a.max_length), seed=a.seed)
     for it in range(a.iterations):
         score, length = train(env, agent, a.max_length)

@@ -14,13 +14,20 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 
 
-def _rollout(n, base, steps, seed):
+def _rollout(n, base, steps, seed, mixed=False):
     import orclib
-    cfg = orclib.default_config("walk", "ik", n, seed=seed, env_index_base=base, auto_reset=1, max_episode_steps=6)
+    if mixed:   # BASELINE configs[4] shape: task drawn per env from its GLOBAL index, mass / friction drawn per reset
+        cfg = orclib.default_config("mixed", "ik", n, seed=seed, env_index_base=base, auto_reset=1, max_episode_steps=6, task_mix=0b111,
+                                    action_repeat=6, solver_iterations=60, mass_scale_lo=0.8, mass_scale_hi=1.2, friction_lo=0.25,
+                                    friction_hi=0.625)
+    else:
+        cfg = orclib.default_config("walk", "ik", n, seed=seed, env_index_base=base, auto_reset=1, max_episode_steps=6)
     env = orclib.OracleEnv(cfg, np.float32)
     obs0 = env.reset()
     rng = np.random.RandomState(42)
     acts = rng.uniform(-0.4, 0.4, (steps, 8, 2)).astype(np.float32)     # global action table for 8 envs
+    if mixed:
+        acts *= 0.025                                                    # inside every task's Box
     seg = {"obs": [], "reward": [], "done": [], "action": []}
     for t in range(steps):
         a = acts[t, base:base + n]
@@ -63,6 +70,20 @@ def test_two_rank_shards_match_single_rank_and_gather():
             assert got.shape[:2] == (8, 8)
             np.testing.assert_array_equal(got, ref[k].astype(np.float32), err_msg=f"rank {rank} {k}")
     assert ref["done"][5].all()   # episode limit 6 hit on every env, auto-reset drew new targets
+
+
+def test_mixed_task_shards_match_the_single_rank_batch():
+    """The mixed-task batch shards like any other: an env's task, its per-reset mass / friction draws and its episode
+    draws are keyed by the GLOBAL env index, so the two halves of an 8-env batch stepped as separate shards (what two ranks
+    do) reproduce the single batch bit for bit."""
+    sys.path.insert(0, HERE)
+    full_obs0, full, full_state = _rollout(8, 0, 8, seed=11, mixed=True)
+    for rank in (0, 1):
+        obs0, seg, state = _rollout(4, 4 * rank, 8, seed=11, mixed=True)
+        np.testing.assert_array_equal(obs0, full_obs0[4 * rank:4 * rank + 4])
+        for k in ("obs", "reward", "done"):
+            np.testing.assert_array_equal(seg[k], full[k][:, 4 * rank:4 * rank + 4], err_msg=k)
+        np.testing.assert_array_equal(state, full_state[:, 4 * rank:4 * rank + 4])
 
 
 def _ppo_worker(rank, world, port, q):
