@@ -85,6 +85,9 @@ def lib():
             raise RexSimError(
                 f"{path} is missing: build it with `python -m rex_gym_amd.build` (needs hipcc). "
                 "rex_gym_amd has no CPU fallback.")
+        # PyTorch first: it carries its own HIP runtime, and a process must not end up with two of them (the library would
+        # bind to the system one if it were loaded before torch, and the second runtime to start sees no device)
+        import torch  # noqa: F401
         l = ctypes.CDLL(path)
         for name, (argtypes, restype) in _SIGS.items():
             fn = getattr(l, name)  # AttributeError if the ABI header and the library disagree
