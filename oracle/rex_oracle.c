@@ -162,7 +162,8 @@ static real P_INERTIA_SCALE = 1;          /* rotational inertias of all links x 
 static real P_LEG_INERTIA_ADD = 0;        /* kg m^2 added to every leg link's principal inertias (rotor / armature) */
 static int P_TOE_MODE = 2;                /* toe manifold stand-in: 2 = both cylinder ends, 1 = the lower end only,
                                              4 = both ends + the arc points 0.3 rad before / behind the lowest line */
-static int P_LIMIT_EXACT = 0;             /* 1: joint-limit rows only once the bound is reached (Bullet's literal rule) */
+static int P_LIMIT_EXACT = 1;             /* 1: joint-limit rows only once the bound is reached (Bullet's literal rule; the default);
+                                             0: a predictive row from 0.15 rad before the bound (round 1's formulation) */
 static real P_BREAKING = CONTACT_BREAKING;
 static real P_MARGIN = (real)REX_COLLISION_MARGIN;
 static int P_FRICTION_DIRS = 2;           /* 1: btPlaneSpace1's first tangent only (no SOLVER_USE_2_FRICTION_DIRECTIONS) */
@@ -877,15 +878,15 @@ static void physics_substep(Phys* s, const real tau[NJ], real dt, int iterations
     if (DBG_STATS && npoint > toe_points) ++DBG_BODY_SUBSTEPS;
   }
   /* non-contact rows come first in every sweep (btMultiBodyConstraintSolver::solveSingleIteration): the URDF joint
-   * limits (btMultiBodyJointLimitConstraint, one unilateral row per bound).  Bullet creates both rows for every joint;
-   * a row whose bound is more than LIMIT_ACTIVATION away can never receive an impulse (|qd| <= 100 rad/s, dt = 1 ms),
-   * so only the near bound of a joint is instantiated. */
+   * limits (btMultiBodyJointLimitConstraint, one unilateral row per bound).  btMultiBodyJointLimitConstraint::
+   * createConstraintRows instantiates a bound's row only once the bound is reached (`if (penetration > 0) continue;`)
+   * and then pushes back through the ERP term; only the near bound of a joint can be. */
   for (int j = 0; j < NJ; ++j) {
     real lo_gap = s->q[j] - m_lower(j), hi_gap = m_upper(j) - s->q[j];
     int lower = lo_gap < hi_gap;
     real gap = lower ? lo_gap : hi_gap;
     if (gap >= LIMIT_ACTIVATION) continue;
-    if (P_LIMIT_EXACT && gap > 0) continue;   /* probe: btMultiBodyJointLimitConstraint skips a row while its bound is not reached */
+    if (P_LIMIT_EXACT && gap > 0) continue;   /* btMultiBodyJointLimitConstraint skips a row while its bound is not reached */
     Row* r = &rows[nrow++];
     real sgn = lower ? (real)1 : (real)-1;
     for (int k = 0; k < NDOF; ++k) r->J[k] = 0;

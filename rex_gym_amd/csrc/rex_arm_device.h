@@ -182,7 +182,7 @@ __device__ __forceinline__ unsigned arm_pass(const BaseKin& bk, const float* __r
     const float lo_gap = q[k] - (float)REXA_LOWER[k], hi_gap = (float)REXA_UPPER[k] - q[k];
     const bool lower = lo_gap < hi_gap;
     const float gap = lower ? lo_gap : hi_gap;
-    const bool act = gap < kLimitActivation;
+    const bool act = gap <= kLimitActivation;
     if (act) active |= 1u << k;
     float e[6], j[6], g[6];
 #pragma unroll

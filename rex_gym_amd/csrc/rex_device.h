@@ -64,7 +64,10 @@ constexpr float kAngDamp = 0.04f;
 constexpr float kMaxCoordVel = 100.0f;     // btMultiBody::m_maxCoordinateVelocity
 constexpr float kErp = 0.2f;               // btContactSolverInfo::m_erp2
 constexpr float kBreaking = 0.02f;         // contact breaking threshold
-constexpr float kLimitActivation = 0.15f;  // a joint bound further away cannot act within one step (|qd| dt <= 0.1)
+// btMultiBodyJointLimitConstraint::createConstraintRows instantiates a bound's row only once the bound is reached
+// (`if (penetration > 0) continue;`): a joint inside its range has no limit row, one at or beyond a bound is pushed back
+// through the ERP term
+constexpr float kLimitActivation = 0.0f;
 constexpr float kMu = 0.5f;                // toe 0.5 x plane 1.0
 constexpr float kInitZ = 0.21f;            // terrain.py:14-20 (default drop height; RexConfig.init_height overrides)
 constexpr float kToeRad = (float)(REX_TOE_RADIUS + REX_COLLISION_MARGIN);
@@ -598,20 +601,20 @@ __device__ __forceinline__ void leg_pass(int leg, const BaseKin& bk, const float
     }
   }
 
-  // --- joint-limit rows (btMultiBodyJointLimitConstraint): the near bound of each joint, active within
-  //     kLimitActivation; J = +-e_k on the leg's joints, so the whitened row is a column of G^-1 ---
+  // --- joint-limit rows (btMultiBodyJointLimitConstraint): the near bound of each joint, once reached
+  //     (kLimitActivation); J = +-e_k on the leg's joints, so the whitened row is a column of G^-1 ---
   const float qv[3] = {q1, q2, q3};
   bool near_any = false;
 #pragma unroll
   for (int k = 0; k < 3; ++k)
-    near_any |= fminf(qv[k] - (float)REX_LEG_LIMIT_LO[k], (float)REX_LEG_LIMIT_HI[k] - qv[k]) < kLimitActivation;
+    near_any |= fminf(qv[k] - (float)REX_LEG_LIMIT_LO[k], (float)REX_LEG_LIMIT_HI[k] - qv[k]) <= kLimitActivation;
   if (__builtin_amdgcn_ballot_w64(near_any) == 0) return;   // no env of this wave has this leg near a bound
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     const float lo_gap = qv[k] - (float)REX_LEG_LIMIT_LO[k], hi_gap = (float)REX_LEG_LIMIT_HI[k] - qv[k];
     const bool lower = lo_gap < hi_gap;
     const float gap = lower ? lo_gap : hi_gap;
-    const bool act = gap < kLimitActivation;
+    const bool act = gap <= kLimitActivation;
     if (act) active_mask |= 1u << (REX_NPOINT + 3 * leg + k);
     const float sgn = lower ? 1.0f : -1.0f;
     const float j1 = k == 0 ? sgn * gi1 : 0.0f;

@@ -24,7 +24,7 @@ from orclib import OracleEnv, default_config  # noqa: E402
 N_ENVS = 16
 STEPS = 2500
 
-DEFAULTS = dict(erp=0.2, slop=0.0, inertia_scale=1.0, leg_inertia_add=0.0, toe_mode=2, limit_exact=0, breaking=0.02,
+DEFAULTS = dict(erp=0.2, slop=0.0, inertia_scale=1.0, leg_inertia_add=0.0, toe_mode=2, limit_exact=1, breaking=0.02,
                 margin=0.001, friction_dirs=2, cone=0, gait_clock=1.0, mu=0.5, lin_damping=0.04, ang_damping=0.04,
                 joint_friction=0.0, body_contacts=0)
 
@@ -90,7 +90,7 @@ ROWS = [
     ("toe collision margin 0", dict(margin=0.0), {}),
     ("toe collision margin 4 mm", dict(margin=0.004), {}),
     ("contact breaking threshold 0 (penetrating points only)", dict(breaking=0.0), {}),
-    ("joint-limit rows only once violated (Bullet's literal rule)", dict(limit_exact=1), {}),
+    ("joint-limit rows from 0.15 rad before the bound (predictive) instead of once reached (Bullet's literal rule)", dict(limit_exact=0), {}),
     ("URDF joint friction honoured: 0.5 N m Coulomb on shoulder / foot joints", dict(joint_friction=0.5), {}),
     ("body-vs-ground box contacts on", dict(body_contacts=1), {}),
     ("solver: 10 sweeps", {}, dict(iters=10)),
