@@ -318,7 +318,10 @@ struct ArmChain {
   // ---- lane-distributed sweep (rex_device.h: pgs_dv): lane p owns arm component p (+ LPE) next to its share of y ----
   // An arm limit row is 16 floats: g' 0..5, j' 6..11, (invd target, invd, diag, 0); float 15 is the zero that the
   // lanes owning no component read.  The parked whitened arm velocity sits in floats 57..62 of the park chunks.
-  int oya[2], oaa[2];   // byte offsets from the LDS base of this lane's y / arm components in arm row 0
+  // This lane's slice of the six arm limit rows, read from LDS once per substep (as pgs_dv does for the contact rows):
+  // its components of the base part and of the arm part, the inverse diagonal, and -target in lane 0 of the group (the
+  // addend that makes the group sum vel - target).  Rows out of reach have invd = 0 and never move.
+  float rjy[6][2], rja[6][2], rki[6], rkt[6];
   float as_[2];
   static constexpr int kRowBytes = REX_ARM_ROW_F4 * EPW * 16;
   __device__ __forceinline__ int foff(int f) const { return ((REX_ARM_BASE_F4 + REX_ARM_PARK_F4 + (f >> 2)) * EPW + sma.slot) * 16 + (f & 3) * 4; }
@@ -330,32 +333,34 @@ struct ArmChain {
 #pragma unroll
     for (int i = 0; i < NY; ++i) {
       const int k = p + i * LPE;
-      oya[i] = foff(k < 6 ? k : 15);
-      oaa[i] = foff(k < 6 ? 6 + k : 15);
+      const int oy = foff(k < 6 ? k : 15), oa = foff(k < 6 ? 6 + k : 15);
       as_[i] = parkf(k < 6 ? 57 + k : 63);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) { rjy[r][i] = ldb(r * kRowBytes + oy); rja[r][i] = ldb(r * kRowBytes + oa); }
     }
 #pragma unroll
-    for (int k = 0; k < 6; ++k) lam_a[k] = 0.0f;
+    for (int r = 0; r < 6; ++r) {
+      const float4 c3 = sma.row(r, 3);                 // (invd * target, invd, diag, 0)
+      rki[r] = c3.y;
+      rkt[r] = (p == 0 && c3.y > 0.0f) ? -c3.x * __builtin_amdgcn_rcpf(c3.y) : 0.0f;
+      lam_a[r] = 0.0f;
+    }
   }
   template <int LPE, int NY>
   __device__ __forceinline__ void dv_sweep(float* ys, float& worst, float thr) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
       if (!((active_any >> k) & 1u)) continue;   // wave-uniform
-      float jy[NY], ja[NY];
+      float part = rkt[k];
 #pragma unroll
-      for (int i = 0; i < NY; ++i) { jy[i] = ldb(k * kRowBytes + oya[i]); ja[i] = ldb(k * kRowBytes + oaa[i]); }
-      const float4 c3 = sma.row(k, 3);
-      float part = 0.0f;
-#pragma unroll
-      for (int i = 0; i < NY; ++i) part = fmaf(jy[i], ys[i], fmaf(ja[i], as_[i], part));
-      const float vel = group_sum<LPE>(part);
-      const float nl = fmaxf(fmaf(-c3.y, vel, lam_a[k] + c3.x), 0.0f);
+      for (int i = 0; i < NY; ++i) part = fmaf(rjy[k][i], ys[i], fmaf(rja[k][i], as_[i], part));
+      const float sum = group_sum<LPE>(part);    // vel - target
+      const float nl = fmaxf(fmaf(-rki[k], sum, lam_a[k]), 0.0f);
       const float dl = nl - lam_a[k];
       lam_a[k] = nl;
-      worst = fmaxf(worst, fmaf(-thr, c3.y, fabsf(dl)));
+      worst = fmaxf(worst, fmaf(-thr, rki[k], fabsf(dl)));
 #pragma unroll
-      for (int i = 0; i < NY; ++i) { ys[i] = fmaf(jy[i], dl, ys[i]); as_[i] = fmaf(ja[i], dl, as_[i]); }
+      for (int i = 0; i < NY; ++i) { ys[i] = fmaf(rjy[k][i], dl, ys[i]); as_[i] = fmaf(rja[k][i], dl, as_[i]); }
     }
   }
   template <int LPE>
