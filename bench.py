@@ -146,6 +146,7 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-walking-workload", action="store_true", help="skip the secondary gait-clock-1.5 measurement (profiling runs)")
+    ap.add_argument("--no-stagger", action="store_true", help="developer A/B runs only: pre-roll without the staggered resets")
     # the default line is BASELINE.json configs[1]; the other supported configs can be timed with these
     ap.add_argument("--task", default="walk", choices=["walk", "gallop", "turn", "poses", "standup"])
     ap.add_argument("--signal", default="ik", choices=["ik", "ol"])
@@ -198,6 +199,13 @@ def main():
     # the solver converges quickly; the number reported is the steady state a training run sees
     for k in range(PREROLL_STEPS):
         env.step(pool[k % 16])
+        if k % 50 == 0 and k < PREROLL_STEPS - 200 and not args.mixed and not args.no_stagger:
+            # stagger the episodes: half the envs (those that walk backwards) never fall, and started together they would
+            # all run into the 2 000-step cap in the same step, stand up together, fall together ... -- a load that swings
+            # by 30 % with a 2 000-step period.  Resetting a random 1 / 32 of the batch every 50 pre-roll steps spreads the
+            # episode ages, as a training run that has been going for a while has them.
+            idx = torch.randperm(n, device=dev, generator=gen)[: max(1, n // 32)].to(torch.int32)
+            env.reset(idx)
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -265,6 +273,8 @@ def main():
         env2.reset()
         for k in range(PREROLL_STEPS + args.warmup):
             env2.step(pool[k % 16])
+            if k % 50 == 0 and k < PREROLL_STEPS - 200:
+                env2.reset(torch.randperm(n, device=dev, generator=gen)[: max(1, n // 32)].to(torch.int32))
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
         for k in range(args.steps):
@@ -292,8 +302,8 @@ def main():
                                    f"{'flat plane' if args.terrain == 'plane' else 'random heightfield pool'}, {args.mark} mark, "
                                    f"dt 1 ms x {env.config.action_repeat} substeps, <= {env.config.solver_iterations} PGS sweeps "
                                    "(Bullet residual threshold 1e-7), auto-reset, episode cap 2000, uniform random actions "
-                                   f"over the env's action Box; {PREROLL_STEPS} untimed pre-roll steps before --warmup (steady "
-                                   "episode-phase mix)",
+                                   f"over the env's action Box; {PREROLL_STEPS} untimed pre-roll steps with staggered resets before --warmup "
+                                   "(stationary episode-age mix)",
                        "envs_total": total_envs, "parallelism": f"env-shards x{world} (no data-path collective)"},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,

@@ -5,7 +5,7 @@ import subprocess
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
-LIB_PATH = os.path.join(PKG_DIR, "librexsim_hip.so")
+LIB_PATH = os.environ.get("REX_LIB_PATH") or os.path.join(PKG_DIR, "librexsim_hip.so")   # REX_LIB_PATH: developer A/B builds
 SOURCES = ["rexsim.hip"]
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h"))   # every header rexsim.hip can include
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-fvisibility=hidden"]

@@ -874,7 +874,7 @@ __device__ __forceinline__ void body_row(const SM& sm, const LN& ln, int bodyoff
   if (leg >= 0) zs[leg] = fmaf(jz, dl, zs[leg]);
 }
 
-template <int LPE, class SM, class ARMP>
+template <int LPE, bool LANECAP, class SM, class ARMP>
 __device__ __forceinline__ void pgs_dv(const SM& sm, ARMP& armp, PgsX& x, int p, const bool (&lim)[4], bool any_contact,
                                        unsigned bgroups, float mu, int iterations, int lane_iterations, float thr, int& nsweeps, int& lane_sweeps) {
   constexpr int EPW = SM::kEpw, NY = (6 + LPE - 1) / LPE;
@@ -926,6 +926,7 @@ __device__ __forceinline__ void pgs_dv(const SM& sm, ARMP& armp, PgsX& x, int p,
     Jz[r] = ln.ld(sm, r * kRow + ln.oz);
     Ki[r] = sm.rowf(r, 10);
     // chunk 2 .y holds invd * target; rows out of reach have invd = 0 and never move, whatever their target
+    // (storing the plain target instead, to save this reciprocal, measured 1.7 % SLOWER: scheduling)
     Kt[r] = (p == 0 && Ki[r] > 0.0f) ? -sm.rowf(r, 9) * __builtin_amdgcn_rcpf(Ki[r]) : 0.0f;
   }
 
@@ -1018,7 +1019,9 @@ __device__ __forceinline__ void pgs_dv(const SM& sm, ARMP& armp, PgsX& x, int p,
           }
         }
       }
-      running = worst > 0.0f && it + 1 < lane_iterations;
+      // (the per-lane cap is compiled in for mixed-task batches only: even as a scalar condition it lengthens the loop's
+      // back edge enough to cost 2.3 % of a step)
+      running = LANECAP ? (worst > 0.0f && it + 1 < lane_iterations) : worst > 0.0f;
     }
     if (__builtin_amdgcn_ballot_w64(running) == 0) break;
   }
@@ -1053,7 +1056,7 @@ __device__ long long g_prof[10 * 1024];  // per block: cycle counters of the sec
 #else
 #define REX_STAMP(var)
 #endif
-template <class SM, class ARMP>
+template <bool LANECAP, class SM, class ARMP>
 __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float dt, int iterations, int lane_iterations,
                                                 float sqrt_res_thr, const SM& sm, const Ground& ground, ARMP& armp, int& lane_sweeps) {
   // lane_sweeps: += the solver sweeps THIS env ran (the host regroups large batches by it, rex_regroup_kernel)
@@ -1333,7 +1336,7 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
     if (pl == 0) sm.parkf(REX_PARK_CPL, 0) = 0.0f;
     mirror_sync();
     const bool lim[4] = {lim0, lim1, lim2, lim3};
-    pgs_dv<LPE>(sm, armp, x, pl, lim, any0 || any1 || any2 || any3, bgroups, ground.mu, iterations, lane_iterations, sqrt_res_thr, nsweeps, lane_sweeps);
+    pgs_dv<LPE, LANECAP>(sm, armp, x, pl, lim, any0 || any1 || any2 || any3, bgroups, ground.mu, iterations, lane_iterations, sqrt_res_thr, nsweeps, lane_sweeps);
   } else {
     // one env per lane (EPW = 64): every lane carries the whole of x, row by row from LDS
     bool running = true;
@@ -1355,7 +1358,7 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
         if (any1) pgs_leg_friction<1>(sm, x, lam, worst, ground.mu);
         if (any2) pgs_leg_friction<2>(sm, x, lam, worst, ground.mu);
         if (any3) pgs_leg_friction<3>(sm, x, lam, worst, ground.mu);
-        running = worst > sqrt_res_thr && it + 1 < lane_iterations;
+        running = LANECAP ? (worst > sqrt_res_thr && it + 1 < lane_iterations) : worst > sqrt_res_thr;
       }
       if (__builtin_amdgcn_ballot_w64(running) == 0) break;
     }

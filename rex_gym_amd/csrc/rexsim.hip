@@ -323,7 +323,7 @@ __device__ __forceinline__ void receive_observation(const DevCfg& c, EnvState& e
 }
 
 // Rex.ApplyAction + stepSimulation + ReceiveObservation (rex.py:158-163, 568-641).
-template <class SM, class ARMP>
+template <bool LANECAP, class SM, class ARMP>
 __device__ __forceinline__ void rex_substep(const DevCfg& c, EnvState& e, int i, bool live, float* cmd, float* tau_obs,
                                             const SM& sm, const Ground& ground, ARMP& armp) {
   constexpr int NM = ARMP::NM;
@@ -364,7 +364,7 @@ __device__ __forceinline__ void rex_substep(const DevCfg& c, EnvState& e, int i,
     }
     asm volatile("" ::: "memory");
   }
-  physics_substep(e.ph, tau, c.dt, c.max_iterations, c.iterations, c.res_thr, sm, ground, armp, e.sweeps);
+  physics_substep<LANECAP>(e.ph, tau, c.dt, c.max_iterations, c.iterations, c.res_thr, sm, ground, armp, e.sweeps);
   if constexpr (kPark) {
     asm volatile("" ::: "memory");
 #pragma unroll
@@ -866,7 +866,7 @@ __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __r
   };
 
   if constexpr (!MIXED) {
-    for (int k = 0; k < c.action_repeat; ++k) rex_substep(c, e, i, live, cmd, tau_obs, sm, ground, armp);   // Rex.Step
+    for (int k = 0; k < c.action_repeat; ++k) rex_substep<false>(c, e, i, live, cmd, tau_obs, sm, ground, armp);   // Rex.Step
     epilogue(live);
   } else {
     // Rex.Step of tasks with different action_repeat in one wave: every lane runs max_repeat substeps (the substep is
@@ -874,7 +874,7 @@ __global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __r
     // before the extra substeps, whose results it never stores
     for (int k = 0; k <= c.max_repeat; ++k) {
       if (k == c_.action_repeat) epilogue(live);
-      if (k < c.max_repeat) rex_substep(c_, e, i, live && k < c_.action_repeat, cmd, tau_obs, sm, ground, armp);
+      if (k < c.max_repeat) rex_substep<true>(c_, e, i, live && k < c_.action_repeat, cmd, tau_obs, sm, ground, armp);
     }
   }
   if (c.clock && threadIdx.x == 0) atomicMax(&c.clock[1], (unsigned long long)wall_clock64());
@@ -938,10 +938,10 @@ __global__ __launch_bounds__(REX_WAVE) void rex_settle_kernel(DevCfg c, float* _
     }
 #pragma unroll
     for (int j = 0; j < 12; ++j) cmd[j] = pose_stand(j);
-    for (int k = 0; k < 100; ++k) rex_substep(cs, e, t, keeps, cmd, tau_obs, sm, ground, armp);   // rex.py:315-318
+    for (int k = 0; k < 100; ++k) rex_substep<false>(cs, e, t, keeps, cmd, tau_obs, sm, ground, armp);   // rex.py:315-318
 #pragma unroll
     for (int j = 0; j < 12; ++j) cmd[j] = reset_pose(c, j);
-    for (int k = 0; k < c.reset_substeps; ++k) rex_substep(cs, e, t, keeps, cmd, tau_obs, sm, ground, armp);   // rex.py:319-322
+    for (int k = 0; k < c.reset_substeps; ++k) rex_substep<false>(cs, e, t, keeps, cmd, tau_obs, sm, ground, armp);   // rex.py:319-322
   }
   receive_observation<NM>(cs, e, t, keeps, tau_obs);                                                           // rex.py:323
   if (!cs.hist) e.hist = 0u;
@@ -1390,12 +1390,9 @@ int rex_step(RexSim* s, const float* d_action, float* d_obs, float* d_reward, ui
     if (!s->ring0[k]) { HIPCHK(hipEventCreate(&s->ring0[k])); HIPCHK(hipEventCreate(&s->ring1[k])); }
     e0 = s->ring0[k]; e1 = s->ring1[k];
   }
-  if (s->timing == 3) {   // device-side timestamps: this launch's (min start, max end) slot, primed to (max, 0)
-    const int k = (int)(s->timed_steps % REX_TIMING_RING);
-    static const unsigned long long init[2] = {~0ull, 0ull};
-    HIPCHK(hipMemcpyAsync(s->d_clock + 2 * k, init, sizeof(init), hipMemcpyHostToDevice, st));
-    s->dev.clock = s->d_clock + 2 * k;
-    s->timed_steps++;
+  if (s->timing == 3 && s->timed_steps < REX_TIMING_RING) {   // device-side timestamps: this launch's (min start, max end) slot
+    s->dev.clock = s->d_clock + 2 * s->timed_steps;           // (all slots were primed by rex_set_timing: nothing is copied per
+    s->timed_steps++;                                         // launch, the queue stays as full as in an untimed run)
   } else s->dev.clock = nullptr;
   if (s->timing == 1 || s->timing == 2) HIPCHK(hipEventRecord(e0, st));
   launch_step(s, blocks, st, d_action, d_obs, d_reward, d_done, d_motor_cmd);
@@ -1425,7 +1422,13 @@ int rex_set_timing(RexSim* s, int enable) {
   s->timing = (enable == 2 || enable == 3) ? enable : (enable ? 1 : 0);
   s->have_timing = 0;
   s->timed_steps = 0;
-  if (s->timing == 3 && !s->d_clock) HIPCHK(hipMalloc(&s->d_clock, sizeof(unsigned long long) * 2 * REX_TIMING_RING));
+  if (s->timing == 3) {   // the next REX_TIMING_RING launches are timed on the device; prime their (min, max) slots
+    if (!s->d_clock) HIPCHK(hipMalloc(&s->d_clock, sizeof(unsigned long long) * 2 * REX_TIMING_RING));
+    static unsigned long long init[2 * REX_TIMING_RING];
+    for (int k = 0; k < REX_TIMING_RING; ++k) { init[2 * k] = ~0ull; init[2 * k + 1] = 0ull; }
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(s->d_clock, init, sizeof(init), hipMemcpyHostToDevice));
+  }
   return REX_OK;
 }
 
@@ -1441,7 +1444,7 @@ int rex_step_times_ms(RexSim* s, float* ms, int max_count) {
     int khz = 100000;   // s_memrealtime: constant 100 MHz on gfx9
     (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, s->device);
     for (int j = 0; j < n; ++j) {
-      const int k = (int)((s->timed_steps - n + j) % REX_TIMING_RING);
+      const int k = (int)(s->timed_steps - n + j);
       ms[j] = (float)((double)(ticks[2 * k + 1] - ticks[2 * k]) / (double)khz);
     }
     return n;
@@ -1504,6 +1507,10 @@ REX_API int rex_debug_prof(long long* out, int reset) {
     else REX_LAUNCH_STEP(16, ARM, MIXED, BODY);                                       \
   } while (0)
 static void launch_step(RexSim* s, int blocks, hipStream_t st, const float* a, float* o, float* r, uint8_t* d, float* m) {
+#ifdef REX_FAST_BUILD   /* developer A/B builds: the 4-envs-per-wave base kernel only */
+  REX_LAUNCH_STEP(4, false, false, false);
+  return;
+#else
   const bool arm = s->cfg.mark == REX_MARK_ARM;
   if (s->cfg.task == REX_TASK_MIXED) {   // lane groups only (rex_create caps the envs per wave at 16)
     if (arm) REX_LAUNCH_BY_EPW(true, true, false); else REX_LAUNCH_BY_EPW(false, true, false);
@@ -1515,8 +1522,13 @@ static void launch_step(RexSim* s, int blocks, hipStream_t st, const float* a, f
     if (s->epw == 64) REX_LAUNCH_STEP(64, false, false, false);
     else REX_LAUNCH_BY_EPW(false, false, false);
   }
+#endif
 }
 static void launch_settle(RexSim* s, int nrec, hipStream_t st, float* snap) {
+#ifdef REX_FAST_BUILD
+  hipLaunchKernelGGL((rex::rex_settle_kernel<false, false>), dim3((nrec + REX_WAVE - 1) / REX_WAVE), dim3(REX_WAVE), 0, st, s->dev, snap);
+  return;
+#endif
   const bool arm = s->cfg.mark == REX_MARK_ARM, body = s->cfg.body_contacts != 0;
   if (arm && body) hipLaunchKernelGGL((rex::rex_settle_kernel<true, true>), dim3((nrec + 15) / 16), dim3(REX_WAVE), 0, st, s->dev, snap);
   else if (arm) hipLaunchKernelGGL((rex::rex_settle_kernel<true, false>), dim3((nrec + 15) / 16), dim3(REX_WAVE), 0, st, s->dev, snap);
