@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define REX_ABI_VERSION 3
+#define REX_ABI_VERSION 4
 #define REX_API __attribute__((visibility("default")))
 
 /* tasks (reference env classes) */
@@ -169,6 +169,12 @@ typedef struct RexConfig {
   /* Height the robot is dropped from at reset (ROBOT_INIT_POSITION[terrain_id][2], model/terrain.py:14-20: 0.21 on
      plane / random / maze, 0.85 on mounts, 1.98 on hills).  0 means 0.21. */
   float   init_height;
+  /* ---- ABI 4 ---- */
+  /* Rex(on_rack=True) (model/rex.py:269-287, rex_gym_env.py:140): the debug mode that hangs the robot on a rack --
+     loadURDF(useFixedBase=True) at INIT_RACK_POSITION = [0, 0, 1].  The base neither moves nor turns, the legs swing
+     under gravity and the motors; the reset pose is [0, 0, 1] (init_height is ignored) and RexTurnEnv starts at its
+     fixed debug yaw 2.1 (turn_env.py:140-143). */
+  int32_t on_rack;
 } RexConfig;
 
 typedef struct RexSim RexSim;

@@ -422,6 +422,7 @@ typedef struct {
   real S[NB][3];       /* joint axis of body i in its own frame (motion subspace = [S; 0]) */
   real L0[6][6];       /* Cholesky factor of the base articulated inertia */
   real a[NB][6];
+  int fixed_base;      /* loadURDF(useFixedBase=True) (on_rack, rex.py:269-287): btMultiBody::m_fixedBase */
 } Aba;
 
 static void cross3(const real a[3], const real b[3], real o[3]) {
@@ -589,7 +590,12 @@ static void aba_forward(const Phys* s, const real tau[NJ], Aba* A, real qdd[NJ],
   chol6(A->IA[0], A->L0);
   real nb[6];
   for (int k = 0; k < 6; ++k) nb[k] = -A->pA[0][k];
-  chol6_solve(A->L0, nb, A->a[0]); /* acceleration relative to free fall (gravity handled as a field) */
+  if (A->fixed_base) {   /* the base does not accelerate: relative to free fall it moves up at g */
+    const real gup[3] = {0, 0, -GRAVITY_Z};
+    A->a[0][0] = A->a[0][1] = A->a[0][2] = 0;
+    matTvec3(A->Rw[0], gup, A->a[0] + 3);
+  } else
+    chol6_solve(A->L0, nb, A->a[0]); /* acceleration relative to free fall (gravity handled as a field) */
   for (int i = 1; i < NB; ++i) {
     int p = m_parent(i);
     mat6vec(A->X[i], A->a[p], A->a[i]);
@@ -605,6 +611,7 @@ static void aba_forward(const Phys* s, const real tau[NJ], Aba* A, real qdd[NJ],
   matvec3(A->Rw[0], A->a[0], wdot_w);
   matvec3(A->Rw[0], al, vdot_w);
   vdot_w[2] += GRAVITY_Z;
+  if (A->fixed_base) for (int k = 0; k < 3; ++k) wdot_w[k] = vdot_w[k] = 0;
 }
 
 /* unit torque impulse on joint jbody-1 (between body jbody and its parent) -> generalized velocity change */
@@ -621,7 +628,8 @@ static void impulse_response_joint(const Aba* A, int jbody, real out[NDOF]) {
   }
   real nb[6];
   for (int k = 0; k < 6; ++k) nb[k] = -pA[0][k];
-  chol6_solve(A->L0, nb, da[0]);
+  if (A->fixed_base) memset(da[0], 0, sizeof(da[0]));
+  else chol6_solve(A->L0, nb, da[0]);
   for (int k = 0; k < 6; ++k) out[k] = da[0][k];
   for (int i = 1; i < NB; ++i) {
     int p = m_parent(i);
@@ -648,7 +656,8 @@ static void impulse_response_at(const Aba* A, int kbody, const real fk[6], real 
   }
   real nb[6];
   for (int k = 0; k < 6; ++k) nb[k] = -pA[0][k];
-  chol6_solve(A->L0, nb, da[0]);
+  if (A->fixed_base) memset(da[0], 0, sizeof(da[0]));
+  else chol6_solve(A->L0, nb, da[0]);
   for (int k = 0; k < 6; ++k) out[k] = da[0][k];
   for (int i = 1; i < NB; ++i) {
     int p = m_parent(i);
@@ -669,7 +678,7 @@ static void impulse_response_at(const Aba* A, int kbody, const real fk[6], real 
 #define HF_INV_CELL ((real)20.0)    /* 1 / HF_CELL: written as a product on both sides (oracle and kernels) */
 typedef struct { int nx, ny; real inv_cx, inv_cy, off_x, off_y, max_x, max_y; } HfGeom;   /* grid geometry of a heightfield pool */
 static const HfGeom HF_RANDOM = {HF_N, HF_N, (real)20.0, (real)20.0, (real)127.5, (real)127.5, (real)254.999, (real)254.999};   /* model/terrain.py:32-54 */
-typedef struct { const float* h; real mid; real base_mass_scale, leg_mass_scale, mu; int has_params; int body_contacts; HfGeom geo; } Ground;
+typedef struct { const float* h; real mid; real base_mass_scale, leg_mass_scale, mu; int has_params; int body_contacts; HfGeom geo; int fixed_base; } Ground;
 
 static void ground_query(const Ground* g, real x, real y, real* height, real n[3]) {
   n[0] = 0; n[1] = 0; n[2] = 1; *height = 0;
@@ -750,6 +759,7 @@ static void physics_substep(Phys* s, const real tau[NJ], real dt, int iterations
   real mu = FRICTION_MU;
   MASS_SCALE_BASE = 1; MASS_SCALE_LEG = 1;
   if (ground && ground->has_params) { MASS_SCALE_BASE = ground->base_mass_scale; MASS_SCALE_LEG = ground->leg_mass_scale; mu = ground->mu; }
+  A.fixed_base = ground && ground->fixed_base;
   aba_forward(s, tau, &A, qdd, wdot, vdot);
   /* v <- v + dt a  (btMultiBodyDynamicsWorld::solveConstraints, before the constraint solve) */
   for (int k = 0; k < 3; ++k) { s->angvel[k] += dt * wdot[k]; s->linvel[k] += dt * vdot[k]; }
@@ -1096,7 +1106,7 @@ static int terrain_index(const Orc* o, int idx, int episode) {
   return (int)(((uint32_t)(o->cfg.env_index_base + idx) + 977u * (uint32_t)episode) % (uint32_t)o->n_terrain);
 }
 static Ground env_ground(const Orc* o, int idx, int episode) {
-  Ground g = {0, 0, 1, 1, FRICTION_MU, 0, o->cfg.body_contacts, o->geo};
+  Ground g = {0, 0, 1, 1, FRICTION_MU, 0, o->cfg.body_contacts, o->geo, o->cfg.on_rack};
   if (o->body_params) {
     int n = o->cfg.num_envs;
     g.has_params = 1; g.base_mass_scale = (real)o->body_params[idx]; g.leg_mass_scale = (real)o->body_params[n + idx];
@@ -1227,13 +1237,15 @@ static void rex_substep(const RexConfig* c, Env* e, const real cmd[NJ], const Gr
   receive_observation(c, e);
 }
 
+/* reset height: INIT_RACK_POSITION (rex.py:11) on the rack, else ROBOT_INIT_POSITION[terrain] (terrain.py:14-20) */
+static real init_z(const RexConfig* c) { return c->on_rack ? (real)1 : c->init_height > 0 ? cfgf(c->init_height) : ROBOT_INIT_Z; }
 static void settle(Orc* o, Env* e, const Ground* ground, const RexConfig* cfgp) {
   (void)o;
   real (*hist)[HIST_WORDS] = e->hist;     /* the snapshot keeps its own ring when a latency is configured */
   memset(e, 0, sizeof(*e));
   if (!hist && (cfgp->pd_latency > 0 || cfgp->control_latency > 0)) hist = calloc(REX_HISTORY_LEN, sizeof(real[HIST_WORDS]));
   e->hist = hist;
-  e->ph.pos[2] = cfgp->init_height > 0 ? cfgf(cfgp->init_height) : ROBOT_INIT_Z;
+  e->ph.pos[2] = init_z(cfgp);
   e->ph.quat[3] = 1;
   full_command(POSE_STAND, e->ph.q); /* ResetPose: INIT_POSES[pose_id='stand'] (+ _ResetArmMotors: ARM_POSES['rest'], rex.py:395-400) */
   e->motor_enabled = (1u << NJ) - 1;
@@ -1321,11 +1333,11 @@ static void env_reset(Orc* o, int idx) {
   }
   if (c->task == REX_TASK_TURN) {                                               /* turn_env.py:129-160 */
     real tgt = (c->orient_fixed & 1) ? cfgf(c->target_orient) : (real)fmaf(5.8f, u01(ctr[1]), 0.2f);
-    real ini = (c->orient_fixed & 2) ? cfgf(c->init_orient) : (real)fmaf(5.8f, u01(ctr[2]), 0.2f);
+    real ini = c->on_rack ? cfgf(2.1f) : (c->orient_fixed & 2) ? cfgf(c->init_orient) : (real)fmaf(5.8f, u01(ctr[2]), 0.2f);   /* turn_env.py:140-143 */
     e->target = tgt; e->aux = ini;
     real rpy[3] = {0, 0, ini};
     euler_to_quat(rpy, e->ph.quat);                                             /* resetBasePositionAndOrientation */
-    e->ph.pos[0] = 0; e->ph.pos[1] = 0; e->ph.pos[2] = c->init_height > 0 ? cfgf(c->init_height) : ROBOT_INIT_Z;
+    e->ph.pos[0] = 0; e->ph.pos[1] = 0; e->ph.pos[2] = init_z(c);
   }
   /* the reference's deque is not touched by reset() after Rex.Reset: it holds the last 100 observations of the reset
    * motion (the newest twice, rex.py:323), and the turn env's teleport (turn_env.py:158-159) happens behind its back --
@@ -1664,7 +1676,7 @@ ORC_API void* orc_create(const RexConfig* cfg) {
     for (int t = 0; t < 5; ++t) if ((cfg->task_mix >> t) & 1) o->mix_task[o->n_mix++] = t;
   }
   o->geo = HF_RANDOM;
-  Ground g0 = {0, 0, 1, 1, FRICTION_MU, 0, cfg->body_contacts, HF_RANDOM};
+  Ground g0 = {0, 0, 1, 1, FRICTION_MU, 0, cfg->body_contacts, HF_RANDOM, cfg->on_rack};
   for (int k = 0; k < o->n_mix; ++k) { RexConfig ct = task_cfg(o, o->mix_task[k]); settle(o, &o->snapshot[k], &g0, &ct); }
   return o;
 }
@@ -1695,7 +1707,7 @@ static void install_terrain(Orc* o, const float* heights, const float* mids, int
 #endif
   for (int r = 0; r < k * o->n_mix; ++r) {
     int t = r / o->n_mix;
-    Ground g = {o->heights + (size_t)t * per, (real)o->mids[t], 1, 1, FRICTION_MU, 0, o->cfg.body_contacts, o->geo};
+    Ground g = {o->heights + (size_t)t * per, (real)o->mids[t], 1, 1, FRICTION_MU, 0, o->cfg.body_contacts, o->geo, o->cfg.on_rack};
     RexConfig ct = task_cfg(o, o->mix_task[r % o->n_mix]);
     settle(o, &o->terrain_snapshot[r], &g, &ct);
   }

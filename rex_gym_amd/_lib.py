@@ -12,7 +12,7 @@ SIGNALS = {"ik": 0, "ol": 1}
 MARKS = {"base": 0, "arm": 1}
 STATE_WORDS = 54      # mark 'base'; rex_state_words(cfg) for the others
 NUM_MOTORS = 12       # mark 'base'; rex_num_motors(cfg) for the others
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class RexConfig(ctypes.Structure):
@@ -31,7 +31,7 @@ class RexConfig(ctypes.Structure):
         ("mark", ctypes.c_int32),
         ("gait_clock_scale", ctypes.c_float), ("body_contacts", ctypes.c_int32), ("noise_stdev", ctypes.c_float * 5),
         ("task_mix", ctypes.c_int32), ("mass_scale_lo", ctypes.c_float), ("mass_scale_hi", ctypes.c_float),
-        ("friction_lo", ctypes.c_float), ("friction_hi", ctypes.c_float), ("init_height", ctypes.c_float),
+        ("friction_lo", ctypes.c_float), ("friction_hi", ctypes.c_float), ("init_height", ctypes.c_float), ("on_rack", ctypes.c_int32),
     ]
 
 

@@ -205,7 +205,11 @@ struct Ground {
   // inertia tensors computed at load time; plus the foot friction coefficient)
   float base_mass_scale, leg_mass_scale, mu;
   HfGeom geo;
+  // on_rack (loadURDF(useFixedBase=True), rex.py:269-287): kRackAnchor added to the mass and the principal inertias of the
+  // base block -- the base's share of every velocity change becomes 1e-9 of what it was, and the integrator drops it; 0 = free base
+  float anchor = 0.0f;
 };
+constexpr float kRackAnchor = 1.0e9f;
 // (every division by the cell size is a multiplication by its inverse, here and in the oracle)
 __device__ __forceinline__ void ground_query(const Ground& g, float x, float y, float& height, f3& n) {
   n = f3{0.f, 0.f, 1.f}; height = 0.0f;
@@ -1095,6 +1099,7 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
     acc.N = cross(bk.w, Iw) + da * Iw;
     acc.F = mk(0.f, 0.f, mbase * kGravity) + (mbase * dl) * bk.v;
   }
+  acc.m += ground.anchor; acc.Io.xx += ground.anchor; acc.Io.yy += ground.anchor; acc.Io.zz += ground.anchor;
 
   unsigned active = 0;
   PgsX x;
@@ -1408,10 +1413,11 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
     }
   }
   armp.back(nu, s);
+  const float free_base = ground.anchor == 0.0f ? 1.0f : 0.0f;   // a fixed base keeps zero velocity exactly
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    s.ang[k] = clampf(nu[k], -kMaxCoordVel, kMaxCoordVel);
-    s.lin[k] = clampf(nu[3 + k], -kMaxCoordVel, kMaxCoordVel);
+    s.ang[k] = free_base * clampf(nu[k], -kMaxCoordVel, kMaxCoordVel);
+    s.lin[k] = free_base * clampf(nu[3 + k], -kMaxCoordVel, kMaxCoordVel);
   }
   // semi-implicit Euler with the NEW velocities
 #pragma unroll

@@ -204,6 +204,7 @@ struct DevCfg {
   HfGeom geo;                // heightfield grid geometry
   int32_t hf_stride;         // floats per field of the pool
   float init_z;              // drop height of the reset (terrain.py:14-20)
+  float anchor;              // on_rack: rex::kRackAnchor, else 0
   float obs_hi_ang, obs_hi_rate;
 };
 
@@ -282,7 +283,7 @@ __device__ __forceinline__ int terrain_index(const DevCfg& c, int gidx, int epis
   return (int)(((uint32_t)gidx + 977u * (uint32_t)episode) % (uint32_t)c.n_terrain);
 }
 __device__ __forceinline__ Ground env_ground(const DevCfg& c, int i, int gidx, int episode) {
-  Ground g{nullptr, 0.0f, 1.0f, 1.0f, kMu, c.geo};
+  Ground g{nullptr, 0.0f, 1.0f, 1.0f, kMu, c.geo, c.anchor};
   if (c.body_params) {
     g.base_mass_scale = c.body_params[i]; g.leg_mass_scale = c.body_params[(size_t)c.n + i]; g.mu = c.body_params[2 * (size_t)c.n + i];
   }
@@ -901,7 +902,7 @@ __global__ __launch_bounds__(REX_WAVE) void rex_settle_kernel(DevCfg c, float* _
   const int rec = (threadIdx.x & (LPE - 1)) == 0 ? first : nrec;        // one lane of the group stores it
   const int t = first < nrec ? first : nrec - 1;
   const int terr = t / c.n_mix, slot = t % c.n_mix;
-  Ground ground{nullptr, 0.0f, 1.0f, 1.0f, kMu, c.geo};
+  Ground ground{nullptr, 0.0f, 1.0f, 1.0f, kMu, c.geo, c.anchor};
   if (c.n_terrain > 0) { ground.h = c.terrain + (size_t)terr * c.hf_stride; ground.mid = c.terrain_mid[terr]; }
   EnvState e;
   memset(&e, 0, sizeof(e));
@@ -1238,6 +1239,8 @@ int rex_create(const RexConfig* cfg, int device, float* d_state, void* stream, R
   d.perm = nullptr; d.sweeps = nullptr; s->d_perm = nullptr; s->d_sweeps = nullptr; d.clock = nullptr; s->d_clock = nullptr;
   d.geo = rex::HfGeom{256, 20.0f, 20.0f, 127.5f, 127.5f, 254.999f, 254.999f}; d.hf_stride = 65536;   /* model/terrain.py:32-54 */
   d.init_z = cfg->init_height > 0.0f ? cfg->init_height : rex::kInitZ;
+  d.anchor = 0.0f;
+  if (cfg->on_rack) { d.init_z = 1.0f; d.anchor = rex::kRackAnchor; }   /* INIT_RACK_POSITION, rex.py:11 */
   d.noise_on = 0;
   for (int k = 0; k < 5; ++k) { d.noise[k] = cfg->noise_stdev[k]; if (cfg->noise_stdev[k] > 0.0f) d.noise_on = 1; }
   d.hist = nullptr; d.pd_latency = cfg->pd_latency; d.control_latency = cfg->control_latency;
@@ -1259,6 +1262,7 @@ int rex_create(const RexConfig* cfg, int device, float* d_state, void* stream, R
     d.obs_hi_rate = (float)(2.0 * M_PI) / cfg->sim_time_step + 0.01f;
   }
   d.target_orient = cfg->target_orient; d.init_orient = cfg->init_orient; d.orient_fixed = cfg->orient_fixed;
+  if (cfg->on_rack) { d.init_orient = 2.1f; d.orient_fixed |= 2; }   /* turn_env.py:140-143 */
   d.gait_clock = cfg->gait_clock_scale > 0.0f ? cfg->gait_clock_scale : 1.0f;
   {
     // Regrouping (opt-in: REX_REGROUP=1) can pay once a SIMD runs several waves one after the other -- below that the launch

@@ -71,19 +71,23 @@ class RexBatchEnv:
                  distance_weight=None, energy_weight=None, drift_weight=None, shake_weight=None,
                  tasks=None, mass_scale_range=None, friction_range=None, observation_noise_stdev=None,
                  heightfield=None, heightfield_cell=None, heightfield_origin=(0.0, 0.0, 0.0), init_height=None,
-                 body_contacts=False, **ignored):
+                 body_contacts=False, on_rack=False, env_randomizer=None, **ignored):
         import torch
         # Reference constructor keywords that only touch the GUI, logging or debugging are accepted and ignored; anything
         # else that would change what the env computes is an error here, not a silent no-op.
         harmless = {"debug", "urdf_version", "num_steps_to_log", "log_path", "terrain_id", "urdf_root", "reflection",
                     "draw_foot_path", "hard_reset", "forward_reward_cap"}
         unknown = sorted(set(ignored) - harmless)
-        if ignored.get("on_rack") or ignored.get("env_randomizer"):
-            raise NotImplementedError("on_rack / env_randomizer objects are not supported: use mass_scale_range / "
-                                      "friction_range (per-reset draws) or set_body_params()")
-        unknown = [k for k in unknown if k not in ("on_rack", "env_randomizer")]
         if unknown:
             raise TypeError(f"RexBatchEnv: unsupported keyword(s) {unknown}")
+        # EnvRandomizer objects (rex_gym_env.py:225,345-346,400-401): host-side hooks, called with this env at every reset()
+        # (`randomize_env`) and step() (`randomize_step`, when the object has one); they reach the robot through `self.rex`
+        self._env_randomizers = ([] if not env_randomizer else list(env_randomizer) if isinstance(env_randomizer, (list, tuple))
+                                 else [env_randomizer])
+        if self._env_randomizers and auto_reset:
+            raise ValueError("env_randomizer hooks run on the host inside reset(); with auto_reset the resets happen inside the "
+                             "launch -- use mass_scale_range / friction_range (per-reset draws in the kernel) instead")
+        self._randomize_indices = None
         if terrain_type in ("hills", "mounts", "maze") and heightfield is None:
             raise NotImplementedError(
                 f"terrain_type={terrain_type!r}: the reference loads this field from the pip package pybullet_data "
@@ -136,6 +140,7 @@ class RexBatchEnv:
             init_height = {"hills": 1.98, "mounts": 0.85}[terrain_type]     # ROBOT_INIT_POSITION, terrain.py:14-20
         if init_height is not None:
             cfg.init_height = float(init_height)
+        cfg.on_rack = int(bool(on_rack))               # debug rack: fixed base at [0, 0, 1] (rex.py:269-287)
         cfg.body_contacts = int(bool(body_contacts))   # link collision boxes vs ground, next to the toe rows (include/rexsim.h)
         cfg.motor_kp, cfg.motor_kd = float(motor_kp), float(motor_kd)
         cfg.gait_clock_scale = float(gait_clock_scale)     # wall-clock seconds per simulated second (gait_planner.py:108-110)
@@ -194,6 +199,8 @@ class RexBatchEnv:
                                           self._stream_ptr(), ctypes.byref(handle)), "rex_create")
         self._h = handle
         self._needs_reset = True
+        from .rex_knobs import RexKnobs
+        self.rex = RexKnobs(self)
         if cfg.pd_latency > 0 or cfg.control_latency > 0:   # observation-history ring of the latency model (rex.py:122)
             with torch.cuda.device(self.device):
                 self.history = torch.zeros((100 * (3 * self.num_motors + 7), self.num_envs), dtype=torch.float32, device=self.device)
@@ -302,6 +309,7 @@ class RexBatchEnv:
         if indices is None:
             _lib.check(self._L.rex_reset(self._h, None, 0, self._obs.data_ptr(), self._stream_ptr()), "rex_reset")
             self._needs_reset = False
+            self._randomize(None)
             return self._obs.clone()
         with self._on_stream():
             idx = torch.as_tensor(indices, dtype=torch.int32, device=self.device).contiguous()
@@ -309,7 +317,18 @@ class RexBatchEnv:
             if idx.numel():
                 _lib.check(self._L.rex_reset(self._h, idx.data_ptr(), idx.numel(), obs.data_ptr(), self._stream_ptr()),
                            "rex_reset")
+                self._randomize(idx)
         return obs
+
+    def add_env_randomizer(self, env_randomizer):     # rex_gym_env.py:293-294
+        self._env_randomizers.append(env_randomizer)
+
+    def _randomize(self, idx):
+        # after Rex.Reset, as in the reference (rex_gym_env.py:341-346): the reset motion is the nominal robot's
+        self._randomize_indices = idx
+        for r in self._env_randomizers:
+            r.randomize_env(self)
+        self._randomize_indices = None
 
     def step(self, actions):
         """actions [N, action_dim] (device float32 tensor, or array-like). Returns device tensors
@@ -317,6 +336,9 @@ class RexBatchEnv:
         torch = self._torch
         if self._needs_reset:
             raise RuntimeError("Must reset environment.")   # wrappers.py:286-288 semantics
+        for r in self._env_randomizers:                     # rex_gym_env.py:400-401
+            if hasattr(r, "randomize_step"):
+                r.randomize_step(self)
         with self._on_stream():
             a = torch.as_tensor(actions, dtype=torch.float32, device=self.device)
             if a.shape != (self.num_envs, self.action_dim):

@@ -10,10 +10,8 @@ class RexPosesEnv(_SingleEnv):
                  render=False, num_steps_to_log=1000, env_randomizer=None, log_path=None, base_y=None, base_z=None,
                  base_roll=None, base_pitch=None, base_yaw=None, signal_type="ik", terrain_type="plane",
                  terrain_id=None, mark="base", **kw):
-        if on_rack or env_randomizer:
-            raise NotImplementedError("on_rack / env_randomizer are not covered by this round")
         super().__init__(signal_type=signal_type, control_time_step=control_time_step, action_repeat=action_repeat,
                          motor_kp=motor_kp, motor_kd=motor_kd, control_latency=control_latency, pd_latency=pd_latency,
-                         render=render, base_y=base_y, base_z=base_z,
+                         render=render, on_rack=on_rack, env_randomizer=env_randomizer, base_y=base_y, base_z=base_z,
                          base_roll=base_roll, base_pitch=base_pitch, base_yaw=base_yaw, terrain_type=terrain_type,
                          mark=mark, **kw)

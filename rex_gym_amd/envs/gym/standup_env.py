@@ -13,8 +13,6 @@ class RexStandupEnv(_SingleEnv):
                  pd_latency=0, on_rack=False, motor_kp=1.0, motor_kd=0.02, remove_default_joint_damping=False,
                  render=False, num_steps_to_log=1000, env_randomizer=None, log_path=None, signal_type="ol",
                  terrain_type="plane", terrain_id=None, mark="base", **kw):
-        if on_rack or env_randomizer:
-            raise NotImplementedError("on_rack / env_randomizer are not covered by this round")
         super().__init__(signal_type=signal_type, control_time_step=control_time_step, action_repeat=action_repeat,
                          motor_kp=motor_kp, motor_kd=motor_kd, control_latency=control_latency, pd_latency=pd_latency,
-                         render=render, terrain_type=terrain_type, mark=mark, **kw)
+                         render=render, on_rack=on_rack, env_randomizer=env_randomizer, terrain_type=terrain_type, mark=mark, **kw)

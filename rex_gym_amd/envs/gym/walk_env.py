@@ -5,6 +5,16 @@ import numpy as np
 from ..batch_env import RexBatchEnv
 
 
+class _Forward:
+    def __init__(self, randomizer, env):
+        self._r, self._env = randomizer, env
+        if hasattr(randomizer, "randomize_step"):
+            self.randomize_step = lambda _batch: randomizer.randomize_step(env)
+
+    def randomize_env(self, _batch):
+        self._r.randomize_env(self._env)
+
+
 class _SingleEnv:
     _TASK = None
     metadata = {"render.modes": ["human", "rgb_array"], "video.frames_per_second": 66}
@@ -14,6 +24,12 @@ class _SingleEnv:
         self.action_space = self._batch.action_space
         self.observation_space = self._batch.observation_space
         self.control_time_step = self._batch.control_time_step
+        self.rex = self._batch.rex     # what an env_randomizer's randomize_env(env) reaches for (envs/rex_knobs.py)
+        # the hooks get THIS env object, as in the reference (rex_gym_env.py:345-346)
+        self._batch._env_randomizers = [_Forward(r, self) for r in self._batch._env_randomizers]
+
+    def add_env_randomizer(self, env_randomizer):
+        self._batch.add_env_randomizer(_Forward(env_randomizer, self))
 
     def seed(self, seed=None):
         return [seed]
@@ -44,9 +60,7 @@ class RexWalkEnv(_SingleEnv):
                  pd_latency=0, on_rack=False, motor_kp=1.0, motor_kd=0.02, render=False, num_steps_to_log=2000,
                  env_randomizer=None, log_path=None, target_position=None, backwards=None, signal_type="ik",
                  terrain_type="plane", terrain_id=None, mark="base", **kw):
-        if on_rack or env_randomizer:
-            raise NotImplementedError("on_rack / env_randomizer are not covered by this round")
         super().__init__(signal_type=signal_type, control_time_step=control_time_step, action_repeat=action_repeat,
                          motor_kp=motor_kp, motor_kd=motor_kd, control_latency=control_latency, pd_latency=pd_latency,
-                         render=render, target_position=target_position,
+                         render=render, on_rack=on_rack, env_randomizer=env_randomizer, target_position=target_position,
                          backwards=backwards, terrain_type=terrain_type, mark=mark, **kw)

@@ -31,7 +31,7 @@ def make_pair(task, signal, n, dtype=np.float32, **kw):
     pkw = dict(kw)
     cfg_kw = {}
     for k in ("seed", "auto_reset", "max_episode_steps", "env_index_base", "motor_kp", "motor_kd", "range_normalize", "pd_latency",
-              "control_latency", "gait_clock_scale", "body_contacts"):
+              "control_latency", "gait_clock_scale", "body_contacts", "on_rack"):
         if k in okw:
             cfg_kw[k] = okw.pop(k)
     if "backwards" in okw:

@@ -1240,3 +1240,78 @@ def test_regrouped_batch_is_bit_identical(torch, monkeypatch):
     for (o0, r0, d0, c0), (o1, r1, d1, c1) in zip(outs["0"][0], outs["1"][0]):
         assert torch.equal(o0, o1) and torch.equal(r0, r1) and torch.equal(d0, d1) and torch.equal(c0, c1)
     assert torch.equal(outs["0"][1], outs["1"][1])
+
+
+@pytest.mark.parametrize("task,signal,mark", [("walk", "ik", "base"), ("turn", "ik", "base"), ("gallop", "ol", "arm")])
+def test_on_rack_debug_mode_against_the_oracle(torch, task, signal, mark):
+    """on_rack=True (loadURDF(useFixedBase=True) at [0, 0, 1], rex.py:269-287): the base stays exactly where the rack holds
+    it, the legs follow the oracle's fixed-base articulated-body dynamics.  Tolerance: joints 1e-4 rad over 40 control
+    steps (no contacts: the chain is smooth)."""
+    n = 96
+    env, orc = make_pair(task, signal, n, np.float32, seed=4, on_rack=1, mark=mark)
+    env.reset(); orc.reset()
+    nm = 18 if mark == "arm" else 12
+    s0 = product_state_to_numeric(env.state)
+    yaw = 2.1 if task == "turn" else 0.0
+    np.testing.assert_allclose(s0[:7], np.tile(np.array([0, 0, 1, 0, 0, np.sin(yaw / 2), np.cos(yaw / 2)], np.float32)[:, None], (1, n)),
+                               atol=1e-7)
+    np.testing.assert_allclose(s0[orclib.S_Q:orclib.S_Q + nm], orc.get_state()[orclib.S_Q:orclib.S_Q + nm], atol=1e-4)
+    rng = np.random.RandomState(2)
+    lo, hi = np.minimum(env.action_space.low, env.action_space.high), np.maximum(env.action_space.low, env.action_space.high)
+    for _ in range(40):
+        a = rng.uniform(lo, hi, (n, env.action_dim)).astype(np.float32)
+        po, pr, pd, _ = env.step(torch.as_tensor(a, device="cuda"))
+        oo, orw, od, _ = orc.step(a)
+        np.testing.assert_allclose(po.cpu().numpy(), oo, atol=2e-4)
+        np.testing.assert_array_equal(pd.cpu().numpy(), od)
+    ps, os_ = product_state_to_numeric(env.state), orc.get_state()
+    np.testing.assert_array_equal(ps[:7], s0[:7])                                    # the rack holds
+    np.testing.assert_array_equal(ps[7:13], np.zeros((6, n), np.float32))
+    np.testing.assert_allclose(ps[orclib.S_Q:orclib.S_Q + nm], os_[orclib.S_Q:orclib.S_Q + nm], atol=1e-4)
+    assert np.ptp(ps[orclib.S_Q:orclib.S_Q + 12], axis=1).max() > 0 or task == "turn"
+    env.close()
+
+
+def test_env_randomizer_hooks_of_the_single_env_classes(torch):
+    """An EnvRandomizer in the reference's protocol (rex_gym_env.py:345-346,400-401): `randomize_env(env)` after every
+    reset's Rex.Reset, `randomize_step(env)` before every step, reaching the robot through env.rex (rex.py:643-692)."""
+    from rex_gym_amd.envs.gym import RexWalkEnv
+
+    class Randomizer:
+        def __init__(self):
+            self.resets = self.steps = 0
+            self.rng = np.random.RandomState(0)
+
+        def randomize_env(self, env):
+            self.resets += 1
+            self.ratio = self.rng.uniform(0.8, 1.2)
+            env.rex.SetBaseMasses([m * self.ratio for m in env.rex.GetBaseMassesFromURDF()])
+            env.rex.SetLegMasses([m * 1.1 for m in env.rex.GetLegMassesFromURDF()])
+            env.rex.SetFootFriction(0.4)
+
+        def randomize_step(self, env):
+            self.steps += 1
+
+    r = Randomizer()
+    env = RexWalkEnv(env_randomizer=r)
+    assert isinstance(env, RexWalkEnv)
+    for episode in range(2):
+        env.reset()
+        np.testing.assert_allclose(env._batch.body_params.cpu().numpy()[:, 0], [r.ratio, 1.1, 0.4], rtol=1e-6)
+        for _ in range(3):
+            env.step(np.zeros(2, np.float32))
+    assert (r.resets, r.steps) == (2, 6)
+    # and the knobs act: a heavier robot sags more on the same motors
+    z = []
+    for scale in (0.8, 1.2):
+        class Fixed:
+            def randomize_env(self, env, scale=scale):
+                env.rex.SetBaseMasses([m * scale for m in env.rex.GetBaseMassesFromURDF()])
+        e = RexWalkEnv(env_randomizer=[Fixed()])
+        e.reset()
+        for _ in range(40):
+            e.step(np.zeros(2, np.float32))
+        z.append(float(e._batch.state[2, 0]))
+        e.close()
+    assert z[1] < z[0] - 1e-4
+    env.close()

@@ -122,3 +122,29 @@ def test_oracle_mixed_task_batch_equals_single_task_batches():
             np.testing.assert_array_equal(c[sel], outs[k][3][sel])
         ref.close()
     mix.close()
+
+
+@pytest.mark.parametrize("task", ["walk", "turn", "standup"])
+def test_oracle_on_rack_holds_the_base(task):
+    """on_rack (loadURDF(useFixedBase=True) at [0, 0, 1], rex.py:269-287): the base never moves, the legs still follow the
+    motors and gravity; RexTurnEnv starts at its debug yaw 2.1 (turn_env.py:140-143)."""
+    n = 3
+    env = orclib.OracleEnv(orclib.default_config(task, "ol" if task == "standup" else "ik", n, on_rack=1, seed=3), np.float64)
+    env.reset()
+    st0 = env.get_state()
+    yaw = 2.1 if task == "turn" else 0.0
+    np.testing.assert_allclose(st0[:3], np.tile([[0.0], [0.0], [1.0]], (1, n)), atol=0)
+    np.testing.assert_allclose(st0[3:7], np.tile([[0.0], [0.0], [np.sin(yaw / 2)], [np.cos(yaw / 2)]], (1, n)), atol=1e-15)
+    rng = np.random.RandomState(0)
+    q = []
+    for _ in range(60):
+        env.step(rng.uniform(-0.01, 0.01, (n, env.action_dim)))
+        q.append(env.get_state()[13:25].copy())
+    st = env.get_state()
+    np.testing.assert_array_equal(st[:7], st0[:7])                       # pose
+    np.testing.assert_array_equal(st[7:13], np.zeros((6, n)))            # base velocities
+    assert np.ptp(np.stack(q), axis=0).max() > 0.05                       # the legs do move
+    free = orclib.OracleEnv(orclib.default_config(task, "ol" if task == "standup" else "ik", n, seed=3), np.float64)
+    free.reset()
+    assert abs(free.get_state()[2, 0] - 1.0) > 0.5                        # and without the rack the robot stands on the floor
+    env.close(); free.close()
