@@ -720,6 +720,7 @@ typedef struct {
   real rhs, invdiag, lo, hi, lambda;
   int normal_row; /* for friction rows: index of the normal row that bounds them; -1 for normals */
   int pair_row;   /* friction rows: the other tangent row of the same point (cone probe), else -1 */
+  real mu;        /* friction rows: the coefficient of their pair of surfaces */
 } Row;
 
 /* Jacobian row of world direction d at world point P on body kbody, in (base body coords, joints) */
@@ -749,7 +750,30 @@ static void contact_jacobian(const Aba* A, int kbody, const real P[3], const rea
  * closest points of separated shapes as well); here the candidates of a box are the four corners of its face most
  * aligned with the ground normal under its centre, each against the ground under ITSELF, active once below it. */
 #define BODY_ACTIVATION ((real)0.0)
+/* A corner becomes a candidate 1 mm before it enters the other box (its row then only bounds the closing speed by
+ * distance / dt, as every contact row at a positive distance does): Bullet keeps a manifold point alive after the boxes
+ * have separated again (until contactBreakingThreshold = 0.02 m), so a resting link-link contact does not switch on and
+ * off around zero depth there either. */
+#define SELF_MARGIN ((real)0.001)
+#define SELF_MU ((real)0.25)   /* btManifoldResult::calculateCombinedFriction: the product of the two links' URDF defaults, 0.5 x 0.5 */
 static int BODY_CONTACTS = 0;
+static int P_SELF_COLLISION = 1;          /* probe: leg boxes against the base body's boxes (only with body_contacts) */
+static long DBG_SELF_POINTS = 0;
+
+/* Jacobian row and impulse response of direction d at point P of body kbody -- against the world, or (self) against the
+ * base body: the row of the relative velocity, whose base part vanishes (the pair's forces are internal to the robot) */
+static void point_row(const Aba* A, int kbody, int self, const real P[3], const real d[3], Row* r) {
+  real fk[6];
+  contact_jacobian(A, kbody, P, d, r->J, fk);
+  impulse_response_at(A, kbody, fk, r->resp);
+  if (self) {
+    real J0[NDOF], r0[NDOF], f0[6];
+    contact_jacobian(A, 0, P, d, J0, f0);
+    impulse_response_at(A, 0, f0, r0);
+    for (int k = 0; k < NDOF; ++k) { r->J[k] -= J0[k]; r->resp[k] -= r0[k]; }
+    for (int k = 0; k < 6; ++k) r->J[k] = 0;
+  }
+}
 static long DBG_BODY_POINTS = 0, DBG_BODY_SUBSTEPS = 0;   /* statistics (single-threaded census runs): active body points, substeps with any */
 
 /* one 1 ms world step: the restated stepSimulation */
@@ -779,7 +803,9 @@ static void physics_substep(Phys* s, const real tau[NJ], real dt, int iterations
   int normal_of_point[MAX_POINTS];
   real PtP[MAX_POINTS][3], PtN[MAX_POINTS][3];
   int PtBody[MAX_POINTS];
+  int PtSelf[MAX_POINTS];    /* 0: against the ground; 1: against a box of the base body (row of the RELATIVE velocity) */
   real PtDist[MAX_POINTS];
+  memset(PtSelf, 0, sizeof(PtSelf));
   const real rad = (real)REX_TOE_RADIUS + P_MARGIN;
   for (int l = 0; l < REX_NLEG; ++l) {
     int kb = REX_TOE_BODY[l];
@@ -833,7 +859,7 @@ static void physics_substep(Phys* s, const real tau[NJ], real dt, int iterations
      * candidate (box order of rex_model_gen.h, corner order below). */
     for (int grp = 0; grp < 1 + REX_NLEG; ++grp) {
       const int slots = grp == 0 ? 4 : 2;
-      real bestD[4]; real bestP[4][3], bestN[4][3]; int bestB[4]; int nbest = 0;
+      real bestD[4]; real bestP[4][3], bestN[4][3]; int bestB[4], bestS[4]; int nbest = 0;
       for (int b = 0; b < REX_NBOX; ++b) {
         int kb = REX_BOX_BODY[b];
         int g_of = kb == 0 ? 0 : 1 + (kb - 1) / 3;
@@ -871,15 +897,71 @@ static void physics_substep(Phys* s, const real tau[NJ], real dt, int iterations
           while (pos > 0 && dist < bestD[pos - 1]) --pos;
           if (pos >= slots) continue;
           int last = nbest < slots ? nbest : slots - 1;
-          for (int k = last; k > pos; --k) { bestD[k] = bestD[k - 1]; bestB[k] = bestB[k - 1]; memcpy(bestP[k], bestP[k - 1], sizeof(bestP[0])); memcpy(bestN[k], bestN[k - 1], sizeof(bestN[0])); }
-          bestD[pos] = dist; bestB[pos] = kb; memcpy(bestP[pos], P, sizeof(P)); memcpy(bestN[pos], n, sizeof(n));
+          for (int k = last; k > pos; --k) { bestD[k] = bestD[k - 1]; bestB[k] = bestB[k - 1]; bestS[k] = bestS[k - 1]; memcpy(bestP[k], bestP[k - 1], sizeof(bestP[0])); memcpy(bestN[k], bestN[k - 1], sizeof(bestN[0])); }
+          bestD[pos] = dist; bestB[pos] = kb; bestS[pos] = 0; memcpy(bestP[pos], P, sizeof(P)); memcpy(bestN[pos], n, sizeof(n));
           if (nbest < slots) ++nbest;
         }
+      }
+      /* self collision (loadURDF(flags=URDF_USE_SELF_COLLISION), rex.py:276-281): the leg-link and foot-link boxes of this
+       * leg against the three boxes of the base body (base_link, chassis_front, chassis_rear) -- the only admissible pairs
+       * that ever overlap (profiles/r02_contact_census.md: the upper-leg box against the edge of the rolled base in
+       * RexPosesEnv).  The face cases of Bullet's box-box detector reduced to their penetrating vertices: a corner of one
+       * box inside (or within SELF_MARGIN of) the other, pushed out through the face of least penetration of the box that contains it; edge-edge
+       * crossings without a contained corner generate nothing.  The candidates compete with the leg's ground candidates
+       * for its two slots, deepest first.  Row: relative velocity of the leg link against the base body at the corner. */
+      if (grp >= 1 && P_SELF_COLLISION) {
+        for (int a = 0; a < 3; ++a)                /* boxes 0..2 of rex_model_gen.h: the base body's */
+          for (int bb = 1; bb <= 2; ++bb) {        /* this leg's leg-link and foot-link boxes (the shoulder is the base's child) */
+            const int b = 3 + 3 * (grp - 1) + bb, kb = REX_BOX_BODY[b];
+            real cA[3], cB[3], t[3];
+            for (int k = 0; k < 3; ++k) t[k] = (real)REX_BOX_CENTER[a][k];
+            matvec3(A.Rw[0], t, cA);
+            for (int k = 0; k < 3; ++k) { cA[k] += A.pw[0][k]; t[k] = (real)REX_BOX_CENTER[b][k]; }
+            matvec3(A.Rw[kb], t, cB);
+            for (int k = 0; k < 3; ++k) cB[k] += A.pw[kb][k];
+            for (int side = 0; side < 2; ++side) {   /* 0: corners of the leg box inside the base box; 1: the other way round */
+              const real (*RX)[3] = side == 0 ? A.Rw[0] : A.Rw[kb];      /* the containing box */
+              const real (*RY)[3] = side == 0 ? A.Rw[kb] : A.Rw[0];      /* the box whose corners are tested */
+              const real* cX = side == 0 ? cA : cB; const real* cY = side == 0 ? cB : cA;
+              const double* hX = side == 0 ? REX_BOX_HALF[a] : REX_BOX_HALF[b];
+              const double* hY = side == 0 ? REX_BOX_HALF[b] : REX_BOX_HALF[a];
+              for (int c = 0; c < 8; ++c) {
+                real loc[3] = {((c & 1) ? (real)1 : (real)-1) * (real)hY[0], ((c & 2) ? (real)1 : (real)-1) * (real)hY[1],
+                               ((c & 4) ? (real)1 : (real)-1) * (real)hY[2]};
+                real P[3], rel[3], inX[3];
+                matvec3(RY, loc, P);
+                for (int k = 0; k < 3; ++k) { P[k] += cY[k]; rel[k] = P[k] - cX[k]; }
+                matTvec3(RX, rel, inX);
+                int ax = -1; real depth = 0;
+                int inside = 1;
+                for (int k = 0; k < 3; ++k) {
+                  real d = (real)hX[k] - fabs(inX[k]);
+                  if (!(d + SELF_MARGIN > 0)) { inside = 0; break; }
+                  if (ax < 0 || d < depth) { ax = k; depth = d; }
+                }
+                if (!inside) continue;
+                /* direction of the push on the LEG link: out of the base box, or into the leg box's own face */
+                real sg = inX[ax] >= 0 ? (real)1 : (real)-1;
+                if (side == 1) sg = -sg;
+                real n[3] = {sg * RX[0][ax], sg * RX[1][ax], sg * RX[2][ax]};
+                real dist = -depth;
+                int pos = nbest;
+                while (pos > 0 && dist < bestD[pos - 1]) --pos;
+                if (pos >= slots) continue;
+                int last = nbest < slots ? nbest : slots - 1;
+                for (int k = last; k > pos; --k) { bestD[k] = bestD[k - 1]; bestB[k] = bestB[k - 1]; bestS[k] = bestS[k - 1]; memcpy(bestP[k], bestP[k - 1], sizeof(bestP[0])); memcpy(bestN[k], bestN[k - 1], sizeof(bestN[0])); }
+                bestD[pos] = dist; bestB[pos] = kb; bestS[pos] = 1; memcpy(bestP[pos], P, sizeof(P)); memcpy(bestN[pos], n, sizeof(n));
+                if (nbest < slots) ++nbest;
+                if (DBG_STATS) ++DBG_SELF_POINTS;
+              }
+            }
+          }
       }
       for (int k = 0; k < nbest; ++k) {
         memcpy(PtP[npoint], bestP[k], sizeof(bestP[0]));
         memcpy(PtN[npoint], bestN[k], sizeof(bestN[0]));
         PtBody[npoint] = bestB[k];
+        PtSelf[npoint] = bestS[k];
         PtDist[npoint] = bestD[k];
         ++npoint;
         if (DBG_STATS) ++DBG_BODY_POINTS;
@@ -919,9 +1001,7 @@ static void physics_substep(Phys* s, const real tau[NJ], real dt, int iterations
   for (int q = 0; q < npoint; ++q) {
     int p = order[q];
     Row* r = &rows[nrow];
-    real fk[6];
-    contact_jacobian(&A, PtBody[p], PtP[p], PtN[p], r->J, fk);
-    impulse_response_at(&A, PtBody[p], fk, r->resp);
+    point_row(&A, PtBody[p], PtSelf[p], PtP[p], PtN[p], r);
     real diag = 0, vel = 0;
     for (int k = 0; k < NDOF; ++k) { diag += r->J[k] * r->resp[k]; vel += r->J[k] * nu[k]; }
     r->invdiag = 1 / diag;
@@ -939,10 +1019,10 @@ static void physics_substep(Phys* s, const real tau[NJ], real dt, int iterations
     for (int d = 0; d < P_FRICTION_DIRS; ++d) {
       int p = order[q];
       Row* r = &rows[nrow];
-      real fk[6], t1[3], t2[3];
+      real t1[3], t2[3];
       plane_space(PtN[p], t1, t2);
-      contact_jacobian(&A, PtBody[p], PtP[p], d == 0 ? t1 : t2, r->J, fk);
-      impulse_response_at(&A, PtBody[p], fk, r->resp);
+      point_row(&A, PtBody[p], PtSelf[p], PtP[p], d == 0 ? t1 : t2, r);
+      r->mu = PtSelf[p] ? SELF_MU : mu;
       real diag = 0, vel = 0;
       for (int k = 0; k < NDOF; ++k) { diag += r->J[k] * r->resp[k]; vel += r->J[k] * nu[k]; }
       r->invdiag = 1 / diag;
@@ -959,7 +1039,7 @@ static void physics_substep(Phys* s, const real tau[NJ], real dt, int iterations
     for (int i = 0; i < nrow; ++i) {
       Row* r = &rows[i];
       real lo = r->lo, hi = r->hi;
-      if (r->normal_row >= 0) { hi = mu * rows[r->normal_row].lambda; lo = -hi; }
+      if (r->normal_row >= 0) { hi = r->mu * rows[r->normal_row].lambda; lo = -hi; }
       real dvel = 0;
       for (int k = 0; k < NDOF; ++k) dvel += r->J[k] * dv[k];
       real dl = r->rhs - dvel * r->invdiag;
@@ -967,7 +1047,7 @@ static void physics_substep(Phys* s, const real tau[NJ], real dt, int iterations
       if (sum < lo) { dl = lo - r->lambda; sum = lo; }
       else if (sum > hi) { dl = hi - r->lambda; sum = hi; }
       if (P_CONE && r->normal_row >= 0 && r->pair_row >= 0) {   /* probe: implicit cone, |(l1, l2)| <= mu ln */
-        real other = rows[r->pair_row].lambda, lim = mu * rows[r->normal_row].lambda;
+        real other = rows[r->pair_row].lambda, lim = r->mu * rows[r->normal_row].lambda;
         real un = r->lambda + (r->rhs - dvel * r->invdiag);
         real mag = sqrt(un * un + other * other);
         real want = mag > lim && mag > 0 ? un * lim / mag : un;
@@ -1816,6 +1896,7 @@ ORC_API void orc_set_friction(real mu) { FRICTION_MU = mu; }
 ORC_API void orc_set_gait_clock(real s) { DBG_GAIT_CLOCK = s; }
 ORC_API void orc_set_body_contacts(int on) { BODY_CONTACTS = on; }
 ORC_API long orc_body_points(int reset) { DBG_STATS = 1; long v = DBG_BODY_POINTS; if (reset) DBG_BODY_POINTS = 0; return v; }
+ORC_API long orc_self_points(int reset) { DBG_STATS = 1; long v = DBG_SELF_POINTS; if (reset) DBG_SELF_POINTS = 0; return v; }
 ORC_API long orc_substeps_with_body_points(int reset) { DBG_STATS = 1; long v = DBG_BODY_SUBSTEPS; if (reset) DBG_BODY_SUBSTEPS = 0; return v; }
 /* sensitivity probes by name (tools/physics_sensitivity.py); returns 0 when the name is known */
 ORC_API int orc_set_probe(const char* name, double v) {
@@ -1836,6 +1917,7 @@ ORC_API int orc_set_probe(const char* name, double v) {
   else if (!strcmp(name, "ang_damping")) MB_ANGULAR_DAMPING = (real)v;
   else if (!strcmp(name, "joint_friction")) { DBG_JOINT_FRICTION = (real)v; DBG_JOINT_VISC = (real)1e3; }
   else if (!strcmp(name, "body_contacts")) BODY_CONTACTS = (int)v;
+  else if (!strcmp(name, "self_collision")) P_SELF_COLLISION = (int)v;
   else return -1;
   return 0;
 }

@@ -210,6 +210,8 @@ struct Ground {
   float anchor = 0.0f;
 };
 constexpr float kRackAnchor = 1.0e9f;
+constexpr float kSelfMargin = 0.001f;   // a corner is a candidate from 1 mm before it enters the other box (oracle: SELF_MARGIN)
+constexpr float kSelfMu = 0.25f;   // btManifoldResult::calculateCombinedFriction: 0.5 x 0.5, the URDF default of both links
 // (every division by the cell size is a multiplication by its inverse, here and in the oracle)
 __device__ __forceinline__ void ground_query(const Ground& g, float x, float y, float& height, f3& n) {
   n = f3{0.f, 0.f, 1.f}; height = 0.0f;
@@ -538,11 +540,48 @@ __device__ __forceinline__ void leg_pass(int leg, const BaseKin& bk, const float
     // a box corner can only be below the ground if the box's lowest point along the normal under its centre is (on the
     // heightfield the ground under a corner may stand up to the field's roughness above that under the centre)
     const bool near = lowest < (ground.h != nullptr ? 0.06f : 0.0f);
-    if (__builtin_amdgcn_ballot_w64(near) != 0) {
+    // self collision (URDF_USE_SELF_COLLISION, rex.py:276-281): this leg's leg-link and foot-link boxes against the three
+    // boxes of the base body (same y / z extents, strung along the base's x axis).  Cheap reject first: the six face axes
+    // of a pair as separating axes.
+    constexpr float kAy = (float)REX_BOX_HALF[0][1], kAz = (float)REX_BOX_HALF[0][2];
+    static_assert(REX_BOX_HALF[1][1] == REX_BOX_HALF[0][1] && REX_BOX_HALF[2][1] == REX_BOX_HALF[0][1] &&
+                  REX_BOX_HALF[1][2] == REX_BOX_HALF[0][2] && REX_BOX_HALF[2][2] == REX_BOX_HALF[0][2] &&
+                  REX_BOX_CENTER[1][1] == 0.0 && REX_BOX_CENTER[1][2] == 0.0 && REX_BOX_CENTER[2][1] == 0.0 && REX_BOX_CENTER[2][2] == 0.0,
+                  "base body boxes: one y-z section, centres on the base's x axis");
+    float Cm[2][3][3], dA0[2][3], dB0[2][3];   // per leg box: C[i][j] = base axis i . box axis j; centre offset in both frames
+    bool selfnear = false;
+#pragma unroll
+    for (int bb = 0; bb < 2; ++bb) {
+      const f3 ea[3] = {bk.ex, bk.ey, bk.ez}, eb[3] = {bx[1 + bb], y1, bz[1 + bb]};
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) Cm[bb][i][j] = dot(ea[i], eb[j]);
+        dA0[bb][i] = dot(ctr[1 + bb], ea[i]);      // the base box centres sit at (cx, 0, 0): subtracted per box below
+        dB0[bb][i] = dot(ctr[1 + bb], eb[i]);
+      }
+      const float hB[3] = {(float)REX_BOX_HALF[B0 + 1 + bb][0], (float)REX_BOX_HALF[B0 + 1 + bb][1], (float)REX_BOX_HALF[B0 + 1 + bb][2]};
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const float cx = (float)REX_BOX_CENTER[a][0], hA[3] = {(float)REX_BOX_HALF[a][0], kAy, kAz};
+        float sep = -1e9f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const float di = dA0[bb][i] - (i == 0 ? cx : 0.0f);
+          sep = fmaxf(sep, fabsf(di) - hA[i] - (hB[0] * fabsf(Cm[bb][i][0]) + hB[1] * fabsf(Cm[bb][i][1]) + hB[2] * fabsf(Cm[bb][i][2])));
+          const float dj = dB0[bb][i] - cx * Cm[bb][0][i];
+          sep = fmaxf(sep, fabsf(dj) - hB[i] - (hA[0] * fabsf(Cm[bb][0][i]) + hA[1] * fabsf(Cm[bb][1][i]) + hA[2] * fabsf(Cm[bb][2][i])));
+        }
+        selfnear |= sep < 2.0f * kSelfMargin;   // (a corner within the margin of a box can be up to sqrt(3) margins away along the other box's axes)
+      }
+    }
+    const bool anyself = __builtin_amdgcn_ballot_w64(selfnear) != 0;
+    if (__builtin_amdgcn_ballot_w64(near) != 0 || anyself) {
       active_mask |= 1u << (21 + leg);
       float bestD[2] = {0.0f, 0.0f};
       f3 bestP[2] = {mk(0.f, 0.f, 0.f), mk(0.f, 0.f, 0.f)}, bestN[2] = {mk(0.f, 0.f, 1.f), mk(0.f, 0.f, 1.f)};
       int bestL[2] = {0, 0};   // 0 = empty slot, else 1 + box (= number of joints that move the point)
+      bool bestS[2] = {false, false};   // the point is held against the base body (row of the relative velocity), not the ground
 #pragma unroll
       for (int b = 0; b < 3; ++b) {
         int fa = 0;
@@ -564,10 +603,60 @@ __device__ __forceinline__ void leg_pass(int leg, const BaseKin& bk, const float
           const float dist = (bk.height + P.z - h) * n.z;
           if (dist < 0.0f) {   // deepest-first list of two; ties keep the earlier candidate
             if (bestL[0] == 0 || dist < bestD[0]) {
-              bestD[1] = bestD[0]; bestP[1] = bestP[0]; bestN[1] = bestN[0]; bestL[1] = bestL[0];
-              bestD[0] = dist; bestP[0] = P; bestN[0] = n; bestL[0] = 1 + b;
+              bestD[1] = bestD[0]; bestP[1] = bestP[0]; bestN[1] = bestN[0]; bestL[1] = bestL[0]; bestS[1] = bestS[0];
+              bestD[0] = dist; bestP[0] = P; bestN[0] = n; bestL[0] = 1 + b; bestS[0] = false;
             } else if (bestL[1] == 0 || dist < bestD[1]) {
-              bestD[1] = dist; bestP[1] = P; bestN[1] = n; bestL[1] = 1 + b;
+              bestD[1] = dist; bestP[1] = P; bestN[1] = n; bestL[1] = 1 + b; bestS[1] = false;
+            }
+          }
+        }
+      }
+      if (anyself) {
+        // The face cases of Bullet's box-box detector reduced to their penetrating vertices: a corner of one box inside
+        // the other, pushed out through the face of least penetration of the box that contains it (oracle/rex_oracle.c,
+        // same candidate order: base box, leg box, side, corner).  The candidates compete with the ground candidates above.
+#pragma unroll 1
+        for (int a = 0; a < 3; ++a) {
+          const float cx = a == 0 ? (float)REX_BOX_CENTER[0][0] : (a == 1 ? (float)REX_BOX_CENTER[1][0] : (float)REX_BOX_CENTER[2][0]);
+          const float hAx = a == 0 ? (float)REX_BOX_HALF[0][0] : (a == 1 ? (float)REX_BOX_HALF[1][0] : (float)REX_BOX_HALF[2][0]);
+          const float hA[3] = {hAx, kAy, kAz};
+          const f3 cA = cx * bk.ex;
+#pragma unroll
+          for (int bb = 0; bb < 2; ++bb) {
+            const float hB[3] = {(float)REX_BOX_HALF[B0 + 1 + bb][0], (float)REX_BOX_HALF[B0 + 1 + bb][1], (float)REX_BOX_HALF[B0 + 1 + bb][2]};
+            const f3 ea[3] = {bk.ex, bk.ey, bk.ez}, eb[3] = {bx[1 + bb], y1, bz[1 + bb]};
+            const float dA[3] = {dA0[bb][0] - cx, dA0[bb][1], dA0[bb][2]};
+            const float dB[3] = {dB0[bb][0] - cx * Cm[bb][0][0], dB0[bb][1] - cx * Cm[bb][0][1], dB0[bb][2] - cx * Cm[bb][0][2]};
+#pragma unroll
+            for (int side = 0; side < 2; ++side) {
+#pragma unroll 1
+              for (int c = 0; c < 8; ++c) {
+                const float sg[3] = {(c & 1) ? 1.0f : -1.0f, (c & 2) ? 1.0f : -1.0f, (c & 4) ? 1.0f : -1.0f};
+                float in[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k)   // the corner in the frame of the box that may contain it
+                  in[k] = side == 0 ? dA[k] + (sg[0] * hB[0] * Cm[bb][k][0] + sg[1] * hB[1] * Cm[bb][k][1] + sg[2] * hB[2] * Cm[bb][k][2])
+                                    : -dB[k] + (sg[0] * hA[0] * Cm[bb][0][k] + sg[1] * hA[1] * Cm[bb][1][k] + sg[2] * hA[2] * Cm[bb][2][k]);
+                const float d0 = (side == 0 ? hA[0] : hB[0]) - fabsf(in[0]), d1 = (side == 0 ? hA[1] : hB[1]) - fabsf(in[1]),
+                            d2 = (side == 0 ? hA[2] : hB[2]) - fabsf(in[2]);
+                if (!(d0 + kSelfMargin > 0.0f && d1 + kSelfMargin > 0.0f && d2 + kSelfMargin > 0.0f)) continue;
+                int ax = 0; float depth = d0;
+                if (d1 < depth) { ax = 1; depth = d1; }
+                if (d2 < depth) { ax = 2; depth = d2; }
+                const float inax = ax == 0 ? in[0] : (ax == 1 ? in[1] : in[2]);
+                const float sgn = (inax >= 0.0f ? 1.0f : -1.0f) * (side == 0 ? 1.0f : -1.0f);   // the push on the LEG link
+                const f3 axv = side == 0 ? (ax == 0 ? ea[0] : (ax == 1 ? ea[1] : ea[2])) : (ax == 0 ? eb[0] : (ax == 1 ? eb[1] : eb[2]));
+                const f3 n = sgn * axv;
+                const f3 P = side == 0 ? ctr[1 + bb] + (sg[0] * hB[0]) * eb[0] + (sg[1] * hB[1]) * eb[1] + (sg[2] * hB[2]) * eb[2]
+                                       : cA + (sg[0] * hA[0]) * ea[0] + (sg[1] * hA[1]) * ea[1] + (sg[2] * hA[2]) * ea[2];
+                const float dist = -depth;
+                if (bestL[0] == 0 || dist < bestD[0]) {
+                  bestD[1] = bestD[0]; bestP[1] = bestP[0]; bestN[1] = bestN[0]; bestL[1] = bestL[0]; bestS[1] = bestS[0];
+                  bestD[0] = dist; bestP[0] = P; bestN[0] = n; bestL[0] = 2 + bb; bestS[0] = true;
+                } else if (bestL[1] == 0 || dist < bestD[1]) {
+                  bestD[1] = dist; bestP[1] = P; bestN[1] = n; bestL[1] = 2 + bb; bestS[1] = true;
+                }
+              }
             }
           }
         }
@@ -578,28 +667,33 @@ __device__ __forceinline__ void leg_pass(int leg, const BaseKin& bk, const float
         const int slot = 4 + 2 * leg + k;
         const bool act = bestL[k] != 0;
         const f3 P = bestP[k], nrm = bestN[k];
+        const bool self = bestS[k];
         f3 t1 = mk(0.f, -1.f, 0.f), t2 = mk(1.f, 0.f, 0.f);
-        if (ground.h != nullptr) plane_space(nrm, t1, t2);
+        if (ground.h != nullptr || anyself) plane_space(nrm, t1, t2);   // (+z gives exactly the constant pair)
         const f3 r1v = P - o1, r2v = P - o2, r3v = P - o3;
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
           const f3 dir = d == 0 ? nrm : (d == 1 ? t1 : t2);
-          const f3 Jw = cross(P, dir);
+          const f3 Jw = self ? mk(0.f, 0.f, 0.f) : cross(P, dir);          // against the base body: the base part of the relative row vanishes
           const float Jq1 = dot(a1, cross(r1v, dir));
           const float Jq2 = bestL[k] >= 2 ? dot(a2, cross(r2v, dir)) : 0.0f;
           const float Jq3 = bestL[k] >= 3 ? dot(a2, cross(r3v, dir)) : 0.0f;
           const float j1 = Jq1 * gi1;
           const float j2 = (Jq2 - g21 * j1) * gi2;
           const float j3 = (Jq3 - g31 * j1 - g32 * j2) * gi3;
-          const float Jb[6] = {Jw.x, Jw.y, Jw.z, dir.x, dir.y, dir.z};
+          const float Jb[6] = {Jw.x, Jw.y, Jw.z, self ? 0.0f : dir.x, self ? 0.0f : dir.y, self ? 0.0f : dir.z};
           float g[6];
 #pragma unroll
           for (int m = 0; m < 6; ++m) g[m] = act ? Jb[m] - (L.Bw[0][m] * j1 + L.Bw[1][m] * j2 + L.Bw[2][m] * j3) : 0.0f;
-          const float target = d == 0 ? -bestD[k] * (kErp / dt) : 0.0f;   // penetrating: position error through ERP
+          // penetrating: position error through ERP; a self-collision candidate still on its way in: the closing speed bound
+          const float target = d == 0 ? (bestD[k] > 0.0f ? -bestD[k] / dt : -bestD[k] * (kErp / dt)) : 0.0f;
           const int r = d == 0 ? slot : (REX_NBSLOT + 2 * slot + (d - 1));
           sm.brow(r, 0) = make_float4(g[0], g[1], g[2], g[3]);
           sm.brow(r, 1) = make_float4(g[4], g[5], act ? j1 : 0.0f, act ? j2 : 0.0f);
-          sm.brow(r, 2) = make_float4(act ? j3 : 0.0f, act ? target : 0.0f, act ? 1.0f : 0.0f, 0.0f);
+          // a friction row has no target: its .y carries the friction coefficient of the pair of surfaces instead (link against
+          // link: the product of the URDF defaults); .w stays 0 -- the element lanes without a component of the row read
+          const float c2y = d == 0 ? (act ? target : 0.0f) : (self ? kSelfMu : ground.mu);
+          sm.brow(r, 2) = make_float4(act ? j3 : 0.0f, c2y, act ? 1.0f : 0.0f, 0.0f);
         }
       }
     }
@@ -868,7 +962,7 @@ __device__ __forceinline__ void body_row(const SM& sm, const LN& ln, int bodyoff
 #pragma unroll
   for (int i = 0; i < NY; ++i) part = fmaf(jy[i], ys[i], part);
   const float vel = group_sum<LPE>(part);
-  float nl = fmaf(-c2.z, vel, lam + c2.y);
+  float nl = fmaf(-c2.z, vel, friction ? lam : lam + c2.y);   // (.y of a friction row is its coefficient, not a target)
   nl = friction ? __builtin_amdgcn_fmed3f(nl, -lim, lim) : fmaxf(nl, 0.0f);
   const float dl = nl - lam;
   lam = nl;
@@ -1017,7 +1111,7 @@ __device__ __forceinline__ void pgs_dv(const SM& sm, ARMP& armp, PgsX& x, int p,
           for (int sl = 0; sl < REX_NBSLOT; ++sl) {
             const int g = sl < 4 ? 0 : 1 + ((sl - 4) >> 1);
             if (!((bgroups >> g) & 1u)) continue;
-            const float lm = mu * lamb[sl];
+            const float lm = sm.brow(REX_NBSLOT + 2 * sl, 2).y * lamb[sl];   // the slot's own coefficient (ground: the env's foot friction; link against link: kSelfMu)
             body_row<LPE, NY>(sm, ln, bodyoff, REX_NBSLOT + 2 * sl, sl < 4 ? -1 : (sl - 4) >> 1, ys, zs, lamb[REX_NBSLOT + 2 * sl], lm, true, worst, thr);
             body_row<LPE, NY>(sm, ln, bodyoff, REX_NBSLOT + 2 * sl + 1, sl < 4 ? -1 : (sl - 4) >> 1, ys, zs, lamb[REX_NBSLOT + 2 * sl + 1], lm, true, worst, thr);
           }
@@ -1227,7 +1321,7 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
           const int r = d == 0 ? k : (REX_NBSLOT + 2 * k + (d - 1));
           sm.brow(r, 0) = act ? make_float4(Jw.x, Jw.y, Jw.z, dir.x) : make_float4(0.f, 0.f, 0.f, 0.f);
           sm.brow(r, 1) = act ? make_float4(dir.y, dir.z, 0.0f, 0.0f) : make_float4(0.f, 0.f, 0.f, 0.f);
-          sm.brow(r, 2) = make_float4(0.0f, act ? target : 0.0f, act ? 1.0f : 0.0f, 0.0f);
+          sm.brow(r, 2) = make_float4(0.0f, d == 0 ? (act ? target : 0.0f) : ground.mu, act ? 1.0f : 0.0f, 0.0f);   // friction rows: .y = the coefficient
         }
       }
     }
@@ -1302,7 +1396,7 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
         const float invd = c2.z != 0.0f ? __builtin_amdgcn_rcpf(diag) : 0.0f;
         sm.brow(r, 0) = make_float4(gw[0], gw[1], gw[2], gw[3]);
         sm.brow(r, 1) = make_float4(gw[4], gw[5], c1.z, c1.w);
-        sm.brow(r, 2) = make_float4(c2.x, c2.y * invd, invd, 0.0f);
+        sm.brow(r, 2) = make_float4(c2.x, r < REX_NBSLOT ? c2.y * invd : c2.y, invd, 0.0f);   // friction rows keep their coefficient in .y
       }
     }
   }

@@ -1315,3 +1315,50 @@ def test_env_randomizer_hooks_of_the_single_env_classes(torch):
         e.close()
     assert z[1] < z[0] - 1e-4
     env.close()
+
+
+def test_self_collision_rows_of_the_rolled_pose(torch):
+    """URDF_USE_SELF_COLLISION (rex.py:276-281) where it acts: RexPosesEnv rolling the base by 0.74 rad drives the edge of
+    the base box 3 mm into the upper-leg boxes of the low side (profiles/r02_contact_census.md).  With body_contacts the
+    leg boxes carry vertex-face rows against the base body's boxes: same rows in the oracle and in the kernels, and the
+    overlap is gone."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import contact_census as cc
+    n = 64
+    env, orc = make_pair("poses", "ik", n, np.float32, seed=6, base_roll=-0.74, body_contacts=1)
+    free, _ = make_pair("poses", "ik", n, np.float32, seed=6, base_roll=-0.74)
+    env.reset(); orc.reset(); free.reset()
+    rng = np.random.RandomState(4)
+    acts = rng.uniform(-0.1, 0.1, (260, n, env.action_dim)).astype(np.float32)
+    for a in acts[:200]:
+        orc.step(a)
+    # single-step parity from the oracle's states while the rows act; tolerance 1e-4 rad / 1e-4 m, 2 % of the envs may
+    # differ (a corner that is inside its box in one precision and outside in the other, at zero depth)
+    bad = np.zeros(n, bool)
+    for a in acts[200:215]:
+        env.state.copy_(numeric_to_product_state(orc.get_state(), torch, env.state.device))
+        env.step(torch.as_tensor(a, device="cuda")); orc.step(a)
+        ps, os_ = product_state_to_numeric(env.state), orc.get_state()
+        bad |= np.abs(ps[orclib.S_Q:orclib.S_Q + 12] - os_[orclib.S_Q:orclib.S_Q + 12]).max(axis=0) > 1e-4
+        bad |= np.abs(ps[:7] - os_[:7]).max(axis=0) > 1e-4
+    assert bad.mean() <= 0.02, bad.mean()
+    # whole rollouts on the GPU: with the rows the boxes stay out of each other, without them they do not
+    env.reset()
+    for a in acts:
+        ta = torch.as_tensor(a, device="cuda")
+        env.step(ta); free.step(ta)
+    t = cc.model_tables(); boxes = cc.link_boxes(t); names = [b[0] for b in boxes]
+
+    def deepest(state):
+        worst = []
+        for i in range(0, n, 8):
+            R, p = cc.fk(t, state[:, i].astype(np.float64))
+            world = [(R[b[1]], p[b[1]] + R[b[1]] @ b[2], b[3]) for b in boxes]
+            worst.append(min(cc.sat_separation(*world[names.index(A)], *world[names.index(leg + "_leg")])
+                             for A in ("base", "chassis_rear", "chassis_front") for leg in ("FL", "FR", "RL", "RR")))
+        return min(worst)
+    with_rows, without = deepest(product_state_to_numeric(env.state)), deepest(product_state_to_numeric(free.state))
+    print("deepest leg-box / base-box overlap [mm]: with rows %.3f, without %.3f" % (1e3 * with_rows, 1e3 * without))
+    assert without < -2e-3 and with_rows > -3e-4
+    env.close(); free.close()
