@@ -147,8 +147,11 @@ typedef struct RexConfig {
      > 1.  The gait phase clock here is simulated time x gait_clock_scale.  0 means 1.0. */
   float   gait_clock_scale;
   /* 1: contact rows for the link collision boxes (base, chassis, shoulder, leg, foot boxes of rex.urdf) against the
-     ground, next to the toe rows; 0: toes only (the fast path; the boxes of a robot that satisfies its env's
-     termination test stay clear of the ground). */
+     ground, next to the toe rows, and for the leg and foot boxes against the boxes of the base body (the reference loads
+     the robot with URDF_USE_SELF_COLLISION, model/rex.py:276-281); 0: toes only (the fast path; the boxes of a robot that
+     satisfies its env's termination test stay clear of the ground and of each other).
+     rex_default_config sets 1 for REX_TASK_POSES -- the env that never terminates and whose roll poses press the base
+     into the upper-leg boxes -- and 0 for every other task. */
   int32_t body_contacts;
   /* Rex(observation_noise_stdev=...) (model/rex.py:22,765-769): Gaussian noise added by the sensor getters --
      [0] motor angles, [1] motor velocities, [2] motor torques, [3] base roll/pitch/yaw, [4] base angular rates.

@@ -1099,6 +1099,9 @@ int rex_default_config(int task, int signal, int num_envs, RexConfig* cfg) {
   cfg->drift_weight = 2.0f;
   cfg->shake_weight = 0.005f;
   cfg->pose_index = -1;
+  /* RexPosesEnv never terminates (poses_env.py:265) and its roll poses press the rolled base's edge into the upper-leg
+     boxes of the low side (profiles/r02_contact_census.md): the one env where the link boxes act */
+  cfg->body_contacts = task == REX_TASK_POSES;
   cfg->solver_residual_threshold = 1e-7f;                        /* PyBullet default solverResidualThreshold */
   if (task == REX_TASK_MIXED) {   /* BASELINE.json configs[4]: walk, gallop and turn; per-task repeat / sweeps / weights apply per env */
     cfg->task_mix = (1 << REX_TASK_WALK) | (1 << REX_TASK_GALLOP) | (1 << REX_TASK_TURN);

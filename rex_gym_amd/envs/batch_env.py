@@ -71,7 +71,7 @@ class RexBatchEnv:
                  distance_weight=None, energy_weight=None, drift_weight=None, shake_weight=None,
                  tasks=None, mass_scale_range=None, friction_range=None, observation_noise_stdev=None,
                  heightfield=None, heightfield_cell=None, heightfield_origin=(0.0, 0.0, 0.0), init_height=None,
-                 body_contacts=False, on_rack=False, env_randomizer=None, **ignored):
+                 body_contacts=None, on_rack=False, env_randomizer=None, **ignored):
         import torch
         # Reference constructor keywords that only touch the GUI, logging or debugging are accepted and ignored; anything
         # else that would change what the env computes is an error here, not a silent no-op.
@@ -141,7 +141,8 @@ class RexBatchEnv:
         if init_height is not None:
             cfg.init_height = float(init_height)
         cfg.on_rack = int(bool(on_rack))               # debug rack: fixed base at [0, 0, 1] (rex.py:269-287)
-        cfg.body_contacts = int(bool(body_contacts))   # link collision boxes vs ground, next to the toe rows (include/rexsim.h)
+        if body_contacts is not None:   # link collision boxes vs ground and vs the base body, next to the toe rows (include/rexsim.h);
+            cfg.body_contacts = int(bool(body_contacts))   # None: the task's default (on for 'poses')
         cfg.motor_kp, cfg.motor_kd = float(motor_kp), float(motor_kd)
         cfg.gait_clock_scale = float(gait_clock_scale)     # wall-clock seconds per simulated second (gait_planner.py:108-110)
         for name, v in (("distance_weight", distance_weight), ("energy_weight", energy_weight),

@@ -1189,7 +1189,7 @@ def test_link_box_ground_contacts(torch, mark, n):
         np.testing.assert_allclose(ps[2], os_[2], atol=1.5e-2)
     env.close()
     if n <= 64:
-        sunk = RexBatchEnv(n, task="poses", signal_type="ik", **kw)
+        sunk = RexBatchEnv(n, task="poses", signal_type="ik", body_contacts=False, **kw)
         sunk.reset()
         sunk.state.copy_(numeric_to_product_state(st, torch, sunk.state.device))
         for k in range(300):
@@ -1327,7 +1327,7 @@ def test_self_collision_rows_of_the_rolled_pose(torch):
     import contact_census as cc
     n = 64
     env, orc = make_pair("poses", "ik", n, np.float32, seed=6, base_roll=-0.74, body_contacts=1)
-    free, _ = make_pair("poses", "ik", n, np.float32, seed=6, base_roll=-0.74)
+    free, _ = make_pair("poses", "ik", n, np.float32, seed=6, base_roll=-0.74, body_contacts=0)
     env.reset(); orc.reset(); free.reset()
     rng = np.random.RandomState(4)
     acts = rng.uniform(-0.1, 0.1, (260, n, env.action_dim)).astype(np.float32)

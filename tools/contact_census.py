@@ -101,7 +101,7 @@ def link_boxes(t):
     return out
 
 
-def census(task, signal, n, steps, seed=0):
+def census(task, signal, n, steps, seed=0, self_rows=False):
     t = model_tables()
     boxes = link_boxes(t)
     pairs = [(a, b) for a, b in itertools.combinations(range(len(boxes)), 2)
@@ -112,10 +112,13 @@ def census(task, signal, n, steps, seed=0):
     lib.orc_body_points.restype = ctypes.c_long
     lib.orc_substeps_with_body_points.restype = ctypes.c_long
     lib.orc_body_points(1); lib.orc_substeps_with_body_points(1)
+    lib.orc_set_probe.argtypes = [ctypes.c_char_p, ctypes.c_double]
+    lib.orc_set_probe(b"self_collision", 1.0 if self_rows else 0.0)    # the census asks what happens WITHOUT the link-link rows
     env.reset()
     rng = np.random.default_rng(seed)
     lo = np.minimum(*_bounds(task, signal)); hi = np.maximum(*_bounds(task, signal))
     min_sep = {}
+    overlapping = samples = 0
     low_corner = np.inf
     age = np.zeros(n, int)
     total_sub = 0
@@ -131,21 +134,27 @@ def census(task, signal, n, steps, seed=0):
                 for bx, (Rw, c, h) in zip(boxes, world):
                     if not bx[0].endswith("_toe"):
                         low_corner = min(low_corner, c[2] - np.sum(h * np.abs(Rw[2, :])))
+                samples += 1
+                worst = np.inf
                 for a, b in pairs:
                     s = sat_separation(*world[a], *world[b])
+                    worst = min(worst, s)
                     key = (re.sub(r"^(FL|FR|RL|RR)_", "", boxes[a][0]), re.sub(r"^(FL|FR|RL|RR)_", "", boxes[b][0]),
                            boxes[a][0][:2] == boxes[b][0][:2] and boxes[a][0][2:3] == "_")
                     if s < min_sep.get(key, np.inf):
                         min_sep[key] = s
+                overlapping += worst < -1e-4
         idx = np.nonzero(done | (age >= 1000))[0]
         if idx.size:
             env.reset(idx)
             age[idx] = 0
     pts = lib.orc_body_points(1)
     sub = lib.orc_substeps_with_body_points(1)
+    lib.orc_set_probe(b"self_collision", 1.0)
     env.close()
     return dict(task=task, signal=signal, substeps=total_sub, substeps_with_body_points=int(sub), body_points=int(pts),
-                lowest_box_corner=float(low_corner), min_sep=min_sep)
+                lowest_box_corner=float(low_corner), min_sep=min_sep,
+                overlap_share=overlapping / max(samples, 1))
 
 
 def _bounds(task, signal):
@@ -170,15 +179,20 @@ def main():
              "",
              f"{a.envs} envs x {a.steps} control steps per env type.  Generated by `tools/contact_census.py`.",
              "",
-             "| env | substeps | substeps with a link-box corner below the ground | lowest box corner [m] | admissible link pairs that come within 5 mm (smallest SAT separation, mm; <= 0 = overlap) |",
-             "|---|---|---|---|---|"]
-    for task, signal in (("walk", "ik"), ("walk", "ol"), ("gallop", "ik"), ("gallop", "ol"), ("turn", "ik"), ("turn", "ol"),
-                         ("poses", "ik"), ("standup", "ol")):
-        r = census(task, signal, a.envs, a.steps)
+             "The link-link rows (`body_contacts`: leg and foot boxes against the base body's boxes) are switched OFF for the census rows --",
+             "it asks where they would be needed; the last row repeats RexPosesEnv with them on.",
+             "",
+             "| env | substeps | substeps with a link-box corner below the ground | lowest box corner [m] | admissible link pairs that come within 5 mm (smallest SAT separation, mm; <= 0 = overlap) | sampled poses with a pair overlapping by > 0.1 mm |",
+             "|---|---|---|---|---|---|"]
+    for task, signal, rows in (("walk", "ik", False), ("walk", "ol", False), ("gallop", "ik", False), ("gallop", "ol", False),
+                               ("turn", "ik", False), ("turn", "ol", False), ("poses", "ik", False), ("standup", "ol", False),
+                               ("poses", "ik", True)):
+        r = census(task, signal, a.envs, a.steps, self_rows=rows)
         ms = sorted(r["min_sep"].items(), key=lambda kv: kv[1])
         near = "; ".join(f"{x}-{y}{' (same leg)' if s else ''} {val * 1000:.2f}" for (x, y, s), val in ms if val < 0.005) or "none"
-        line = (f"| {task}-{signal} | {r['substeps']} | {r['substeps_with_body_points']} "
-                f"({100.0 * r['substeps_with_body_points'] / r['substeps']:.2f} %) | {r['lowest_box_corner']:.4f} | {near} |")
+        line = (f"| {task}-{signal}{' WITH the link-link rows' if rows else ''} | {r['substeps']} | {r['substeps_with_body_points']} "
+                f"({100.0 * r['substeps_with_body_points'] / r['substeps']:.2f} %) | {r['lowest_box_corner']:.4f} | {near} | "
+                f"{100.0 * r['overlap_share']:.2f} % |")
         print(line, flush=True)
         lines.append(line)
     with open(a.out, "w") as f:
