@@ -7,6 +7,7 @@ What is restated, piece by piece:
   StreamingNormalize     agents/ppo/normalize.py:18-153   (Welford mean / variance, centre, scale, clip)
   discounted_return ...  agents/ppo/utility.py:71-143     (Monte-Carlo return, TD-lambda return, diagonal normals)
   ForwardGaussianPolicy  agents/scripts/networks.py:69-112, scripts/utility.py:100-117 (initialisers)
+  RecurrentGaussianPolicy  agents/scripts/networks.py:113-159 (GRU last policy layer; no shipped config selects it)
   PPOAgent               agents/ppo/algorithm.py:26-531   (episode buffers, memory of `update_every` episodes, policy /
                                                            value updates, KL penalty adaptation)
   train                  agents/tools/simulate.py:15-131  (reset done envs, act, step, hand transitions to the agent)
@@ -41,6 +42,7 @@ class PPOConfig:
     kl_cutoff_coef: float = 1000.0
     kl_init_penalty: float = 1.0
     max_length: int = 2000
+    network: str = "forward"        # "forward": ForwardGaussianPolicy (every shipped config); "recurrent": RecurrentGaussianPolicy
 
 
 class StreamingNormalize:
@@ -196,6 +198,57 @@ class ForwardGaussianPolicy(torch.nn.Module):
         return mean, logstd, value
 
 
+class RecurrentGaussianPolicy(ForwardGaussianPolicy):
+    """networks.py:113-159: as ForwardGaussianPolicy, but the LAST policy layer is a GRU cell of 100 units
+    (tf.contrib.rnn.GRUBlockCell(100), whatever size policy_layers[-1] names); the value network stays feed-forward.
+    The cell is TensorFlow's: r, u = sigmoid(W_ru [x, h] + b_ru) (gate biases start at 1), c = tanh(W_c [x, r h] + b_c),
+    h' = u h + (1 - u) c -- the reset gate acts BEFORE the candidate's matrix product, unlike torch.nn.GRU.
+    The state starts at zero with every episode (tf.nn.dynamic_rnn over whole episodes, algorithm.py:513-531)."""
+    state_size = 100
+
+    def __init__(self, obs_dim, action_dim, cfg):
+        import copy
+        inner = copy.copy(cfg)
+        inner.policy_layers = tuple(cfg.policy_layers[:-1])
+        super().__init__(obs_dim, action_dim, inner)
+        feat = inner.policy_layers[-1] if inner.policy_layers else obs_dim
+        H = self.state_size
+        self.gates = torch.nn.Linear(feat + H, 2 * H)
+        self.candidate = torch.nn.Linear(feat + H, H)
+        for lin, bias in ((self.gates, 1.0), (self.candidate, 0.0)):
+            torch.nn.init.xavier_uniform_(lin.weight)
+            torch.nn.init.constant_(lin.bias, bias)
+        self.mean = torch.nn.Linear(H, action_dim)
+        std = math.sqrt(1.3 * cfg.init_mean_factor / H)
+        torch.nn.init.trunc_normal_(self.mean.weight, std=std, a=-2 * std, b=2 * std)
+        torch.nn.init.zeros_(self.mean.bias)
+
+    def policy_parameters(self):
+        return super().policy_parameters() + list(self.gates.parameters()) + list(self.candidate.parameters())
+
+    def cell(self, x, h):
+        r, u = torch.sigmoid(self.gates(torch.cat([x, h], -1))).chunk(2, -1)
+        c = torch.tanh(self.candidate(torch.cat([x, r * h], -1)))
+        return u * h + (1.0 - u) * c
+
+    def step(self, observ, state):
+        """one control step of a batch: observ [N, O], state [N, 100] -> (mean, logstd, value), new state"""
+        state = self.cell(self.policy(observ), state)
+        mean = torch.tanh(self.mean(state))
+        return (mean, self.logstd.expand_as(mean), self.value_out(self.value(observ))[..., 0]), state
+
+    def forward(self, observ):
+        """whole episodes: observ [R, T, O], zero initial state"""
+        x = self.policy(observ)
+        h = torch.zeros(observ.shape[0], self.state_size, device=observ.device, dtype=observ.dtype)
+        out = []
+        for t in range(observ.shape[1]):
+            h = self.cell(x[:, t], h)
+            out.append(h)
+        mean = torch.tanh(self.mean(torch.stack(out, 1)))
+        return mean, self.logstd.expand_as(mean), self.value_out(self.value(observ))[..., 0]
+
+
 class PPOAgent:
     """algorithm.py:26-531 for `num_agents` parallel environments whose tensors live on `device`."""
 
@@ -205,7 +258,10 @@ class PPOAgent:
         gen = torch.Generator(device="cpu"); gen.manual_seed(seed)
         with torch.random.fork_rng(devices=[]):
             torch.manual_seed(seed)
-            self.net = ForwardGaussianPolicy(obs_dim, action_dim, cfg).to(self.device)
+            if cfg.network not in ("forward", "recurrent"):
+                raise ValueError("PPOConfig.network must be 'forward' or 'recurrent'")
+            self.net = (RecurrentGaussianPolicy if cfg.network == "recurrent" else ForwardGaussianPolicy)(obs_dim, action_dim, cfg).to(self.device)
+        self.state = torch.zeros((num_agents, RecurrentGaussianPolicy.state_size), device=self.device) if cfg.network == "recurrent" else None
         self._gen = torch.Generator(device=self.device); self._gen.manual_seed(seed + 1)
         self.observ_filter = StreamingNormalize((obs_dim,), center=True, scale=True, clip=5, device=self.device)   # :48-52
         self.reward_filter = StreamingNormalize((), center=False, scale=True, clip=10, device=self.device)         # :53-57
@@ -228,10 +284,15 @@ class PPOAgent:
     # ---- acting (algorithm.py:100-136) ----
     def begin_episode(self, indices):
         self.episode_length[indices] = 0
+        if self.state is not None:
+            self.state[indices] = 0.0
 
     @torch.no_grad()
     def perform(self, observ, training=True):
-        mean, logstd, _ = self.net(self.observ_filter.transform(observ))
+        if self.state is not None:
+            (mean, logstd, _), self.state = self.net.step(self.observ_filter.transform(observ), self.state)
+        else:
+            mean, logstd, _ = self.net(self.observ_filter.transform(observ))
         if training:
             action = mean + torch.exp(logstd) * torch.randn(mean.shape, device=self.device, generator=self._gen)
         else:

@@ -3,6 +3,7 @@
 import math
 
 import numpy as np
+import pytest
 import torch
 
 from rex_gym_amd.agents import PPOAgent, PPOConfig, StreamingNormalize, train
@@ -154,3 +155,48 @@ def test_padding_beyond_an_episode_never_enters_the_advantage():
             stats = agent._update_policy(obs, act, mean.detach(), logstd.detach(), rew, length)
             results.append(stats["policy_loss"])
         assert abs(results[0] - results[1]) < 1e-6, (lam, results)
+
+
+def test_recurrent_policy_is_the_reference_gru_and_learns():
+    """RecurrentGaussianPolicy (networks.py:113-159): last policy layer = TensorFlow's GRU block cell of 100 units (the
+    reset gate acts before the candidate's product, gate biases start at 1); acting step by step with a carried state
+    equals evaluating the whole episode from a zero state; the state is cleared at episode begin; PPO learns with it."""
+    torch.manual_seed(2)
+    cfg = PPOConfig(policy_layers=(16, 100), value_layers=(8,), network="recurrent")
+    net = ppo.RecurrentGaussianPolicy(3, 2, cfg).double()
+    assert [m.out_features for m in net.policy if isinstance(m, torch.nn.Linear)] == [16] and net.mean.in_features == 100
+    assert torch.all(net.gates.bias == 1.0) and torch.all(net.candidate.bias == 0.0)
+    obs = torch.randn(4, 9, 3, dtype=torch.float64)
+    mean, logstd, value = net(obs)
+    assert mean.shape == (4, 9, 2) and value.shape == (4, 9)
+    # numpy restatement of the cell, step by step
+    W = {k: v.detach().numpy() for k, v in net.state_dict().items()}
+    def dense(x, name):
+        return x @ W[name + ".weight"].T + W[name + ".bias"]
+    h = np.zeros((4, 100))
+    state = torch.zeros(4, 100, dtype=torch.float64)
+    for t in range(9):
+        x = np.maximum(dense(obs[:, t].numpy(), "policy.0"), 0.0)
+        ru = 1.0 / (1.0 + np.exp(-dense(np.concatenate([x, h], 1), "gates")))
+        r, u = ru[:, :100], ru[:, 100:]
+        c = np.tanh(dense(np.concatenate([x, r * h], 1), "candidate"))
+        h = u * h + (1.0 - u) * c
+        np.testing.assert_allclose(mean[:, t].detach().numpy(), np.tanh(dense(h, "mean")), rtol=1e-10, atol=1e-12)
+        (m1, _, v1), state = net.step(obs[:, t], state)
+        np.testing.assert_allclose(m1.detach().numpy(), mean[:, t].detach().numpy(), rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(v1.detach().numpy(), value[:, t].detach().numpy(), rtol=1e-10, atol=1e-12)
+    # the agent: state carried between perform() calls, cleared by begin_episode(); learning on the toy task
+    n = 32
+    cfg = PPOConfig(policy_layers=(16, 100), value_layers=(32,), update_every=n, update_epochs_policy=10, update_epochs_value=10,
+                    policy_lr=3e-3, value_lr=3e-3, max_length=8, discount=0.9, init_mean_factor=0.1, network="recurrent")
+    env, agent = _PointEnv(n), PPOAgent(n, 1, 1, cfg, device="cpu", seed=3)
+    agent.perform(torch.ones(n, 1))
+    assert float(agent.state.abs().max()) > 0
+    agent.begin_episode(torch.tensor([0, 5]))
+    assert float(agent.state[[0, 5]].abs().max()) == 0 and float(agent.state[1].abs().max()) > 0
+    first, _ = train(env, agent, 8 * 3)
+    for _ in range(10):
+        last, _ = train(env, agent, 8 * 3)
+    assert agent.updates >= 20 and last > first + 0.5, (first, last)
+    with pytest.raises(ValueError):
+        PPOAgent(2, 1, 1, PPOConfig(network="lstm"), device="cpu")
