@@ -300,6 +300,7 @@ def main():
             "config": {"workload": f"{n} Rex envs per GPU, " + ("every env's task drawn from walk/gallop/turn-IK, mass and friction drawn per reset, one launch "
                                    "per step, " if args.mixed else f"{args.task}-{args.signal.upper()}, ") + f""
                                    f"{'flat plane' if args.terrain == 'plane' else 'random heightfield pool'}, {args.mark} mark, "
+                                   f"{'link-box rows (ground + self collision) on, ' if env.config.body_contacts else ''}"
                                    f"dt 1 ms x {env.config.action_repeat} substeps, <= {env.config.solver_iterations} PGS sweeps "
                                    "(Bullet residual threshold 1e-7), auto-reset, episode cap 2000, uniform random actions "
                                    f"over the env's action Box; {PREROLL_STEPS} untimed pre-roll steps with staggered resets before --warmup "

@@ -549,7 +549,7 @@ __device__ __forceinline__ void leg_pass(int leg, const BaseKin& bk, const float
                   REX_BOX_CENTER[1][1] == 0.0 && REX_BOX_CENTER[1][2] == 0.0 && REX_BOX_CENTER[2][1] == 0.0 && REX_BOX_CENTER[2][2] == 0.0,
                   "base body boxes: one y-z section, centres on the base's x axis");
     float Cm[2][3][3], dA0[2][3], dB0[2][3];   // per leg box: C[i][j] = base axis i . box axis j; centre offset in both frames
-    bool selfnear = false;
+    unsigned pairnear = 0;   // bit 3 bb + a: leg box bb and base box a are not separated by a face axis
 #pragma unroll
     for (int bb = 0; bb < 2; ++bb) {
       const f3 ea[3] = {bk.ex, bk.ey, bk.ez}, eb[3] = {bx[1 + bb], y1, bz[1 + bb]};
@@ -572,12 +572,14 @@ __device__ __forceinline__ void leg_pass(int leg, const BaseKin& bk, const float
           const float dj = dB0[bb][i] - cx * Cm[bb][0][i];
           sep = fmaxf(sep, fabsf(dj) - hB[i] - (hA[0] * fabsf(Cm[bb][0][i]) + hA[1] * fabsf(Cm[bb][1][i]) + hA[2] * fabsf(Cm[bb][2][i])));
         }
-        selfnear |= sep < 2.0f * kSelfMargin;   // (a corner within the margin of a box can be up to sqrt(3) margins away along the other box's axes)
+        if (sep < 2.0f * kSelfMargin) pairnear |= 1u << (3 * bb + a);   // (a corner within the margin of a box can be up to sqrt(3) margins away along the other box's axes)
       }
     }
-    const bool anyself = __builtin_amdgcn_ballot_w64(selfnear) != 0;
+    unsigned pairs = 0;      // wave-uniform: the pairs some env of the wave has to look at corner by corner
+#pragma unroll
+    for (int b6 = 0; b6 < 6; ++b6) if (__builtin_amdgcn_ballot_w64((pairnear >> b6) & 1u) != 0) pairs |= 1u << b6;
+    const bool anyself = pairs != 0;
     if (__builtin_amdgcn_ballot_w64(near) != 0 || anyself) {
-      active_mask |= 1u << (21 + leg);
       float bestD[2] = {0.0f, 0.0f};
       f3 bestP[2] = {mk(0.f, 0.f, 0.f), mk(0.f, 0.f, 0.f)}, bestN[2] = {mk(0.f, 0.f, 1.f), mk(0.f, 0.f, 1.f)};
       int bestL[2] = {0, 0};   // 0 = empty slot, else 1 + box (= number of joints that move the point)
@@ -623,6 +625,7 @@ __device__ __forceinline__ void leg_pass(int leg, const BaseKin& bk, const float
           const f3 cA = cx * bk.ex;
 #pragma unroll
           for (int bb = 0; bb < 2; ++bb) {
+            if (!((pairs >> (3 * bb + a)) & 1u)) continue;   // wave-uniform
             const float hB[3] = {(float)REX_BOX_HALF[B0 + 1 + bb][0], (float)REX_BOX_HALF[B0 + 1 + bb][1], (float)REX_BOX_HALF[B0 + 1 + bb][2]};
             const f3 ea[3] = {bk.ex, bk.ey, bk.ez}, eb[3] = {bx[1 + bb], y1, bz[1 + bb]};
             const float dA[3] = {dA0[bb][0] - cx, dA0[bb][1], dA0[bb][2]};
@@ -661,6 +664,9 @@ __device__ __forceinline__ void leg_pass(int leg, const BaseKin& bk, const float
           }
         }
       }
+      // bits 21 + leg / 25 + leg: the leg's first / second link-box slot holds a point (the solver skips empty slots wave by wave)
+      if (bestL[0] != 0) active_mask |= 1u << (21 + leg);
+      if (bestL[1] != 0) active_mask |= 1u << (25 + leg);
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         if (esel >= 0 && k != esel) continue;   // 8 lanes per env: the two lanes of a leg take one slot each
@@ -1062,13 +1068,16 @@ __device__ __forceinline__ void pgs_dv(const SM& sm, ARMP& armp, PgsX& x, int p,
       armp.template dv_sweep<LPE, NY>(ys, worst, thr);
       if constexpr (SM::kBody) {
         // link-box normals (among the normals they come before the toe points: the toe rows stay one pipelined block)
-        if (bgroups != 0) {
+        // one branch per GROUP (wave-uniform), its rows in one block: the row loads of a group issue together
+        if (bgroups & 1u) {
 #pragma unroll
-          for (int sl = 0; sl < REX_NBSLOT; ++sl) {
-            const int g = sl < 4 ? 0 : 1 + ((sl - 4) >> 1);
-            if (!((bgroups >> g) & 1u)) continue;      // wave-uniform
-            body_row<LPE, NY>(sm, ln, bodyoff, sl, sl < 4 ? -1 : (sl - 4) >> 1, ys, zs, lamb[sl], 0.0f, false, worst, thr);
-          }
+          for (int sl = 0; sl < 4; ++sl) body_row<LPE, NY>(sm, ln, bodyoff, sl, -1, ys, zs, lamb[sl], 0.0f, false, worst, thr);
+        }
+#pragma unroll
+        for (int l = 0; l < REX_NLEG; ++l) {
+          if (!((bgroups >> (1 + l)) & 1u)) continue;       // (a second slot is never filled before the first)
+          body_row<LPE, NY>(sm, ln, bodyoff, 4 + 2 * l, l, ys, zs, lamb[4 + 2 * l], 0.0f, false, worst, thr);
+          if ((bgroups >> (5 + l)) & 1u) body_row<LPE, NY>(sm, ln, bodyoff, 5 + 2 * l, l, ys, zs, lamb[5 + 2 * l], 0.0f, false, worst, thr);
         }
       }
       if (any_contact) {
@@ -1106,14 +1115,26 @@ __device__ __forceinline__ void pgs_dv(const SM& sm, ARMP& armp, PgsX& x, int p,
         }
       }
       if constexpr (SM::kBody) {
-        if (bgroups != 0) {       // link-box friction pairs: after the toe friction rows
+        // link-box friction pairs: after the toe friction rows; the coefficient of a slot sits in its first friction row
+        // (ground: the env's foot friction; link against link: kSelfMu)
+        if (bgroups & 1u) {
 #pragma unroll
-          for (int sl = 0; sl < REX_NBSLOT; ++sl) {
-            const int g = sl < 4 ? 0 : 1 + ((sl - 4) >> 1);
-            if (!((bgroups >> g) & 1u)) continue;
-            const float lm = sm.brow(REX_NBSLOT + 2 * sl, 2).y * lamb[sl];   // the slot's own coefficient (ground: the env's foot friction; link against link: kSelfMu)
-            body_row<LPE, NY>(sm, ln, bodyoff, REX_NBSLOT + 2 * sl, sl < 4 ? -1 : (sl - 4) >> 1, ys, zs, lamb[REX_NBSLOT + 2 * sl], lm, true, worst, thr);
-            body_row<LPE, NY>(sm, ln, bodyoff, REX_NBSLOT + 2 * sl + 1, sl < 4 ? -1 : (sl - 4) >> 1, ys, zs, lamb[REX_NBSLOT + 2 * sl + 1], lm, true, worst, thr);
+          for (int sl = 0; sl < 4; ++sl) {
+            const float lm = sm.brow(REX_NBSLOT + 2 * sl, 2).y * lamb[sl];
+            body_row<LPE, NY>(sm, ln, bodyoff, REX_NBSLOT + 2 * sl, -1, ys, zs, lamb[REX_NBSLOT + 2 * sl], lm, true, worst, thr);
+            body_row<LPE, NY>(sm, ln, bodyoff, REX_NBSLOT + 2 * sl + 1, -1, ys, zs, lamb[REX_NBSLOT + 2 * sl + 1], lm, true, worst, thr);
+          }
+        }
+#pragma unroll
+        for (int l = 0; l < REX_NLEG; ++l) {
+          if (!((bgroups >> (1 + l)) & 1u)) continue;
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            if (k == 1 && !((bgroups >> (5 + l)) & 1u)) continue;
+            const int sl = 4 + 2 * l + k;
+            const float lm = sm.brow(REX_NBSLOT + 2 * sl, 2).y * lamb[sl];
+            body_row<LPE, NY>(sm, ln, bodyoff, REX_NBSLOT + 2 * sl, l, ys, zs, lamb[REX_NBSLOT + 2 * sl], lm, true, worst, thr);
+            body_row<LPE, NY>(sm, ln, bodyoff, REX_NBSLOT + 2 * sl + 1, l, ys, zs, lamb[REX_NBSLOT + 2 * sl + 1], lm, true, worst, thr);
           }
         }
       }
@@ -1363,7 +1384,7 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
   REX_STAMP(t_chol);
   // finish the rows: whiten the base part, inverse diagonal (0 disables an inactive point)
   armp.finish(Lc);
-  const bool any_limit = __builtin_amdgcn_ballot_w64((active >> REX_NPOINT) != 0) != 0;
+  const bool any_limit = __builtin_amdgcn_ballot_w64(((active >> REX_NPOINT) & 0xFFFu) != 0) != 0;   // bits 8..19: the 12 leg joints
   for (int r = pl; r < (any_limit ? REX_NROW : REX_NCROW); r += kSplitLegs ? LPE : 1) {   // lane p: rows p, p + LPE, ...
     float4 c0 = sm.row(r, 0), c1 = sm.row(r, 1), c2 = sm.row(r, 2);
     const float g[6] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y};
@@ -1377,15 +1398,17 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
     sm.row(r, 2) = make_float4(c2.x, c2.y * invd, invd, kSplitLegs ? 0.0f : diag);   // .w = 0: see pgs_dv
   }
 
-  unsigned bgroups = 0;   // bit g: link-box group g (0 base, 1 + leg) has rows in reach of some env of the wave
+  // bit 0: the base group has rows in reach of some env of the wave; bit 1 + leg / 5 + leg: the leg's first / second slot holds a
+  // point in some env of the wave
+  unsigned bgroups = 0;
   if constexpr (SM::kBody) {
 #pragma unroll
-    for (int g = 0; g < 5; ++g) if (__builtin_amdgcn_ballot_w64((active >> (20 + g)) & 1u) != 0) bgroups |= 1u << g;
+    for (int g = 0; g < 9; ++g) if (__builtin_amdgcn_ballot_w64((active >> (20 + g)) & 1u) != 0) bgroups |= 1u << g;
     if (bgroups != 0) {
       mirror_sync();
       for (int r = pl; r < REX_NBROW; r += LPE) {   // lane p: rows p, p + LPE, ...
         const int slot = r < REX_NBSLOT ? r : (r - REX_NBSLOT) >> 1;
-        const int g = slot < 4 ? 0 : 1 + ((slot - 4) >> 1);
+        const int g = slot < 4 ? 0 : 1 + ((slot - 4) >> 1) + 4 * ((slot - 4) & 1);
         if (!((bgroups >> g) & 1u)) continue;
         float4 c0 = sm.brow(r, 0), c1 = sm.brow(r, 1), c2 = sm.brow(r, 2);
         const float gq[6] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y};

@@ -1206,7 +1206,8 @@ def test_link_box_rows_change_nothing_while_no_box_touches_the_ground(torch):
     a = RexBatchEnv(n, task="walk", signal_type="ik", seed=3, body_contacts=True)
     b = RexBatchEnv(n, task="walk", signal_type="ik", seed=3)
     oa, ob = a.reset(), b.reset()
-    np.testing.assert_allclose(oa.cpu().numpy(), ob.cpu().numpy(), atol=1e-5)
+    # (the two template instantiations round differently: the settled robot's residual rates, 3e-5 rad/s, differ in sign)
+    np.testing.assert_allclose(oa.cpu().numpy(), ob.cpu().numpy(), atol=1e-4)
     g = torch.Generator(device="cuda"); g.manual_seed(3)
     for k in range(40):
         act = torch.rand((n, 2), device="cuda", generator=g) * 0.8 - 0.4

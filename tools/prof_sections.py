@@ -4,7 +4,7 @@
 Builds rexsim.hip with -DREX_PROF (clock64() stamps around the sections of physics_substep, accumulated per
 workgroup by lane 0) into scratch/librexsim_prof.so, runs walk-IK at N envs and prints cycles per substep for:
 leg factorisation, base Cholesky, row finishing, PGS sweeps, back-substitution + integration.
-  python tools/prof_sections.py [N=4096] [--arm] [--task=standup|poses|...] [--rebuild]
+  python tools/prof_sections.py [N=4096] [--arm] [--task=standup|poses|...] [--roll=R] [--body=0|1] [--rebuild]
 """
 import ctypes
 import os
@@ -31,7 +31,14 @@ args = [a for a in sys.argv[1:] if not a.startswith("--")]
 n = int(args[0]) if args else 4096
 mark = "arm" if "--arm" in sys.argv else "base"
 task = next((a.split("=")[1] for a in sys.argv if a.startswith("--task=")), "walk")
-env = RexBatchEnv(n, task=task, signal_type="ol" if task == "standup" else "ik", seed=0, auto_reset=True, max_episode_steps=2000, mark=mark)
+extra = {}
+for a in sys.argv:
+    if a.startswith("--roll="):
+        extra["base_roll"] = float(a.split("=")[1])          # poses: every env holds this roll (the self-collision regime at -0.74)
+    if a.startswith("--body="):
+        extra["body_contacts"] = bool(int(a.split("=")[1]))
+env = RexBatchEnv(n, task=task, signal_type="ol" if task == "standup" else "ik", seed=0, auto_reset=True, max_episode_steps=2000, mark=mark,
+                  **extra)
 env.reset()
 _lo = torch.as_tensor(env.action_space.low, device="cuda").minimum(torch.as_tensor(env.action_space.high, device="cuda"))
 acts = [torch.rand((n, env.action_dim), device="cuda") * (-2 * _lo) + _lo for _ in range(8)]
