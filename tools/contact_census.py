@@ -182,7 +182,7 @@ def main():
              "The link-link rows (`body_contacts`: leg and foot boxes against the base body's boxes) are switched OFF for the census rows --",
              "it asks where they would be needed; the last row repeats RexPosesEnv with them on.",
              "",
-             "| env | substeps | substeps with a link-box corner below the ground | lowest box corner [m] | admissible link pairs that come within 5 mm (smallest SAT separation, mm; <= 0 = overlap) | sampled poses with a pair overlapping by > 0.1 mm |",
+             "| env | substeps | substeps with a kept link-box point (a corner below the ground; in the last row also a link-link candidate) | lowest box corner [m] | admissible link pairs that come within 5 mm (smallest SAT separation, mm; <= 0 = overlap) | sampled poses with a pair overlapping by > 0.1 mm |",
              "|---|---|---|---|---|---|"]
     for task, signal, rows in (("walk", "ik", False), ("walk", "ol", False), ("gallop", "ik", False), ("gallop", "ol", False),
                                ("turn", "ik", False), ("turn", "ol", False), ("poses", "ik", False), ("standup", "ol", False),
