@@ -1318,7 +1318,8 @@ def test_env_randomizer_hooks_of_the_single_env_classes(torch):
     env.close()
 
 
-def test_self_collision_rows_of_the_rolled_pose(torch):
+@pytest.mark.parametrize("n,epw", [(64, 4), (4096, 4), (2048, 8)])
+def test_self_collision_rows_of_the_rolled_pose(torch, n, epw, monkeypatch):
     """URDF_USE_SELF_COLLISION (rex.py:276-281) where it acts: RexPosesEnv rolling the base by 0.74 rad drives the edge of
     the base box 3 mm into the upper-leg boxes of the low side (profiles/r02_contact_census.md).  With body_contacts the
     leg boxes carry vertex-face rows against the base body's boxes: same rows in the oracle and in the kernels, and the
@@ -1326,8 +1327,9 @@ def test_self_collision_rows_of_the_rolled_pose(torch):
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import contact_census as cc
-    n = 64
+    monkeypatch.setenv("REX_ENVS_PER_WAVE", str(epw))
     env, orc = make_pair("poses", "ik", n, np.float32, seed=6, base_roll=-0.74, body_contacts=1)
+    assert env._L.rex_envs_per_wave(env._h) == epw          # both link-box instantiations, at BASELINE batch sizes
     free, _ = make_pair("poses", "ik", n, np.float32, seed=6, base_roll=-0.74, body_contacts=0)
     env.reset(); orc.reset(); free.reset()
     rng = np.random.RandomState(4)
@@ -1353,7 +1355,7 @@ def test_self_collision_rows_of_the_rolled_pose(torch):
 
     def deepest(state):
         worst = []
-        for i in range(0, n, 8):
+        for i in range(0, n, n // 8):
             R, p = cc.fk(t, state[:, i].astype(np.float64))
             world = [(R[b[1]], p[b[1]] + R[b[1]] @ b[2], b[3]) for b in boxes]
             worst.append(min(cc.sat_separation(*world[names.index(A)], *world[names.index(leg + "_leg")])
