@@ -758,21 +758,26 @@ static void contact_jacobian(const Aba* A, int kbody, const real P[3], const rea
 #define SELF_MU ((real)0.25)   /* btManifoldResult::calculateCombinedFriction: the product of the two links' URDF defaults, 0.5 x 0.5 */
 static int BODY_CONTACTS = 0;
 static int P_SELF_COLLISION = 1;          /* probe: leg boxes against the base body's boxes (only with body_contacts) */
+static int P_SELF_DIAG_BULLET = 1;        /* a link-link row's diagonal as btMultiBodyConstraintSolver::setupMultiBodyContactConstraint builds it:
+                                             denom0 + denom1, the two links' own terms without their cross term; 0 (probe): the exact diagonal */
 static long DBG_SELF_POINTS = 0;
 
 /* Jacobian row and impulse response of direction d at point P of body kbody -- against the world, or (self) against the
  * base body: the row of the relative velocity, whose base part vanishes (the pair's forces are internal to the robot) */
-static void point_row(const Aba* A, int kbody, int self, const real P[3], const real d[3], Row* r) {
+static real point_row(const Aba* A, int kbody, int self, const real P[3], const real d[3], Row* r) {
   real fk[6];
   contact_jacobian(A, kbody, P, d, r->J, fk);
   impulse_response_at(A, kbody, fk, r->resp);
+  real diag_separate = 0;   /* the two links' own terms only, as btMultiBodyConstraintSolver sums them */
   if (self) {
     real J0[NDOF], r0[NDOF], f0[6];
     contact_jacobian(A, 0, P, d, J0, f0);
     impulse_response_at(A, 0, f0, r0);
+    for (int k = 0; k < NDOF; ++k) diag_separate += r->J[k] * r->resp[k] + J0[k] * r0[k];
     for (int k = 0; k < NDOF; ++k) { r->J[k] -= J0[k]; r->resp[k] -= r0[k]; }
     for (int k = 0; k < 6; ++k) r->J[k] = 0;
   }
+  return diag_separate;
 }
 static long DBG_BODY_POINTS = 0, DBG_BODY_SUBSTEPS = 0;   /* statistics (single-threaded census runs): active body points, substeps with any */
 
@@ -1001,9 +1006,10 @@ static void physics_substep(Phys* s, const real tau[NJ], real dt, int iterations
   for (int q = 0; q < npoint; ++q) {
     int p = order[q];
     Row* r = &rows[nrow];
-    point_row(&A, PtBody[p], PtSelf[p], PtP[p], PtN[p], r);
+    real dsep = point_row(&A, PtBody[p], PtSelf[p], PtP[p], PtN[p], r);
     real diag = 0, vel = 0;
     for (int k = 0; k < NDOF; ++k) { diag += r->J[k] * r->resp[k]; vel += r->J[k] * nu[k]; }
+    if (PtSelf[p] && P_SELF_DIAG_BULLET) diag = dsep;
     r->invdiag = 1 / diag;
     real pen = PtDist[p] + P_SLOP;
     real poserr = 0, velerr = -vel;
@@ -1021,10 +1027,11 @@ static void physics_substep(Phys* s, const real tau[NJ], real dt, int iterations
       Row* r = &rows[nrow];
       real t1[3], t2[3];
       plane_space(PtN[p], t1, t2);
-      point_row(&A, PtBody[p], PtSelf[p], PtP[p], d == 0 ? t1 : t2, r);
+      real dsep = point_row(&A, PtBody[p], PtSelf[p], PtP[p], d == 0 ? t1 : t2, r);
       r->mu = PtSelf[p] ? SELF_MU : mu;
       real diag = 0, vel = 0;
       for (int k = 0; k < NDOF; ++k) { diag += r->J[k] * r->resp[k]; vel += r->J[k] * nu[k]; }
+      if (PtSelf[p] && P_SELF_DIAG_BULLET) diag = dsep;
       r->invdiag = 1 / diag;
       r->rhs = -vel * r->invdiag;
       r->lambda = 0; r->normal_row = normal_of_point[p];
@@ -1918,6 +1925,7 @@ ORC_API int orc_set_probe(const char* name, double v) {
   else if (!strcmp(name, "joint_friction")) { DBG_JOINT_FRICTION = (real)v; DBG_JOINT_VISC = (real)1e3; }
   else if (!strcmp(name, "body_contacts")) BODY_CONTACTS = (int)v;
   else if (!strcmp(name, "self_collision")) P_SELF_COLLISION = (int)v;
+  else if (!strcmp(name, "self_diag_bullet")) P_SELF_DIAG_BULLET = (int)v;
   else return -1;
   return 0;
 }

@@ -51,7 +51,10 @@
 #define REX_MOTOR_PARK_F4 ((REX_MOTOR_PARK_WORDS + 3) / 4)
 #define REX_NBSLOT 12
 #define REX_NBROW (3 * REX_NBSLOT)
-#define REX_BODY_F4 (REX_NBROW * REX_ROW_F4)
+// behind the rows: the base Jacobian (2 chunks) of each of the 24 leg-group rows when its point is held against the base
+// body -- what the Bullet diagonal of a link-link row needs besides the relative row (physics_substep, row finishing)
+#define REX_NBJAC (3 * (REX_NBSLOT - 4))
+#define REX_BODY_F4 (REX_NBROW * REX_ROW_F4 + 2 * REX_NBJAC)
 #define REX_PARK_XY 0
 #define REX_PARK_CPL 2
 
@@ -86,6 +89,7 @@ struct Lds {
   float4* pm;   // motor-side state parked around the physics call (mark 'arm', <= 8 envs per wave; else null): REX_MOTOR_PARK_F4 chunks per env
   __device__ __forceinline__ float& motorf(int f) const { return reinterpret_cast<float*>(&pm[(f >> 2) * EPW + slot])[f & 3]; }
   __device__ __forceinline__ float4& brow(int r, int c) const { return pb[(r * REX_ROW_F4 + c) * EPW + slot]; }
+  __device__ __forceinline__ float4& bjac(int i, int c) const { return pb[(REX_NBROW * REX_ROW_F4 + 2 * i + c) * EPW + slot]; }   // i = 3 (slot - 4) + direction
   __device__ __forceinline__ float4& park(int c) const { return pk[c * EPW + slot]; }
   // scalar views for the lanes that own single components (pgs_dv): float f of a chunk sequence starting at chunk c0
   __device__ __forceinline__ float& parkf(int c0, int f) const { return reinterpret_cast<float*>(&pk[(c0 + (f >> 2)) * EPW + slot])[f & 3]; }
@@ -680,7 +684,11 @@ __device__ __forceinline__ void leg_pass(int leg, const BaseKin& bk, const float
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
           const f3 dir = d == 0 ? nrm : (d == 1 ? t1 : t2);
-          const f3 Jw = self ? mk(0.f, 0.f, 0.f) : cross(P, dir);          // against the base body: the base part of the relative row vanishes
+          const f3 Jb0 = cross(P, dir);
+          const f3 Jw = self ? mk(0.f, 0.f, 0.f) : Jb0;                    // against the base body: the base part of the relative row vanishes
+          // ... and the base's own Jacobian at the point goes next to the row, for the diagonal Bullet gives such a row
+          sm.bjac(3 * (slot - 4) + d, 0) = make_float4(Jb0.x, Jb0.y, Jb0.z, dir.x);
+          sm.bjac(3 * (slot - 4) + d, 1) = make_float4(dir.y, dir.z, act && self ? 1.0f : 0.0f, 0.0f);
           const float Jq1 = dot(a1, cross(r1v, dir));
           const float Jq2 = bestL[k] >= 2 ? dot(a2, cross(r2v, dir)) : 0.0f;
           const float Jq3 = bestL[k] >= 3 ? dot(a2, cross(r3v, dir)) : 0.0f;
@@ -1414,8 +1422,23 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
         const float gq[6] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y};
         float gw[6];
         fwd6(Lc, gq, gw);
-        const float diag = gw[0] * gw[0] + gw[1] * gw[1] + gw[2] * gw[2] + gw[3] * gw[3] + gw[4] * gw[4] + gw[5] * gw[5] +
-                           c1.z * c1.z + c1.w * c1.w + c2.x * c2.x;
+        float diag = gw[0] * gw[0] + gw[1] * gw[1] + gw[2] * gw[2] + gw[3] * gw[3] + gw[4] * gw[4] + gw[5] * gw[5] +
+                     c1.z * c1.z + c1.w * c1.w + c2.x * c2.x;
+        if (slot >= 4) {
+          // a point held against the base body: btMultiBodyConstraintSolver::setupMultiBodyContactConstraint sums the two
+          // links' own terms J_A M^-1 J_A^T + J_B M^-1 J_B^T and leaves their cross term out, also when both links belong to
+          // one multibody.  With a = whitened link row, b = whitened base row and the relative row g = a - b stored:
+          // |a|^2 + |b|^2 = |g|^2 + 2 g.b + 2 |b|^2
+          const int i3 = 3 * (slot - 4) + (r < REX_NBSLOT ? 0 : 1 + ((r - REX_NBSLOT) & 1));
+          const float4 j0 = sm.bjac(i3, 0), j1 = sm.bjac(i3, 1);
+          const float jb[6] = {j0.x, j0.y, j0.z, j0.w, j1.x, j1.y};
+          float bw[6];
+          fwd6(Lc, jb, bw);
+          float gb = 0.0f, bb = 0.0f;
+#pragma unroll
+          for (int k = 0; k < 6; ++k) { gb = fmaf(gw[k], bw[k], gb); bb = fmaf(bw[k], bw[k], bb); }
+          if (j1.z != 0.0f) diag += 2.0f * (gb + bb);
+        }
         const float invd = c2.z != 0.0f ? __builtin_amdgcn_rcpf(diag) : 0.0f;
         sm.brow(r, 0) = make_float4(gw[0], gw[1], gw[2], gw[3]);
         sm.brow(r, 1) = make_float4(gw[4], gw[5], c1.z, c1.w);

@@ -1223,7 +1223,8 @@ int rex_create(const RexConfig* cfg, int device, float* d_state, void* stream, R
   d.action_dim = rex_action_dim(cfg); d.obs_dim = rex_obs_dim(cfg);
   s->epw = pick_envs_per_wave(cfg->num_envs);
   if ((cfg->mark == REX_MARK_ARM || cfg->task == REX_TASK_MIXED || cfg->body_contacts) && s->epw > 16) s->epw = 16;
-  if (cfg->body_contacts && s->epw > 8) s->epw = 8;   // the link-box rows of 16 envs take 64.5 KB of LDS: two workgroups per CU, half the SIMDs idle
+  if (cfg->body_contacts && s->epw > 8) s->epw = 8;   // the link-box rows of 16 envs take 76.8 KB of LDS: two workgroups per CU, half the SIMDs idle
+  if (cfg->body_contacts && cfg->mark == REX_MARK_ARM) s->epw = 4;   // mark arm: 42.6 KB at 8 envs per wave would leave room for three workgroups per CU
   d.n_mix = 1; d.mix_task[0] = cfg->task; d.max_repeat = cfg->action_repeat; d.max_iterations = cfg->solver_iterations;
   for (int k = 1; k < 5; ++k) d.mix_task[k] = cfg->task;
   if (cfg->task == REX_TASK_MIXED) {
@@ -1523,7 +1524,7 @@ static void launch_step(RexSim* s, int blocks, hipStream_t st, const float* a, f
   if (s->cfg.task == REX_TASK_MIXED) {   // lane groups only (rex_create caps the envs per wave at 16)
     if (arm) REX_LAUNCH_BY_EPW(true, true, false); else REX_LAUNCH_BY_EPW(false, true, false);
   } else if (s->cfg.body_contacts) {     // link-box contact rows: 4 or 8 envs per wave (rex_create caps it)
-    if (arm) { if (s->epw == 4) REX_LAUNCH_STEP(4, true, false, true); else REX_LAUNCH_STEP(8, true, false, true); }
+    if (arm) REX_LAUNCH_STEP(4, true, false, true);
     else { if (s->epw == 4) REX_LAUNCH_STEP(4, false, false, true); else REX_LAUNCH_STEP(8, false, false, true); }
   } else if (arm) {
     REX_LAUNCH_BY_EPW(true, false, false);
