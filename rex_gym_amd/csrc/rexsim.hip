@@ -681,8 +681,14 @@ __device__ __forceinline__ void standup_command(const DevCfg& c, const EnvState&
 }
 
 // ------------------------------------------------------------------------------------------
+#ifndef REX_STEP_KERNEL_ATTR
+#define REX_STEP_KERNEL_ATTR          /* developer experiments: e.g. -DREX_STEP_KERNEL_ATTR='__attribute__((amdgpu_waves_per_eu(2,2)))' */
+#endif
+#ifndef REX_FAST_EPW
+#define REX_FAST_EPW 4
+#endif
 template <int EPW, bool ARM, bool MIXED, bool BODY>
-__global__ __launch_bounds__(REX_WAVE) void rex_step_kernel(DevCfg c, float* __restrict__ state, const float* __restrict__ snap,
+__global__ __launch_bounds__(REX_WAVE) REX_STEP_KERNEL_ATTR void rex_step_kernel(DevCfg c, float* __restrict__ state, const float* __restrict__ snap,
                                                             const float* __restrict__ action, float* __restrict__ obs_out,
                                                             float* __restrict__ reward_out, uint8_t* __restrict__ done_out,
                                                             float* __restrict__ cmd_out) {
@@ -1517,7 +1523,7 @@ REX_API int rex_debug_prof(long long* out, int reset) {
   } while (0)
 static void launch_step(RexSim* s, int blocks, hipStream_t st, const float* a, float* o, float* r, uint8_t* d, float* m) {
 #ifdef REX_FAST_BUILD   /* developer A/B builds: the 4-envs-per-wave base kernel only (2: its link-box variant, 3: mark arm) */
-  REX_LAUNCH_STEP(4, REX_FAST_BUILD == 3, false, REX_FAST_BUILD == 2);
+  REX_LAUNCH_STEP(REX_FAST_EPW, REX_FAST_BUILD == 3, false, REX_FAST_BUILD == 2);
   return;
 #else
   const bool arm = s->cfg.mark == REX_MARK_ARM;
