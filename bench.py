@@ -253,7 +253,7 @@ def main():
     traffic = None
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            t = json.load(f).get(f"{args.task}-{args.signal}/{args.terrain}/{args.mark}/{n}")
+            t = json.load(f).get(f"{'mixed' if args.mixed else args.task}-{args.signal}/{args.terrain}/{args.mark}/{n}")
         traffic = t and t["bytes_per_launch"]
     except (OSError, ValueError, KeyError):
         pass
