@@ -1523,7 +1523,7 @@ REX_API int rex_debug_prof(long long* out, int reset) {
   } while (0)
 static void launch_step(RexSim* s, int blocks, hipStream_t st, const float* a, float* o, float* r, uint8_t* d, float* m) {
 #ifdef REX_FAST_BUILD   /* developer A/B builds: the 4-envs-per-wave base kernel only (2: its link-box variant, 3: mark arm) */
-  REX_LAUNCH_STEP(REX_FAST_EPW, REX_FAST_BUILD == 3, false, REX_FAST_BUILD == 2);
+  REX_LAUNCH_STEP(REX_FAST_EPW, REX_FAST_BUILD == 3 || REX_FAST_BUILD == 4, REX_FAST_BUILD == 4, REX_FAST_BUILD == 2);   /* 4: mixed tasks, mark arm */
   return;
 #else
   const bool arm = s->cfg.mark == REX_MARK_ARM;
@@ -1544,7 +1544,7 @@ static void launch_settle(RexSim* s, int nrec, hipStream_t st, float* snap) {
 #ifdef REX_FAST_BUILD
 #if REX_FAST_BUILD == 2
   hipLaunchKernelGGL((rex::rex_settle_kernel<false, true>), dim3((nrec + 15) / 16), dim3(REX_WAVE), 0, st, s->dev, snap);
-#elif REX_FAST_BUILD == 3
+#elif REX_FAST_BUILD == 3 || REX_FAST_BUILD == 4
   hipLaunchKernelGGL((rex::rex_settle_kernel<true, false>), dim3((nrec + 15) / 16), dim3(REX_WAVE), 0, st, s->dev, snap);
 #else
   hipLaunchKernelGGL((rex::rex_settle_kernel<false, false>), dim3((nrec + REX_WAVE - 1) / REX_WAVE), dim3(REX_WAVE), 0, st, s->dev, snap);
