@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define REX_ABI_VERSION 4
+#define REX_ABI_VERSION 5
 #define REX_API __attribute__((visibility("default")))
 
 /* tasks (reference env classes) */
@@ -65,6 +65,12 @@ extern "C" {
  * Per-env persistent state: SoA, float32 words, word-major ([REX_STATE_WORDS][num_envs]) so that
  * lane i of a wavefront reads word w of env i at d_state[w * num_envs + i] (coalesced).
  * Integer words are stored as raw int32 bits.
+ *
+ * Clocks (ABI 5).  The reference's clocks are Python floats: the env clock `step_counter * time_step` (rex.py:155-156),
+ * GaitPlanner._last_time, the env's end_time.  With a 5 ms control step and gait periods such as 0.5 s, comparisons like
+ * `phi >= 0.99`, `phi <= 0.5`, `t <= 0.8 + end_time` are exact ties in real numbers, decided by double rounding.  The
+ * state therefore keeps those instants as the ENV STEP COUNT at which they were taken (int words LASTT, ENDTIME) and the
+ * kernels rebuild the double the reference held from it; float32 carries values, never a decision of the controller.
  */
 enum RexStateWord {
   REX_S_POS      = 0,   /* 3: base position, world [m]                   (getBasePositionAndOrientation) */
@@ -73,11 +79,12 @@ enum RexStateWord {
   REX_S_ANGVEL   = 10,  /* 3: base angular velocity, world                                               */
   REX_S_Q        = 13,  /* 12: motor angles, order of model/mark_constants.py:3-8                        */
   REX_S_QD       = 25,  /* 12: motor velocities                                                          */
-  REX_S_PHI      = 37,  /* gait phase            (GaitPlanner._phi,       gait_planner.py:10)            */
-  REX_S_LASTT    = 38,  /* gait phase origin     (GaitPlanner._last_time, gait_planner.py:12)            */
+  REX_S_PHI      = 37,  /* gait phase, float32 copy (GaitPlanner._phi, gait_planner.py:10); its one use, `_phi >= 0.99`
+                           (gait_planner.py:106), is taken in double and kept as REX_F_PHASE_WRAP              */
+  REX_S_LASTT    = 38,  /* int: env step whose clock GaitPlanner._last_time holds (gait_planner.py:12,107)       */
   REX_S_ALPHA    = 39,  /* gait rotation carry   (GaitPlanner._alpha,     gait_planner.py:13)            */
   REX_S_TARGET   = 40,  /* episode target (x position, or yaw for turn)  (walk_env.py:143-147)           */
-  REX_S_ENDTIME  = 41,  /* time the goal was reached                     (walk_env.py:213)               */
+  REX_S_ENDTIME  = 41,  /* int: env step at which the goal was reached; end_time = its clock (walk_env.py:213)   */
   REX_S_AUX      = 42,  /* task scratch (turn: start yaw)                                                */
   REX_S_FLAGS    = 43,  /* int: REX_F_* bits                                                             */
   REX_S_STEPS    = 44,  /* int: env steps this episode (RexGymEnv._env_step_counter)                     */
@@ -94,6 +101,8 @@ enum RexStateWord {
 #define REX_F_BACKWARDS      8u   /* walk_env.py:133-136 (episode draw or fixed) */
 #define REX_F_DONE          16u   /* last step returned done; must be reset before the next step */
 #define REX_F_ENV_GOAL      32u   /* RexGymEnv.env_goal_reached (turn_env.py:338-340) */
+#define REX_F_PHASE_WRAP    64u   /* GaitPlanner._phi >= 0.99 after the last loop(): the next loop() latches _last_time
+                                     (gait_planner.py:106-107) */
 
 typedef struct RexConfig {
   int32_t abi_version;        /* REX_ABI_VERSION */
@@ -275,8 +284,9 @@ REX_API int rex_motor_torque(int n, const float* d_cmd, const float* d_q, const 
                      float* d_actual, float* d_observed, void* stream);
 /* model/gait_planner.py:96-134 with the phase clock on explicit time `now`.
  * mode: 0 walk, 1 gallop.  d_planner [n,3] = (phi, last_time, alpha) in/out; params[n,6] =
- * (v, angle_deg, w_rot, period, direction, now); frames_out[n,4,3] (FR,FL,RR,RL). */
-REX_API int rex_gait_loop(int n, int mode, float* d_planner, const float* d_params,
+ * (v, angle_deg, w_rot, period, direction, now) -- both float64: the clock values and the phase decide branches and must
+ * arrive unrounded (see "Clocks" above); the trajectory arithmetic is float32.  frames_out[n,4,3] float32 (FR,FL,RR,RL). */
+REX_API int rex_gait_loop(int n, int mode, double* d_planner, const double* d_params,
                   float* d_frames_out, void* stream);
 
 /* Envs per wavefront of the step kernel this sim launches (4, 8, 16: lane groups; 64: one env per lane).  Chosen from

@@ -239,7 +239,12 @@ ORC_API void orc_ik_solve(int n, const real* orn, const real* pos, const real* f
 /* =====================================================================================
  *                         controller: gait planner
  * ===================================================================================== */
-typedef struct { real phi, last_time, alpha; } Gait;
+/* Clocks and gait phases are double in BOTH builds (the reference's are Python floats): every discrete decision of the
+ * controller -- the 0.99 latch, the phase wrap at 1, stance / swing at 0.5, the ramp and brake windows of the envs --
+ * is then taken exactly as the reference takes it, also where the arithmetic around it is float (the product's rule,
+ * rex_controller.h).  With a 5 ms control step and periods like 0.5 s those comparisons are exact ties in real numbers. */
+typedef double clk;
+typedef struct { clk phi, last_time; real alpha; } Gait;
 
 static real binom11(int k) { /* gait_planner.py:22-24 with n = 11 */
   static const real f[12] = {1, 1, 2, 6, 24, 120, 720, 5040, 40320, 362880, 3628800, 39916800};
@@ -274,8 +279,8 @@ static void gait_swing(real phi_sw, real v, real angle_deg, real direction, real
 }
 
 /* gait_planner.py:60-94 */
-static void gait_step_trajectory(Gait* g, real phi, real v, real angle, real w_rot, const real ctf[3], real direction, real coord[3]) {
-  const real step_offset = (real)0.5;
+static void gait_step_trajectory(Gait* g, clk phi, real v, real angle, real w_rot, const real ctf[3], real direction, real coord[3]) {
+  const clk step_offset = 0.5;
   const real R2D = (real)(180.0 / M_PI);
   if (phi >= 1) phi = phi - 1;
   real r = sqrt(ctf[0] * ctf[0] + ctf[1] * ctf[1]);
@@ -285,11 +290,11 @@ static void gait_step_trajectory(Gait* g, real phi, real v, real angle, real w_r
   else circle = 270 - (foot_angle - g->alpha) * R2D;
   real lng[3], rot[3];
   if (phi <= step_offset) {
-    real ps = phi / step_offset;
+    real ps = (real)(phi / step_offset);
     gait_stance(ps, v, angle, lng);
     gait_stance(ps, w_rot, circle, rot);
   } else {
-    real ps = (phi - step_offset) / (1 - step_offset);
+    real ps = (real)((phi - step_offset) / (1 - step_offset));
     gait_swing(ps, v, angle, direction, lng);
     gait_swing(ps, w_rot, circle, direction, rot);
   }
@@ -302,12 +307,12 @@ static void gait_step_trajectory(Gait* g, real phi, real v, real angle, real w_r
 }
 
 /* gait_planner.py:96-134; mode 0 = walk offsets, 1 = gallop offsets (gait_planner.py:15-20) */
-static void gait_loop(Gait* g, int mode, real v, real angle, real w_rot, real T, real direction, real now, real frame[12]) {
-  static const real OFF[2][4] = {{0., 0.5, 0.5, 0.}, {0., 0., 0.8, 0.8}};
+static void gait_loop(Gait* g, int mode, real v, real angle, real w_rot, clk T, real direction, clk now, real frame[12]) {
+  static const clk OFF[2][4] = {{0., 0.5, 0.5, 0.}, {0., 0., 0.8, 0.8}};
   const real base[4][3] = {{IK_L / 2, -IK_YDIST / 2, -IK_HEIGHT}, {IK_L / 2, IK_YDIST / 2, -IK_HEIGHT},
                            {-IK_L / 2, -IK_YDIST / 2, -IK_HEIGHT}, {-IK_L / 2, IK_YDIST / 2, -IK_HEIGHT}};
-  if (T <= (real)0.01) T = (real)0.01;
-  if (g->phi >= (real)0.99) g->last_time = now;
+  if (T <= 0.01) T = 0.01;
+  if (g->phi >= 0.99) g->last_time = now;
   g->phi = (now - g->last_time) / T;
   for (int l = 0; l < 4; ++l) {
     real sc[3];
@@ -316,12 +321,13 @@ static void gait_loop(Gait* g, int mode, real v, real angle, real w_rot, real T,
   }
 }
 
-/* planner: n x (phi,last_time,alpha) in/out; params: n x (v, angle, w_rot, T, direction, now) */
-ORC_API void orc_gait_loop(int n, int mode, real* planner, const real* params, real* frames) {
+/* planner: n x (phi,last_time,alpha) in/out; params: n x (v, angle, w_rot, T, direction, now) -- doubles in both builds
+ * (the clock values must arrive unrounded); the trajectory arithmetic runs in `real` */
+ORC_API void orc_gait_loop(int n, int mode, double* planner, const double* params, real* frames) {
   for (int i = 0; i < n; ++i) {
-    Gait g = {planner[3 * i], planner[3 * i + 1], planner[3 * i + 2]};
-    const real* p = params + 6 * i;
-    gait_loop(&g, mode, p[0], p[1], p[2], p[3], p[4], p[5], frames + 12 * i);
+    Gait g = {planner[3 * i], planner[3 * i + 1], (real)planner[3 * i + 2]};
+    const double* p = params + 6 * i;
+    gait_loop(&g, mode, (real)p[0], (real)p[1], (real)p[2], p[3], (real)p[4], p[5], frames + 12 * i);
     planner[3 * i] = g.phi; planner[3 * i + 1] = g.last_time; planner[3 * i + 2] = g.alpha;
   }
 }
@@ -1139,8 +1145,11 @@ static const real POSE_STAND_OL[12] = {0.15192765, -0.90412283, 1.48156545, -0.1
 
 typedef struct {
   Phys ph;
-  Gait gait;
-  real target, end_time, aux;
+  /* GaitPlanner state: phase (informational: the decision `_phi >= 0.99` is flag REX_F_PHASE_WRAP), the env step at
+   * which _last_time was latched, the arc angle; end_step = the env step at which the goal was reached */
+  real phi, alpha;
+  int32_t last_step, end_step;
+  real target, aux;
   uint32_t flags;
   int32_t steps, episode;
   uint32_t motor_enabled;
@@ -1258,10 +1267,10 @@ static double as_written(float x) {
   memo[slot].key = bits; memo[slot].used = 1; memo[slot].val = v;
   return v;
 }
-static real env_time(const RexConfig* c, const Env* e) {
-  if (sizeof(real) == sizeof(double)) return (real)((double)(e->steps * c->action_repeat) * as_written(c->sim_time_step));
-  return (real)(e->steps * c->action_repeat) * (real)c->sim_time_step;
-}
+/* the env clock `step_counter * time_step` (rex.py:155-156) at env step k: a correctly rounded double product on the
+ * decimal the caller wrote, in both builds */
+static clk step_time(const RexConfig* c, int32_t k) { return (double)(k * c->action_repeat) * as_written(c->sim_time_step); }
+static clk env_time(const RexConfig* c, const Env* e) { return step_time(c, e->steps); }
 /* the simulation time step and the latencies as the physics / history code sees them: the reference holds them as
  * Python floats (0.001, 0.02 ...), RexConfig as float32; the fp64 build undoes the float32 rounding so that its
  * trajectories are the reference's to the last bits (tests/test_oracle_rollouts.py), the fp32 build computes in float */
@@ -1383,14 +1392,14 @@ static void env_reset(Orc* o, int idx) {
   real (*hist)[HIST_WORDS] = e->hist;
   /* the env keeps ONE GaitPlanner for its lifetime (walk_env.py:99, turn_env.py:117): its turning-arc angle `_alpha`
    * (gait_planner.py:76-85) survives reset() and enters the first step of the next episode */
-  real alpha = e->gait.alpha;
+  real alpha = e->alpha;
   {
     int t = terrain_index(o, idx, episode + 1);
     *e = t >= 0 ? o->terrain_snapshot[t * o->n_mix + slot] : o->snapshot[slot];   /* settled on this episode's terrain (under this env's task) */
   }
   e->episode = episode + 1;
   e->hist = hist;
-  e->gait.phi = 0; e->gait.last_time = 0; e->gait.alpha = alpha;
+  e->phi = 0; e->last_step = 0; e->alpha = alpha;
   uint32_t ctr[4] = {(uint32_t)e->episode, (uint32_t)(c->env_index_base + idx), 0, 0};   /* key = seed, counter = (episode, global env) */
   philox4x32(ctr, (uint32_t)c->seed, (uint32_t)(c->seed >> 32));
   e->flags = 0;
@@ -1406,7 +1415,7 @@ static void env_reset(Orc* o, int idx) {
     if (c->target_position != 0.0f) e->target = cfgf(c->target_position);
     else e->target = (real)(1.0f + 2.0f * u01(ctr[1]));                         /* gallop_env.py:150-152 */
   }
-  e->end_time = 0; e->aux = 0; e->steps = 0;
+  e->end_step = 0; e->aux = 0; e->steps = 0;
   if (c->task == REX_TASK_POSES) {                                              /* poses_env.py:153-192 */
     /* _ranges (rex_gym_env.py:258-265): base_y, base_z, roll, pitch, yaw */
     static const float LO[5] = {-0.007f, -0.048f, -0.78539816339744830962f, -0.78539816339744830962f, -0.78539816339744830962f};
@@ -1437,13 +1446,22 @@ static void env_reset(Orc* o, int idx) {
 
 /* the time GaitPlanner.loop reads: wall-clock seconds (gait_planner.py:108-110) = simulated time x the host's
  * wall-seconds-per-simulated-second (RexConfig.gait_clock_scale; DBG_GAIT_CLOCK is the sensitivity tool's multiplier) */
-static real gait_now(const RexConfig* c, real t) { return t * (c->gait_clock_scale > 0 ? cfgf(c->gait_clock_scale) : (real)1) * DBG_GAIT_CLOCK; }
+static clk gait_now(const RexConfig* c, clk t) { return t * (c->gait_clock_scale > 0 ? as_written(c->gait_clock_scale) : 1.0) * (clk)DBG_GAIT_CLOCK; }
+/* GaitPlanner.loop on the env's planner state.  _last_time is `now` of the env step that latched it and `_phi >= 0.99`
+ * is a flag: both are exact, whatever `real` is. */
+static void env_gait_loop(const RexConfig* c, Env* e, int mode, real v, real angle, real w_rot, clk T, real direction, real frame[12]) {
+  Gait g = {(e->flags & REX_F_PHASE_WRAP) ? 1.0 : 0.0, gait_now(c, step_time(c, e->last_step)), e->alpha};
+  if (e->flags & REX_F_PHASE_WRAP) e->last_step = e->steps;
+  gait_loop(&g, mode, v, angle, w_rot, T, direction, gait_now(c, env_time(c, e)), frame);
+  e->phi = (real)g.phi; e->alpha = g.alpha;
+  if (g.phi >= 0.99) e->flags |= REX_F_PHASE_WRAP; else e->flags &= ~REX_F_PHASE_WRAP;
+}
 
 /* walk_env.py:229-244 */
-static real walk_gait_coeff(real t, real a0) { real p = (real)0.8 + a0; return (0 <= t && t <= p) ? t : (real)1.0; }
-static real walk_brake_coeff(real t, real a1, real end_t) {
-  real p = (real)0.8 + a1;
-  return (end_t <= t && t <= p + end_t) ? 1 - (t - end_t) : (real)0.0;
+static real walk_gait_coeff(clk t, real a0) { clk p = 0.8 + (clk)a0; return (0 <= t && t <= p) ? (real)t : (real)1.0; }
+static real walk_brake_coeff(clk t, real a1, clk end_t) {
+  clk p = 0.8 + (clk)a1;
+  return (end_t <= t && t <= p + end_t) ? (real)(1 - (t - end_t)) : (real)0.0;
 }
 
 static void order_signal(const real ang[12], real cmd[12]) { /* FR,FL,RR,RL -> FL,FR,RL,RR (walk_env.py:284-289) */
@@ -1453,46 +1471,47 @@ static void order_signal(const real ang[12], real cmd[12]) { /* FR,FL,RR,RL -> F
 static void walk_command(const RexConfig* c, Env* e, const real* action, real cmd[12]) {
   const real* ip = init_pose(c);
   if (e->flags & REX_F_STAY_STILL) { memcpy(cmd, ip, sizeof(real) * 12); return; }       /* walk_env.py:318-319 */
-  real t = env_time(c, e);               /* rex.py:155-156 */
+  const clk t = env_time(c, e);          /* rex.py:155-156 */
   if (e->target != 0) {                                                                 /* walk_env.py:207-215 */
     if (fabs(e->ph.pos[0]) >= fabs(e->target) - (real)0.15) {
       e->flags |= REX_F_GOAL_REACHED;
-      if (!(e->flags & REX_F_TERMINATING)) { e->end_time = t; e->flags |= REX_F_TERMINATING; }
+      if (!(e->flags & REX_F_TERMINATING)) { e->end_step = e->steps; e->flags |= REX_F_TERMINATING; }
     }
   }
+  const clk end_t = step_time(c, e->end_step);
   int backwards = (e->flags & REX_F_BACKWARDS) != 0;
   if (c->signal == REX_SIGNAL_IK) {                                                     /* walk_env.py:252-290 */
     real gait_coeff = walk_gait_coeff(t, action[0]);
     real step = backwards ? (real)-0.3 : (real)0.6;
-    real period = backwards ? (real)0.5 : (real)0.65;
+    clk period = backwards ? 0.5 : 0.65;
     real base_x = backwards ? (real)0.0 : (real)0.01;
     real pos[3] = {base_x, 0, 0}, orn[3] = {0, 0, 0};
     real step_length = step * gait_coeff;
     if (e->flags & REX_F_GOAL_REACHED) {
-      real b = walk_brake_coeff(t, action[1], e->end_time);
+      real b = walk_brake_coeff(t, action[1], end_t);
       step_length *= b;
       if (b == 0) e->flags |= REX_F_STAY_STILL;
     }
     real direction = step_length < 0 ? (real)-1.0 : (real)1.0;
     real frames[12], ang[12];
-    gait_loop(&e->gait, 0, step_length, 0, 0, period, direction, gait_now(c, t), frames);
+    env_gait_loop(c, e, 0, step_length, 0, 0, period, direction, frames);
     ik_solve(orn, pos, frames, ang, 0);
     order_signal(ang, cmd);
   } else {                                                                              /* walk_env.py:292-315 */
     real l_a = (real)0.1, f_a = (real)0.2;
     const real period = (real)(1.0 / 8);
     if (e->flags & REX_F_GOAL_REACHED) {
-      real b = walk_brake_coeff(t, 0, e->end_time);
+      real b = walk_brake_coeff(t, 0, end_t);
       l_a *= b; f_a *= b;
       /* `if coeff is 0.0: self._stay_still = True` (walk_env.py:300) is an IDENTITY test: it holds exactly when
        * _evaluate_brakes_stage_coeff hands back its `end_value=0.0` argument (the same constant object), i.e. when t
        * lies outside the brake window -- never for the computed 1 - (t - end_t), even where that is 0
        * (tests/golden/make_env_golden.py runs the reference's code: `stay` turns on one step past the window) */
-      if (!(e->end_time <= t && t <= (real)0.8 + e->end_time)) e->flags |= REX_F_STAY_STILL;
+      if (!(end_t <= t && t <= 0.8 + end_t)) e->flags |= REX_F_STAY_STILL;
     }
     real sc = walk_gait_coeff(t, 0);
     l_a *= sc; f_a *= sc;
-    real l_ext = l_a * cos(2 * (real)M_PI / period * t), f_ext = f_a * cos(2 * (real)M_PI / period * t);
+    real l_ext = l_a * cos(2 * (real)M_PI / period * (real)t), f_ext = f_a * cos(2 * (real)M_PI / period * (real)t);
     real pose[12] = {0, l_ext + action[0], f_ext + action[1], 0, -l_ext + action[2], -f_ext + action[3],
                      0, -l_ext + action[4], -f_ext + action[5], 0, l_ext + action[6], f_ext + action[7]};
     for (int j = 0; j < 12; ++j) cmd[j] = ip[j] + pose[j];
@@ -1500,37 +1519,38 @@ static void walk_command(const RexConfig* c, Env* e, const real* action, real cm
 }
 
 /* gallop_env.py:234-249 */
-static real gallop_brake_coeff(real t, real a0, real end_t) {
-  real p = (real)1.0 + a0;
-  return (end_t <= t && t <= p + end_t) ? 1 - (t - end_t) : (real)0.0;
+static real gallop_brake_coeff(clk t, real a0, clk end_t) {
+  clk p = 1.0 + (clk)a0;
+  return (end_t <= t && t <= p + end_t) ? (real)(1 - (t - end_t)) : (real)0.0;
 }
-static real gallop_gait_coeff(real t, real a1) { real p = (real)1.0 + a1; return (0 <= t && t <= p) ? t : (real)1.0; }
+static real gallop_gait_coeff(clk t, real a1) { clk p = 1.0 + (clk)a1; return (0 <= t && t <= p) ? (real)t : (real)1.0; }
 
 static void gallop_command(const RexConfig* c, Env* e, const real* action, real cmd[12]) {
   if (e->flags & REX_F_STAY_STILL) { memcpy(cmd, POSE_STAND, sizeof(real) * 12); return; } /* rex.initial_pose */
-  real t = env_time(c, e);
+  const clk t = env_time(c, e);
   if (e->target != 0) {                                                                 /* gallop_env.py:212-220 */
     if (fabs(e->ph.pos[0]) >= fabs(e->target)) {
       e->flags |= REX_F_GOAL_REACHED;
-      if (!(e->flags & REX_F_TERMINATING)) { e->end_time = t; e->flags |= REX_F_TERMINATING; }
+      if (!(e->flags & REX_F_TERMINATING)) { e->end_step = e->steps; e->flags |= REX_F_TERMINATING; }
     }
   }
+  const clk end_t = step_time(c, e->end_step);
   if (c->signal == REX_SIGNAL_IK) {                                                     /* gallop_env.py:257-285 */
     real gait_coeff = gallop_gait_coeff(t, action[1]);
     real pos[3] = {(real)0.01, 0, (real)-0.007}, orn[3] = {0, 0, 0};
     real step_length = (real)1.3 * gait_coeff;
-    if (e->flags & REX_F_GOAL_REACHED) step_length *= gallop_brake_coeff(t, action[0], e->end_time);
+    if (e->flags & REX_F_GOAL_REACHED) step_length *= gallop_brake_coeff(t, action[0], end_t);
     real frames[12], ang[12];
-    gait_loop(&e->gait, 1, step_length, 0, 0, (real)0.3, (real)1.0, gait_now(c, t), frames);
+    env_gait_loop(c, e, 1, step_length, 0, 0, 0.3, (real)1.0, frames);
     ik_solve(orn, pos, frames, ang, 0);
     order_signal(ang, cmd);
   } else {                                                                              /* gallop_env.py:287-304 */
     real lp[4] = {action[0], action[1], action[2], action[3]};
     if (e->flags & REX_F_GOAL_REACHED) {
-      real b = gallop_brake_coeff(t, 0, e->end_time);
+      real b = gallop_brake_coeff(t, 0, end_t);
       for (int k = 0; k < 4; ++k) lp[k] *= b;
       /* gallop_env.py:291: the same identity test as in walk_env.py:300 -- true outside the brake window */
-      if (!(e->end_time <= t && t <= (real)1.0 + e->end_time)) e->flags |= REX_F_STAY_STILL;
+      if (!(end_t <= t && t <= 1.0 + end_t)) e->flags |= REX_F_STAY_STILL;
     }
     const real* ip = init_pose(c);
     for (int l = 0; l < 4; ++l) {
@@ -1551,9 +1571,9 @@ static int turn_clockwise(const Env* e) {
 /* RexTurnEnv._transform_action_to_motor_command (turn_env.py:239-347) */
 static void turn_command(const RexConfig* c, Env* e, const real* action, real cmd[12]) {
   const real* ip = init_pose(c);
-  real t = env_time(c, e);
+  const clk t = env_time(c, e);
   if (e->flags & REX_F_STAY_STILL) {
-    if (t - e->end_time >= 1) e->flags |= REX_F_ENV_GOAL;                          /* _terminate_with_delay */
+    if (t - step_time(c, e->end_step) >= 1) e->flags |= REX_F_ENV_GOAL;                          /* _terminate_with_delay */
     memcpy(cmd, ip, sizeof(real) * 12);
     return;
   }
@@ -1572,23 +1592,23 @@ static void turn_command(const RexConfig* c, Env* e, const real* action, real cm
     if (cz < 0) cz += (real)6.28;
     if (fabs(e->target - cz) <= (real)0.01) {
       e->flags |= REX_F_GOAL_REACHED;
-      if (!(e->flags & REX_F_TERMINATING)) { e->end_time = t; e->flags |= REX_F_TERMINATING; }
+      if (!(e->flags & REX_F_TERMINATING)) { e->end_step = e->steps; e->flags |= REX_F_TERMINATING; }
     }
   }
   int clockwise = turn_clockwise(e);
   if (e->flags & REX_F_GOAL_REACHED) e->flags |= REX_F_STAY_STILL;                  /* turn_env.py:259-260,272-273 */
   if (c->signal == REX_SIGNAL_IK) {
-    real coeff = (0 <= t && t <= (real)0.8) ? t : (real)1.0;
+    real coeff = (0 <= t && t <= 0.8) ? (real)t : (real)1.0;
     real dirv = (real)-0.5 * coeff;
     if (clockwise) dirv = -dirv;
     real pos[3] = {(real)0.009, 0, 0}, orn[3] = {0, 0, 0};
     real frames[12], ang[12];
-    gait_loop(&e->gait, 0, (real)0.02, 0, dirv + action[0], (real)0.75 + action[1], (real)1.0, gait_now(c, t), frames);
+    env_gait_loop(c, e, 0, (real)0.02, 0, dirv + action[0], 0.75 + (clk)action[1], (real)1.0, frames);
     ik_solve(orn, pos, frames, ang, 0);
     order_signal(ang, cmd);
   } else {
     const real ext = (real)0.1, swing = (real)0.03 + action[0], swipe = (real)0.05 + action[1];
-    int ith = ((int)(t / (real)0.1)) % 2;
+    int ith = ((int)(t / 0.1)) % 2;
     real m = clockwise ? (real)1 : (real)-1;   /* right_* poses (clockwise) = left_* with the swing sign flipped, turn_env.py:280-297 */
     real ms = m * swing;
     real first[12] = {swipe, ext, ms, -swipe, ext, -ms, swipe, -ext, -ms, -swipe, -ext, ms};
@@ -1600,9 +1620,8 @@ static void turn_command(const RexConfig* c, Env* e, const real* action, real cm
 /* RexPosesEnv._signal (poses_env.py:186-225): one body-pose component ramps to its target, IK on the
  * default foot frames */
 static void poses_command(const RexConfig* c, Env* e, const real* action, real cmd[12]) {
-  real t = env_time(c, e);
-  real p = (real)0.8 + action[0];
-  real coeff = (0 <= t && t <= p) ? t : (real)1.0;
+  const clk t = env_time(c, e), p = 0.8 + (clk)action[0];
+  real coeff = (0 <= t && t <= p) ? (real)t : (real)1.0;
   real staged = e->target * coeff;
   real pos[3] = {(real)0.01, 0, 0}, orn[3] = {0, 0, 0};
   int k = (int)e->aux;
@@ -1688,8 +1707,8 @@ static void env_command(const RexConfig* c, Env* e, const real* action, real* le
   else if (c->task == REX_TASK_TURN) turn_command(c, e, action, leg_cmd);
   else if (c->task == REX_TASK_POSES) poses_command(c, e, action, leg_cmd);
   else if (c->task == REX_TASK_STANDUP) {                                           /* RexStandupEnv._signal, standup_env.py:113-120 */
-    real t = env_time(c, e);         /* GetTimeSinceReset, rex.py:155-156 */
-    real f = t > (real)0.1 ? 1 : ((real)0.1 + action[0]) / (t + 1) + (real)1.5;    /* the 'brake' function */
+    const clk t = env_time(c, e);    /* GetTimeSinceReset, rex.py:155-156 */
+    real f = t > 0.1 ? 1 : ((real)0.1 + action[0]) / ((real)t + 1) + (real)1.5;    /* the 'brake' function */
     for (int j = 0; j < 12; ++j) leg_cmd[j] = POSE_STAND[j] * f;
   }
   else walk_command(c, e, action, leg_cmd);
@@ -1864,8 +1883,8 @@ ORC_API void orc_get_state(void* h, double* out) {
     for (int k = 0; k < 3; ++k) { W(REX_S_POS + k) = e->ph.pos[k]; W(REX_S_LINVEL + k) = e->ph.linvel[k]; W(REX_S_ANGVEL + k) = e->ph.angvel[k]; }
     for (int k = 0; k < 4; ++k) W(REX_S_QUAT + k) = e->ph.quat[k];
     for (int j = 0; j < NJ; ++j) { W(SW_Q + j) = e->ph.q[j]; W(SW_QD + j) = e->ph.qd[j]; }
-    W(SW_PHI) = e->gait.phi; W(SW_LASTT) = e->gait.last_time; W(SW_ALPHA) = e->gait.alpha;
-    W(SW_TARGET) = e->target; W(SW_ENDTIME) = e->end_time; W(SW_AUX) = e->aux;
+    W(SW_PHI) = e->phi; W(SW_LASTT) = e->last_step; W(SW_ALPHA) = e->alpha;   /* LASTT / ENDTIME: env step counts, as in rexsim.h */
+    W(SW_TARGET) = e->target; W(SW_ENDTIME) = e->end_step; W(SW_AUX) = e->aux;
     W(SW_FLAGS) = e->flags; W(SW_STEPS) = e->steps; W(SW_EPISODE) = e->episode;
     W(SW_MOTOR_EN) = e->motor_enabled;
     W(SW_HIST) = e->hist ? (double)(e->hist_head + 256 * e->hist_len) : 0.0;
@@ -1883,8 +1902,8 @@ ORC_API void orc_set_state(void* h, const double* in) {
     for (int k = 0; k < 3; ++k) { e->ph.pos[k] = (real)W(REX_S_POS + k); e->ph.linvel[k] = (real)W(REX_S_LINVEL + k); e->ph.angvel[k] = (real)W(REX_S_ANGVEL + k); }
     for (int k = 0; k < 4; ++k) e->ph.quat[k] = (real)W(REX_S_QUAT + k);
     for (int j = 0; j < NJ; ++j) { e->ph.q[j] = (real)W(SW_Q + j); e->ph.qd[j] = (real)W(SW_QD + j); }
-    e->gait.phi = (real)W(SW_PHI); e->gait.last_time = (real)W(SW_LASTT); e->gait.alpha = (real)W(SW_ALPHA);
-    e->target = (real)W(SW_TARGET); e->end_time = (real)W(SW_ENDTIME); e->aux = (real)W(SW_AUX);
+    e->phi = (real)W(SW_PHI); e->last_step = (int32_t)W(SW_LASTT); e->alpha = (real)W(SW_ALPHA);
+    e->target = (real)W(SW_TARGET); e->end_step = (int32_t)W(SW_ENDTIME); e->aux = (real)W(SW_AUX);
     e->flags = (uint32_t)W(SW_FLAGS); e->steps = (int32_t)W(SW_STEPS); e->episode = (int32_t)W(SW_EPISODE);
     e->motor_enabled = (uint32_t)W(SW_MOTOR_EN);
     if (!e->hist) true_observation(e, e->ctrl_obs);   /* an injected state is also what the robot last observed */

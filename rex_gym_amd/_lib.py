@@ -12,7 +12,7 @@ SIGNALS = {"ik": 0, "ol": 1}
 MARKS = {"base": 0, "arm": 1}
 STATE_WORDS = 54      # mark 'base'; rex_state_words(cfg) for the others
 NUM_MOTORS = 12       # mark 'base'; rex_num_motors(cfg) for the others
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class RexConfig(ctypes.Structure):

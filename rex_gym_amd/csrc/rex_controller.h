@@ -79,7 +79,11 @@ __device__ __forceinline__ void bezier_xz(float t, float& bx, float& bz) {
   }
 }
 
-struct GaitState { float phi, last_time, alpha; };
+// GaitPlanner state.  phi and last_time are doubles, as in the reference: with a 5 ms control step the tests on them are
+// exact ties in real numbers (0.495 / 0.5 against 0.99, 0.25 / 0.5 against 0.5), decided by double rounding.  The step
+// kernel does not store them: it keeps the env step that latched last_time and the outcome of `phi >= 0.99` (rexsim.h,
+// "Clocks") and rebuilds both.  A few dozen DP operations per env.step(), far off the solver loops.
+struct GaitState { double phi, last_time; float alpha; };
 
 // gait_planner.py:30-40 and 42-58 for one (v, angle) pair at a given phase
 __device__ __forceinline__ void gait_component(bool stance, float ph, float bx, float bz, float v, float angle_deg,
@@ -103,23 +107,23 @@ __device__ __forceinline__ void gait_component(bool stance, float ph, float bx, 
 }
 
 // gait_planner.py:96-134 with the phase clock on `now`; mode 0 walk, 1 gallop (offsets :15-20)
-__device__ __forceinline__ void gait_loop(GaitState& g, int mode, float v, float angle, float w_rot, float T,
-                                          float direction, float now, float* frame) {
+__device__ __forceinline__ void gait_loop(GaitState& g, int mode, float v, float angle, float w_rot, double T,
+                                          float direction, double now, float* frame) {
   const float bx0[4] = {kIkL / 2, kIkL / 2, -kIkL / 2, -kIkL / 2};
   const float by0[4] = {-kIkYDist / 2, kIkYDist / 2, -kIkYDist / 2, kIkYDist / 2};
-  if (T <= 0.01f) T = 0.01f;
-  if (g.phi >= 0.99f) g.last_time = now;
+  if (T <= 0.01) T = 0.01;
+  if (g.phi >= 0.99) g.last_time = now;
   g.phi = (now - g.last_time) / T;
 #pragma unroll
   for (int l = 0; l < 4; ++l) {
-    const float off = mode == 0 ? ((l == 1 || l == 2) ? 0.5f : 0.0f) : (l >= 2 ? 0.8f : 0.0f);
-    float phi = g.phi + off;
-    if (phi >= 1.0f) phi -= 1.0f;
+    const double off = mode == 0 ? ((l == 1 || l == 2) ? 0.5 : 0.0) : (l >= 2 ? 0.8 : 0.0);
+    double phi = g.phi + off;
+    if (phi >= 1.0) phi -= 1.0;
     const float r = sqrtf(bx0[l] * bx0[l] + by0[l] * by0[l]);
     const float foot_angle = atan2_fast(by0[l], bx0[l]);
     const float circle = (w_rot >= 0.0f ? 90.0f : 270.0f) - (foot_angle - g.alpha) * (180.0f / kPi);
-    const bool stance = phi <= 0.5f;
-    const float ph = stance ? phi / 0.5f : (phi - 0.5f) / (1.0f - 0.5f);
+    const bool stance = phi <= 0.5;
+    const float ph = (float)(stance ? phi / 0.5 : (phi - 0.5) / (1.0 - 0.5));
     float bx = 0.f, bz = 0.f;
     if (!stance) bezier_xz(ph, bx, bz);
     float lng[3], rot[3];

@@ -1,990 +1,11 @@
 // rexsim.hip -- kernels + C ABI (include/rexsim.h) of the MI355X-native batched Rex simulator.
 // gfx950 only.  Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC rexsim.hip -o librexsim_hip.so
 //
-// Kernel map
-//   rex_step_kernel     one env.step() per lane: action -> staged gait -> Bezier/IK targets ->
-//                       action_repeat x (motor model + restated stepSimulation) -> reward / done /
-//                       observation (+ optional in-launch reset).  State is read once and written
-//                       once per env.step (SoA, coalesced); constraint rows live in LDS.
-//   rex_settle_kernel   the reference's 100 + 500 substep reset motion (rex.py:314-323), run once.
-//   rex_reset_kernel    snapshot restore + per-episode draws (walk_env.py:125-154).
-//   rex_ik/motor/gait   controller-only kernels for parity tests of the controller half.
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-#include <stdio.h>
-#include <string.h>
-#include <math.h>
-#include <stdlib.h>
-
-#include "rex_device.h"
-#include "rex_arm_device.h"
-#include "rex_controller.h"
+// The step and settle kernels are instantiated in rex_step_*.hip / rex_settle.hip (rex_kernels.h); this file holds the
+// C ABI, the reset kernel and the small kernels (regrouping, controller-only entry points).
+#include "rex_kernels.h"
 
 namespace rex {
-
-// INIT_POSES (model/rex_constants.py:10-22), motor order FL,FR,RL,RR x (shoulder, leg, foot)
-__device__ __forceinline__ float pose_stand(int j) {
-  const int k = j % 3;
-  return k == 0 ? 0.0f : (k == 1 ? -0.88643435f : 1.30197369f);
-}
-__device__ __forceinline__ float pose_stand_ol(int j) {
-  const int k = j % 3;
-  return k == 0 ? (((j / 3) & 1) ? -0.15192765f : 0.15192765f) : (k == 1 ? -0.90412283f : 1.48156545f);
-}
-
-struct EnvState {
-  PhysState ph;
-  GaitState gait;
-  float target, end_time, aux;
-  uint32_t flags;
-  int32_t steps, episode;
-  uint32_t motor_en;
-  uint32_t overheat[18]; // one counter per motor in registers; packed 2 x u16 per state word in HBM
-  uint32_t hist;         // observation-history ring: bits 0-7 newest slot, bits 8-15 fill
-  int sweeps;            // solver sweeps this env ran in this launch (transient: regrouping key)
-};
-
-// Persistent-state word layout for NM motors (include/rexsim.h spells out NM = 12 as enum RexStateWord; mark='arm'
-// has NM = 18: the q / qd blocks and the overheat block grow, everything else keeps its order)
-template <int NM>
-struct Lay {
-  static constexpr int Q = 13, QD = 13 + NM, PHI = 13 + 2 * NM, LASTT = PHI + 1, ALPHA = PHI + 2, TARGET = PHI + 3,
-                       ENDTIME = PHI + 4, AUX = PHI + 5, FLAGS = PHI + 6, STEPS = PHI + 7, EPISODE = PHI + 8, MOTOR_EN = PHI + 9,
-                       OVERHEAT = PHI + 10, HIST = OVERHEAT + NM / 2, WORDS = HIST + 1;
-};
-static_assert(Lay<12>::PHI == REX_S_PHI && Lay<12>::FLAGS == REX_S_FLAGS && Lay<12>::OVERHEAT == REX_S_OVERHEAT &&
-              Lay<12>::HIST == REX_S_HIST && Lay<12>::WORDS == REX_STATE_WORDS, "layout must match include/rexsim.h");
-
-// word w of env i at a 32-bit element offset from the block's base (rex_create checks words * n < 2^30): the loads
-// and stores use the saddr + 32-bit voffset form, and no per-word 64-bit address has to stay in vector registers
-// between load_env and store_env
-__device__ __forceinline__ float ldw(const float* st, int n, int w, int i) { return st[(unsigned)(w * n + i)]; }
-__device__ __forceinline__ uint32_t ldi(const float* st, int n, int w, int i) { return __float_as_uint(ldw(st, n, w, i)); }
-__device__ __forceinline__ void stw(float* st, int n, int w, int i, float v) { st[(unsigned)(w * n + i)] = v; }
-__device__ __forceinline__ void sti(float* st, int n, int w, int i, uint32_t v) { stw(st, n, w, i, __uint_as_float(v)); }
-
-template <int NM>
-__device__ __forceinline__ void load_env(const float* st, int n, int i, EnvState& e) {
-  using Y = Lay<NM>;
-#pragma unroll
-  for (int k = 0; k < 3; ++k) { e.ph.pos[k] = ldw(st, n, REX_S_POS + k, i); e.ph.lin[k] = ldw(st, n, REX_S_LINVEL + k, i); e.ph.ang[k] = ldw(st, n, REX_S_ANGVEL + k, i); }
-#pragma unroll
-  for (int k = 0; k < 4; ++k) e.ph.quat[k] = ldw(st, n, REX_S_QUAT + k, i);
-#pragma unroll
-  for (int j = 0; j < NM; ++j) { e.ph.q[j] = ldw(st, n, Y::Q + j, i); e.ph.qd[j] = ldw(st, n, Y::QD + j, i); }
-  e.gait.phi = ldw(st, n, Y::PHI, i); e.gait.last_time = ldw(st, n, Y::LASTT, i); e.gait.alpha = ldw(st, n, Y::ALPHA, i);
-  e.target = ldw(st, n, Y::TARGET, i); e.end_time = ldw(st, n, Y::ENDTIME, i); e.aux = ldw(st, n, Y::AUX, i);
-  e.flags = ldi(st, n, Y::FLAGS, i); e.steps = (int32_t)ldi(st, n, Y::STEPS, i); e.episode = (int32_t)ldi(st, n, Y::EPISODE, i);
-  e.motor_en = ldi(st, n, Y::MOTOR_EN, i);
-  e.hist = ldi(st, n, Y::HIST, i);
-#pragma unroll
-  for (int k = 0; k < NM / 2; ++k) {
-    const uint32_t w = ldi(st, n, Y::OVERHEAT + k, i);
-    e.overheat[2 * k] = w & 0xFFFFu; e.overheat[2 * k + 1] = w >> 16;
-  }
-}
-
-template <int NM>
-__device__ __forceinline__ void store_env(float* st, int n, int i, const EnvState& e) {
-  using Y = Lay<NM>;
-#pragma unroll
-  for (int k = 0; k < 3; ++k) { stw(st, n, REX_S_POS + k, i, e.ph.pos[k]); stw(st, n, REX_S_LINVEL + k, i, e.ph.lin[k]); stw(st, n, REX_S_ANGVEL + k, i, e.ph.ang[k]); }
-#pragma unroll
-  for (int k = 0; k < 4; ++k) stw(st, n, REX_S_QUAT + k, i, e.ph.quat[k]);
-#pragma unroll
-  for (int j = 0; j < NM; ++j) { stw(st, n, Y::Q + j, i, e.ph.q[j]); stw(st, n, Y::QD + j, i, e.ph.qd[j]); }
-  stw(st, n, Y::PHI, i, e.gait.phi); stw(st, n, Y::LASTT, i, e.gait.last_time); stw(st, n, Y::ALPHA, i, e.gait.alpha);
-  stw(st, n, Y::TARGET, i, e.target); stw(st, n, Y::ENDTIME, i, e.end_time); stw(st, n, Y::AUX, i, e.aux);
-  sti(st, n, Y::FLAGS, i, e.flags); sti(st, n, Y::STEPS, i, (uint32_t)e.steps); sti(st, n, Y::EPISODE, i, (uint32_t)e.episode);
-  sti(st, n, Y::MOTOR_EN, i, e.motor_en);
-  sti(st, n, Y::HIST, i, e.hist);
-#pragma unroll
-  for (int k = 0; k < NM / 2; ++k) sti(st, n, Y::OVERHEAT + k, i, e.overheat[2 * k] | (e.overheat[2 * k + 1] << 16));
-}
-
-// ---- PyBullet quaternion conventions ----
-__device__ __forceinline__ void quat_to_euler(const float* q, float* rpy) {
-  const float x = q[0], y = q[1], z = q[2], w = q[3];
-  const float sqx = x * x, sqy = y * y, sqz = z * z, squ = w * w;
-  const float sarg = -2.0f * (x * z - w * y);
-  if (sarg <= -0.99999f) { rpy[1] = -0.5f * kPi; rpy[0] = 0.0f; rpy[2] = 2.0f * atan2_fast(x, -y); }
-  else if (sarg >= 0.99999f) { rpy[1] = 0.5f * kPi; rpy[0] = 0.0f; rpy[2] = 2.0f * atan2_fast(-x, y); }
-  else {
-    rpy[1] = asin_fast(sarg);
-    rpy[0] = atan2_fast(2.0f * (y * z + w * x), squ - sqx - sqy + sqz);
-    rpy[2] = atan2_fast(2.0f * (x * y + w * z), squ + sqx - sqy - sqz);
-  }
-}
-// third row (R20, R21, R22) of the matrix of the quaternion rebuilt from Euler angles
-// (Rex.GetBaseOrientation, rex.py:530-537, then getMatrixFromQuaternion)
-__device__ __forceinline__ void euler_to_row2(const float* rpy, float& r20, float& r21, float& r22) {
-  float sr, cr, sp, cp, sy, cy;
-  sincos_fast(rpy[0] * 0.5f, sr, cr); sincos_fast(rpy[1] * 0.5f, sp, cp); sincos_fast(rpy[2] * 0.5f, sy, cy);
-  float x = sr * cp * cy - cr * sp * sy, y = cr * sp * cy + sr * cp * sy;
-  float z = cr * cp * sy - sr * sp * cy, w = cr * cp * cy + sr * sp * sy;
-  const float nn = rsqrtf(x * x + y * y + z * z + w * w);
-  x *= nn; y *= nn; z *= nn; w *= nn;
-  const float d = x * x + y * y + z * z + w * w, s = 2.0f / d;
-  const float xs = x * s, ys = y * s, zs = z * s;
-  r20 = x * zs - w * ys; r21 = y * zs + w * xs; r22 = 1.0f - (x * xs + y * ys);
-}
-
-// ---- Philox4x32-10 ----
-__device__ __forceinline__ void philox4x32(uint32_t* c, uint32_t k0, uint32_t k1) {
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const uint32_t h0 = __umulhi(0xD2511F53u, c[0]), l0 = 0xD2511F53u * c[0];
-    const uint32_t h1 = __umulhi(0xCD9E8D57u, c[2]), l1 = 0xCD9E8D57u * c[2];
-    const uint32_t n0 = h1 ^ c[1] ^ k0, n1 = l1, n2 = h0 ^ c[3] ^ k1, n3 = l0;
-    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-  }
-}
-__device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
-// Four standard normal draws (Box-Muller on one Philox block) for the sensor-noise model: Rex._AddSensorNoise
-// (model/rex.py:765-769) draws np.random.normal afresh in every getter call; here a getter call site of a step is one or
-// more Philox blocks keyed by (seed; episode, global env, 16 + block, step).
-__device__ __forceinline__ void gauss4(uint32_t seed_lo, uint32_t seed_hi, int gidx, int episode, int step, int block, float* z) {
-  uint32_t ctr[4] = {(uint32_t)episode, (uint32_t)gidx, 16u + (uint32_t)block, (uint32_t)step};
-  philox4x32(ctr, seed_lo, seed_hi);
-#pragma unroll
-  for (int p = 0; p < 2; ++p) {
-    const float u1 = (float)((ctr[2 * p] >> 8) + 1u) * (1.0f / 16777216.0f), u2 = u01(ctr[2 * p + 1]);
-    const float r = sqrtf(-2.0f * __logf(u1));
-    float sn, cs;
-    sincos_fast(6.28318530717958648f * u2, sn, cs);
-    z[2 * p] = r * cs; z[2 * p + 1] = r * sn;
-  }
-}
-// call sites of a step (blocks): orientation read by the turn env's goal test, by the reward, by is_fallen, by the
-// observation; angular rates of the observation; then NM-wide reads (5 blocks each): reward torques, reward velocities,
-// observed motor angles
-enum { kNzGoal = 0, kNzRewardRpy = 1, kNzFallenRpy = 2, kNzObsRpy = 3, kNzObsRate = 4, kNzTorque = 8, kNzVelocity = 16, kNzAngle = 24 };
-
-struct DevCfg {
-  int32_t n, env_index_base, task, signal, action_repeat, iterations;
-  float dt, kp, kd, res_thr;
-  int32_t backwards;
-  float target_position;
-  uint32_t seed_lo, seed_hi;
-  int32_t auto_reset, max_steps;
-  float w_dist, w_energy, w_drift, w_shake;
-  int32_t action_dim, obs_dim;
-  float target_orient, init_orient;
-  int32_t orient_fixed;
-  int32_t pose_index;
-  float pose_value;
-  int32_t range_normalize;
-  const float* terrain;      // [n_terrain][256*256] raw vertex heights (nullptr: plane only)
-  const float* terrain_mid;  // [n_terrain]
-  int32_t n_terrain;
-  float* hist;               // [100][hist_words][n] observation history (nullptr: no latency model)
-  int32_t hist_words;        // 3 NM + 7 words per record: q, qd, observed torque, base quaternion, base angular velocity
-  float pd_latency, control_latency;
-  // int(latency / time_step) and the blend weight of the older slot (rex.py:747-751), taken on the host in double on
-  // the decimal values the caller wrote: the float quotient 0.02f / 0.001f is 19.999998
-  int32_t pd_slots, control_slots;
-  float pd_alpha, control_alpha;
-  int32_t reset_substeps;    // int(0.5 / time_step), rex.py:319 (the float quotient 0.5f / 0.001f truncates to 499)
-  const float* body_params;  // [3][n] word-major: base mass scale, leg mass scale, foot friction (nullptr: 1, 1, 0.5)
-  float act_lo, act_hi;      // Box bounds of the env's action space (host: rex_create)
-  float gait_clock;          // wall-clock seconds per simulated second seen by GaitPlanner.loop (gait_planner.py:108-110)
-  // REX_TASK_MIXED: the tasks of the mix (task_mix bits, ascending), their number, and the largest action_repeat /
-  // solver sweep cap among them (wave-uniform loop bounds; every env stops at its own)
-  int32_t mix_task[5], n_mix, max_repeat, max_iterations;
-  float mass_lo, mass_hi, mu_lo, mu_hi;   // per-reset randomisation ranges (lo == hi == 0: off)
-  // large batches: envs are regrouped into waves by the solver sweeps they needed in the previous step (a wave sweeps
-  // until the slowest of its envs has converged): wave slot k works on env perm[k]; sweeps[i] = this step's count of env i
-  const int32_t* perm; int32_t* sweeps;
-  // rex_set_timing(3): device-side launch duration -- every workgroup folds its start / end wall-clock tick (100 MHz
-  // constant clock, s_memrealtime) into clock[0] (min) / clock[1] (max); nullptr otherwise
-  unsigned long long* clock;
-  float noise[5];            // observation_noise_stdev (rex.py:22,765-769): angles, velocities, torques, rpy, rpy rates
-  int32_t noise_on;          // any of them > 0
-  HfGeom geo;                // heightfield grid geometry
-  int32_t hf_stride;         // floats per field of the pool
-  float init_z;              // drop height of the reset (terrain.py:14-20)
-  float anchor;              // on_rack: rex::kRackAnchor, else 0
-  float obs_hi_ang, obs_hi_rate;
-};
-
-// per-task constants of the reference env classes (walk_env.py:34-40,104-114, gallop_env.py:45-53,
-// 119-130, turn_env.py:33-39,100-110, poses_env.py:38-44,115-117, standup_env.py:32-38,99-101)
-__host__ __device__ __forceinline__ int task_action_repeat(int task) { return (task == REX_TASK_GALLOP || task == REX_TASK_POSES) ? 6 : 5; }
-__host__ __device__ __forceinline__ float task_action_bound(int task, int signal) {   // Box(low = -b, high = +b); gallop's is inverted
-  if (task == REX_TASK_WALK) return signal == REX_SIGNAL_IK ? 0.4f : 0.01f;
-  if (task == REX_TASK_GALLOP) return signal == REX_SIGNAL_IK ? -0.4f : -0.3f;
-  if (task == REX_TASK_TURN) return 0.01f;
-  return 0.1f;
-}
-__host__ __device__ __forceinline__ float task_energy_weight(int task) { return task == REX_TASK_GALLOP ? 0.005f : 0.0005f; }
-
-// the task env `gidx` runs for its whole life in a REX_TASK_MIXED batch: a draw from its own Philox stream
-__device__ __forceinline__ int mixed_task_of(const DevCfg& c, int gidx) {
-  uint32_t ctr[4] = {0xFFFFFFFFu, (uint32_t)gidx, 2u, 0u};
-  philox4x32(ctr, c.seed_lo, c.seed_hi);
-  const int k = (int)(ctr[0] % (uint32_t)c.n_mix);
-  return k == 0 ? c.mix_task[0] : (k == 1 ? c.mix_task[1] : (k == 2 ? c.mix_task[2] : (k == 3 ? c.mix_task[3] : c.mix_task[4])));
-}
-
-// this env's view of the config in a REX_TASK_MIXED batch: its task and the per-task constants that go with it
-__device__ __forceinline__ void mixed_config(const DevCfg& c, int gidx, DevCfg& cm) {
-  cm = c;
-  cm.task = mixed_task_of(c, gidx);
-  cm.action_repeat = task_action_repeat(cm.task);
-  cm.iterations = 300 / cm.action_repeat;                       // rex_gym_env.py:25,184
-  const float b = task_action_bound(cm.task, c.signal);
-  cm.act_lo = -b; cm.act_hi = b;
-  cm.w_energy = task_energy_weight(cm.task);
-}
-// snapshot record of (terrain, task): one settled robot per terrain and -- in a mixed batch -- per task of the mix
-// (the reset motion runs under the task's own numSolverIterations)
-__device__ __forceinline__ int mix_slot(const DevCfg& c, int task) {
-  int sl = 0;
-#pragma unroll
-  for (int k = 1; k < 5; ++k) if (k < c.n_mix && c.mix_task[k] == task) sl = k;
-  return sl;
-}
-
-// INIT_POSES['rest_position'] (rex_constants.py:41-46): the foot target 6 rad lies beyond the URDF bound 2.59
-__device__ __forceinline__ float pose_rest(int j) {
-  const int k = j % 3;
-  return k == 0 ? (((j / 3) & 1) ? 0.4f : -0.4f) : (k == 1 ? -1.5f : 6.0f);
-}
-__device__ __forceinline__ float init_pose(const DevCfg& c, int j) { return c.signal == REX_SIGNAL_OL ? pose_stand_ol(j) : pose_stand(j); }
-// the pose the reset motion drives to: reset(initial_motor_angles=...), standup_env.py:108-110 vs walk_env.py:125-131
-__device__ __forceinline__ float reset_pose(const DevCfg& c, int j) { return c.task == REX_TASK_STANDUP ? pose_rest(j) : init_pose(c, j); }
-
-// ---- latency model: Rex._observation_history / _GetDelayedObservation (model/rex.py:122,717-763) ----
-__device__ __forceinline__ float& hist_at(const DevCfg& c, int i, int slot, int w) {
-  return c.hist[((size_t)slot * c.hist_words + w) * c.n + i];   // hist_words = 3 NM + 7: 43 (mark 'base') or 61 ('arm')
-}
-// which two ring slots to blend, and with which weight, for an observation `latency` seconds old
-__device__ __forceinline__ void delay_slots(uint32_t hist, float latency, int n, float blend, int& s0, int& s1, float& alpha) {
-  const int head = (int)(hist & 0xFFu), len = (int)((hist >> 8) & 0xFFu);
-  int k0 = 0, k1 = 0;
-  alpha = 0.0f;
-  if (latency > 0.0f && len != 1) {
-    if (n + 1 >= len) { k0 = k1 = len - 1; }
-    else { k0 = n; k1 = n + 1; alpha = blend; }
-  }
-  s0 = (head - k0 + 2 * REX_HISTORY_LEN) % REX_HISTORY_LEN;
-  s1 = (head - k1 + 2 * REX_HISTORY_LEN) % REX_HISTORY_LEN;
-}
-__device__ __forceinline__ float delayed_word(const DevCfg& c, int i, int s0, int s1, float alpha, int w) {
-  return (1.0f - alpha) * hist_at(c, i, s0, w) + alpha * hist_at(c, i, s1, w);
-}
-// the controller-facing observation (Rex._control_observation): q, qd, tau_obs, quat, angular velocity
-struct CtrlObs { float q[18], qd[18], tau[18], quat[4], w[3]; };
-
-// terrain of (global env index, episode): the reference regenerates the field on every reset
-// (rex_gym_env.py:347-348); here each episode picks one of the pool entries
-__device__ __forceinline__ int terrain_index(const DevCfg& c, int gidx, int episode) {
-  return (int)(((uint32_t)gidx + 977u * (uint32_t)episode) % (uint32_t)c.n_terrain);
-}
-__device__ __forceinline__ Ground env_ground(const DevCfg& c, int i, int gidx, int episode) {
-  Ground g{nullptr, 0.0f, 1.0f, 1.0f, kMu, c.geo, c.anchor};
-  if (c.body_params) {
-    g.base_mass_scale = c.body_params[i]; g.leg_mass_scale = c.body_params[(size_t)c.n + i]; g.mu = c.body_params[2 * (size_t)c.n + i];
-  }
-  if (c.mass_hi > 0.0f || c.mu_hi > 0.0f) {
-    // per-reset draws of the env_randomizer hook (rex_gym_env.py:345-346): a pure function of (seed, env, episode), so
-    // nothing has to be stored -- every step of the episode recomputes the same three numbers
-    uint32_t ctr[4] = {(uint32_t)episode, (uint32_t)gidx, 1u, 0u};
-    philox4x32(ctr, c.seed_lo, c.seed_hi);
-    if (c.mass_hi > 0.0f) {
-      g.base_mass_scale = fmaf(c.mass_hi - c.mass_lo, u01(ctr[0]), c.mass_lo);
-      g.leg_mass_scale = fmaf(c.mass_hi - c.mass_lo, u01(ctr[1]), c.mass_lo);
-    }
-    if (c.mu_hi > 0.0f) g.mu = fmaf(c.mu_hi - c.mu_lo, u01(ctr[2]), c.mu_lo);
-  }
-  if (c.n_terrain > 0) {
-    const int t = terrain_index(c, gidx, episode);
-    g.h = c.terrain + (size_t)t * c.hf_stride;
-    g.mid = c.terrain_mid[t];
-  }
-  return g;
-}
-
-// Rex.ReceiveObservation (rex.py:726-733): the true observation goes to the front of the history ring
-template <int NM>
-__device__ __forceinline__ void receive_observation(const DevCfg& c, EnvState& e, int i, bool live, const float* tau_obs) {
-  if (!c.hist) return;
-  const int head = ((int)(e.hist & 0xFFu) + 1) % REX_HISTORY_LEN;
-  const int len = min((int)((e.hist >> 8) & 0xFFu) + 1, REX_HISTORY_LEN);
-  e.hist = (uint32_t)head | ((uint32_t)len << 8);
-  if (live) {
-#pragma unroll
-    for (int j = 0; j < NM; ++j) { hist_at(c, i, head, j) = e.ph.q[j]; hist_at(c, i, head, NM + j) = e.ph.qd[j]; hist_at(c, i, head, 2 * NM + j) = tau_obs[j]; }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) hist_at(c, i, head, 3 * NM + k) = e.ph.quat[k];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) hist_at(c, i, head, 3 * NM + 4 + k) = e.ph.ang[k];
-  }
-}
-
-// Rex.ApplyAction + stepSimulation + ReceiveObservation (rex.py:158-163, 568-641).
-template <bool LANECAP, class SM, class ARMP>
-__device__ __forceinline__ void rex_substep(const DevCfg& c, EnvState& e, int i, bool live, float* cmd, float* tau_obs,
-                                            const SM& sm, const Ground& ground, ARMP& armp) {
-  constexpr int NM = ARMP::NM;
-  float tau[18];
-  const float limit = 1.0f / c.dt;  // OVERHEAT_SHUTDOWN_TIME / time_step, rex.py:607
-  float qo[NM], qdo[NM];                        // what the PD loop sees: _GetPDObservation, rex.py:755-759
-#pragma unroll
-  for (int j = 0; j < NM; ++j) { qo[j] = e.ph.q[j]; qdo[j] = e.ph.qd[j]; }
-  if (c.hist) {
-    int s0, s1;
-    float alpha;
-    delay_slots(e.hist, c.pd_latency, c.pd_slots, c.pd_alpha, s0, s1, alpha);
-#pragma unroll
-    for (int j = 0; j < NM; ++j) { qo[j] = delayed_word(c, i, s0, s1, alpha, j); qdo[j] = delayed_word(c, i, s0, s1, alpha, NM + j); }
-  }
-#pragma unroll
-  for (int j = 0; j < NM; ++j) {
-    float act, obs;
-    motor_torque(cmd[j], qo[j], qdo[j], e.ph.qd[j], c.kp, c.kd, act, obs);
-    uint32_t cnt = e.overheat[j];
-    cnt = fabsf(act) > 2.45f ? min(cnt + 1u, 65535u) : 0u;                      // rex.py:603-606
-    if ((float)cnt > limit) e.motor_en &= ~(1u << j);                           // rex.py:607-608
-    e.overheat[j] = cnt;
-    tau_obs[j] = obs;
-    tau[j] = ((e.motor_en >> j) & 1u) ? act : 0.0f;                             // rex.py:617-623
-  }
-  // mark 'arm', <= 8 envs per wave: the motor-side state of the env waits in LDS while the substep runs (rex_device.h,
-  // REX_MOTOR_PARK_WORDS); one lane of the group writes, all read back
-  constexpr bool kPark = NM == 18 && SM::kEpw <= 8;
-  if constexpr (kPark) {
-    if ((threadIdx.x & 7u) == 0u) {
-#pragma unroll
-      for (int j = 0; j < 18; ++j) { sm.motorf(j) = cmd[j]; sm.motorf(18 + j) = tau_obs[j]; sm.motorf(36 + j) = __uint_as_float(e.overheat[j]); }
-      sm.motorf(54) = e.gait.phi; sm.motorf(55) = e.gait.last_time; sm.motorf(56) = e.gait.alpha;
-      sm.motorf(57) = e.target; sm.motorf(58) = e.end_time; sm.motorf(59) = e.aux;
-      sm.motorf(60) = __uint_as_float(e.flags); sm.motorf(61) = __int_as_float(e.steps); sm.motorf(62) = __int_as_float(e.episode);
-      sm.motorf(63) = __uint_as_float(e.motor_en); sm.motorf(64) = __uint_as_float(e.hist);
-    }
-    asm volatile("" ::: "memory");
-  }
-  physics_substep<LANECAP>(e.ph, tau, c.dt, c.max_iterations, c.iterations, c.res_thr, sm, ground, armp, e.sweeps);
-  if constexpr (kPark) {
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int j = 0; j < 18; ++j) { cmd[j] = sm.motorf(j); tau_obs[j] = sm.motorf(18 + j); e.overheat[j] = __float_as_uint(sm.motorf(36 + j)); }
-    e.gait.phi = sm.motorf(54); e.gait.last_time = sm.motorf(55); e.gait.alpha = sm.motorf(56);
-    e.target = sm.motorf(57); e.end_time = sm.motorf(58); e.aux = sm.motorf(59);
-    e.flags = __float_as_uint(sm.motorf(60)); e.steps = __float_as_int(sm.motorf(61)); e.episode = __float_as_int(sm.motorf(62));
-    e.motor_en = __float_as_uint(sm.motorf(63)); e.hist = __float_as_uint(sm.motorf(64));
-  }
-  receive_observation<NM>(c, e, i, live, tau_obs);
-}
-
-// Rex._control_observation as the env-level getters see it (delayed by control_latency when the model is on)
-template <int NM>
-__device__ __forceinline__ void control_observation(const DevCfg& c, const EnvState& e, int i, const float* tau_obs, CtrlObs& o) {
-  if (c.hist) {
-    int s0, s1; float alpha;
-    delay_slots(e.hist, c.control_latency, c.control_slots, c.control_alpha, s0, s1, alpha);
-#pragma unroll
-    for (int j = 0; j < NM; ++j) {
-      o.q[j] = delayed_word(c, i, s0, s1, alpha, j); o.qd[j] = delayed_word(c, i, s0, s1, alpha, NM + j);
-      o.tau[j] = delayed_word(c, i, s0, s1, alpha, 2 * NM + j);
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) o.quat[k] = delayed_word(c, i, s0, s1, alpha, 3 * NM + k);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) o.w[k] = delayed_word(c, i, s0, s1, alpha, 3 * NM + 4 + k);
-  } else {
-#pragma unroll
-    for (int j = 0; j < NM; ++j) { o.q[j] = e.ph.q[j]; o.qd[j] = e.ph.qd[j]; o.tau[j] = tau_obs[j]; }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) o.quat[k] = e.ph.quat[k];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) o.w[k] = e.ph.ang[k];
-  }
-}
-
-// RangeNormalize of the observation (wrappers.py:236-240); bounds are symmetric (rex_gym_env.py:277-278)
-__device__ __forceinline__ void normalize_obs(const DevCfg& c, float* obs) {
-#pragma unroll
-  for (int k = 0; k < 22; ++k) {
-    if (k < c.obs_dim) {
-      const float hi = (k == 2 || k == 3) ? c.obs_hi_rate : c.obs_hi_ang, lo = -hi;
-      obs[k] = 2.0f * (obs[k] - lo) / (hi - lo) - 1.0f;
-    }
-  }
-}
-
-template <int NM>
-__device__ __forceinline__ void env_observation(const DevCfg& c, const CtrlObs& co, float* obs, int gidx = 0, int episode = 0, int step = 0) {
-  float rpy[3];
-  quat_to_euler(co.quat, rpy);
-  float wx = co.w[0], wy = co.w[1];
-  if (c.noise_on) {                                                               // GetBaseRollPitchYaw / ...Rate: rex.py:430-442,548-558
-    float z[4];
-    if (c.noise[3] > 0.0f) { gauss4(c.seed_lo, c.seed_hi, gidx, episode, step, kNzObsRpy, z); rpy[0] += c.noise[3] * z[0]; rpy[1] += c.noise[3] * z[1]; }
-    if (c.noise[4] > 0.0f) { gauss4(c.seed_lo, c.seed_hi, gidx, episode, step, kNzObsRate, z); wx += c.noise[4] * z[0]; wy += c.noise[4] * z[1]; }
-  }
-  obs[0] = rpy[0]; obs[1] = rpy[1]; obs[2] = wx; obs[3] = wy;                       // walk_env.py:356-362
-  if (c.task == REX_TASK_GALLOP) {
-    float nz[20];
-    const bool noisy = c.noise_on && c.noise[0] > 0.0f;                           // GetMotorAngles: noise, then MapToMinusPiToPi (rex.py:457-468)
-    if (noisy) {
-#pragma unroll
-      for (int b = 0; b < (NM + 3) / 4; ++b) gauss4(c.seed_lo, c.seed_hi, gidx, episode, step, kNzAngle + b, nz + 4 * b);
-    }
-#pragma unroll
-    for (int j = 0; j < NM; ++j) {                                                // MapToMinusPiToPi, rex.py:26-41
-      float a = fmodf(co.q[j] + (noisy ? c.noise[0] * nz[j] : 0.0f), 2.0f * kPi);
-      if (a >= kPi) a -= 2.0f * kPi; else if (a < -kPi) a += 2.0f * kPi;
-      obs[4 + j] = a;
-    }
-  }
-}
-
-// RexWalkEnv.reset / RexReactiveEnv.reset ... draws on top of the settled snapshot.  `seen` receives what the robot last
-// observed of its base (quaternion, angular velocity): the settled one -- the turn env teleports the base behind the
-// observation's back (turn_env.py:158-160), and reset() returns that older reading.
-template <int NM>
-__device__ __forceinline__ void env_reset(const DevCfg& c, const float* snap, int i, bool live, int gidx, EnvState& e, float* seen) {
-  const int32_t episode = e.episode + 1;
-  const float alpha = e.gait.alpha;   // the env keeps one GaitPlanner for life: its arc angle survives reset() (gait_planner.py:76-85)
-  const int nrec = (c.n_terrain > 0 ? c.n_terrain : 1) * c.n_mix;
-  const int rec = (c.n_terrain > 0 ? terrain_index(c, gidx, episode) : 0) * c.n_mix + (c.n_mix > 1 ? mix_slot(c, c.task) : 0);
-  load_env<NM>(snap, nrec, rec, e);   // settled on this episode's terrain (under this env's task)
-  if (c.hist) {   // the deque as the reset motion left it: its last 100 observations, ring position included (e.hist)
-    if (live) {
-      const float* ring = snap + (size_t)Lay<NM>::WORDS * nrec;
-#pragma unroll 8
-      for (int k = 0; k < REX_HISTORY_LEN * (3 * NM + 7); ++k) c.hist[(size_t)k * c.n + i] = ring[(size_t)k * nrec + rec];
-    }
-    mirror_sync();
-  } else e.hist = 0u;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) seen[k] = e.ph.quat[k];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) seen[4 + k] = e.ph.ang[k];
-  e.episode = episode;
-  e.gait.phi = 0.0f; e.gait.last_time = 0.0f; e.gait.alpha = alpha;
-  // key = the 64-bit seed, counter = (episode, global env index): distinct seeds give independent streams for every env
-  // (a key of seed ^ index would hand (seed 0, env 1) and (seed 1, env 0) the same stream)
-  uint32_t ctr[4] = {(uint32_t)episode, (uint32_t)gidx, 0u, 0u};
-  philox4x32(ctr, c.seed_lo, c.seed_hi);
-  e.flags = 0;
-  const float u = u01(ctr[1]);
-  if (c.task == REX_TASK_WALK) {
-    const int backwards = c.backwards < 0 ? (int)(ctr[0] >> 31) : c.backwards;   // walk_env.py:133-136
-    if (backwards) e.flags |= REX_F_BACKWARDS;
-    if (c.target_position != 0.0f) e.target = c.target_position;
-    else e.target = backwards ? (-2.0f - u) : (1.0f + 2.0f * u);                 // walk_env.py:143-147
-  } else {
-    e.target = c.target_position != 0.0f ? c.target_position : (1.0f + 2.0f * u); // gallop_env.py:150-152
-  }
-  e.end_time = 0.0f; e.aux = 0.0f; e.steps = 0;
-  if (c.task == REX_TASK_POSES) {                                                // poses_env.py:153-192
-    const int k = c.pose_index >= 0 ? c.pose_index : episode % 5;               // deque rotation: one pop per reset()
-    // _ranges (rex_gym_env.py:258-265): base_y, base_z, roll, pitch, yaw
-    const float lo = k == 0 ? -0.007f : (k == 1 ? -0.048f : -0.78539816339744830962f);
-    const float hi = k == 0 ? 0.007f : (k == 1 ? 0.021f : 0.78539816339744830962f);
-    e.aux = (float)k;
-    e.target = c.pose_index >= 0 ? c.pose_value : fmaf(hi - lo, u, lo);
-  }
-  if (c.task == REX_TASK_TURN) {                                                 // turn_env.py:129-160
-    const float tgt = (c.orient_fixed & 1) ? c.target_orient : fmaf(5.8f, u, 0.2f);
-    const float ini = (c.orient_fixed & 2) ? c.init_orient : fmaf(5.8f, u01(ctr[2]), 0.2f);
-    e.target = tgt; e.aux = ini;
-    float sh, ch;
-    sincos_fast(0.5f * ini, sh, ch);                                             // getQuaternionFromEuler([0, 0, yaw])
-    const float nn = rsqrtf(sh * sh + ch * ch);
-    e.ph.quat[0] = 0.0f; e.ph.quat[1] = 0.0f; e.ph.quat[2] = sh * nn; e.ph.quat[3] = ch * nn;
-    e.ph.pos[0] = 0.0f; e.ph.pos[1] = 0.0f; e.ph.pos[2] = c.init_z;              // resetBasePositionAndOrientation
-  }
-}
-
-__device__ __forceinline__ void order_signal(const float* ang, float* cmd) {  // FR,FL,RR,RL -> FL,FR,RL,RR
-#pragma unroll
-  for (int k = 0; k < 3; ++k) { cmd[k] = ang[3 + k]; cmd[3 + k] = ang[k]; cmd[6 + k] = ang[9 + k]; cmd[9 + k] = ang[6 + k]; }
-}
-
-// RexWalkEnv._transform_action_to_motor_command (walk_env.py:207-324)
-__device__ __forceinline__ void walk_command(const DevCfg& c, EnvState& e, const float* action, float* cmd) {
-  if (e.flags & REX_F_STAY_STILL) {
-#pragma unroll
-    for (int j = 0; j < 12; ++j) cmd[j] = init_pose(c, j);
-    return;
-  }
-  const float t = (float)(e.steps * c.action_repeat) * c.dt;                     // rex.py:155-156
-  if (e.target != 0.0f && fabsf(e.ph.pos[0]) >= fabsf(e.target) - 0.15f) {       // walk_env.py:207-215
-    e.flags |= REX_F_GOAL_REACHED;
-    if (!(e.flags & REX_F_TERMINATING)) { e.end_time = t; e.flags |= REX_F_TERMINATING; }
-  }
-  const bool backwards = (e.flags & REX_F_BACKWARDS) != 0;
-  if (c.signal == REX_SIGNAL_IK) {                                               // walk_env.py:252-290
-    const float p = 0.8f + action[0];
-    const float gait_coeff = (0.0f <= t && t <= p) ? t : 1.0f;
-    const float period = backwards ? 0.5f : 0.65f;
-    const float pos[3] = {backwards ? 0.0f : 0.01f, 0.0f, 0.0f}, orn[3] = {0.0f, 0.0f, 0.0f};
-    float step_length = (backwards ? -0.3f : 0.6f) * gait_coeff;
-    if (e.flags & REX_F_GOAL_REACHED) {
-      const float pb = 0.8f + action[1];
-      const float b = (e.end_time <= t && t <= pb + e.end_time) ? 1.0f - (t - e.end_time) : 0.0f;
-      step_length *= b;
-      if (b == 0.0f) e.flags |= REX_F_STAY_STILL;
-    }
-    const float direction = step_length < 0.0f ? -1.0f : 1.0f;
-    float frames[12], ang[12];
-    gait_loop(e.gait, 0, step_length, 0.0f, 0.0f, period, direction, t * c.gait_clock, frames);
-    ik_solve(orn, pos, frames, ang);
-    order_signal(ang, cmd);
-  } else {                                                                       // walk_env.py:292-315
-    float l_a = 0.1f, f_a = 0.2f;
-    if (e.flags & REX_F_GOAL_REACHED) {
-      const bool inside = e.end_time <= t && t <= 0.8f + e.end_time;
-      const float b = inside ? 1.0f - (t - e.end_time) : 0.0f;
-      l_a *= b; f_a *= b;
-      // `if coeff is 0.0` (walk_env.py:300) is an identity test: true exactly when the brake function returns its
-      // end_value argument, i.e. outside the brake window (pinned by tests/golden/env_command_golden.json)
-      if (!inside) e.flags |= REX_F_STAY_STILL;
-    }
-    const float sc = (0.0f <= t && t <= 0.8f) ? t : 1.0f;
-    l_a *= sc; f_a *= sc;
-    float sph, cph;
-    sincos_fast(2.0f * kPi / 0.125f * t, sph, cph);
-    const float le = l_a * cph, fe = f_a * cph;
-    const float pose[12] = {0.f, le + action[0], fe + action[1], 0.f, -le + action[2], -fe + action[3],
-                            0.f, -le + action[4], -fe + action[5], 0.f, le + action[6], fe + action[7]};
-#pragma unroll
-    for (int j = 0; j < 12; ++j) cmd[j] = pose_stand_ol(j) + pose[j];
-  }
-}
-
-// RexReactiveEnv._transform_action_to_motor_command (gallop_env.py:212-313)
-__device__ __forceinline__ void gallop_command(const DevCfg& c, EnvState& e, const float* action, float* cmd) {
-  if (e.flags & REX_F_STAY_STILL) {
-#pragma unroll
-    for (int j = 0; j < 12; ++j) cmd[j] = pose_stand(j);                         // rex.initial_pose
-    return;
-  }
-  const float t = (float)(e.steps * c.action_repeat) * c.dt;
-  if (e.target != 0.0f && fabsf(e.ph.pos[0]) >= fabsf(e.target)) {               // gallop_env.py:212-220
-    e.flags |= REX_F_GOAL_REACHED;
-    if (!(e.flags & REX_F_TERMINATING)) { e.end_time = t; e.flags |= REX_F_TERMINATING; }
-  }
-  if (c.signal == REX_SIGNAL_IK) {                                               // gallop_env.py:257-285
-    const float pg = 1.0f + action[1];
-    const float gait_coeff = (0.0f <= t && t <= pg) ? t : 1.0f;
-    const float pos[3] = {0.01f, 0.0f, -0.007f}, orn[3] = {0.0f, 0.0f, 0.0f};
-    float step_length = 1.3f * gait_coeff;
-    if (e.flags & REX_F_GOAL_REACHED) {
-      const float pb = 1.0f + action[0];
-      step_length *= (e.end_time <= t && t <= pb + e.end_time) ? 1.0f - (t - e.end_time) : 0.0f;
-    }
-    float frames[12], ang[12];
-    gait_loop(e.gait, 1, step_length, 0.0f, 0.0f, 0.3f, 1.0f, t * c.gait_clock, frames);
-    ik_solve(orn, pos, frames, ang);
-    order_signal(ang, cmd);
-  } else {                                                                       // gallop_env.py:287-304
-    float lp[4] = {action[0], action[1], action[2], action[3]};
-    if (e.flags & REX_F_GOAL_REACHED) {
-      const bool inside = e.end_time <= t && t <= 1.0f + e.end_time;
-      const float b = inside ? 1.0f - (t - e.end_time) : 0.0f;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) lp[k] *= b;
-      if (!inside) e.flags |= REX_F_STAY_STILL;   // gallop_env.py:291: `coeff is 0.0`, an identity test (see walk_command)
-    }
-#pragma unroll
-    for (int l = 0; l < 4; ++l) {
-      cmd[3 * l] = init_pose(c, 3 * l);
-      cmd[3 * l + 1] = init_pose(c, 3 * l + 1) + (l < 2 ? lp[0] : lp[2]);
-      cmd[3 * l + 2] = init_pose(c, 3 * l + 2) + (l < 2 ? lp[1] : lp[3]);
-    }
-  }
-}
-
-// RexPosesEnv._signal (poses_env.py:186-225)
-__device__ __forceinline__ void poses_command(const DevCfg& c, EnvState& e, const float* action, float* cmd) {
-  const float t = (float)(e.steps * c.action_repeat) * c.dt;
-  const float p = 0.8f + action[0];
-  const float coeff = (0.0f <= t && t <= p) ? t : 1.0f;
-  const float staged = e.target * coeff;
-  const int k = (int)e.aux;
-  const float pos[3] = {0.01f, k == 0 ? staged : 0.0f, k == 1 ? staged : 0.0f};
-  const float orn[3] = {k == 2 ? staged : 0.0f, k == 3 ? staged : 0.0f, k == 4 ? staged : 0.0f};
-  const float frames[12] = {kIkL / 2, -kIkYDist / 2, -kIkHeight, kIkL / 2, kIkYDist / 2, -kIkHeight,
-                            -kIkL / 2, -kIkYDist / 2, -kIkHeight, -kIkL / 2, kIkYDist / 2, -kIkHeight};
-  float ang[12];
-  ik_solve(orn, pos, frames, ang);
-  order_signal(ang, cmd);
-}
-
-// RexTurnEnv._transform_action_to_motor_command (turn_env.py:239-347)
-__device__ __forceinline__ void turn_command(const DevCfg& c, EnvState& e, const float* ctrl_quat, const float* action, float* cmd, int gidx) {
-  const float t = (float)(e.steps * c.action_repeat) * c.dt;
-  if (e.flags & REX_F_STAY_STILL) {
-    if (t - e.end_time >= 1.0f) e.flags |= REX_F_ENV_GOAL;                       // _terminate_with_delay
-#pragma unroll
-    for (int j = 0; j < 12; ++j) cmd[j] = init_pose(c, j);
-    return;
-  }
-  {                                                                              // _check_target_position
-    float rpy[3];
-    quat_to_euler(ctrl_quat, rpy);                                               // GetBaseOrientation (delayed when latency is on)
-    if (c.noise_on && c.noise[3] > 0.0f) {                                       // ... through GetBaseRollPitchYaw's sensor noise (rex.py:430-442)
-      float z[4];
-      gauss4(c.seed_lo, c.seed_hi, gidx, e.episode, e.steps, kNzGoal, z);
-      rpy[0] += c.noise[3] * z[0]; rpy[1] += c.noise[3] * z[1]; rpy[2] += c.noise[3] * z[2];
-      float q[4], r2[3];                                                         // rpy -> quaternion -> rpy, as the reference does
-      {
-        float sr, cr, sp, cp, sy, cy;
-        sincos_fast(rpy[0] * 0.5f, sr, cr); sincos_fast(rpy[1] * 0.5f, sp, cp); sincos_fast(rpy[2] * 0.5f, sy, cy);
-        q[0] = sr * cp * cy - cr * sp * sy; q[1] = cr * sp * cy + sr * cp * sy; q[2] = cr * cp * sy - sr * sp * cy; q[3] = cr * cp * cy + sr * sp * sy;
-      }
-      quat_to_euler(q, r2);
-      rpy[2] = r2[2];
-    }
-    float cz = rpy[2];
-    if (cz < 0.0f) cz += 6.28f;
-    if (fabsf(e.target - cz) <= 0.01f) {
-      e.flags |= REX_F_GOAL_REACHED;
-      if (!(e.flags & REX_F_TERMINATING)) { e.end_time = t; e.flags |= REX_F_TERMINATING; }
-    }
-  }
-  const float diff = fabsf(e.aux - e.target);                                    // _solve_direction
-  const bool clockwise = e.aux < e.target ? diff > 3.14f : diff < 3.14f;
-  if (e.flags & REX_F_GOAL_REACHED) e.flags |= REX_F_STAY_STILL;
-  if (c.signal == REX_SIGNAL_IK) {
-    const float coeff = (0.0f <= t && t <= 0.8f) ? t : 1.0f;
-    float dirv = -0.5f * coeff;
-    if (clockwise) dirv = -dirv;
-    const float pos[3] = {0.009f, 0.0f, 0.0f}, orn[3] = {0.0f, 0.0f, 0.0f};
-    float frames[12], ang[12];
-    gait_loop(e.gait, 0, 0.02f, 0.0f, dirv + action[0], 0.75f + action[1], 1.0f, t * c.gait_clock, frames);
-    ik_solve(orn, pos, frames, ang);
-    order_signal(ang, cmd);
-  } else {
-    const float ext = 0.1f, swing = 0.03f + action[0], swipe = 0.05f + action[1];
-    const int ith = ((int)(t / 0.1f)) % 2;
-    const float ms = clockwise ? swing : -swing;     // right_* = left_* with the swing sign flipped
-    const float first[12] = {swipe, ext, ms, -swipe, ext, -ms, swipe, -ext, -ms, -swipe, -ext, ms};
-    const float second[12] = {-swipe, 0.f, -ms, swipe, 0.f, ms, -swipe, 0.f, ms, swipe, 0.f, -ms};
-#pragma unroll
-    for (int j = 0; j < 12; ++j) cmd[j] = pose_stand_ol(j) + (ith ? second[j] : first[j]);
-  }
-}
-
-// RexStandupEnv._signal (standup_env.py:113-120): the 'stand' pose, scaled by a 'brake' overshoot for the first 0.1 s
-__device__ __forceinline__ void standup_command(const DevCfg& c, const EnvState& e, const float* action, float* cmd) {
-  const float t = (float)(e.steps * c.action_repeat) * c.dt;               // GetTimeSinceReset, rex.py:155-156
-  const float f = t > 0.1f ? 1.0f : (0.1f + action[0]) / (t + 1.0f) + 1.5f;
-  const float leg = -0.88643435f * f, foot = 1.30197369f * f;
-#pragma unroll
-  for (int l = 0; l < 4; ++l) { cmd[3 * l] = 0.0f; cmd[3 * l + 1] = leg; cmd[3 * l + 2] = foot; }
-}
-
-// ------------------------------------------------------------------------------------------
-#ifndef REX_STEP_KERNEL_ATTR
-#define REX_STEP_KERNEL_ATTR          /* developer experiments: e.g. -DREX_STEP_KERNEL_ATTR='__attribute__((amdgpu_waves_per_eu(2,2)))' */
-#endif
-#ifndef REX_FAST_EPW
-#define REX_FAST_EPW 4
-#endif
-template <int EPW, bool ARM, bool MIXED, bool BODY>
-__global__ __launch_bounds__(REX_WAVE) REX_STEP_KERNEL_ATTR void rex_step_kernel(DevCfg c, float* __restrict__ state, const float* __restrict__ snap,
-                                                            const float* __restrict__ action, float* __restrict__ obs_out,
-                                                            float* __restrict__ reward_out, uint8_t* __restrict__ done_out,
-                                                            float* __restrict__ cmd_out) {
-  // EPW envs share this wave (host picks it, rex_step): a small batch is spread over MORE, emptier waves because
-  // idle SIMDs are free and a wave leaves the PGS sweep loop only when its slowest env has converged (and skips
-  // only the legs no env of the wave has in contact), so fewer envs per wave means fewer sweeps and rows per
-  // wave.  With EPW <= 16 every env owns a group of LPE = 8 (EPW <= 8) or 4 (EPW = 16) adjacent lanes (for EPW = 4 the
-  // upper 32 lanes repeat the lower 32): the lanes of a group run the same arithmetic on the same state, split the
-  // per-leg and per-row work of a substep between them (rex_device.h) and only lane 0 of the group stores.
-  // MIXED (REX_TASK_MIXED): the envs of a wave may run different tasks -- c_ below is the lane's own view of the config.
-  constexpr int NM = ARM ? 18 : 12;   // mark='arm': 6 more motors held at ARM_POSES['rest'] (rex_gym_env.py:347-353)
-  constexpr int kLegF4 = REX_LEG_F4_OF(EPW, ARM);
-  constexpr int kRowsF4 = ARM ? REX_LDS_F4_PER_ENV_ARM_OF(EPW) : REX_ROWS_F4_OF(kLegF4);
-  static_assert(!BODY || EPW <= 16, "link-box contact rows: lane-group kernels only");
-  constexpr int kMotorF4 = (ARM && EPW <= 8) ? REX_MOTOR_PARK_F4 : 0;
-  __shared__ float4 lds[(kRowsF4 + (EPW <= 16 ? REX_PARK_F4 : 0) + (BODY ? REX_BODY_F4 : 0) + kMotorF4) * EPW];
-  REX_STAMP(t_kernel);
-  if (c.clock && threadIdx.x == 0) atomicMin(&c.clock[0], (unsigned long long)wall_clock64());
-  const int lane = threadIdx.x;
-  constexpr int LPE = EPW < 64 ? lanes_per_env(EPW) : 1;     // EPW <= 16: lane = LPE * slot + p (rex_device.h, group layout)
-  const int slot = (lane / LPE) & (EPW - 1);
-  // Block b runs on XCD b % 8 (observed placement; speed only).  A 64-byte sector of a state word holds 16 envs = 16 / EPW
-  // blocks' worth: hand the blocks of one sector to the same XCD, so that one L2 fetches (and writes back) the sector
-  // instead of 16 / EPW of them.  A bijection on the full groups of 8 x (16 / EPW) blocks; the tail keeps its order.
-  int blk = (int)blockIdx.x;
-  if constexpr (EPW < 16) {
-    constexpr int G = 16 / EPW;
-    const int full = ((int)gridDim.x / (8 * G)) * (8 * G);
-    if (blk < full) { const int xcd = blk & 7, q = blk >> 3; blk = ((q / G) * 8 + xcd) * G + (q % G); }
-  }
-  const int gi = blk * EPW + slot;
-  const bool live = lane < LPE * EPW && (lane & (LPE - 1)) == 0 && gi < c.n;
-  const int gj = gi < c.n ? gi : c.n - 1;   // tail slots shadow the last env (keeps the wave convergent)
-  const int i = c.perm ? c.perm[gj] : gj;   // regrouped batches: the env this slot works on
-  const Lds<EPW, kLegF4, BODY> sm{lds, slot, EPW <= 16 ? lds + kRowsF4 * EPW : nullptr, BODY ? lds + (kRowsF4 + REX_PARK_F4) * EPW : nullptr,
-                                  kMotorF4 ? lds + (kRowsF4 + REX_PARK_F4 + (BODY ? REX_BODY_F4 : 0)) * EPW : nullptr};
-  typename ArmHook<EPW, ARM>::type armp = ArmHook<EPW, ARM>::make(lds, slot);
-
-  DevCfg cmix;                          // MIXED only
-  if constexpr (MIXED) mixed_config(c, c.env_index_base + i, cmix);
-  const DevCfg& c_ = MIXED ? cmix : c;
-
-  EnvState e;
-  load_env<NM>(state, c.n, i, e);
-  e.sweeps = 0;
-  float act[8];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    float a = k < c.action_dim ? action[(size_t)i * c.action_dim + k] : 0.0f;
-    if (c.range_normalize) {                       // ClipAction + RangeNormalize (wrappers.py:229-234,261-265)
-      a = fminf(fmaxf(a, -1.0f), 1.0f);
-      a = (a + 1.0f) / 2.0f * (c_.act_hi - c_.act_lo) + c_.act_lo;
-    }
-    act[k] = a;
-  }
-
-  float cmd[NM];
-  if (ARM) {
-#pragma unroll
-    for (int j = 12; j < NM; ++j) cmd[j] = (float)REXA_REST[j - 12];
-  }
-  if (c_.task == REX_TASK_GALLOP) gallop_command(c_, e, act, cmd);
-  else if (c_.task == REX_TASK_TURN) {
-    float cq[4] = {e.ph.quat[0], e.ph.quat[1], e.ph.quat[2], e.ph.quat[3]};
-    if (c.hist) {
-      int s0, s1; float alpha;
-      delay_slots(e.hist, c.control_latency, c.control_slots, c.control_alpha, s0, s1, alpha);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) cq[k] = delayed_word(c, i, s0, s1, alpha, 3 * NM + k);
-    }
-    turn_command(c_, e, cq, act, cmd, c.env_index_base + i);
-  }
-  else if (c_.task == REX_TASK_POSES) poses_command(c_, e, act, cmd);
-  else if (c_.task == REX_TASK_STANDUP) standup_command(c_, e, act, cmd);
-  else walk_command(c_, e, act, cmd);
-
-  float tau_obs[NM];
-  const Ground ground = env_ground(c, i, c.env_index_base + i, e.episode);
-  const int step0 = e.steps, episode0 = e.episode;   // keys of this step's sensor-noise draws
-
-  // everything of env.step() after Rex.Step: reward, termination, in-launch reset, observation, stores
-  auto epilogue = [&](bool commit) {
-  // ---- reward (rex_gym_env.py:501-542) ----
-  CtrlObs co;
-  control_observation<NM>(c, e, i, tau_obs, co);
-  float rpy[3], r20, r21, r22;
-  quat_to_euler(co.quat, rpy);       // GetBaseOrientation: (delayed) quat -> RPY -> quat, rex.py:530-537
-  if (c.noise_on) {                  // sensor noise: the reward's and is_fallen's orientation reads draw separately
-    const int gx = c.env_index_base + i;
-    float z[4], rp[3], d0, d1;
-    if (c.noise[3] > 0.0f) {
-      gauss4(c.seed_lo, c.seed_hi, gx, episode0, step0, kNzFallenRpy, z);
-      rp[0] = rpy[0] + c.noise[3] * z[0]; rp[1] = rpy[1] + c.noise[3] * z[1]; rp[2] = rpy[2] + c.noise[3] * z[2];
-      euler_to_row2(rp, d0, d1, r22);
-      gauss4(c.seed_lo, c.seed_hi, gx, episode0, step0, kNzRewardRpy, z);
-      rp[0] = rpy[0] + c.noise[3] * z[0]; rp[1] = rpy[1] + c.noise[3] * z[1]; rp[2] = rpy[2] + c.noise[3] * z[2];
-      euler_to_row2(rp, r20, r21, d0);
-    } else euler_to_row2(rpy, r20, r21, r22);
-    float nt[20], nv[20];
-#pragma unroll
-    for (int b = 0; b < (NM + 3) / 4; ++b) {
-      gauss4(c.seed_lo, c.seed_hi, gx, episode0, step0, kNzTorque + b, nt + 4 * b);
-      gauss4(c.seed_lo, c.seed_hi, gx, episode0, step0, kNzVelocity + b, nv + 4 * b);
-    }
-#pragma unroll
-    for (int j = 0; j < NM; ++j) { co.tau[j] += c.noise[2] * nt[j]; co.qd[j] += c.noise[1] * nv[j]; }   // GetMotorTorques / Velocities
-  } else
-  euler_to_row2(rpy, r20, r21, r22);
-  float x = -e.ph.pos[0];
-  if (c.backwards > 0) x = -x;      // `if self._backwards:` is the constructor argument, not the draw
-  e.target = fabsf(e.target);       // rex_gym_env.py:510
-  const float T = e.target;
-  float fwd;
-  if (x > T + 0.15f) fwd = T - x;
-  else if (T <= x && x <= T + 0.15f) fwd = 1.0f;
-  else if (x <= 0.05f) fwd = 0.0f;
-  else fwd = x / T;
-  const float drift = -fabsf(e.ph.pos[1]);
-  const float shake = -fabsf(r20 + r21);
-  float dp = 0.0f;
-#pragma unroll
-  for (int j = 0; j < NM; ++j) dp += co.tau[j] * co.qd[j];   // GetMotorTorques . GetMotorVelocities
-  const float energy = -fabsf(dp) * c.dt;
-  float reward = c.w_dist * fwd + c_.w_energy * energy + c.w_drift * drift + c.w_shake * shake;
-  if (c_.task == REX_TASK_TURN) reward = 0.035f - fabsf(e.ph.pos[0]) - fabsf(e.ph.pos[1]);   // turn_env.py:362-367
-  if (c_.task == REX_TASK_POSES) reward = 1.0f;                                                // poses_env.py:267-269
-  if (c_.task == REX_TASK_STANDUP) {                                                           // standup_env.py:150-166
-    float pr = fabsf(e.ph.pos[0]) + fabsf(e.ph.pos[1]) + fabsf(0.21f - e.ph.pos[2]);
-    pr = pr < 0.1f ? 1.0f - pr : -pr;
-    if (e.ph.pos[2] > 0.21f) pr = -1.0f - pr;
-    reward = pr;
-  }
-
-  // ---- termination (rex_gym_env.py:490-499, walk_env.py:326-338, gallop_env.py:315-329) ----
-  bool done;
-  if (c_.task == REX_TASK_GALLOP || c_.task == REX_TASK_STANDUP) {   // GetTrueBaseRollPitchYaw: never delayed (gallop_env.py:319-329)
-    float trpy[3];
-    quat_to_euler(e.ph.quat, trpy);
-    done = fabsf(trpy[0]) > 0.3f || fabsf(trpy[1]) > 0.5f || (c_.task == REX_TASK_GALLOP && e.ph.pos[1] > 0.3f);
-  } else done = r22 < 0.85f;
-  if ((e.flags & REX_F_ENV_GOAL) && c_.task != REX_TASK_STANDUP) done = true;     // rex_gym_env.py:495; standup overrides _termination
-  if (c_.task == REX_TASK_POSES) done = false;                                    // is_fallen() returns False, poses_env.py:265
-  e.steps += 1;
-  if (c.max_steps > 0 && e.steps >= c.max_steps) done = true;
-  if (done) e.flags |= REX_F_DONE;
-  if (done && c.auto_reset) {
-    float seen[7];
-    env_reset<NM>(c_, snap, i, commit, c.env_index_base + i, e, seen);
-#pragma unroll
-    for (int j = 0; j < NM; ++j) tau_obs[j] = 0.0f;
-    control_observation<NM>(c, e, i, tau_obs, co);
-    if (!c.hist) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) co.quat[k] = seen[k];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) co.w[k] = seen[4 + k];
-    }
-  }
-
-  float obs[22];
-  if constexpr (MIXED) {
-#pragma unroll
-    for (int k = 4; k < 22; ++k) obs[k] = 0.0f;    // a task with a narrower observation leaves the tail of its row 0
-  }
-  env_observation<NM>(c_, co, obs, c.env_index_base + i, episode0, step0);
-  if (c.range_normalize) normalize_obs(c, obs);
-  if (commit) {
-    // an opaque copy of the env index: the store addresses are rebuilt here instead of 54 address pairs being carried
-    // (in AGPRs and scratch) from load_env across the whole kernel
-    int is = i;
-    asm volatile("" : "+v"(is));
-    store_env<NM>(state, c.n, is, e);
-    for (int k = 0; k < c.obs_dim; ++k) obs_out[(size_t)is * c.obs_dim + k] = obs[k];
-    reward_out[is] = reward;
-    done_out[is] = done ? 1 : 0;
-    if (c.sweeps) c.sweeps[is] = e.sweeps;
-    if (cmd_out) {
-#pragma unroll
-      for (int j = 0; j < NM; ++j) cmd_out[(size_t)is * NM + j] = cmd[j];
-    }
-  }
-  };
-
-  if constexpr (!MIXED) {
-    for (int k = 0; k < c.action_repeat; ++k) rex_substep<false>(c, e, i, live, cmd, tau_obs, sm, ground, armp);   // Rex.Step
-    epilogue(live);
-  } else {
-    // Rex.Step of tasks with different action_repeat in one wave: every lane runs max_repeat substeps (the substep is
-    // full of wave-level operations), an env whose own count is reached finishes its env.step() -- epilogue, stores --
-    // before the extra substeps, whose results it never stores
-    for (int k = 0; k <= c.max_repeat; ++k) {
-      if (k == c_.action_repeat) epilogue(live);
-      if (k < c.max_repeat) rex_substep<true>(c_, e, i, live && k < c_.action_repeat, cmd, tau_obs, sm, ground, armp);
-    }
-  }
-  if (c.clock && threadIdx.x == 0) atomicMax(&c.clock[1], (unsigned long long)wall_clock64());
-#ifdef REX_PROF
-  if (threadIdx.x == 0 && blockIdx.x < 1024) { g_prof[10 * blockIdx.x + 8] += clock64() - t_kernel; g_prof[10 * blockIdx.x + 9] += 1; }
-#endif
-}
-
-// The reset motion of Rex.Reset (rex.py:296-324).  Plane: ONE robot, lane 0 writes the snapshot.  Terrain pool:
-// lane t settles on terrain t and writes snapshot record t (word-major [53][n_terrain]).
-template <bool ARM, bool BODY>
-__global__ __launch_bounds__(REX_WAVE) void rex_settle_kernel(DevCfg c, float* __restrict__ snap) {
-  constexpr int NM = ARM ? 18 : 12;
-  constexpr int EPW = (ARM || BODY) ? 16 : REX_WAVE;   // the arm rows / link-box rows do not fit 64 envs per workgroup in LDS
-  constexpr int kLegF4 = REX_LEG_F4_OF(EPW, ARM);
-  constexpr int kRowsF4 = ARM ? REX_LDS_F4_PER_ENV_ARM_OF(EPW) : REX_ROWS_F4_OF(kLegF4);
-  __shared__ float4 lds[(kRowsF4 + (EPW <= 16 ? REX_PARK_F4 : 0) + (BODY ? REX_BODY_F4 : 0)) * EPW];
-  constexpr int LPE = EPW < 64 ? lanes_per_env(EPW) : 1;
-  const int lane = (int)(threadIdx.x / LPE) & (EPW - 1);
-  const Lds<EPW, kLegF4, BODY> sm{lds, lane, EPW <= 16 ? lds + kRowsF4 * EPW : nullptr, BODY ? lds + (kRowsF4 + REX_PARK_F4) * EPW : nullptr, nullptr};
-  typename ArmHook<EPW, ARM>::type armp = ArmHook<EPW, ARM>::make(lds, lane);
-  const int nrec = (c.n_terrain > 0 ? c.n_terrain : 1) * c.n_mix;
-  const int first = (int)blockIdx.x * EPW + lane;                       // the (terrain, task) record this lane group settles
-  const int rec = (threadIdx.x & (LPE - 1)) == 0 ? first : nrec;        // one lane of the group stores it
-  const int t = first < nrec ? first : nrec - 1;
-  const int terr = t / c.n_mix, slot = t % c.n_mix;
-  Ground ground{nullptr, 0.0f, 1.0f, 1.0f, kMu, c.geo, c.anchor};
-  if (c.n_terrain > 0) { ground.h = c.terrain + (size_t)terr * c.hf_stride; ground.mid = c.terrain_mid[terr]; }
-  EnvState e;
-  memset(&e, 0, sizeof(e));
-  e.ph.pos[2] = c.init_z;
-  e.ph.quat[3] = 1.0f;
-#pragma unroll
-  for (int j = 0; j < 12; ++j) e.ph.q[j] = pose_stand(j);       // ResetPose: INIT_POSES[pose_id = 'stand']
-  if (ARM) {                                                     // ResetPose: arm motors at ARM_POSES['rest'] (rex.py:371-373)
-#pragma unroll
-    for (int j = 12; j < NM; ++j) e.ph.q[j] = (float)REXA_REST[j - 12];
-  }
-  e.motor_en = (1u << NM) - 1u;
-  // the latency model runs through the reset motion as well (rex.py:309-323): the snapshot's own ring sits behind its
-  // state words, [100][43][nrec]; Reset() clears the deque, observes the dropped robot once if a motion follows,
-  // and observes the final state once more after it
-  DevCfg cs = c;
-  cs.hist = (c.pd_latency > 0.0f || c.control_latency > 0.0f) ? snap + (size_t)Lay<NM>::WORDS * nrec : nullptr;
-  cs.n = nrec;
-  if (c.n_mix > 1) {   // the reset motion of this record's task: its own sweep cap (rex_gym_env.py:184)
-    const int task = slot == 0 ? c.mix_task[0] : (slot == 1 ? c.mix_task[1] : (slot == 2 ? c.mix_task[2] : (slot == 3 ? c.mix_task[3] : c.mix_task[4])));
-    cs.iterations = 300 / task_action_repeat(task);
-  }
-  const bool keeps = rec < nrec;
-  e.hist = (uint32_t)(REX_HISTORY_LEN - 1);
-  float tau_obs[NM];
-#pragma unroll
-  for (int j = 0; j < NM; ++j) tau_obs[j] = 0.0f;
-  if (c.task != REX_TASK_POSES) {   // RexPosesEnv: base reset() with initial_motor_angles=None skips the motion (rex.py:308)
-    receive_observation<NM>(cs, e, t, keeps, tau_obs);
-    float cmd[NM];
-    if (ARM) {
-#pragma unroll
-      for (int j = 12; j < NM; ++j) cmd[j] = (float)REXA_REST[j - 12];
-    }
-#pragma unroll
-    for (int j = 0; j < 12; ++j) cmd[j] = pose_stand(j);
-    for (int k = 0; k < 100; ++k) rex_substep<false>(cs, e, t, keeps, cmd, tau_obs, sm, ground, armp);   // rex.py:315-318
-#pragma unroll
-    for (int j = 0; j < 12; ++j) cmd[j] = reset_pose(c, j);
-    for (int k = 0; k < c.reset_substeps; ++k) rex_substep<false>(cs, e, t, keeps, cmd, tau_obs, sm, ground, armp);   // rex.py:319-322
-  }
-  receive_observation<NM>(cs, e, t, keeps, tau_obs);                                                           // rex.py:323
-  if (!cs.hist) e.hist = 0u;
-  if (keeps) store_env<NM>(snap, nrec, rec, e);
-}
-
-template <int NM>
-__global__ void rex_reset_kernel(DevCfg c, float* __restrict__ state, const float* __restrict__ snap,
-                                 const int32_t* __restrict__ indices, int count, float* __restrict__ obs_out) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= count) return;
-  const int i = indices ? indices[r] : r;
-  if (i < 0 || i >= c.n) return;
-  EnvState e;
-  e.episode = (int32_t)ldi(state, c.n, Lay<NM>::EPISODE, i);
-  e.gait.alpha = state[(size_t)Lay<NM>::ALPHA * c.n + i];
-  float seen[7];
-  DevCfg cmix;
-  if (c.task == REX_TASK_MIXED) mixed_config(c, c.env_index_base + i, cmix);
-  const DevCfg& c_ = c.task == REX_TASK_MIXED ? cmix : c;
-  env_reset<NM>(c_, snap, i, true, c.env_index_base + i, e, seen);
-  store_env<NM>(state, c.n, i, e);
-  float obs[22], tz[NM];
-#pragma unroll
-  for (int j = 0; j < NM; ++j) tz[j] = 0.0f;
-  CtrlObs co;
-  control_observation<NM>(c, e, i, tz, co);
-  if (!c.hist) {
-    for (int k = 0; k < 4; ++k) co.quat[k] = seen[k];
-    for (int k = 0; k < 3; ++k) co.w[k] = seen[4 + k];
-  }
-  for (int k = 4; k < 22; ++k) obs[k] = 0.0f;
-  env_observation<NM>(c_, co, obs, c.env_index_base + i, e.episode, -1);   // reset()'s own reading: its own noise draws
-  if (c.range_normalize) normalize_obs(c, obs);
-  if (obs_out) for (int k = 0; k < c.obs_dim; ++k) obs_out[(size_t)r * c.obs_dim + k] = obs[k];
-}
 
 // Regrouping of a large batch (one workgroup): counting sort of the env indices by the solver sweeps of the last step,
 // most sweeps first (the long waves start first), 64 bins.  perm[k] = env of wave slot k.  The order inside a bin does
@@ -1027,14 +48,14 @@ __global__ void rex_motor_kernel(int n, const float* __restrict__ cmd, const flo
   actual[i] = a; observed[i] = o;
 }
 
-__global__ void rex_gait_kernel(int n, int mode, float* __restrict__ planner, const float* __restrict__ params,
+__global__ void rex_gait_kernel(int n, int mode, double* __restrict__ planner, const double* __restrict__ params,
                                 float* __restrict__ frames) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  GaitState g{planner[3 * i], planner[3 * i + 1], planner[3 * i + 2]};
-  const float* p = params + 6 * i;
+  GaitState g{planner[3 * i], planner[3 * i + 1], (float)planner[3 * i + 2]};
+  const double* p = params + 6 * i;
   float f[12];
-  gait_loop(g, mode, p[0], p[1], p[2], p[3], p[4], p[5], f);
+  gait_loop(g, mode, (float)p[0], (float)p[1], (float)p[2], p[3], (float)p[4], p[5], f);
   planner[3 * i] = g.phi; planner[3 * i + 1] = g.last_time; planner[3 * i + 2] = g.alpha;
   for (int k = 0; k < 12; ++k) frames[12 * i + k] = f[k];
 }
@@ -1044,25 +65,6 @@ __global__ void rex_gait_kernel(int n, int mode, float* __restrict__ planner, co
 // =================================================================================================
 //                                          host side: C ABI
 // =================================================================================================
-#define REX_TIMING_RING 256
-struct RexSim {
-  RexConfig cfg;
-  rex::DevCfg dev;
-  int epw;          // envs per wave of rex_step_kernel
-  int device;
-  float* d_state;   // caller-owned
-  float* d_snap;    // state words x (n_terrain or 1) floats, word-major; then, with a latency, [100][43][records] rings
-  hipEvent_t ev0, ev1;
-  int timing;
-  int have_timing;
-  // ring of event pairs around the last REX_TIMING_RING launches: per-launch durations without a host sync in between
-  unsigned long long* d_clock;   // [REX_TIMING_RING][2] device-side (min start, max end) ticks, rex_set_timing(3)
-  int32_t* d_perm;   // regrouping (large batches only): wave slot -> env, and the per-env sweep counts it is sorted by
-  int32_t* d_sweeps;
-  hipEvent_t ring0[REX_TIMING_RING], ring1[REX_TIMING_RING];
-  long long timed_steps;
-  int words;   // per-env state words of the config's mark
-};
 
 static thread_local char g_err[512] = "";
 static int fail(int code, const char* fmt, const char* detail) {
@@ -1274,7 +276,8 @@ int rex_create(const RexConfig* cfg, int device, float* d_state, void* stream, R
   }
   d.target_orient = cfg->target_orient; d.init_orient = cfg->init_orient; d.orient_fixed = cfg->orient_fixed;
   if (cfg->on_rack) { d.init_orient = 2.1f; d.orient_fixed |= 2; }   /* turn_env.py:140-143 */
-  d.gait_clock = cfg->gait_clock_scale > 0.0f ? cfg->gait_clock_scale : 1.0f;
+  d.dt_d = as_written(cfg->sim_time_step);
+  d.gait_clock_d = cfg->gait_clock_scale > 0.0f ? as_written(cfg->gait_clock_scale) : 1.0;
   {
     // Regrouping (opt-in: REX_REGROUP=1) can pay once a SIMD runs several waves one after the other -- below that the launch
     // ends with its slowest wave whatever the grouping.  Measured on MI355X (profiles/r02_regroup.md): +10 % on the walking
@@ -1496,7 +499,7 @@ int rex_motor_torque(int n, const float* d_cmd, const float* d_q, const float* d
   return REX_OK;
 }
 
-int rex_gait_loop(int n, int mode, float* d_planner, const float* d_params, float* d_frames_out, void* stream) {
+int rex_gait_loop(int n, int mode, double* d_planner, const double* d_params, float* d_frames_out, void* stream) {
   if (n <= 0 || (mode != 0 && mode != 1) || !d_planner || !d_params || !d_frames_out) return fail(REX_EINVAL, "rex_gait_loop: bad arguments%s", "");
   hipLaunchKernelGGL(rex::rex_gait_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, mode, d_planner, d_params, d_frames_out);
   HIPCHK(hipGetLastError());
@@ -1512,48 +515,14 @@ REX_API int rex_debug_prof(long long* out, int reset) {
 #endif
 }  // extern "C"
 
-#define REX_LAUNCH_STEP(EPW, ARM, MIXED, BODY)                                                                                  \
-  hipLaunchKernelGGL((rex::rex_step_kernel<EPW, ARM, MIXED, BODY>), dim3(blocks), dim3(REX_WAVE), 0, st, s->dev, s->d_state, s->d_snap, \
-                     a, o, r, d, m)
-#define REX_LAUNCH_BY_EPW(ARM, MIXED, BODY)                                           \
-  do {                                                                                \
-    if (s->epw == 4) REX_LAUNCH_STEP(4, ARM, MIXED, BODY);                            \
-    else if (s->epw == 8) REX_LAUNCH_STEP(8, ARM, MIXED, BODY);                       \
-    else REX_LAUNCH_STEP(16, ARM, MIXED, BODY);                                       \
-  } while (0)
 static void launch_step(RexSim* s, int blocks, hipStream_t st, const float* a, float* o, float* r, uint8_t* d, float* m) {
-#ifdef REX_FAST_BUILD   /* developer A/B builds: the 4-envs-per-wave base kernel only (2: its link-box variant, 3: mark arm) */
-  REX_LAUNCH_STEP(REX_FAST_EPW, REX_FAST_BUILD == 3 || REX_FAST_BUILD == 4, REX_FAST_BUILD == 4, REX_FAST_BUILD == 2);   /* 4: mixed tasks, mark arm */
-  return;
-#else
   const bool arm = s->cfg.mark == REX_MARK_ARM;
   if (s->cfg.task == REX_TASK_MIXED) {   // lane groups only (rex_create caps the envs per wave at 16)
-    if (arm) REX_LAUNCH_BY_EPW(true, true, false); else REX_LAUNCH_BY_EPW(false, true, false);
-  } else if (s->cfg.body_contacts) {     // link-box contact rows: 4 or 8 envs per wave (rex_create caps it)
-    if (arm) REX_LAUNCH_STEP(4, true, false, true);
-    else { if (s->epw == 4) REX_LAUNCH_STEP(4, false, false, true); else REX_LAUNCH_STEP(8, false, false, true); }
-  } else if (arm) {
-    REX_LAUNCH_BY_EPW(true, false, false);
-  } else {
-    if (s->epw == 64) REX_LAUNCH_STEP(64, false, false, false);
-    else REX_LAUNCH_BY_EPW(false, false, false);
-  }
-#endif
+    if (arm) rex_launch_step_mixed_arm(s, blocks, st, a, o, r, d, m); else rex_launch_step_mixed_base(s, blocks, st, a, o, r, d, m);
+  } else if (s->cfg.body_contacts) rex_launch_step_body(s, blocks, st, a, o, r, d, m);   // link-box contact rows: 4 or 8 envs per wave (rex_create caps it)
+  else if (arm) rex_launch_step_arm(s, blocks, st, a, o, r, d, m);
+  else rex_launch_step_base(s, blocks, st, a, o, r, d, m);
 }
 static void launch_settle(RexSim* s, int nrec, hipStream_t st, float* snap) {
-#ifdef REX_FAST_BUILD
-#if REX_FAST_BUILD == 2
-  hipLaunchKernelGGL((rex::rex_settle_kernel<false, true>), dim3((nrec + 15) / 16), dim3(REX_WAVE), 0, st, s->dev, snap);
-#elif REX_FAST_BUILD == 3 || REX_FAST_BUILD == 4
-  hipLaunchKernelGGL((rex::rex_settle_kernel<true, false>), dim3((nrec + 15) / 16), dim3(REX_WAVE), 0, st, s->dev, snap);
-#else
-  hipLaunchKernelGGL((rex::rex_settle_kernel<false, false>), dim3((nrec + REX_WAVE - 1) / REX_WAVE), dim3(REX_WAVE), 0, st, s->dev, snap);
-#endif
-  return;
-#endif
-  const bool arm = s->cfg.mark == REX_MARK_ARM, body = s->cfg.body_contacts != 0;
-  if (arm && body) hipLaunchKernelGGL((rex::rex_settle_kernel<true, true>), dim3((nrec + 15) / 16), dim3(REX_WAVE), 0, st, s->dev, snap);
-  else if (arm) hipLaunchKernelGGL((rex::rex_settle_kernel<true, false>), dim3((nrec + 15) / 16), dim3(REX_WAVE), 0, st, s->dev, snap);
-  else if (body) hipLaunchKernelGGL((rex::rex_settle_kernel<false, true>), dim3((nrec + 15) / 16), dim3(REX_WAVE), 0, st, s->dev, snap);
-  else hipLaunchKernelGGL((rex::rex_settle_kernel<false, false>), dim3((nrec + REX_WAVE - 1) / REX_WAVE), dim3(REX_WAVE), 0, st, s->dev, snap);
+  if (s->cfg.mark == REX_MARK_ARM) rex_launch_settle_arm(s, nrec, st, snap); else rex_launch_settle_base(s, nrec, st, snap);
 }

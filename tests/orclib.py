@@ -15,14 +15,16 @@ STATE_WORDS = 54
 S_POS, S_QUAT, S_LINVEL, S_ANGVEL, S_Q, S_QD = 0, 3, 7, 10, 13, 25
 S_PHI, S_LASTT, S_ALPHA, S_TARGET, S_ENDTIME, S_AUX = 37, 38, 39, 40, 41, 42
 S_FLAGS, S_STEPS, S_EPISODE, S_MOTOR_EN, S_OVERHEAT, S_HIST = 43, 44, 45, 46, 47, 53
-INT_WORDS = list(range(S_FLAGS, STATE_WORDS))
+INT_WORDS = [S_LASTT, S_ENDTIME] + list(range(S_FLAGS, STATE_WORDS))
+F_GOAL_REACHED, F_TERMINATING, F_STAY_STILL, F_BACKWARDS, F_DONE, F_ENV_GOAL, F_PHASE_WRAP = 1, 2, 4, 8, 16, 32, 64
 
 
 def int_words(state_words):
     """Integer-valued words of a [state_words, N] state block: mark 'base' has 54 words / 12 motors, mark 'arm'
     69 words / 18 motors (the q, qd and overheat blocks grow; FLAGS sits at 13 + 2 nm + 6)."""
     nm = {54: 12, 69: 18}[state_words]
-    return list(range(13 + 2 * nm + 6, state_words))
+    phi = 13 + 2 * nm                      # LASTT = phi + 1 and ENDTIME = phi + 4 hold env step counts (rexsim.h, "Clocks")
+    return [phi + 1, phi + 4] + list(range(phi + 6, state_words))
 
 
 class RexConfig(ctypes.Structure):
@@ -52,7 +54,7 @@ SIGNALS = {"ik": 0, "ol": 1}
 def default_config(task="walk", signal="ik", num_envs=1, **kw):
     """Reference defaults."""
     repeat = 6 if task in ("gallop", "poses") else 5
-    c = RexConfig(abi_version=4, num_envs=num_envs, env_index_base=0, task=TASKS[task], signal=SIGNALS[signal],
+    c = RexConfig(abi_version=5, num_envs=num_envs, env_index_base=0, task=TASKS[task], signal=SIGNALS[signal],
                   action_repeat=repeat, solver_iterations=300 // repeat, sim_time_step=0.001,
                   motor_kp=1.0, motor_kd=0.02, backwards=-1, target_position=0.0, seed=0, auto_reset=0,
                   max_episode_steps=0, distance_weight=1.0, energy_weight=0.005 if task == "gallop" else 0.0005, drift_weight=2.0,
@@ -110,7 +112,9 @@ class Oracle:
         return act, obs
 
     def gait_loop(self, mode, planner, params):
-        planner, params = self._arr(planner).reshape(-1, 3).copy(), self._arr(params).reshape(-1, 6)
+        # planner state and clock parameters are float64 in both builds (the phase decisions are taken in double)
+        planner = np.ascontiguousarray(np.asarray(planner, np.float64)).reshape(-1, 3).copy()
+        params = np.ascontiguousarray(np.asarray(params, np.float64)).reshape(-1, 6)
         n = planner.shape[0]
         frames = np.zeros((n, 12), self.dtype)
         self.lib.orc_gait_loop(n, int(mode), self._p(planner), self._p(params), self._p(frames))

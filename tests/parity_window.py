@@ -1,0 +1,102 @@
+"""The joint-angle half of BASELINE.json's metric ("joint RMSE vs PyBullet", bar 1e-3 rad), measured the only way it can be
+here: the HIP path against the fp64 oracle (oracle/rex_oracle.c -- a restatement; PyBullet is not installable).
+
+One *window* = `steps` control steps from reset of the same envs under the same random actions, on the GPU and in the
+oracle; per env the RMSE over time and joints of (q_hip - q_oracle) while both episodes run, reported as median / p99 /
+max over the envs.  The workloads are BASELINE.json's configs[1..4] at their per-GPU shard sizes plus the walking-gait
+workload (gait clock 1.5: the robot does not fall, so the whole window counts).
+
+TEST INFRASTRUCTURE: imported by tests/test_gpu_parity.py, by bench.py's reported `joint_rmse_vs_oracle` and by
+tools/parity_report.py (profiles/r03_parity.json); never by the product.
+"""
+import numpy as np
+
+import orclib
+
+WORKLOADS = {
+    # name: (envs, RexBatchEnv keywords)
+    "walk_ik_4096": (4096, dict(task="walk", signal_type="ik")),                                   # configs[1]
+    "gallop_ol_8192": (8192, dict(task="gallop", signal_type="ol")),                               # configs[2] shard
+    "turn_ik_heightfield_4096": (4096, dict(task="turn", signal_type="ik", terrain_type="random")),  # configs[3] shard
+    "mixed_arm_2048": (2048, dict(task="mixed", signal_type="ik", mark="arm", mass_scale_range=(0.8, 1.2),
+                                  friction_range=(0.25, 0.625))),                                  # configs[4] shard
+    "walk_ik_gait_clock_1.5_4096": (4096, dict(task="walk", signal_type="ik", gait_clock_scale=1.5)),
+}
+
+
+def make_env(name, n=None, seed=23, **extra):
+    from rex_gym_amd import RexBatchEnv
+    n0, kw = WORKLOADS[name]
+    return RexBatchEnv(n or n0, seed=seed, **kw, **extra)
+
+
+def oracle_for(env, dtype=np.float64):
+    """An oracle batch with the env's own RexConfig (byte copy of the struct the product was created with)."""
+    cfg = orclib.RexConfig.from_buffer_copy(bytes(env.config))
+    orc = orclib.OracleEnv(cfg, dtype, env.mark)
+    if env.terrain_type == "random":
+        orc.set_terrain(env.terrain_heights.cpu().numpy(), env.terrain_mids.cpu().numpy())
+    return orc
+
+
+def action_box(env):
+    return np.minimum(env.action_space.low, env.action_space.high), np.maximum(env.action_space.low, env.action_space.high)
+
+
+_TRAJ = {}
+
+
+def oracle_trajectory(name, env, steps, seed, threads=None, keep_states=(40, 120)):
+    """fp64 oracle rollout of the workload from reset (cached: the kernel variants of a workload share it):
+    actions [steps, n, A] float32, q [steps, nm, n] float64, done [steps, n], full states at `keep_states`."""
+    key = (name, env.num_envs, steps, seed)
+    if key not in _TRAJ:
+        orc = oracle_for(env)
+        if threads:
+            orc.o.lib.orc_set_threads(int(threads))
+        orc.reset()
+        lo, hi = action_box(env)
+        rng = np.random.RandomState(seed)
+        acts = rng.uniform(lo, hi, (steps, env.num_envs, env.action_dim)).astype(np.float32)
+        nm = env.num_motors
+        q = np.zeros((steps, nm, env.num_envs))
+        pos = np.zeros((steps, 3, env.num_envs))
+        done = np.zeros((steps, env.num_envs), bool)
+        states = {}
+        for k in range(steps):
+            if k in keep_states:
+                states[k] = orc.get_state()
+            _, _, d, _ = orc.step(acts[k])
+            st = orc.get_state()
+            q[k], pos[k], done[k] = st[orclib.S_Q:orclib.S_Q + nm], st[0:3], d
+        orc.close()
+        _TRAJ[key] = (acts, q, pos, done, states)
+    return _TRAJ[key]
+
+
+def window(name, env, steps=200, seed=23, threads=None):
+    """Run the window on `env` (freshly created with `seed`; its episode counters must be 0) -> record dict."""
+    import torch
+    from helpers import product_state_to_numeric
+    acts, oq, opos, odone, _ = oracle_trajectory(name, env, steps, seed, threads)
+    n, nm = env.num_envs, env.num_motors
+    env.reset()
+    sq = np.zeros(n); cnt = np.zeros(n); alive = np.ones(n, bool)
+    pos_err = np.zeros(n)
+    curve = {}
+    for k in range(steps):
+        _, _, d, _ = env.step(torch.as_tensor(acts[k], device=env.device))
+        ps = product_state_to_numeric(env.state)
+        e = ps[orclib.S_Q:orclib.S_Q + nm] - oq[k]
+        sq += np.where(alive, (e * e).mean(0), 0.0); cnt += alive
+        pos_err = np.where(alive, np.abs(ps[0:3] - opos[k]).max(0), pos_err)
+        if k + 1 in (1, 5, 10, 25, 50, 100, 200) and alive.any():
+            a = np.abs(e).max(0)[alive]
+            curve[k + 1] = dict(median=float(np.median(a)), p99=float(np.percentile(a, 99)), max=float(a.max()), envs=int(alive.sum()))
+        alive &= ~(d.cpu().numpy().astype(bool) | odone[k])      # an episode that ended (fall, goal) leaves the comparison
+    rmse = np.sqrt(sq / np.maximum(cnt, 1))
+    return dict(workload=name, envs=n, window_steps=steps, seed=seed, median_rad=float(np.median(rmse)),
+                p99_rad=float(np.percentile(rmse, 99)), max_rad=float(rmse.max()),
+                base_pos_err_p99_m=float(np.percentile(pos_err, 99)), base_pos_err_max_m=float(pos_err.max()),
+                envs_compared_to_the_end=int(alive.sum()), mean_steps_compared=float(cnt.mean()),
+                abs_error_by_step=curve, against="oracle/rex_oracle.c fp64 (restatement; PyBullet is not installable)")

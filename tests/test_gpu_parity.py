@@ -60,21 +60,25 @@ def test_motor_kernel_vs_reference_golden(torch, L, golden):
 
 
 def test_gait_kernel_vs_reference_golden(torch, L, golden):
+    """Planner state and clock parameters go in as float64 (rexsim.h, "Clocks"): the 0.99 latch, the wrap at 1 and the
+    stance / swing split are then the reference's own decisions on EVERY call -- including the sequence whose period
+    clamps to 0.01 s, where every 5 ms call lands exactly on a threshold -- and only float32 trajectory arithmetic is
+    left between the kernel and the reference."""
+    worst = 0.0
     for seq in golden["gait"]:
         mode = 0 if seq["mode"] == "walk" else 1
-        planner = torch.zeros((1, 3), device="cuda")
+        planner = torch.zeros((1, 3), device="cuda", dtype=torch.float64)
         frames = torch.zeros((1, 12), device="cuda")
-        errs = []
-        for c in seq["calls"]:
-            params = _dev(torch, [[c["v"], c["angle"], c["w_rot"], c["T"], c["direction"], c["now"]]])
+        for k, c in enumerate(seq["calls"]):
+            params = torch.tensor([[c["v"], c["angle"], c["w_rot"], c["T"], c["direction"], c["now"]]], device="cuda", dtype=torch.float64)
             L.check(L.lib().rex_gait_loop(1, mode, planner.data_ptr(), params.data_ptr(), frames.data_ptr(), None), "rex_gait_loop")
-            errs.append(np.abs(frames.cpu().numpy()[0] - np.array(c["frames"])).max())
-        errs = np.array(errs)
-        # fp32 vs fp64: the handful of calls that land exactly on a phase threshold may take the other branch
-        assert np.median(errs) < 1e-6
-        if min(c["T"] for c in seq["calls"]) < 0.01:
-            continue  # period clamps to 0.01 s: EVERY 5 ms call lands exactly on a phase threshold (0.5 / 1.0)
-        assert np.mean(errs < 2e-5) > 0.97, (seq["mode"], np.sort(errs)[-10:])
+            err = np.abs(frames.cpu().numpy()[0] - np.array(c["frames"])).max()
+            assert err < 2e-6, (seq["mode"], k, err)
+            st = planner.cpu().numpy()[0]
+            assert abs(st[0] - c["phi"]) < 1e-12 and abs(st[1] - c["last_time"]) < 1e-12, (seq["mode"], k)   # the double state, exactly
+            assert abs(st[2] - c["alpha"]) < 2e-6
+            worst = max(worst, err)
+    print("largest |frame - reference| over all planner calls: %.2e m" % worst)
 
 
 # ------------------------------------------------------------------ full step vs oracle
@@ -100,26 +104,26 @@ def test_settled_snapshot_matches_oracle(torch):
 @pytest.mark.parametrize("task,signal", [("walk", "ik"), ("walk", "ol"), ("gallop", "ol"), ("gallop", "ik"),
                                          ("turn", "ik"), ("turn", "ol"), ("poses", "ik"), ("standup", "ol")])
 def test_single_step_parity_from_common_states(torch, task, signal):
-    """One env.step() from identical states: isolates per-step error from chaotic divergence.
-    Tolerance: 1e-4 rad / 1e-4 m / 2e-2 rad/s over 5-6 substeps x 50-60 PGS iterations.
-    The oracle runs in fp32 here so that the controller's discrete phase decisions (phi <= 0.5,
-    phi >= 0.99, ramp ends), which sit exactly on control-step multiples, round the same way; the
-    fp64 oracle is compared in test_single_step_parity_fp64_walk_ik."""
+    """One env.step() from identical states against the fp64 oracle: isolates per-step error from chaotic divergence.
+    Tolerance: 1e-4 rad / 1e-4 m / 2e-2 rad/s over 5-6 substeps x 50-60 PGS iterations.  The controller's discrete
+    decisions (phi <= 0.5, phi >= 0.99, ramp and brake windows -- exact ties on a 5 ms control step) are taken in double
+    by the kernels as by the reference (rexsim.h, "Clocks"), so the flags words must agree exactly and no env may sit
+    on the other side of a threshold."""
     n = 64
-    env, orc = make_pair(task, signal, n, np.float32, seed=11)
+    env, orc = make_pair(task, signal, n, np.float64, seed=11)
     env.reset(); orc.reset()
     rng = np.random.RandomState(5)
     lo, hi = np.minimum(env.action_space.low, env.action_space.high), np.maximum(env.action_space.low, env.action_space.high)
     # walk a few steps on the oracle to get diverse, physically consistent states
     for k in range(30):
-        a = rng.uniform(lo, hi, (n, env.action_dim))
+        a = rng.uniform(lo, hi, (n, env.action_dim)).astype(np.float32)
         orc.step(a)
     for k in range(10):
         st = orc.get_state()
         env.state.copy_(numeric_to_product_state(st, torch, env.state.device))
         a = rng.uniform(lo, hi, (n, env.action_dim)).astype(np.float32)
         obs, rew, done, info = env.step(torch.as_tensor(a, device="cuda"))
-        oobs, orew, odone, ocmd = orc.step(a.astype(np.float64))
+        oobs, orew, odone, ocmd = orc.step(a)
         ps, os_ = product_state_to_numeric(env.state), orc.get_state()
         np.testing.assert_allclose(info["action"].cpu().numpy(), ocmd, atol=3e-5)
         np.testing.assert_allclose(ps[orclib.S_Q:orclib.S_Q + 12], os_[orclib.S_Q:orclib.S_Q + 12], atol=1e-4)
@@ -129,45 +133,20 @@ def test_single_step_parity_from_common_states(torch, task, signal):
         np.testing.assert_allclose(rew.cpu().numpy(), orew, atol=1e-4)
         np.testing.assert_array_equal(done.cpu().numpy(), odone)
         np.testing.assert_allclose(obs.cpu().numpy(), oobs, atol=5e-3)
-    env.close()
-
-
-def test_single_step_parity_fp64_walk_ik(torch):
-    """Same as above against the fp64 oracle (what fp32 costs): walk-IK, 1e-4 rad / 1e-4 m."""
-    n = 64
-    env, orc = make_pair("walk", "ik", n, np.float64, seed=12)
-    env.reset(); orc.reset()
-    rng = np.random.RandomState(6)
-    for k in range(37):
-        orc.step(rng.uniform(-0.4, 0.4, (n, 2)))
-    for k in range(5):
-        st = orc.get_state()
-        env.state.copy_(numeric_to_product_state(st, torch, env.state.device))
-        a = rng.uniform(-0.4, 0.4, (n, 2)).astype(np.float32)
-        env.step(torch.as_tensor(a, device="cuda"))
-        orc.step(a.astype(np.float64))
-        ps, os_ = product_state_to_numeric(env.state), orc.get_state()
-        np.testing.assert_allclose(ps[orclib.S_Q:orclib.S_Q + 12], os_[orclib.S_Q:orclib.S_Q + 12], atol=1e-4)
-        np.testing.assert_allclose(ps[:7], os_[:7], atol=1e-4)
+        for w in (orclib.S_FLAGS, orclib.S_LASTT, orclib.S_ENDTIME, orclib.S_STEPS):    # every discrete decision of the step
+            np.testing.assert_array_equal(ps[w], os_[w])
     env.close()
 
 
 def test_walk_ik_trajectory_rmse(torch):
-    """first 200 control steps (1 s) from the settled reset state, same actions:
-    joint-angle RMSE vs the oracle <= 1e-3 rad (target of BASELINE.json) on the median env."""
-    n = 256
-    env, orc = make_pair("walk", "ik", n, np.float32, seed=1)
-    env.reset(); orc.reset()
-    rng = np.random.RandomState(0)
-    worst = np.zeros(n)
-    for k in range(200):
-        a = rng.uniform(-0.4, 0.4, (n, 2)).astype(np.float32)
-        env.step(torch.as_tensor(a, device="cuda"))
-        orc.step(a)
-        r = joint_rmse(product_state_to_numeric(env.state), orc.get_state())
-        worst = np.maximum(worst, r)
-    print("walk-ik 200-step joint RMSE vs f32 oracle: median %.3e max %.3e" % (np.median(worst), worst.max()))
-    assert np.median(worst) < 1e-4 and worst.max() < 5e-2      # measured 2e-6 / 1e-2 (profiles/r02_parity.json); BASELINE's bar: 1e-3
+    """BASELINE.json: "joint trajectories within 1e-3 rad RMSE" -- first 200 control steps (1 s) from the settled reset
+    state, same actions, HIP path against the fp64 oracle; per env the RMSE over the window and the joints."""
+    import parity_window as pw
+    env = pw.make_env("walk_ik_4096", n=256, seed=1)
+    rec = pw.window("walk_ik_4096", env, steps=200, seed=1)
+    print("walk-ik 200-step joint RMSE vs the fp64 oracle: median %.2e p99 %.2e max %.2e rad" % (rec["median_rad"], rec["p99_rad"], rec["max_rad"]))
+    assert rec["p99_rad"] <= 1e-3                                        # BASELINE.json's bar, on the 99th percentile env
+    assert rec["median_rad"] <= 1e-5 and rec["max_rad"] <= 1e-3, rec     # measured 3.4e-6 / 4e-4 (profiles/r03_parity.json)
     env.close()
 
 
@@ -993,52 +972,42 @@ def test_rollout_gather_runs_on_rccl(torch):
 
 
 # ------------------------------------------------------------------ every kernel variant against the oracle, at BASELINE sizes
-_ORACLE_TRAJ = {}
-
-
-def _oracle_trajectory(task, signal, n, steps, seed):
-    """fp32 oracle rollout of `n` envs from reset (cached per workload: the four kernel variants share it)."""
-    key = (task, signal, n, steps, seed)
-    if key not in _ORACLE_TRAJ:
-        orc = orclib.OracleEnv(orclib.default_config(task, signal, n, seed=seed), np.float32)
-        orc.reset()
-        lo, hi = {"walk": (-0.4, 0.4), "gallop": (-0.3, 0.3)}[task]
-        rng = np.random.RandomState(seed)
-        acts = rng.uniform(lo, hi, (steps, n, orc.action_dim)).astype(np.float32)
-        q = np.zeros((steps, 12, n), np.float32)
-        pos = np.zeros((steps, 3, n), np.float32)
-        done = np.zeros((steps, n), bool)
-        states = {}
-        for k in range(steps):
-            if k in (40, 120):
-                states[k] = orc.get_state()
-            _, _, d, _ = orc.step(acts[k])
-            st = orc.get_state()
-            q[k], pos[k], done[k] = st[orclib.S_Q:orclib.S_Q + 12], st[0:3], d
-        _ORACLE_TRAJ[key] = (acts, q, pos, done, states)
-        orc.close()
-    return _ORACLE_TRAJ[key]
+# per-env joint RMSE over the 200-step window against the fp64 oracle: (median, p99, max) bounds = 2 x the values measured
+# on MI355X (profiles/r03_parity.json); BASELINE.json's bar is 1e-3 rad
+_PARITY_BOUNDS = {
+    "walk_ik_4096": (1e-5, 1e-3, 1e-2),
+    "gallop_ol_8192": (1e-5, 1e-3, 1e-2),
+    "turn_ik_heightfield_4096": (1e-5, 1e-3, 1e-2),
+    "mixed_arm_2048": (1e-4, 1e-3, 1e-2),
+    "walk_ik_gait_clock_1.5_4096": (1e-5, 1e-3, 1e-2),
+}
 
 
 @pytest.mark.parametrize("epw", [4, 8, 16, 64])
-@pytest.mark.parametrize("task,signal,n", [("walk", "ik", 4096), ("gallop", "ol", 8192)])
-def test_every_kernel_variant_against_the_oracle_at_baseline_sizes(torch, task, signal, n, epw, monkeypatch):
-    """BASELINE.json configs[1] (4 096 walk-IK envs) and the per-GPU shard of configs[2] (8 192 gallop-OL envs), each
-    kernel variant (4 / 8 / 16 envs per wave = lane groups, 64 = one env per lane) DIRECTLY against the fp32 oracle:
+@pytest.mark.parametrize("name", ["walk_ik_4096", "gallop_ol_8192", "turn_ik_heightfield_4096", "mixed_arm_2048", "walk_ik_gait_clock_1.5_4096"])
+def test_every_kernel_variant_against_the_oracle_at_baseline_sizes(torch, name, epw, monkeypatch):
+    """BASELINE.json configs[1..4] at their per-GPU shard sizes (4 096 walk-IK, 8 192 gallop-OL, 4 096 turn-IK on the
+    heightfield pool, 2 048 mark-arm envs with per-env mixed tasks and per-reset mass / friction draws) and the walking
+    workload (gait clock 1.5), each kernel variant (4 / 8 / 16 envs per wave = lane groups, 64 = one env per lane) DIRECTLY
+    against the FP64 oracle:
       * single env.step() from common oracle states (taken 40 and 120 steps into the rollout): max over ALL envs of the
-        joint-angle error <= 2e-4 rad, base position <= 2e-4 m;
+        joint-angle error <= 2e-4 rad, base position <= 2e-4 m, and the flags word -- every discrete decision -- equal;
       * the first 200 control steps (1 s of robot time) from reset under the same actions: per-env joint RMSE over the
-        window -- median <= 1e-3 rad (BASELINE.json's bar), 99th percentile and max bounded as stated below.  Contact
-        dynamics amplify fp32 round-off (a toe that touches down one substep apart), so the max is looser than the
-        median; it is asserted, and the divergence curve is written to gpurun_out/ for profiles/r02_parity.json."""
+        window -- 99th percentile <= 1e-3 rad (BASELINE.json's bar) and median / p99 / max within twice the measured
+        values.  Contact dynamics amplify fp32 round-off (a toe that touches down one substep apart is a transient of
+        ~1e-2 rad), so the max is looser than the median; the divergence curve goes to gpurun_out/ for
+        profiles/r03_parity.json."""
     import json
     import os
-    from rex_gym_amd import RexBatchEnv
+    import parity_window as pw
+    if epw == 64 and name == "mixed_arm_2048":
+        pytest.skip("mark arm / mixed tasks: lane-group kernels only")
     monkeypatch.setenv("REX_ENVS_PER_WAVE", str(epw))
     steps, seed = 200, 23
-    acts, oq, opos, odone, ostates = _oracle_trajectory(task, signal, n, steps, seed)
-    env = RexBatchEnv(n, task=task, signal_type=signal, seed=seed)
+    env = pw.make_env(name, seed=seed)
     assert env._L.rex_envs_per_wave(env._h) == epw
+    acts, oq, opos, odone, ostates = pw.oracle_trajectory(name, env, steps, seed)
+    nm = env.num_motors
     # --- single steps from common states
     for k0, st in ostates.items():
         env.reset()
@@ -1046,34 +1015,27 @@ def test_every_kernel_variant_against_the_oracle_at_baseline_sizes(torch, task, 
         env.step(torch.as_tensor(acts[k0], device="cuda"))
         ps = product_state_to_numeric(env.state)
         live = ~odone[k0]
-        eq = np.abs(ps[orclib.S_Q:orclib.S_Q + 12] - oq[k0])[:, live]
+        eq = np.abs(ps[orclib.S_Q:orclib.S_Q + nm] - oq[k0])[:, live]
         ep = np.abs(ps[0:3] - opos[k0])[:, live]
-        assert eq.max() <= 2e-4 and ep.max() <= 2e-4, (epw, k0, eq.max(), ep.max())
+        if "heightfield" in name:
+            # a toe point within float32 resolution of a triangle edge of the field (45-degree facets between the 2 x 2
+            # blocks) takes the neighbouring facet's normal in one of the two precisions: expected for about one env in a
+            # few thousand per step, a jump of several 1e-3 rad for that env
+            assert (eq.max(0) <= 2e-4).mean() >= 0.999 and (ep.max(0) <= 2e-4).mean() >= 0.999, (epw, k0, eq.max(), ep.max())
+        else:
+            assert eq.max() <= 2e-4 and ep.max() <= 2e-4, (epw, k0, eq.max(), ep.max())
     # --- 200-step window from reset (episode counters back to 0: the oracle's rollout is every env's FIRST episode, and the
     #     episode number keys the Philox draws of target / direction)
     env.state.zero_()
-    env.reset()
-    sq = np.zeros(n); cnt = np.zeros(n); alive = np.ones(n, bool)
-    curve = {}
-    for k in range(steps):
-        _, _, d, _ = env.step(torch.as_tensor(acts[k], device="cuda"))
-        ps = product_state_to_numeric(env.state)
-        e = ps[orclib.S_Q:orclib.S_Q + 12] - oq[k]
-        sq += np.where(alive, (e * e).mean(0), 0.0); cnt += alive
-        if k + 1 in (1, 5, 10, 25, 50, 100, 200):
-            a = np.abs(e).max(0)[alive]
-            curve[k + 1] = dict(median=float(np.median(a)), p99=float(np.percentile(a, 99)), max=float(a.max()), envs=int(alive.sum()))
-        alive &= ~(d.cpu().numpy().astype(bool) | odone[k])
-    rmse = np.sqrt(sq / np.maximum(cnt, 1))
-    rec = dict(task=task, signal=signal, envs=n, envs_per_wave=epw, window_steps=steps, median_rad=float(np.median(rmse)),
-               p99_rad=float(np.percentile(rmse, 99)), max_rad=float(rmse.max()), abs_error_by_step=curve)
+    rec = pw.window(name, env, steps=steps, seed=seed)
+    rec["envs_per_wave"] = epw
     os.makedirs(os.path.join(os.path.dirname(__file__), "..", "gpurun_out"), exist_ok=True)
-    with open(os.path.join(os.path.dirname(__file__), "..", "gpurun_out", "r02_parity.jsonl"), "a") as f:
+    with open(os.path.join(os.path.dirname(__file__), "..", "gpurun_out", "r03_parity.jsonl"), "a") as f:
         f.write(json.dumps(rec) + "\n")
     print(json.dumps(rec))
-    assert rec["median_rad"] <= 1e-4                           # measured 2e-6 (profiles/r02_parity.json); BASELINE.json's bar is 1e-3
-    assert rec["p99_rad"] <= 5e-3 and rec["max_rad"] <= 2e-2, rec   # measured 4e-4 / 1.8e-3
-    assert curve[25]["max"] <= 2e-2 and curve[100]["median"] <= 1e-4
+    med, p99, mx = _PARITY_BOUNDS[name]
+    assert rec["p99_rad"] <= 1e-3, rec                          # BASELINE.json's bar
+    assert rec["median_rad"] <= med and rec["p99_rad"] <= p99 and rec["max_rad"] <= mx, rec
     env.close()
 
 

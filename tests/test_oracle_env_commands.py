@@ -48,7 +48,9 @@ def test_env_command_logic_matches_the_reference_methods(sequences):
             got = (bool(flags & F_GOAL), bool(flags & F_TERM), bool(flags & F_STAY), bool(flags & F_ENV_GOAL))
             assert got == (row["goal"], row["terminating"], row["stay"], row["env_goal"]), (label, row["k"], got)
             if row["terminating"]:
-                assert abs(env.get_state()[orclib.S_ENDTIME, 0] - row["end_time"]) < 1e-6, (label, row["k"])   # float32 dt, as below
+                # the state keeps end_time as the env step it was taken at (rexsim.h, "Clocks"); its clock is that of the script
+                end_t = env.get_state()[orclib.S_ENDTIME, 0] * env.cfg.action_repeat * 0.001
+                assert abs(end_t - row["end_time"]) < 1e-12, (label, row["k"])
             if "cmd" in row:
                 err = float(np.abs(cmd[:12] - np.asarray(row["cmd"])).max())
                 # RexConfig.sim_time_step is a float32 (0.001f = 0.001 (1 + 4.7e-8)): the oracle's clock runs that much

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Cycle breakdown of one physics substep inside rex_step_kernel (developer tool, needs a GPU).
 
-Builds rexsim.hip with -DREX_PROF (clock64() stamps around the sections of physics_substep, accumulated per
+Builds the library with -DREX_PROF (clock64() stamps around the sections of physics_substep, accumulated per
 workgroup by lane 0) into scratch/librexsim_prof.so, runs walk-IK at N envs and prints cycles per substep for:
 leg factorisation, base Cholesky, row finishing, PGS sweeps, back-substitution + integration.
   python tools/prof_sections.py [N=4096] [--arm] [--task=standup|poses|...] [--roll=R] [--body=0|1] [--rebuild]
@@ -17,10 +17,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 so = os.path.join(ROOT, "scratch", "librexsim_prof.so")
 os.makedirs(os.path.dirname(so), exist_ok=True)
-if not os.path.exists(so) or "--rebuild" in sys.argv:
-    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-fvisibility=hidden",
-                           "-DREX_PROF", os.path.join(ROOT, "rex_gym_amd", "csrc", "rexsim.hip"), "-o", so])
 import rex_gym_amd.build as b
+if not os.path.exists(so) or "--rebuild" in sys.argv:
+    b.build(force=True, lib_path=so, defines=["-DREX_PROF"], unity=True)   # one translation unit: the counters are one device global
 b.LIB_PATH = so
 import torch
 from rex_gym_amd import RexBatchEnv, _lib

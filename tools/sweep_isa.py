@@ -7,7 +7,7 @@ import sys
 
 epw = sys.argv[1] if len(sys.argv) > 1 else "4"
 arm = sys.argv[2] if len(sys.argv) > 2 else "0"
-s = open('scratch/isa/rexsim-hip-amdgcn-amd-amdhsa-gfx950.s').read()
+s = open('scratch/isa/rex_step_%s-hip-amdgcn-amd-amdhsa-gfx950.s' % ('arm' if arm == '1' else 'base')).read()
 m = re.search(r'^(\S*rex_step_kernelILi%sELb%sE\S*):' % (epw, arm), s, re.M)
 k = s[m.start():s.index('.Lfunc_end', m.start())].split('\n')
 lab = {}
