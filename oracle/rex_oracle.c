@@ -1952,12 +1952,15 @@ ORC_API void orc_set_damping(real lin, real ang) { MB_LINEAR_DAMPING = lin; MB_A
 
 /* ---- physics-only probes used by the oracle's own unit tests (tests/test_oracle_physics.py) ---- */
 /* state: pos3 quat4 linvel3 angvel3 q12 qd12 = 37 reals, in/out; tau 12 */
+static int PROBE_FIXED_BASE = 0;   /* orc_physics_substep only: the body hangs on the rack (loadURDF(useFixedBase=True), rex.py:269-287) */
+ORC_API void orc_physics_fixed_base(int on) { PROBE_FIXED_BASE = on; }
 ORC_API void orc_physics_substep(real* st, const real* tau, real dt, int iterations, int nsteps, real residual_threshold) {
   Phys p;
+  Ground rack = {0, 0, 1, 1, FRICTION_MU, 0, 0, HF_RANDOM, 1};
   memcpy(p.pos, st, sizeof(real) * 3); memcpy(p.quat, st + 3, sizeof(real) * 4);
   memcpy(p.linvel, st + 7, sizeof(real) * 3); memcpy(p.angvel, st + 10, sizeof(real) * 3);
   memcpy(p.q, st + 13, sizeof(real) * NJ); memcpy(p.qd, st + 13 + NJ, sizeof(real) * NJ);
-  for (int k = 0; k < nsteps; ++k) physics_substep(&p, tau, dt, iterations, residual_threshold, 0);
+  for (int k = 0; k < nsteps; ++k) physics_substep(&p, tau, dt, iterations, residual_threshold, PROBE_FIXED_BASE ? &rack : 0);
   memcpy(st, p.pos, sizeof(real) * 3); memcpy(st + 3, p.quat, sizeof(real) * 4);
   memcpy(st + 7, p.linvel, sizeof(real) * 3); memcpy(st + 10, p.angvel, sizeof(real) * 3);
   memcpy(st + 13, p.q, sizeof(real) * NJ); memcpy(st + 13 + NJ, p.qd, sizeof(real) * NJ);

@@ -92,7 +92,7 @@ class OraclePhysicsClient:
     def loadURDF(self, path, position=None, orientation=None, useFixedBase=False, flags=0):
         if not path.endswith(("rex.urdf", "rex_arm.urdf")):
             return 0                                 # plane.urdf: the ground of orc_physics_substep
-        assert not useFixedBase
+        self.fixed_base = bool(useFixedBase)         # on_rack: the base hangs at INIT_RACK_POSITION (rex.py:269-287)
         mark = "arm" if path.endswith("rex_arm.urdf") else "base"
         self.orc = orclib.Oracle(np.float64, mark)
         nm = self.nm = self.orc.num_motors
@@ -138,7 +138,8 @@ class OraclePhysicsClient:
             assert controlMode == self.VELOCITY_CONTROL and force == 0   # "disable the default motor", rex.py:369-388
     def stepSimulation(self):
         self.st = self.orc.physics_substep(self.st, self.tau, dt=self.dt, iterations=self.iterations, nsteps=1,
-                                           residual_threshold=float(np.float32(1e-7)))   # pybullet's default, never changed
+                                           residual_threshold=float(np.float32(1e-7)),   # pybullet's default, never changed
+                                           fixed_base=self.fixed_base)
         self.tau[:] = 0                                                  # external torques last one step
         self.calls += 1
 
@@ -228,6 +229,14 @@ SCENARIOS = [
      dict(task="walk", signal="ik", target_position=1.0, backwards=0, range_normalize=1, max_episode_steps=25), 40, 3),
     ("gallop_ol_wrapped", gallop_env.RexReactiveEnv, dict(target_position=2.0, signal_type="ol", wrap=20),
      dict(task="gallop", signal="ol", target_position=2.0, range_normalize=1, max_episode_steps=20), 40, 2),
+    # (appended last: a scenario's seed is 100 + its index)
+    # the overheat shut-down (rex.py:601-608,617-623): on the debug rack, an open-loop command 3 rad below the front-left
+    # foot joint's lower bound keeps that motor at its torque limit (> 2.45 N m) for more than 1 000 substeps; the robot
+    # then switches it off until the next Reset, which re-enables it (rex.py:301-302).  Every event also records
+    # Rex._motor_enabled_list and Rex._overheat_counter.
+    ("walk_ol_on_rack_overheat", walk_env.RexWalkEnv, dict(target_position=1.0, backwards=False, signal_type="ol", on_rack=True,
+                                                          action_bias=[0, -3.0, 0, 0, 0, 0, 0, 0]),
+     dict(task="walk", signal="ol", target_position=1.0, backwards=0, on_rack=1), 215, 2),
 ]
 
 
@@ -270,6 +279,7 @@ def build_env(cls, kwargs):
     kwargs = dict(kwargs)
     wrap = kwargs.pop("wrap", None)
     kwargs.pop("batch", None)
+    kwargs.pop("action_bias", None)
     env = cls(render=False, terrain_id="plane", **kwargs)   # the reference's constructor (terrain_id as its CLI passes it): hard reset, drop, settle
     if getattr(env, "_gait_planner", None) is not None:
         ENV_OF_PLANNER[id(env._gait_planner)] = env
@@ -329,15 +339,21 @@ def run(name, cls, kwargs, steps, episodes, seed):
     if "wrap" in kwargs:
         lo, hi = -1.5 * np.ones_like(lo), 1.5 * np.ones_like(hi)
     events = []
+    bias = np.asarray(kwargs.get("action_bias", 0.0), float)
+
+    def motors():   # the overheat bookkeeping of Rex.ApplyAction (rex.py:601-608)
+        rex = client_env.rex
+        return dict(motor_enabled=[bool(b) for b in rex._motor_enabled_list], overheat=[int(c) for c in rex._overheat_counter])
+
     for ep in range(episodes):
         obs = env.reset()                             # soft reset (hard_reset=False after the constructor)
         restart_phase(client_env)
-        events.append(dict(kind="reset", obs=np.asarray(obs, float).tolist(), body=body(client)))
+        events.append(dict(kind="reset", obs=np.asarray(obs, float).tolist(), body=body(client), **motors()))
         for k in range(steps):
-            a = rng.uniform(lo, hi)
+            a = rng.uniform(lo, hi) + bias
             obs, reward, done, info = env.step(a)
             events.append(dict(kind="step", action=a.tolist(), obs=np.asarray(obs, float).tolist(), reward=float(reward),
-                               done=bool(done), cmd=np.asarray(info["action"], float).tolist(), body=body(client)))
+                               done=bool(done), cmd=np.asarray(info["action"], float).tolist(), body=body(client), **motors()))
             if done:
                 break
     return events

@@ -121,9 +121,10 @@ class Oracle:
         return planner, frames
 
     # ---- physics probes ----
-    def physics_substep(self, st, tau, dt=0.001, iterations=60, nsteps=1, residual_threshold=1e-7):
+    def physics_substep(self, st, tau, dt=0.001, iterations=60, nsteps=1, residual_threshold=1e-7, fixed_base=False):
         st = self._arr(st).ravel().copy()
         tau = self._arr(tau).ravel()
+        self.lib.orc_physics_fixed_base(int(bool(fixed_base)))     # loadURDF(useFixedBase=True): the on_rack debug mode
         self.lib.orc_physics_substep(self._p(st), self._p(tau), self.creal(dt), int(iterations), int(nsteps),
                                      self.creal(residual_threshold))
         return st

@@ -875,6 +875,47 @@ def test_hip_path_reproduces_reference_rollouts(torch, sc):
     env.close()
 
 
+def test_overheat_shutdown_on_the_gpu(torch):
+    """Rex.ApplyAction's overheat protection (rex.py:601-608,617-623; every task env enables it): a motor whose torque
+    stays above 2.45 N m for more than 1 000 substeps is switched off until the next Reset.  The fixture is what the
+    reference's own Rex class did on the debug rack when the front-left foot joint was commanded 3 rad below its lower
+    bound (rollout golden `walk_ol_on_rack_overheat`; the reference's _motor_enabled_list and _overheat_counter are
+    recorded with every event).  The HIP path, through the same constructor arguments and actions: the enable mask agrees
+    on EVERY event -- the shut-down lands on the same control step, the reset re-enables the motor -- the counter of the
+    saturated motor agrees exactly (the others hover around the 2.45 N m threshold in both precisions: within a few
+    counts), and after the shut-down the joint falls away from its bound under zero torque as the reference's does."""
+    from rex_gym_amd import RexBatchEnv
+    sc = next(s for s in _rollout_scenarios() if s["name"] == "walk_ol_on_rack_overheat")
+    kw = dict(sc["env_kwargs"]); kw.pop("action_bias"); signal = kw.pop("signal_type")
+    n = 8
+    env = RexBatchEnv(n, task="walk", signal_type=signal, **kw)
+    en_w, oh_w = orclib.S_MOTOR_EN, orclib.S_OVERHEAT
+    off_event, seen_off, seen_back_on = None, False, False
+    for k, ev in enumerate(sc["events"]):
+        if ev["kind"] == "reset":
+            env.reset()
+        else:
+            env.step(torch.as_tensor(np.tile(np.asarray(ev["action"], np.float32), (n, 1)), device="cuda"))
+        ps = product_state_to_numeric(env.state)
+        assert np.all(ps == ps[:, :1]), "identical envs must stay identical"
+        mask = int(ps[en_w, 0])
+        assert [bool((mask >> j) & 1) for j in range(12)] == ev["motor_enabled"], (k, bin(mask), ev["motor_enabled"])
+        packed = ps[oh_w:oh_w + 6, 0].astype(np.int64)
+        counters = np.array([int(packed[j // 2] >> (16 * (j & 1))) & 0xFFFF for j in range(12)])
+        assert counters[2] == ev["overheat"][2], (k, counters, ev["overheat"])
+        assert np.abs(counters - np.asarray(ev["overheat"])).max() <= 6, (k, counters, ev["overheat"])
+        if not ev["motor_enabled"][2]:
+            if not seen_off:
+                off_event, seen_off = k, True
+                assert ev["overheat"][2] > 1000
+            if k - off_event <= 10:     # zero torque on the joint: it leaves the bound exactly as the reference's does
+                np.testing.assert_allclose(ps[orclib.S_Q:orclib.S_Q + 12, 0], np.asarray(ev["body"])[13:25], atol=2e-3)
+        elif seen_off:
+            seen_back_on = True
+    assert seen_off and seen_back_on
+    env.close()
+
+
 def test_policy_player_runs_a_checkpoint_on_the_batch_env(torch, tmp_path):
     """SimplePPOPolicy + play() on device tensors: a bundle written here stands in for a shipped checkpoint."""
     from test_agents_policy_player import policy_tensors, write_bundle

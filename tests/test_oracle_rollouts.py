@@ -51,7 +51,15 @@ def test_oracle_reproduces_reference_rollout(sc):
             assert d.tolist() == np.atleast_1d(ev["done"]).tolist(), f"event {k}: done"
             worst["reward"] = max(worst["reward"], float(np.max(np.abs(r - np.atleast_1d(ev["reward"])))))
             worst["cmd"] = max(worst["cmd"], float(np.max(np.abs(c - shape(ev["cmd"])))))
-        body = env.get_state()[:13 + 2 * nm].T
+        state = env.get_state()
+        body = state[:13 + 2 * nm].T
+        if "motor_enabled" in ev and not batched:      # Rex._motor_enabled_list / _overheat_counter (rex.py:301-302,601-608): exact
+            w = 13 + 2 * nm + 9
+            mask = int(state[w, 0])
+            assert [bool((mask >> j) & 1) for j in range(nm)] == ev["motor_enabled"], f"event {k}: motor_enabled"
+            packed = state[w + 1:w + 1 + nm // 2, 0].astype(np.int64)
+            counters = [int(packed[j // 2] >> (16 * (j & 1))) & 0xFFFF for j in range(nm)]
+            assert counters == ev["overheat"], f"event {k}: overheat counters"
         worst["obs"] = max(worst["obs"], float(np.max(np.abs(obs - ref_obs))))
         ref = shape(ev["body"])
         scale = np.maximum(1.0, np.abs(ref))            # velocities are O(1..10): compare relative to their scale
