@@ -185,10 +185,11 @@ def main():
     n = args.envs_per_gpu
     if args.mixed:
         env = RexMixedBatchEnv(n, device=local_rank, seed=0, env_index_base=rank * n, auto_reset=True, max_episode_steps=2000,
-                               terrain_type=args.terrain, mark=args.mark, mass_scale_range=(0.8, 1.2), friction_range=(0.25, 0.625))
+                               terrain_type=args.terrain, mark=args.mark, mass_scale_range=(0.8, 1.2), friction_range=(0.25, 0.625),
+                               check_actions=False)
     else:
         env = RexBatchEnv(n, task=args.task, signal_type=args.signal, device=local_rank, seed=0, env_index_base=rank * n,
-                          auto_reset=True, max_episode_steps=2000, terrain_type=args.terrain, mark=args.mark)
+                          auto_reset=True, max_episode_steps=2000, terrain_type=args.terrain, mark=args.mark, check_actions=False)
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
     lo = torch.as_tensor(env.action_space.low, device=dev).minimum(torch.as_tensor(env.action_space.high, device=dev))
@@ -269,7 +270,8 @@ def main():
     walking = None
     if world == 1 and not args.mixed and not args.no_walking_workload and args.signal == "ik" and args.task in ("walk", "turn", "gallop"):
         env2 = RexBatchEnv(n, task=args.task, signal_type=args.signal, device=local_rank, seed=0, env_index_base=rank * n,
-                           auto_reset=True, max_episode_steps=2000, terrain_type=args.terrain, mark=args.mark, gait_clock_scale=1.5)
+                           auto_reset=True, max_episode_steps=2000, terrain_type=args.terrain, mark=args.mark, gait_clock_scale=1.5,
+                           check_actions=False)
         env2.reset()
         for k in range(PREROLL_STEPS + args.warmup):
             env2.step(pool[k % 16])

@@ -187,6 +187,10 @@ typedef struct RexConfig {
      under gravity and the motors; the reset pose is [0, 0, 1] (init_height is ignored) and RexTurnEnv starts at its
      fixed debug yaw 2.1 (turn_env.py:140-143). */
   int32_t on_rack;
+  /* ---- ABI 5 ---- */
+  /* RexGymEnv(forward_reward_cap=...) (envs/rex_gym_env.py:81,217,525): `forward_reward = min(forward_reward, cap)` in the
+     base reward.  +inf (the reference default, what rex_default_config sets): no cap.  NaN is rejected. */
+  float   forward_reward_cap;
 } RexConfig;
 
 typedef struct RexSim RexSim;

@@ -1644,6 +1644,7 @@ static real base_reward(const RexConfig* c, Env* e) {
   else if (T <= x && x <= T + (real)0.15) fwd = 1;
   else if (x <= (real)0.05) fwd = 0;
   else fwd = x / T;
+  if (fwd > (real)c->forward_reward_cap) fwd = (real)c->forward_reward_cap;   /* min(forward_reward, cap), rex_gym_env.py:525 (+inf: none) */
   real drift = -fabs(e->ph.pos[1]);
   real co[HIST_WORDS], rpy[3], qq[4], R[3][3];
   control_observation(e, co);

@@ -175,6 +175,7 @@ struct DevCfg {
   uint32_t seed_lo, seed_hi;
   int32_t auto_reset, max_steps;
   float w_dist, w_energy, w_drift, w_shake;
+  float fwd_cap;             // forward_reward_cap (rex_gym_env.py:525); +inf: none
   int32_t action_dim, obs_dim;
   float target_orient, init_orient;
   int32_t orient_fixed;
@@ -826,6 +827,7 @@ __global__ __launch_bounds__(REX_WAVE) REX_STEP_KERNEL_ATTR void rex_step_kernel
   else if (T <= x && x <= T + 0.15f) fwd = 1.0f;
   else if (x <= 0.05f) fwd = 0.0f;
   else fwd = x / T;
+  fwd = fminf(fwd, c.fwd_cap);      // rex_gym_env.py:525
   const float drift = -fabsf(e.ph.pos[1]);
   const float shake = -fabsf(r20 + r21);
   float dp = 0.0f;

@@ -111,6 +111,7 @@ int rex_default_config(int task, int signal, int num_envs, RexConfig* cfg) {
      boxes of the low side (profiles/r02_contact_census.md): the one env where the link boxes act */
   cfg->body_contacts = task == REX_TASK_POSES;
   cfg->solver_residual_threshold = 1e-7f;                        /* PyBullet default solverResidualThreshold */
+  cfg->forward_reward_cap = INFINITY;                            /* rex_gym_env.py:81 */
   if (task == REX_TASK_MIXED) {   /* BASELINE.json configs[4]: walk, gallop and turn; per-task repeat / sweeps / weights apply per env */
     cfg->task_mix = (1 << REX_TASK_WALK) | (1 << REX_TASK_GALLOP) | (1 << REX_TASK_TURN);
     cfg->action_repeat = 6; cfg->solver_iterations = 60;         /* the largest of the mix (loop bounds only) */
@@ -196,6 +197,9 @@ static int validate(const RexConfig* c) {
     const int allowed = (1 << REX_TASK_WALK) | (1 << REX_TASK_GALLOP) | (1 << REX_TASK_TURN);   // tasks that share one reset pose per signal
     if (c->task_mix == 0 || (c->task_mix & ~allowed)) return fail(REX_EINVAL, "task_mix must be a non-empty subset of {walk, gallop, turn}%s", "");
   }
+  if (c->forward_reward_cap != c->forward_reward_cap) return fail(REX_EINVAL, "forward_reward_cap is NaN (use +inf for no cap)%s", "");
+  if (c->task == REX_TASK_MIXED && c->energy_weight != rex::task_energy_weight(REX_TASK_WALK))
+    return fail(REX_EINVAL, "energy_weight is a per-task constant in a REX_TASK_MIXED batch (gallop 0.005, the others 0.0005): leave it at the default%s", "");
   if (c->mass_scale_lo < 0.0f || c->mass_scale_hi < c->mass_scale_lo || c->friction_lo < 0.0f || c->friction_hi < c->friction_lo)
     return fail(REX_EINVAL, "randomisation ranges must satisfy 0 <= lo <= hi%s", "");
   return REX_OK;
@@ -228,6 +232,7 @@ int rex_create(const RexConfig* cfg, int device, float* d_state, void* stream, R
   d.seed_lo = (uint32_t)cfg->seed; d.seed_hi = (uint32_t)(cfg->seed >> 32);
   d.auto_reset = cfg->auto_reset; d.max_steps = cfg->max_episode_steps;
   d.w_dist = cfg->distance_weight; d.w_energy = cfg->energy_weight; d.w_drift = cfg->drift_weight; d.w_shake = cfg->shake_weight;
+  d.fwd_cap = cfg->forward_reward_cap;
   d.action_dim = rex_action_dim(cfg); d.obs_dim = rex_obs_dim(cfg);
   s->epw = pick_envs_per_wave(cfg->num_envs);
   if ((cfg->mark == REX_MARK_ARM || cfg->task == REX_TASK_MIXED || cfg->body_contacts) && s->epw > 16) s->epw = 16;

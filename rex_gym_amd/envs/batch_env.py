@@ -66,17 +66,17 @@ class RexBatchEnv:
                  motor_kp=1.0, motor_kd=0.02, control_time_step=None, action_repeat=None, control_latency=0.0,
                  pd_latency=0.0,
                  solver_iterations=None, solver_residual_threshold=None,
-                 range_normalize=False, check_actions=False, terrain_type="plane", terrain_pool=64, terrain_seed=10,
+                 range_normalize=False, check_actions=True, terrain_type="plane", terrain_pool=64, terrain_seed=10,
                  mark="base", render=False, stream=None, gait_clock_scale=1.0,
                  distance_weight=None, energy_weight=None, drift_weight=None, shake_weight=None,
                  tasks=None, mass_scale_range=None, friction_range=None, observation_noise_stdev=None,
                  heightfield=None, heightfield_cell=None, heightfield_origin=(0.0, 0.0, 0.0), init_height=None,
-                 body_contacts=None, on_rack=False, env_randomizer=None, **ignored):
+                 body_contacts=None, on_rack=False, env_randomizer=None, forward_reward_cap=None, **ignored):
         import torch
         # Reference constructor keywords that only touch the GUI, logging or debugging are accepted and ignored; anything
         # else that would change what the env computes is an error here, not a silent no-op.
         harmless = {"debug", "urdf_version", "num_steps_to_log", "log_path", "terrain_id", "urdf_root", "reflection",
-                    "draw_foot_path", "hard_reset", "forward_reward_cap"}
+                    "draw_foot_path", "hard_reset"}
         unknown = sorted(set(ignored) - harmless)
         if unknown:
             raise TypeError(f"RexBatchEnv: unsupported keyword(s) {unknown}")
@@ -149,6 +149,10 @@ class RexBatchEnv:
                         ("drift_weight", drift_weight), ("shake_weight", shake_weight)):   # rex_gym_env.py:56-59
             if v is not None:
                 setattr(cfg, name, float(v))
+        if forward_reward_cap is not None:     # `min(forward_reward, cap)` in the base reward, rex_gym_env.py:81,525
+            cfg.forward_reward_cap = float(forward_reward_cap)
+        if task == "mixed" and energy_weight is not None:
+            raise ValueError("energy_weight is a per-task constant in a mixed batch (gallop 0.005, walk / turn 0.0005)")
         cfg.backwards = -1 if backwards is None else int(bool(backwards))
         cfg.target_position = 0.0 if not target_position else float(target_position)
         if target_orient:                      # `if not self._target_orient` -> drawn (turn_env.py:137)
@@ -188,6 +192,7 @@ class RexBatchEnv:
             self.observation_space = Box(-np.ones(self.observation_space.shape), np.ones(self.observation_space.shape))
         self.control_time_step = cfg.sim_time_step * cfg.action_repeat
         self.check_actions = bool(check_actions)
+        self._act_lo = self._act_hi = None
         self._stream = stream
         with torch.cuda.device(self.device):
             self.state = torch.zeros((self.state_words, self.num_envs), dtype=torch.float32, device=self.device)
@@ -345,11 +350,22 @@ class RexBatchEnv:
             if a.shape != (self.num_envs, self.action_dim):
                 raise ValueError(f"actions must have shape {(self.num_envs, self.action_dim)}, got {tuple(a.shape)}")
             a = a.contiguous()
-        if self.check_actions:   # batch_env.py:76-79
-            lo = torch.as_tensor(np.minimum(self.action_space.low, self.action_space.high), device=self.device)
-            hi = torch.as_tensor(np.maximum(self.action_space.low, self.action_space.high), device=self.device)
-            if bool(((a < lo) | (a > hi) | ~torch.isfinite(a)).any()):
-                raise ValueError("Invalid action")
+        if self.check_actions:
+            # BatchEnv.step: `if not env.action_space.contains(action): raise ValueError` for every env (agents/tools/
+            # batch_env.py:76-79), in the Box's own dtype (float32).  Behind the folded ClipAction the space is unbounded
+            # (wrappers.py:254-259): only non-finite actions are invalid.  The verdict is read back from the device, i.e. one
+            # host synchronisation per step, as in the reference; throughput loops that have validated their actions
+            # beforehand pass check_actions=False.
+            bad = ~torch.isfinite(a)
+            if not self.config.range_normalize:
+                if self._act_lo is None:
+                    self._act_lo = torch.as_tensor(np.minimum(self.action_space.low, self.action_space.high).astype(np.float32), device=self.device)
+                    self._act_hi = torch.as_tensor(np.maximum(self.action_space.low, self.action_space.high).astype(np.float32), device=self.device)
+                bad |= (a < self._act_lo) | (a > self._act_hi)
+            rows = bad.any(dim=1)
+            if bool(rows.any()):
+                i = int(torch.nonzero(rows)[0])
+                raise ValueError(f"Invalid action at index {i}: {a[i].tolist()}")
         _lib.check(self._L.rex_step(self._h, a.data_ptr(), self._obs.data_ptr(), self._reward.data_ptr(),
                                     self._done.data_ptr(), self._cmd.data_ptr(), self._stream_ptr()), "rex_step")
         return self._obs, self._reward, self._done.view(self._torch.bool), {"action": self._cmd}

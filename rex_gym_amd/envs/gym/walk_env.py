@@ -20,6 +20,7 @@ class _SingleEnv:
     metadata = {"render.modes": ["human", "rgb_array"], "video.frames_per_second": 66}
 
     def __init__(self, signal_type="ik", **kw):
+        kw.setdefault("check_actions", False)   # RexGymEnv.step takes any action (rex_gym_env.py:369-414); BatchEnv is what checks
         self._batch = RexBatchEnv(1, task=self._TASK, signal_type=signal_type, **kw)
         self.action_space = self._batch.action_space
         self.observation_space = self._batch.observation_space

@@ -49,6 +49,7 @@ def make_pair(task, signal, n, dtype=np.float32, **kw):
     terrain = okw.pop("terrain_type", "plane")
     pool, tseed = okw.pop("terrain_pool", 64), okw.pop("terrain_seed", 10)
     mark = okw.pop("mark", "base")
+    okw.pop("check_actions", None)     # product-side only: BatchEnv's per-step Box test (tests that leave the Box switch it off)
     cfg_kw["mark"] = {"base": 0, "arm": 1}[mark]
     assert not okw, okw
     env = RexBatchEnv(n, task=task, signal_type=signal, **pkw)

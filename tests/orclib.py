@@ -44,6 +44,7 @@ class RexConfig(ctypes.Structure):
         ("gait_clock_scale", ctypes.c_float), ("body_contacts", ctypes.c_int32), ("noise_stdev", ctypes.c_float * 5),
         ("task_mix", ctypes.c_int32), ("mass_scale_lo", ctypes.c_float), ("mass_scale_hi", ctypes.c_float),
         ("friction_lo", ctypes.c_float), ("friction_hi", ctypes.c_float), ("init_height", ctypes.c_float), ("on_rack", ctypes.c_int32),
+        ("forward_reward_cap", ctypes.c_float),
     ]
 
 
@@ -58,7 +59,8 @@ def default_config(task="walk", signal="ik", num_envs=1, **kw):
                   action_repeat=repeat, solver_iterations=300 // repeat, sim_time_step=0.001,
                   motor_kp=1.0, motor_kd=0.02, backwards=-1, target_position=0.0, seed=0, auto_reset=0,
                   max_episode_steps=0, distance_weight=1.0, energy_weight=0.005 if task == "gallop" else 0.0005, drift_weight=2.0,
-                  shake_weight=0.005, solver_residual_threshold=1e-7, pose_index=-1, body_contacts=int(task == "poses"))
+                  shake_weight=0.005, solver_residual_threshold=1e-7, pose_index=-1, body_contacts=int(task == "poses"),
+                  forward_reward_cap=float("inf"))
     for k, v in kw.items():
         setattr(c, k, v)
     return c

@@ -750,7 +750,7 @@ def test_single_step_parity_along_long_oracle_rollouts(torch, task, signal, mark
     quantile form allows for contacts that switch one substep apart)."""
     n = 48
     env, orc = make_pair(task, signal, n, np.float32, seed=31, mark=mark, terrain_type=terrain, terrain_pool=8,
-                         auto_reset=True, max_episode_steps=90)
+                         auto_reset=True, max_episode_steps=90, check_actions=False)
     env.reset(); orc.reset()
     rng = np.random.RandomState(12)
     lo, hi = np.minimum(env.action_space.low, env.action_space.high), np.maximum(env.action_space.low, env.action_space.high)
@@ -828,6 +828,8 @@ def test_hip_path_reproduces_reference_rollouts(torch, sc):
     rest to the single-step tolerances of this file accumulated over the episode."""
     from rex_gym_amd import RexBatchEnv
     kw = dict(sc["env_kwargs"])
+    if kw.pop("action_bias", None) is not None:
+        kw["check_actions"] = False     # the overheat scenario commands a joint far outside the env's Box on purpose
     batch = kw.pop("batch", None)       # N different envs behind the reference's BatchEnv (per-env actions, resets by index)
     n = batch or 8                      # otherwise 8 copies of the one env
     task = sc["oracle_config"]["task"]
@@ -888,7 +890,7 @@ def test_overheat_shutdown_on_the_gpu(torch):
     sc = next(s for s in _rollout_scenarios() if s["name"] == "walk_ol_on_rack_overheat")
     kw = dict(sc["env_kwargs"]); kw.pop("action_bias"); signal = kw.pop("signal_type")
     n = 8
-    env = RexBatchEnv(n, task="walk", signal_type=signal, **kw)
+    env = RexBatchEnv(n, task="walk", signal_type=signal, check_actions=False, **kw)
     en_w, oh_w = orclib.S_MOTOR_EN, orclib.S_OVERHEAT
     off_event, seen_off, seen_back_on = None, False, False
     for k, ev in enumerate(sc["events"]):
@@ -914,6 +916,37 @@ def test_overheat_shutdown_on_the_gpu(torch):
             seen_back_on = True
     assert seen_off and seen_back_on
     env.close()
+
+
+def test_forward_reward_cap_and_action_check_of_the_batch_env(torch):
+    """Two pieces of the reference's caller-facing semantics: RexGymEnv(forward_reward_cap=c) clips the forward term of
+    the reward (rex_gym_env.py:525; lock step with the oracle), and the batch env rejects an action outside the env's Box
+    like BatchEnv.step does (agents/tools/batch_env.py:76-79) -- by default, in float32, naming the env."""
+    n = 64
+    import parity_window as pw
+    from rex_gym_amd import RexBatchEnv
+    kw = dict(task="walk", signal_type="ik", seed=2, backwards=False, target_position=1.0, gait_clock_scale=1.5)   # the walking regime
+    env = RexBatchEnv(n, forward_reward_cap=0.06, **kw)
+    orc = pw.oracle_for(env)
+    ref = RexBatchEnv(n, **kw)
+    env.reset(); orc.reset(); ref.reset()
+    rng = np.random.RandomState(0)
+    gap = 0.0
+    for k in range(200):
+        a = rng.uniform(-0.4, 0.4, (n, 2)).astype(np.float32)
+        _, r, _, _ = env.step(torch.as_tensor(a, device="cuda"))
+        _, r0, _, _ = ref.step(torch.as_tensor(a, device="cuda"))
+        _, orr, _, _ = orc.step(a)
+        np.testing.assert_allclose(r.cpu().numpy(), orr, atol=2e-4)
+        gap = max(gap, float((r0 - r).max()))
+    assert gap > 0.03                                        # the uncapped reward did run ahead of the capped one
+    with pytest.raises(ValueError, match="Invalid action at index 5"):
+        bad = np.zeros((n, 2), np.float32); bad[5, 1] = 0.41
+        env.step(bad)
+    with pytest.raises(ValueError, match="Invalid action at index 0"):
+        env.step(np.full((n, 2), np.nan, np.float32))
+    env.step(np.full((n, 2), 0.4, np.float32))               # the bound itself (float32(0.4) > 0.4 in double) is inside
+    env.close(); ref.close()
 
 
 def test_policy_player_runs_a_checkpoint_on_the_batch_env(torch, tmp_path):

@@ -182,3 +182,24 @@ def test_rex_knobs_map_reference_mass_setters_to_group_scales():
         rex.SetBaseMasses([1.0, 2.0])
     with pytest.raises(ValueError, match="one factor"):
         rex.SetBaseMasses([1.3, 0.05, 0.05])
+
+
+def test_config_validation_happens_before_any_device_call():
+    """rex_create validates the config first, so a bad one is reported (REX_EINVAL + message) on any host: a NaN
+    forward_reward_cap, and a caller-set energy_weight in a REX_TASK_MIXED batch (a per-task constant there; silently
+    ignoring the caller's value would contradict 'anything that changes the computation is an error')."""
+    import ctypes
+    from rex_gym_amd import _lib as L
+    lib = L.lib()
+    cfg = L.RexConfig()
+    assert lib.rex_default_config(L.TASKS["walk"], L.SIGNALS["ik"], 8, ctypes.byref(cfg)) == 0
+    assert cfg.forward_reward_cap == float("inf")            # rex_gym_env.py:81
+    dummy = (ctypes.c_float * 4)()
+    out = ctypes.c_void_p()
+    cfg.forward_reward_cap = float("nan")
+    assert lib.rex_create(ctypes.byref(cfg), 0, ctypes.cast(dummy, ctypes.c_void_p), None, ctypes.byref(out)) == -1
+    assert b"forward_reward_cap" in lib.rex_last_error()
+    assert lib.rex_default_config(L.TASKS["mixed"], L.SIGNALS["ik"], 8, ctypes.byref(cfg)) == 0
+    cfg.energy_weight = 0.01
+    assert lib.rex_create(ctypes.byref(cfg), 0, ctypes.cast(dummy, ctypes.c_void_p), None, ctypes.byref(out)) == -1
+    assert b"energy_weight" in lib.rex_last_error()

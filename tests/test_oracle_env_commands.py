@@ -59,3 +59,26 @@ def test_env_command_logic_matches_the_reference_methods(sequences):
                 worst = max(worst, err)
         env.close()
     print("largest |command - reference| over all sequences: %.2e rad" % worst)
+
+
+def test_forward_reward_cap_is_applied_to_the_forward_term_only():
+    """RexGymEnv(forward_reward_cap=c): `forward_reward = min(forward_reward, c)` (rex_gym_env.py:525) -- the reward of a
+    capped env equals that of the uncapped one minus distance_weight x the clipped part of the forward term."""
+    n = 6
+    envs = [OracleEnv(default_config("walk", "ik", n, seed=2, backwards=0, target_position=1.0, gait_clock_scale=1.5, forward_reward_cap=c), np.float64)
+            for c in (float("inf"), 0.06)]
+    for e in envs:
+        e.reset()
+    rng = np.random.RandomState(0)
+    clipped = 0
+    for k in range(200):
+        a = rng.uniform(-0.4, 0.4, (n, 2))
+        (_, r0, d0, _), (_, r1, d1, _) = envs[0].step(a), envs[1].step(a)
+        x = -envs[0].get_state()[0]                       # the capped env's physics is the same
+        fwd = np.where(x > 1.15, 1.0 - x, np.where(x >= 1.0, 1.0, np.where(x <= 0.05, 0.0, x / 1.0)))
+        np.testing.assert_allclose(r1, r0 - 1.0 * (fwd - np.minimum(fwd, 0.06)), atol=1e-12)
+        assert (d0 == d1).all()
+        clipped += int((fwd > 0.06).sum())
+    assert clipped > 100                                   # the cap did act
+    for e in envs:
+        e.close()

@@ -4,7 +4,7 @@ import torch
 from rex_gym_amd import RexBatchEnv
 def run(n, epw, steps=150, warm=400):
     os.environ['REX_ENVS_PER_WAVE']=str(epw)
-    env = RexBatchEnv(n, seed=0, auto_reset=True, max_episode_steps=2000)
+    env = RexBatchEnv(n, check_actions=False, seed=0, auto_reset=True, max_episode_steps=2000)
     env.reset()
     acts=[torch.rand((n,2),device='cuda')*0.8-0.4 for _ in range(8)]
     for k in range(warm): env.step(acts[k%8])

@@ -15,7 +15,7 @@ def run(repeat, n=4096, steps=2000):
     import importlib
     import rex_gym_amd
     from rex_gym_amd import RexBatchEnv
-    env = RexBatchEnv(n, task="walk", signal_type="ik", seed=0, auto_reset=True, max_episode_steps=2000)
+    env = RexBatchEnv(n, check_actions=False, task="walk", signal_type="ik", seed=0, auto_reset=True, max_episode_steps=2000)
     g = torch.Generator(device="cuda"); g.manual_seed(1)
     pool = [torch.rand((n, 2), device="cuda", generator=g) * 0.8 - 0.4 for _ in range(16)]
     env.reset()

@@ -4,7 +4,7 @@ import sys, time, torch
 sys.path.insert(0, '.')
 from rex_gym_amd import RexBatchEnv
 n = 4096
-env = RexBatchEnv(n, task="walk", signal_type="ik", auto_reset=True, max_episode_steps=2000, seed=0)
+env = RexBatchEnv(n, check_actions=False, task="walk", signal_type="ik", auto_reset=True, max_episode_steps=2000, seed=0)
 env.reset()
 g = torch.Generator(device="cuda"); g.manual_seed(1)
 pool = [torch.rand((n, 2), device="cuda", generator=g) * 0.8 - 0.4 for _ in range(64)]

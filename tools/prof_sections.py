@@ -36,7 +36,7 @@ for a in sys.argv:
         extra["base_roll"] = float(a.split("=")[1])          # poses: every env holds this roll (the self-collision regime at -0.74)
     if a.startswith("--body="):
         extra["body_contacts"] = bool(int(a.split("=")[1]))
-env = RexBatchEnv(n, task=task, signal_type="ol" if task == "standup" else "ik", seed=0, auto_reset=True, max_episode_steps=2000, mark=mark,
+env = RexBatchEnv(n, check_actions=False, task=task, signal_type="ol" if task == "standup" else "ik", seed=0, auto_reset=True, max_episode_steps=2000, mark=mark,
                   **extra)
 env.reset()
 _lo = torch.as_tensor(env.action_space.low, device="cuda").minimum(torch.as_tensor(env.action_space.high, device="cuda"))

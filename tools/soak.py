@@ -7,7 +7,7 @@ cases=[("poses","ik","plane","base",8192,{}),("poses","ik","plane","arm",4096,{}
        ("gallop","ik","plane","base",8192,dict(body_contacts=True)),("standup","ol","plane","base",4096,dict(body_contacts=True)),
        ("walk","ik","plane","base",4096,dict(on_rack=True)),("turn","ik","plane","arm",2048,dict(on_rack=True))]
 for task,signal,terrain,mark,n,kw in cases:
-    env=RexBatchEnv(n,task=task,signal_type=signal,terrain_type=terrain,mark=mark,auto_reset=True,max_episode_steps=1000,seed=7,**kw)
+    env=RexBatchEnv(n, check_actions=False,task=task,signal_type=signal,terrain_type=terrain,mark=mark,auto_reset=True,max_episode_steps=1000,seed=7,**kw)
     lo=torch.as_tensor(env.action_space.low,device=env.device); hi=torch.as_tensor(env.action_space.high,device=env.device)
     lo,hi=torch.minimum(lo,hi),torch.maximum(lo,hi)
     env.reset(); t0=time.time(); dones=0; bad=0

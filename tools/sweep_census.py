@@ -18,7 +18,7 @@ from rex_gym_amd import RexBatchEnv, _lib  # noqa: E402
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
     clock = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
-    env = RexBatchEnv(n, task="walk", signal_type="ik", seed=0, auto_reset=True, max_episode_steps=2000, gait_clock_scale=clock)
+    env = RexBatchEnv(n, check_actions=False, task="walk", signal_type="ik", seed=0, auto_reset=True, max_episode_steps=2000, gait_clock_scale=clock)
     env.reset()
     g = torch.Generator(device="cuda"); g.manual_seed(1)
     pool = [torch.rand((n, 2), device="cuda", generator=g) * 0.8 - 0.4 for _ in range(16)]

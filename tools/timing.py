@@ -4,7 +4,7 @@ import sys, time; sys.path.insert(0,'.')
 import torch
 from rex_gym_amd import RexBatchEnv
 def run(n, steps=300, warm=300, **kw):
-    env = RexBatchEnv(n, seed=0, auto_reset=True, max_episode_steps=2000, **kw)
+    env = RexBatchEnv(n, check_actions=False, seed=0, auto_reset=True, max_episode_steps=2000, **kw)
     env.reset()
     lo=torch.as_tensor(env.action_space.low,device='cuda'); hi=torch.as_tensor(env.action_space.high,device='cuda')
     lo,hi=torch.minimum(lo,hi),torch.maximum(lo,hi)
