@@ -7,9 +7,14 @@
 
 A "step" is ONE launch of rex_step_kernel = one env.step() of every env of the shard
 (controller + 5 x [motor model + restated stepSimulation with 60 PGS iterations] + reward/done/obs,
-with in-launch auto-reset).  Workload = BASELINE.json configs[1]: 4 096 Rex envs per GPU, walk-IK,
-flat plane, random actions U(-0.4, 0.4) from a pre-generated pool that is resident in HBM before
-the timed region (weak scaling: 4 096 envs on every GPU, independent shards, no data-path collective).
+with in-launch auto-reset), writing its observation / reward / done into slice t of a rollout segment.
+Workload = BASELINE.json configs[1]: 4 096 Rex envs per GPU, walk-IK, flat plane, random actions
+U(-0.4, 0.4) from a pre-generated pool that is resident in HBM before the timed region (weak scaling:
+4 096 envs on every GPU, independent shards, no data-path collective).  With N > 1 every rank all-gathers
+its finished 25-step segment to all ranks (RCCL over xGMI: the learner hand-off, the design's only
+collective) while the next segment is stepped; the line reports the throughput with it (`value`) and
+without it.  `--config 3|4|5` runs BASELINE.json's other configs at their TOTAL sizes divided over the
+GPUs (strong scaling).
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -99,43 +104,30 @@ def orclib_mark(mark):
     return 1 if mark == "arm" else 0
 
 
-def joint_rmse_vs_oracle(task, signal, mark, n=256, steps=200, seed=11):
+def joint_rmse_vs_oracle(workload, kwargs, n=256, steps=200, seed=11):
     """Half of BASELINE.json's metric ("joint RMSE vs PyBullet"): PyBullet cannot run here, so this is the HIP path
-    against the fp64 oracle -- the same `n` envs from reset, the same random actions, `steps` control steps (1 s of
-    robot time); per env the RMSE over time and joints of (q_hip - q_oracle), reported as median and max over envs,
-    and the base-position error at the end of the window."""
-    import numpy as np
-    import torch
+    against the fp64 oracle -- `n` envs of the bench workload from reset, the same random actions, `steps` control steps
+    (1 s of robot time); per env the RMSE over time and joints of (q_hip - q_oracle), median / p99 / max over the envs
+    (tests/parity_window.py; the full-size windows of every BASELINE config are in profiles/r03_parity.json)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import orclib
-    from helpers import product_state_to_numeric
+    import torch
+    import parity_window as pw
     from rex_gym_amd import RexBatchEnv
-    env = RexBatchEnv(n, task=task, signal_type=signal, device=torch.cuda.current_device(), seed=seed, mark=mark)
-    orc = orclib.OracleEnv(orclib.default_config(task, signal, n, seed=seed, mark=orclib_mark(mark)), np.float64, mark=mark)
-    orc.o.lib.orc_set_threads(usable_cores())
-    env.reset(); orc.reset()
-    nm = env.num_motors
-    lo = np.minimum(env.action_space.low, env.action_space.high); hi = np.maximum(env.action_space.low, env.action_space.high)
-    rng = np.random.RandomState(seed)
-    sq = np.zeros(n)
-    alive = np.ones(n, bool)
-    cnt = np.zeros(n)
-    for _ in range(steps):
-        a = rng.uniform(lo, hi, (n, env.action_dim)).astype(np.float32)
-        _, _, d, _ = env.step(torch.as_tensor(a, device=env.device))
-        _, _, od, _ = orc.step(a)
-        ps, os_ = product_state_to_numeric(env.state), orc.get_state()
-        e = ps[orclib.S_Q:orclib.S_Q + nm] - os_[orclib.S_Q:orclib.S_Q + nm]
-        sq += np.where(alive, (e * e).mean(0), 0.0)
-        cnt += alive
-        alive &= ~(d.cpu().numpy().astype(bool) | od)      # an episode that ended (fall) leaves the comparison
-    rmse = np.sqrt(sq / np.maximum(cnt, 1))
-    pos = np.abs(ps[0:3] - os_[0:3]).max(0)
-    env.close(); orc.close()
-    return {"window_steps": steps, "envs": n, "median_rad": float(np.median(rmse)), "max_rad": float(rmse.max()),
-            "p99_rad": float(np.percentile(rmse, 99)), "base_pos_err_max_m": float(pos[alive].max()) if alive.any() else None,
-            "envs_compared_to_the_end": int(alive.sum()), "against": "oracle/rex_oracle.c fp64 (restatement; PyBullet is not installable)"}
+    env = RexBatchEnv(n, device=torch.cuda.current_device(), seed=seed, **kwargs)
+    rec = pw.window(f"bench:{workload}", env, steps=steps, seed=seed, threads=usable_cores())
+    env.close()
+    rec.pop("abs_error_by_step", None)
+    return rec
 
+
+# BASELINE.json configs, numbered as SURVEY.md 8(d) numbers them (config 1 is the 1-env CPU plumbing case): what --config N runs.
+# total = envs of the WHOLE job (strong scaling: divided over the GPUs); None = 4 096 per GPU (weak scaling, configs[1])
+CONFIGS = {
+    2: dict(task="walk", signal="ik", terrain="plane", mark="base", mixed=False, total=None),
+    3: dict(task="gallop", signal="ol", terrain="plane", mark="base", mixed=False, total=65536),
+    4: dict(task="turn", signal="ik", terrain="random", mark="base", mixed=False, total=32768),
+    5: dict(task="walk", signal="ik", terrain="plane", mark="arm", mixed=True, total=16384),
+}
 
 
 def main():
@@ -143,11 +135,19 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--envs-per-gpu", type=int, default=None)
+    ap.add_argument("--config", type=int, default=None, choices=sorted(CONFIGS),
+                    help="a BASELINE.json config by its SURVEY 8(d) number: 2 = 4 096 walk-IK envs per GPU (the default line, weak "
+                         "scaling); 3 / 4 / 5 = 65 536 gallop-OL / 32 768 turn-IK on the heightfield pool / 16 384 mark-arm mixed-task "
+                         "envs in TOTAL, divided over --gpus (strong scaling)")
+    ap.add_argument("--gather-every", type=int, default=25, help="T: steps per rollout segment; every T steps the segment (obs, action, "
+                    "reward, done of the shard) is all-gathered to all ranks -- the learner hand-off, the design's one collective")
+    ap.add_argument("--no-gather", action="store_true", help="time the independent shards only (no learner hand-off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-walking-workload", action="store_true", help="skip the secondary gait-clock-1.5 measurement (profiling runs)")
     ap.add_argument("--no-stagger", action="store_true", help="developer A/B runs only: pre-roll without the staggered resets")
-    # the default line is BASELINE.json configs[1]; the other supported configs can be timed with these
+    ap.add_argument("--no-device-timing", action="store_true", help="developer A/B runs only: no device-side kernel timestamps in the timed region")
+    # the default line is BASELINE.json configs[1]; the other supported workloads can be timed with these
     ap.add_argument("--task", default="walk", choices=["walk", "gallop", "turn", "poses", "standup"])
     ap.add_argument("--signal", default="ik", choices=["ik", "ol"])
     ap.add_argument("--terrain", default="plane", choices=["plane", "random"])
@@ -165,6 +165,15 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    scaling = "weak"
+    if args.config is not None:
+        c = CONFIGS[args.config]
+        args.task, args.signal, args.terrain, args.mark, args.mixed = c["task"], c["signal"], c["terrain"], c["mark"], c["mixed"]
+        if c["total"] is not None and args.envs_per_gpu is None:
+            if c["total"] % world:
+                raise SystemExit(f"config {args.config}: {c['total']} envs do not divide over {world} GPUs")
+            args.envs_per_gpu, scaling = c["total"] // world, "strong"
+    n = args.envs_per_gpu or ENVS_PER_GPU
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -181,25 +190,27 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    from rex_gym_amd import RexBatchEnv, RexMixedBatchEnv
-    n = args.envs_per_gpu
+    from rex_gym_amd import RexBatchEnv
+    from rex_gym_amd.sharding import gather_rollout
+    # (the action pool below is drawn inside the env's Box and lives in HBM before the timed region: BatchEnv's per-step Box
+    #  test -- a host synchronisation per step -- has nothing to find and is switched off)
+    env_kw = dict(task="mixed" if args.mixed else args.task, signal_type=args.signal, terrain_type=args.terrain, mark=args.mark)
     if args.mixed:
-        env = RexMixedBatchEnv(n, device=local_rank, seed=0, env_index_base=rank * n, auto_reset=True, max_episode_steps=2000,
-                               terrain_type=args.terrain, mark=args.mark, mass_scale_range=(0.8, 1.2), friction_range=(0.25, 0.625),
-                               check_actions=False)
-    else:
-        env = RexBatchEnv(n, task=args.task, signal_type=args.signal, device=local_rank, seed=0, env_index_base=rank * n,
-                          auto_reset=True, max_episode_steps=2000, terrain_type=args.terrain, mark=args.mark, check_actions=False)
+        env_kw.update(mass_scale_range=(0.8, 1.2), friction_range=(0.25, 0.625))
+    env = RexBatchEnv(n, device=local_rank, seed=0, env_index_base=rank * n, auto_reset=True, max_episode_steps=2000, check_actions=False,
+                      **env_kw)
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
-    lo = torch.as_tensor(env.action_space.low, device=dev).minimum(torch.as_tensor(env.action_space.high, device=dev))
-    hi = torch.as_tensor(env.action_space.low, device=dev).maximum(torch.as_tensor(env.action_space.high, device=dev))
-    pool = [(torch.rand((n, env.action_dim), device=dev, generator=gen) * (hi - lo) + lo).contiguous() for _ in range(16)]
+    lo = torch.as_tensor(env.action_space.low, device=dev).minimum(torch.as_tensor(env.action_space.high, device=dev)).float()
+    hi = torch.as_tensor(env.action_space.low, device=dev).maximum(torch.as_tensor(env.action_space.high, device=dev)).float()
+    T = max(1, args.gather_every)
+    pool = (torch.rand((T, n, env.action_dim), device=dev, generator=gen) * (hi - lo) + lo).contiguous()   # one rollout segment of actions
+    assert bool(((pool >= lo) & (pool <= hi)).all())
     env.reset()
     # pre-roll (untimed, outside --warmup): right after a synchronous reset every env is in the same episode phase and
     # the solver converges quickly; the number reported is the steady state a training run sees
     for k in range(PREROLL_STEPS):
-        env.step(pool[k % 16])
+        env.step(pool[k % T])
         if k % 50 == 0 and k < PREROLL_STEPS - 200 and not args.mixed and not args.no_stagger:
             # stagger the episodes: half the envs (those that walk backwards) never fall, and started together they would
             # all run into the 2 000-step cap in the same step, stand up together, fall together ... -- a load that swings
@@ -214,54 +225,103 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for k in range(args.warmup):
-        env.step(pool[k % 16])
+    # The step writes observation / reward / done straight into slice t of a rollout segment [T, n, ...] (no copies); every
+    # T steps the finished segment is all-gathered to all ranks (the learner hand-off, sharding.gather_rollout) while the
+    # next segment fills the other buffer: the collective runs on RCCL's stream, the steps keep the compute stream busy.
+    seg = [dict(obs=torch.zeros((T, n, env.obs_dim), device=dev), reward=torch.zeros((T, n), device=dev),
+                done=torch.zeros((T, n), dtype=torch.uint8, device=dev), action=pool) for _ in range(2)]
+    seg_bytes = sum(v.numel() * v.element_size() for v in seg[0].values())
+    do_gather = not args.no_gather
+
+    def run(steps, gather):
+        pending = [None, None]
+        for k in range(steps):
+            b, t = (k // T) & 1, k % T
+            if t == 0 and pending[b] is not None:
+                pending[b].wait(); pending[b] = None         # this buffer's previous segment has left before it is overwritten
+            s = seg[b]
+            env.step(pool[t], out=(s["obs"][t], s["reward"][t], s["done"][t]))
+            if gather and t == T - 1:
+                pending[b] = gather_rollout(s, async_op=True, slot=b)
+        for p in pending:
+            if p is not None:
+                p.wait()
+
+    run(args.warmup, do_gather)
+    if not args.no_device_timing:
+        env.set_timing(3)      # device-side (first wave start, last wave end) ticks of the next launches: no event, no sync in the loop
     barrier()
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        env.step(pool[k % 16])
+    run(args.steps, do_gather)
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     barrier()
+    kms = sorted(env.step_times_ms(min(args.steps, 4096))) if not args.no_device_timing else []
+    env.set_timing(False)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # Launch duration of the dominant kernel, two ways, both on the launch stream and inside the timed regime:
-    #  * kernel_ms: device-side timestamps (rex_set_timing(3)): first-wave start to last-wave end of each of m back-to-back
-    #    launches, averaged -- the kernel alone, comparable with rocprofv3's kernel trace (profiles/);
-    #  * launch_ms: two HIP events around m back-to-back launches / m (RexBatchEnv launches on torch's current stream, so
-    #    torch.cuda.Event records on that very stream) -- the kernel plus the hand-over between two dependent dispatches.
-    timed = env
+    # the same K steps without the hand-off, and the hand-off on its own (blocking, nothing to overlap with): N > 1 only
+    gather_info = None
+    if dist is not None and do_gather:
+        barrier()
+        t1 = time.perf_counter()
+        run(args.steps, False)
+        torch.cuda.synchronize(dev)
+        e_plain = time.perf_counter() - t1
+        barrier()
+        reps = 10
+        t2 = time.perf_counter()
+        for _ in range(reps):
+            gather_rollout(seg[0], slot=0)
+        torch.cuda.synchronize(dev)
+        g_ms = (time.perf_counter() - t2) / reps * 1e3
+        barrier()
+        tt = torch.tensor([e_plain, g_ms], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        e_plain, g_ms = float(tt[0].item()), float(tt[1].item())
+        gather_info = {"every_steps": T, "segment_bytes_per_rank": seg_bytes, "segment_bytes_all_ranks": seg_bytes * world,
+                       "bytes_per_env_step": seg_bytes / (T * n), "gather_ms_blocking": g_ms,
+                       "value_without_gather": n * world * args.steps / e_plain, "ms_per_step_without_gather": e_plain / args.steps * 1e3,
+                       "backend": args.backend, "overlap": "segment k is gathered on the collective stream while segment k+1 is stepped"}
+
+    # Launch duration of the dominant kernel over the TIMED launches: device-side timestamps (rex_set_timing(3)): first-wave
+    # start to last-wave end of each launch -- the kernel alone, comparable with rocprofv3's kernel trace (profiles/).
+    # launch_ms: two HIP events around m back-to-back launches / m on the launch stream (RexBatchEnv launches on torch's
+    # current stream, so torch.cuda.Event records on that very stream) -- the kernel plus the dispatch hand-over.
     m = min(256, max(20, args.steps // 8))
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev0.record(torch.cuda.current_stream(dev))
     for k in range(m):
-        env.step(pool[k % 16])
+        env.step(pool[k % T])
     ev1.record(torch.cuda.current_stream(dev))
     ev1.synchronize()
     launch_ms = ev0.elapsed_time(ev1) / m
-    timed.set_timing(3)
-    for k in range(m):
-        env.step(pool[k % 16])
-    kms = sorted(timed.step_times_ms(m))
-    timed.set_timing(False)
+    if not kms:
+        env.set_timing(3)
+        for k in range(m):
+            env.step(pool[k % T])
+        kms = sorted(env.step_times_ms(m))
+        env.set_timing(False)
     kernel_ms = sum(kms) / len(kms)
 
-    # HBM bytes per launch as measured with rocprofv3 PMC passes of this same command (cannot be collected from inside
-    # the process); null when no measurement of this workload is committed
-    traffic = None
+    # HBM bytes per launch and the VALU issue fraction as measured with rocprofv3 PMC passes of this same command (cannot be
+    # collected from inside the process); null when no measurement of this workload is committed
+    traffic = issue_frac = None
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             t = json.load(f).get(f"{'mixed' if args.mixed else args.task}-{args.signal}/{args.terrain}/{args.mark}/{n}")
         traffic = t and t["bytes_per_launch"]
+        issue_frac = t and t.get("issue_frac")
     except (OSError, ValueError, KeyError):
         pass
 
     # sanity: the rollout must be alive (finite observations, some episodes running)
-    obs = env._obs
-    finite = bool(torch.isfinite(obs).all().item())
+    finite = bool(torch.isfinite(seg[0]["obs"]).all().item() and torch.isfinite(seg[1]["obs"]).all().item())
+    act_dim, obs_dim, state_words = env.action_dim, env.obs_dim, env.state_words
+    body_contacts, repeat, sweeps = env.config.body_contacts, env.config.action_repeat, env.config.solver_iterations
     env.close()
 
     # the same workload with the gait phase clock of a host that runs 1.5 wall-seconds per simulated second (the regime in
@@ -269,26 +329,23 @@ def main():
     # steps): reported next to the headline, never instead of it
     walking = None
     if world == 1 and not args.mixed and not args.no_walking_workload and args.signal == "ik" and args.task in ("walk", "turn", "gallop"):
-        env2 = RexBatchEnv(n, task=args.task, signal_type=args.signal, device=local_rank, seed=0, env_index_base=rank * n,
-                           auto_reset=True, max_episode_steps=2000, terrain_type=args.terrain, mark=args.mark, gait_clock_scale=1.5,
-                           check_actions=False)
+        env2 = RexBatchEnv(n, device=local_rank, seed=0, env_index_base=rank * n, auto_reset=True, max_episode_steps=2000,
+                           gait_clock_scale=1.5, check_actions=False, **env_kw)
         env2.reset()
         for k in range(PREROLL_STEPS + args.warmup):
-            env2.step(pool[k % 16])
+            env2.step(pool[k % T])
             if k % 50 == 0 and k < PREROLL_STEPS - 200:
                 env2.reset(torch.randperm(n, device=dev, generator=gen)[: max(1, n // 32)].to(torch.int32))
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
         for k in range(args.steps):
-            env2.step(pool[k % 16])
+            env2.step(pool[k % T])
         torch.cuda.synchronize(dev)
         e2 = time.perf_counter() - t1
         walking = {"gait_clock_scale": 1.5, "value": n * args.steps / e2, "unit": "env-steps/s", "ms_per_step": e2 / args.steps * 1e3}
         env2.close()
 
     task_name = "mixed" if args.mixed else args.task
-    act_dim, obs_dim = env.action_dim, env.obs_dim
-    state_words = env.state_words
     if rank == 0:
         total_envs = n * world
         value = total_envs * args.steps / elapsed
@@ -297,42 +354,50 @@ def main():
         out = {
             "metric": "env-steps/sec (all envs) Rex " + ("mixed walk/gallop/turn-IK" if args.mixed else f"{args.task}-{args.signal.upper()}"),
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{n} Rex envs per GPU, " + ("every env's task drawn from walk/gallop/turn-IK, mass and friction drawn per reset, one launch "
                                    "per step, " if args.mixed else f"{args.task}-{args.signal.upper()}, ") + f""
                                    f"{'flat plane' if args.terrain == 'plane' else 'random heightfield pool'}, {args.mark} mark, "
-                                   f"{'link-box rows (ground + self collision) on, ' if env.config.body_contacts else ''}"
-                                   f"dt 1 ms x {env.config.action_repeat} substeps, <= {env.config.solver_iterations} PGS sweeps "
+                                   f"{'link-box rows (ground + self collision) on, ' if body_contacts else ''}"
+                                   f"dt 1 ms x {repeat} substeps, <= {sweeps} PGS sweeps "
                                    "(Bullet residual threshold 1e-7), auto-reset, episode cap 2000, uniform random actions "
-                                   f"over the env's action Box; {PREROLL_STEPS} untimed pre-roll steps with staggered resets before --warmup "
-                                   "(stationary episode-age mix)",
-                       "envs_total": total_envs, "parallelism": f"env-shards x{world} (no data-path collective)"},
+                                   f"over the env's action Box (pool validated against the Box before the timed region); {PREROLL_STEPS} "
+                                   "untimed pre-roll steps with staggered resets before --warmup (stationary episode-age mix); every step "
+                                   f"writes obs / reward / done into a {T}-step rollout segment" +
+                                   (f", all-gathered to all {world} ranks every {T} steps (RCCL, overlapped with the next segment)" if gather_info else ""),
+                       "baseline_config": args.config if args.config is not None else (2 if (task_name, args.signal, args.terrain, args.mark, n) == ("walk", "ik", "plane", "base", ENVS_PER_GPU) else None),
+                       "envs_total": total_envs, "parallelism": f"env-shards x{world} (no data-path collective; learner hand-off = one all-gather per rollout segment)"},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "rex_step_kernel", "kernel_ms": kernel_ms, "kernel_ms_min": kms[0], "launch_ms": launch_ms,
+                         "kernel": "rex_step_kernel", "kernel_ms": kernel_ms, "kernel_ms_min": kms[0],
+                         "kernel_ms_over": f"{len(kms)} of the {args.steps} timed launches" if not args.no_device_timing else f"{len(kms)} launches after the timed region",
+                         "launch_ms": launch_ms,
                          "algorithmic_bytes_per_env_step": algo_bytes,
                          "layout_bytes_per_env_step": layout_bytes(state_words, act_dim, obs_dim),
                          "note": "the fused step is bound by the VALU issue rate of one wave per SIMD through the sequential "
-                                 "contact solver (about 550 flop/B, SURVEY.md 8d; DESIGN.md 5-6), not by HBM: see valu_frac",
+                                 "contact solver (about 550 flop/B, SURVEY.md 8d; DESIGN.md 5-6), not by HBM: see issue_frac / valu_frac",
+                         "issue_frac": issue_frac,
                          "valu_tflops_est": ALGO_FLOP_PER_ENV_STEP * n / (kernel_ms * 1e-3) / 1e12,
                          "valu_frac": ALGO_FLOP_PER_ENV_STEP * n / (kernel_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS},
             "finite": finite,
         }
+        if gather_info:
+            out["rollout_gather"] = gather_info
         if walking:
             out["walking_gait_workload"] = walking
-        if not args.no_cpu_baseline and world == 1 and not args.mixed:
-            try:   # SURVEY.md 8(d) baseline (ii): the CPU restatement on all granted threads and on one
-                out["cpu_baseline"] = cpu_baseline(args.task, args.signal, args.mark, n)
-                out["cpu_baseline_1thread"] = cpu_baseline(args.task, args.signal, args.mark, min(n, 256), cores=1, max_seconds=8.0)
-            except Exception as e:  # the baseline is reporting only; never fail the GPU line for it
-                out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": 0, "kind": "port",
-                                       "sample": f"failed: {e}"}
-            if args.terrain == "plane":
-                try:   # the other half of BASELINE.json's metric
-                    out["joint_rmse_vs_oracle"] = joint_rmse_vs_oracle(args.task, args.signal, args.mark)
-                except Exception as e:
-                    out["joint_rmse_vs_oracle"] = {"failed": str(e)}
+        if not args.no_cpu_baseline and world == 1:
+            if not args.mixed:
+                try:   # SURVEY.md 8(d) baseline (ii): the CPU restatement on all granted threads and on one
+                    out["cpu_baseline"] = cpu_baseline(args.task, args.signal, args.mark, n)
+                    out["cpu_baseline_1thread"] = cpu_baseline(args.task, args.signal, args.mark, min(n, 256), cores=1, max_seconds=8.0)
+                except Exception as e:  # the baseline is reporting only; never fail the GPU line for it
+                    out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": 0, "kind": "port",
+                                           "sample": f"failed: {e}"}
+            try:   # the other half of BASELINE.json's metric
+                out["joint_rmse_vs_oracle"] = joint_rmse_vs_oracle(f"{task_name}-{args.signal}/{args.terrain}/{args.mark}", env_kw)
+            except Exception as e:
+                out["joint_rmse_vs_oracle"] = {"failed": str(e)}
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -268,8 +268,8 @@ REX_API int rex_step(RexSim* sim, const float* d_action, float* d_obs, float* d_
  * rex_last_step_ms (synchronises on the launch).  rex_set_timing(2): a ring of event pairs around the last 256 launches,
  * recorded without any host synchronisation between launches (the stream stays full, so a duration is that of the kernel
  * itself, not of an idle queue being refilled); rex_step_times_ms waits for the newest one and returns the last
- * min(max_count, recorded, 256) durations, oldest first -- the return value is their number (< 0: error).
- * rex_set_timing(3): the next 256 launches are timed on the DEVICE: every workgroup of a launch folds its first / last wall-clock
+ * min(max_count, recorded, 256 -- 4096 in mode 3) durations, oldest first -- the return value is their number (< 0: error).
+ * rex_set_timing(3): the next 4096 launches are timed on the DEVICE: every workgroup of a launch folds its first / last wall-clock
  * tick (constant 100 MHz counter) into a (min, max) pair, so a duration is first-wave-start to last-wave-end of the kernel
  * alone -- what rocprofv3's kernel trace reports -- with no event or dispatch hand-over in it. */
 REX_API int rex_set_timing(RexSim* sim, int enable);

@@ -949,7 +949,8 @@ __global__ __launch_bounds__(REX_WAVE) void rex_settle_kernel(DevCfg c, float* _
   DevCfg cs = c;
   cs.hist = (c.pd_latency > 0.0f || c.control_latency > 0.0f) ? snap + (size_t)Lay<NM>::WORDS * nrec : nullptr;
   cs.n = nrec;
-  if (c.n_mix > 1) {   // the reset motion of this record's task: its own sweep cap (rex_gym_env.py:184)
+  if (c.n_mix > 1) {   // the reset motion of this record's task: its own sweep cap (rex_gym_env.py:184) -- a per-lane cap, the
+    // records of a wave belong to different tasks (rex_substep<true>: the wave sweeps to max_iterations, a lane to its own)
     const int task = slot == 0 ? c.mix_task[0] : (slot == 1 ? c.mix_task[1] : (slot == 2 ? c.mix_task[2] : (slot == 3 ? c.mix_task[3] : c.mix_task[4])));
     cs.iterations = 300 / task_action_repeat(task);
   }
@@ -967,10 +968,10 @@ __global__ __launch_bounds__(REX_WAVE) void rex_settle_kernel(DevCfg c, float* _
     }
 #pragma unroll
     for (int j = 0; j < 12; ++j) cmd[j] = pose_stand(j);
-    for (int k = 0; k < 100; ++k) rex_substep<false>(cs, e, t, keeps, cmd, tau_obs, sm, ground, armp);   // rex.py:315-318
+    for (int k = 0; k < 100; ++k) rex_substep<true>(cs, e, t, keeps, cmd, tau_obs, sm, ground, armp);   // rex.py:315-318
 #pragma unroll
     for (int j = 0; j < 12; ++j) cmd[j] = reset_pose(c, j);
-    for (int k = 0; k < c.reset_substeps; ++k) rex_substep<false>(cs, e, t, keeps, cmd, tau_obs, sm, ground, armp);   // rex.py:319-322
+    for (int k = 0; k < c.reset_substeps; ++k) rex_substep<true>(cs, e, t, keeps, cmd, tau_obs, sm, ground, armp);   // rex.py:319-322
   }
   receive_observation<NM>(cs, e, t, keeps, tau_obs);                                                           // rex.py:323
   if (!cs.hist) e.hist = 0u;
@@ -1011,7 +1012,8 @@ __global__ void rex_reset_kernel(DevCfg c, float* __restrict__ state, const floa
 }  // namespace rex
 
 // ---- host side shared by the translation units ----
-#define REX_TIMING_RING 256
+#define REX_TIMING_RING 256     /* event pairs of rex_set_timing(2) */
+#define REX_CLOCK_SLOTS 4096    /* device-side (start, end) tick pairs of rex_set_timing(3) */
 struct RexSim {
   RexConfig cfg;
   rex::DevCfg dev;
@@ -1023,7 +1025,8 @@ struct RexSim {
   int timing;
   int have_timing;
   // ring of event pairs around the last REX_TIMING_RING launches: per-launch durations without a host sync in between
-  unsigned long long* d_clock;   // [REX_TIMING_RING][2] device-side (min start, max end) ticks, rex_set_timing(3)
+  unsigned long long* d_clock;   // [REX_CLOCK_SLOTS][2] device-side (min start, max end) ticks, rex_set_timing(3)
+  unsigned long long* h_clock;   // host staging of the same (per sim: no buffer is shared between sims or threads)
   int32_t* d_perm;   // regrouping (large batches only): wave slot -> env, and the per-env sweep counts it is sorted by
   int32_t* d_sweeps;
   hipEvent_t ring0[REX_TIMING_RING], ring1[REX_TIMING_RING];

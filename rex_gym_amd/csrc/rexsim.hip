@@ -254,7 +254,7 @@ int rex_create(const RexConfig* cfg, int device, float* d_state, void* stream, R
   d.pose_index = cfg->pose_index; d.pose_value = cfg->pose_value;
   d.range_normalize = cfg->range_normalize;
   d.terrain = nullptr; d.terrain_mid = nullptr; d.n_terrain = 0; d.body_params = nullptr;
-  d.perm = nullptr; d.sweeps = nullptr; s->d_perm = nullptr; s->d_sweeps = nullptr; d.clock = nullptr; s->d_clock = nullptr;
+  d.perm = nullptr; d.sweeps = nullptr; s->d_perm = nullptr; s->d_sweeps = nullptr; d.clock = nullptr; s->d_clock = nullptr; s->h_clock = nullptr;
   d.geo = rex::HfGeom{256, 20.0f, 20.0f, 127.5f, 127.5f, 254.999f, 254.999f}; d.hf_stride = 65536;   /* model/terrain.py:32-54 */
   d.init_z = cfg->init_height > 0.0f ? cfg->init_height : rex::kInitZ;
   d.anchor = 0.0f;
@@ -375,6 +375,7 @@ int rex_destroy(RexSim* s) {
   (void)hipSetDevice(s->device);
   (void)hipFree(s->d_snap);
   if (s->d_clock) (void)hipFree(s->d_clock);
+  free(s->h_clock);
   if (s->d_perm) (void)hipFree(s->d_perm);
   if (s->d_sweeps) (void)hipFree(s->d_sweeps);
   (void)hipEventDestroy(s->ev0);
@@ -413,7 +414,7 @@ int rex_step(RexSim* s, const float* d_action, float* d_obs, float* d_reward, ui
     if (!s->ring0[k]) { HIPCHK(hipEventCreate(&s->ring0[k])); HIPCHK(hipEventCreate(&s->ring1[k])); }
     e0 = s->ring0[k]; e1 = s->ring1[k];
   }
-  if (s->timing == 3 && s->timed_steps < REX_TIMING_RING) {   // device-side timestamps: this launch's (min start, max end) slot
+  if (s->timing == 3 && s->timed_steps < REX_CLOCK_SLOTS) {   // device-side timestamps: this launch's (min start, max end) slot
     s->dev.clock = s->d_clock + 2 * s->timed_steps;           // (all slots were primed by rex_set_timing: nothing is copied per
     s->timed_steps++;                                         // launch, the queue stays as full as in an untimed run)
   } else s->dev.clock = nullptr;
@@ -445,12 +446,14 @@ int rex_set_timing(RexSim* s, int enable) {
   s->timing = (enable == 2 || enable == 3) ? enable : (enable ? 1 : 0);
   s->have_timing = 0;
   s->timed_steps = 0;
-  if (s->timing == 3) {   // the next REX_TIMING_RING launches are timed on the device; prime their (min, max) slots
-    if (!s->d_clock) HIPCHK(hipMalloc(&s->d_clock, sizeof(unsigned long long) * 2 * REX_TIMING_RING));
-    static unsigned long long init[2 * REX_TIMING_RING];
-    for (int k = 0; k < REX_TIMING_RING; ++k) { init[2 * k] = ~0ull; init[2 * k + 1] = 0ull; }
+  if (s->timing == 3) {   // the next REX_CLOCK_SLOTS launches are timed on the device; prime their (min, max) slots
+    HIPCHK(hipSetDevice(s->device));
+    if (!s->d_clock) HIPCHK(hipMalloc(&s->d_clock, sizeof(unsigned long long) * 2 * REX_CLOCK_SLOTS));
+    if (!s->h_clock) s->h_clock = (unsigned long long*)malloc(sizeof(unsigned long long) * 2 * REX_CLOCK_SLOTS);
+    if (!s->h_clock) return fail(REX_ENOMEM, "rex_set_timing: host buffer%s", "");
+    for (int k = 0; k < REX_CLOCK_SLOTS; ++k) { s->h_clock[2 * k] = ~0ull; s->h_clock[2 * k + 1] = 0ull; }
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpy(s->d_clock, init, sizeof(init), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(s->d_clock, s->h_clock, sizeof(unsigned long long) * 2 * REX_CLOCK_SLOTS, hipMemcpyHostToDevice));
   }
   return REX_OK;
 }
@@ -458,12 +461,14 @@ int rex_set_timing(RexSim* s, int enable) {
 int rex_step_times_ms(RexSim* s, float* ms, int max_count) {
   if (!s || !ms || max_count <= 0) return fail(REX_EINVAL, "rex_step_times_ms: bad arguments%s", "");
   if ((s->timing != 2 && s->timing != 3) || s->timed_steps == 0) return 0;
-  long long have = s->timed_steps < REX_TIMING_RING ? s->timed_steps : REX_TIMING_RING;
+  const long long cap = s->timing == 3 ? REX_CLOCK_SLOTS : REX_TIMING_RING;
+  long long have = s->timed_steps < cap ? s->timed_steps : cap;
   int n = (int)(have < max_count ? have : max_count);
+  HIPCHK(hipSetDevice(s->device));
   if (s->timing == 3) {
-    static unsigned long long ticks[2 * REX_TIMING_RING];
+    unsigned long long* ticks = s->h_clock;
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpy(ticks, s->d_clock, sizeof(ticks), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(ticks, s->d_clock, sizeof(unsigned long long) * 2 * REX_CLOCK_SLOTS, hipMemcpyDeviceToHost));
     int khz = 100000;   // s_memrealtime: constant 100 MHz on gfx9
     (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, s->device);
     for (int j = 0; j < n; ++j) {

@@ -336,9 +336,13 @@ class RexBatchEnv:
             r.randomize_env(self)
         self._randomize_indices = None
 
-    def step(self, actions):
+    def step(self, actions, out=None):
         """actions [N, action_dim] (device float32 tensor, or array-like). Returns device tensors
-        (obs [N,O], reward [N], done [N] bool) and info {'action': motor command [N,12]}."""
+        (obs [N,O], reward [N], done [N] bool) and info {'action': motor command [N,12]}.
+
+        out=(obs [N,O] float32, reward [N] float32, done [N] uint8 or bool): the launch writes its results straight into
+        these contiguous device tensors -- e.g. slice t of a rollout segment [T, N, ...] that is handed to the learner
+        (sharding.gather_rollout) -- instead of the env's own buffers; nothing is copied."""
         torch = self._torch
         if self._needs_reset:
             raise RuntimeError("Must reset environment.")   # wrappers.py:286-288 semantics
@@ -366,6 +370,13 @@ class RexBatchEnv:
             if bool(rows.any()):
                 i = int(torch.nonzero(rows)[0])
                 raise ValueError(f"Invalid action at index {i}: {a[i].tolist()}")
-        _lib.check(self._L.rex_step(self._h, a.data_ptr(), self._obs.data_ptr(), self._reward.data_ptr(),
-                                    self._done.data_ptr(), self._cmd.data_ptr(), self._stream_ptr()), "rex_step")
-        return self._obs, self._reward, self._done.view(self._torch.bool), {"action": self._cmd}
+        obs, reward, done = (self._obs, self._reward, self._done) if out is None else out
+        if out is not None:
+            for t, shape, dt in ((obs, (self.num_envs, self.obs_dim), (torch.float32,)), (reward, (self.num_envs,), (torch.float32,)),
+                                 (done, (self.num_envs,), (torch.uint8, torch.bool))):
+                if tuple(t.shape) != shape or t.dtype not in dt or not t.is_contiguous() or t.device != self.device:
+                    raise ValueError(f"out tensors must be contiguous on {self.device}: obs {(self.num_envs, self.obs_dim)} float32, "
+                                     f"reward {(self.num_envs,)} float32, done {(self.num_envs,)} uint8 / bool")
+        _lib.check(self._L.rex_step(self._h, a.data_ptr(), obs.data_ptr(), reward.data_ptr(),
+                                    done.data_ptr(), self._cmd.data_ptr(), self._stream_ptr()), "rex_step")
+        return obs, reward, done if done.dtype == torch.bool else done.view(torch.bool), {"action": self._cmd}

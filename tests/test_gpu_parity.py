@@ -737,6 +737,30 @@ def test_bench_prints_one_json_line_with_the_contract_fields(torch):
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert abs(d["value"] - 4096 * 60 / (d["ms_per_step"] * 1e-3 * 60)) / d["value"] < 1e-9
     assert 0.05 < r["kernel_ms"] < 5.0 and r["kernel_ms_min"] <= r["kernel_ms"]
+    assert r["kernel_ms_over"].startswith("60 of the 60 timed launches")         # the kernel time is that of the timed launches
+    assert abs(r["kernel_ms"] - d["ms_per_step"]) / d["ms_per_step"] < 0.2
+
+
+def test_bench_two_ranks_gather_rollout_segments(torch):
+    """The multi-GPU launch path of bench.py on a one-GPU box: two ranks (gloo, sharing the GPU) run a strong-scaling shard of
+    BASELINE configs[2] each and all-gather their rollout segments every 25 steps (the design's one collective, SURVEY 8e);
+    the line reports the hand-off's bytes and time next to the throughput with and without it."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29300 + os.getpid() % 500
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "50", "--warmup", "25",
+                          "--config", "3", "--envs-per-gpu", "1024", "--backend", "gloo", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["envs_total"] == 2048 and d["finite"]
+    g = d["rollout_gather"]
+    # gallop-OL: obs 16 x 4 + action 4 x 4 + reward 4 + done 1 = 85 B per env-step (SURVEY 8e)
+    assert g["every_steps"] == 25 and g["bytes_per_env_step"] == 85 and g["segment_bytes_per_rank"] == 85 * 25 * 1024
+    assert g["gather_ms_blocking"] > 0 and g["value_without_gather"] > 0
 
 
 @pytest.mark.parametrize("task,signal,mark,terrain", [
