@@ -151,6 +151,7 @@ static real FRICTION_MU = (real)0.5;      /* toe 0.5 x plane 1.0, 9.2-7 (variabl
  * the 16-thread throughput of the cpu_baseline). */
 static int DBG_STATS = 0;
 static long DBG_HIST[64] __attribute__((aligned(128))) = {0};
+static long DBG_LEGS[5][5] = {{0}};   /* [legs within breaking distance][legs carrying load] per substep (single-threaded census runs) */
 static long DBG_SWEEPS = 0, DBG_SUBSTEPS = 0;
 static real DBG_JOINT_FRICTION = 0, DBG_JOINT_VISC = 0; /* sensitivity probe only (off by default) */
 /* ---- sensitivity probes over the Bullet-behaviour assumptions of SURVEY.md 9.2 (tools/physics_sensitivity.py).
@@ -1078,6 +1079,17 @@ static void physics_substep(Phys* s, const real tau[NJ], real dt, int iterations
     if (DBG_STATS && it == iterations - 1) DBG_HIST[63]++;
   }
   if (DBG_STATS) ++DBG_SUBSTEPS;
+  if (DBG_STATS) {   /* census: legs with a toe point within the breaking distance / legs that carry a normal impulse */
+    int act[REX_NLEG] = {0}, load[REX_NLEG] = {0};
+    for (int p = 0; p < toe_points; ++p) {
+      int l = (PtBody[p] - 1) / 3;
+      act[l] = 1;
+      if (rows[normal_of_point[p]].lambda > 0) load[l] = 1;
+    }
+    int na = 0, nl = 0;
+    for (int l = 0; l < REX_NLEG; ++l) { na += act[l]; nl += load[l]; }
+    DBG_LEGS[na][nl]++;
+  }
   /* apply, clamp (btMultiBody::applyDeltaVeeMultiDof), integrate positions with the NEW velocities */
   real dw[3], dl[3];
   matvec3(A.Rw[0], dv, dw);
@@ -1917,6 +1929,7 @@ ORC_API void orc_set_state(void* h, const double* in) {
 }
 
 ORC_API void orc_set_joint_friction(real f, real visc) { DBG_JOINT_FRICTION = f; DBG_JOINT_VISC = visc; }
+ORC_API void orc_leg_census(long* out, int reset) { DBG_STATS = 1; memcpy(out, DBG_LEGS, sizeof(DBG_LEGS)); if (reset) memset(DBG_LEGS, 0, sizeof(DBG_LEGS)); }
 ORC_API void orc_solver_hist(long* h) { DBG_STATS = 1; for (int i = 0; i < 64; ++i) { h[i] = DBG_HIST[i]; DBG_HIST[i] = 0; } }
 ORC_API void orc_solver_stats(long* sweeps, long* substeps, int reset) { DBG_STATS = 1; *sweeps = DBG_SWEEPS; *substeps = DBG_SUBSTEPS; if (reset) { DBG_SWEEPS = 0; DBG_SUBSTEPS = 0; } }
 ORC_API void orc_set_friction(real mu) { FRICTION_MU = mu; }

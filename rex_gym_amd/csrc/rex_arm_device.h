@@ -302,7 +302,7 @@ struct ArmChain {
 
   __device__ __forceinline__ void pass(const BaseKin& bk, PhysState& s, const float* tau, float dt, BaseAccum& acc, const Ground& ground) {
     ArmFactor L;
-    const unsigned act = arm_pass(bk, s.q + 12, s.qd + 12, tau + 12, dt, L, acc, sma, ground);
+    const unsigned act = arm_pass(bk, s.q + 12, s.qd + 12, tau, dt, L, acc, sma, ground);   // tau: the arm's 6 torques
     arm_park(sma, L);
     active_any = 0;
 #pragma unroll

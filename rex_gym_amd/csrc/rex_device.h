@@ -34,8 +34,11 @@
    (7 chunks per leg).  Lane groups: a lane needs the factor of ITS leg only; it stays in registers (1 chunk per leg: the
    whitened leg velocity z, which every lane reads) where registers are cheaper than LDS -- 8 lanes per env (200 VGPRs)
    and mark 'arm' (LDS-bound: 3 -> 4 workgroups per CU at 16 envs per wave) -- and is parked at 16 envs per wave of mark
-   'base', whose 4 lanes per env already run into the AGPRs. */
-#define REX_LEG_F4_OF(EPW, ARM) (((EPW) <= 8 || ((EPW) <= 16 && (ARM))) ? 1 : REX_LEG_F4)
+   'base', whose 4 lanes per env already run into the AGPRs
+   -- and in the link-box kernels of mark 'base': with the factor held in registers across the sweep loop those kernels
+   (140 KB of code, 450 registers) came out of hipcc 7.2 with the joint velocities of the back-substitution wrong although
+   no link-box row was in reach (same source minus the never-executed candidate search: correct), round 3. */
+#define REX_LEG_F4_OF(EPW, ARM, BODY) ((((EPW) <= 8 && !((BODY) && !(ARM))) || ((EPW) <= 16 && (ARM))) ? 1 : REX_LEG_F4)
 #define REX_ROWS_F4_OF(LEGF4) (REX_NROW * REX_ROW_F4 + REX_NLEG * (LEGF4))   /* rows + leg chunks: 136 (2.2 KB) or 112 */
 #define REX_LDS_F4_PER_ENV REX_ROWS_F4_OF(REX_LEG_F4)
 /* small-batch waves (EPW <= 16) only: chunks 0..1 the whitened base velocity y on its way to / from the lanes that own
@@ -44,11 +47,6 @@
 /* link-box contact rows (RexConfig.body_contacts): 12 point slots -- 0..3 the base group (base + chassis boxes), 4 + 2 L + k
    leg L's boxes -- with a normal row (index slot) and two friction rows (12 + 2 slot + d) each, 3 chunks per row like the
    toe rows, in their own LDS region behind the hand-over chunks; lane groups only */
-/* mark 'arm' at <= 8 envs per wave: what the motor model keeps per env across a physics substep -- 18 commands, 18 observed
-   torques, 18 overheat counters, 11 scalars of the env state -- waits in LDS while the substep runs, instead of in
-   registers the 19-body substep then spills (ScratchSize 204 / 208 B per lane before) */
-#define REX_MOTOR_PARK_WORDS (3 * 18 + 11)
-#define REX_MOTOR_PARK_F4 ((REX_MOTOR_PARK_WORDS + 3) / 4)
 #define REX_NBSLOT 12
 #define REX_NBROW (3 * REX_NBSLOT)
 // behind the rows: the base Jacobian (2 chunks) of each of the 24 leg-group rows when its point is held against the base
@@ -86,8 +84,6 @@ struct Lds {
   float4* p; int slot;
   float4* pk;   // hand-over region of pgs_dv (REX_PARK_F4 chunks per env, behind the rows of all marks); null when EPW = 64
   float4* pb;   // link-box contact rows (BODY only): REX_BODY_F4 chunks per env behind the hand-over region
-  float4* pm;   // motor-side state parked around the physics call (mark 'arm', <= 8 envs per wave; else null): REX_MOTOR_PARK_F4 chunks per env
-  __device__ __forceinline__ float& motorf(int f) const { return reinterpret_cast<float*>(&pm[(f >> 2) * EPW + slot])[f & 3]; }
   __device__ __forceinline__ float4& brow(int r, int c) const { return pb[(r * REX_ROW_F4 + c) * EPW + slot]; }
   __device__ __forceinline__ float4& bjac(int i, int c) const { return pb[(REX_NBROW * REX_ROW_F4 + 2 * i + c) * EPW + slot]; }   // i = 3 (slot - 4) + direction
   __device__ __forceinline__ float4& park(int c) const { return pk[c * EPW + slot]; }
@@ -1168,7 +1164,8 @@ __device__ __forceinline__ void pgs_dv(const SM& sm, ARMP& armp, PgsX& x, int p,
   armp.dv_gather();
 }
 
-// The restated pybullet.stepSimulation for one env (one lane): tau is held for this substep.
+// The restated pybullet.stepSimulation for one env: tau is held for this substep (one env per lane: the 12 leg torques in
+// motor order; lane groups: the 3 torques of the lane's own leg, then the arm's 6 for mark 'arm').
 template <class T>
 __device__ __forceinline__ void rotate_leg(T* a) {   // 12-entry per-joint array: leg k+1 moves into leg k's slots
   const T t0 = a[0], t1 = a[1], t2 = a[2];
@@ -1235,7 +1232,7 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
   if constexpr (kSplitLegs) {
     const float ql[3] = {pick_leg(s.q, mleg, 0), pick_leg(s.q, mleg, 1), pick_leg(s.q, mleg, 2)};
     const float qdl[3] = {pick_leg(s.qd, mleg, 0), pick_leg(s.qd, mleg, 1), pick_leg(s.qd, mleg, 2)};
-    const float tl[3] = {pick_leg(tau, mleg, 0), pick_leg(tau, mleg, 1), pick_leg(tau, mleg, 2)};
+    const float tl[3] = {tau[0], tau[1], tau[2]};   // lane groups: `tau` holds the torques of the lane's own leg (then the arm's)
     BaseAccum part;
     part.Io = s33{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     part.h = part.N = part.F = mk(0.f, 0.f, 0.f);
@@ -1355,7 +1352,7 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
       }
     }
   }
-  armp.pass(bk, s, tau, dt, acc, ground);   // extra branch on the base (mark='arm'), no-op otherwise
+  armp.pass(bk, s, tau + (kSplitLegs ? 3 : 12), dt, acc, ground);   // extra branch on the base (mark='arm'; its 6 torques), no-op otherwise
 
   // base articulated inertia A = [[Io, hx],[hx^T, m]] - S, then A = Lc Lc^T
   float A[21];

@@ -22,6 +22,9 @@
 #include "rex_controller.h"
 
 
+#define REX_CLOCK_SLOTS 4096    /* launches timed by rex_set_timing(3) */
+#define REX_CLOCK_WAYS 64       /* (start, end) tick pairs per launch: workgroup b folds into pair b % 64 -- one shared pair serialises 1 024 atomics */
+
 namespace rex {
 
 // INIT_POSES (model/rex_constants.py:10-22), motor order FL,FR,RL,RR x (shoulder, leg, foot)
@@ -65,6 +68,37 @@ __device__ __forceinline__ float ldw(const float* st, int n, int w, int i) { ret
 __device__ __forceinline__ uint32_t ldi(const float* st, int n, int w, int i) { return __float_as_uint(ldw(st, n, w, i)); }
 __device__ __forceinline__ void stw(float* st, int n, int w, int i, float v) { st[(unsigned)(w * n + i)] = v; }
 __device__ __forceinline__ void sti(float* st, int n, int w, int i, uint32_t v) { stw(st, n, w, i, __uint_as_float(v)); }
+
+// What a lane carries of the MOTOR side of its env (commands, observed torques, overheat counters).  One env per lane
+// (NL = 4): all four legs.  Lane groups (NL = 1): the lane's OWN leg only -- leg `leg0` of the motor order FL, FR, RL, RR;
+// the group's lanes split the controller (Bezier + IK), the motor model and the observation words by leg exactly as they
+// split the leg factorisations of the physics, and meet again in the reward's dot product (a DPP sum) and in the state
+// words lane 0 stores.  The 6 arm motors of mark 'arm' are carried by every lane (local indices 3 NL ...).
+template <int NL, bool ARM>
+struct MotorSide {
+  static constexpr int NLM = 3 * NL, NA = ARM ? 6 : 0, N = NLM + NA;
+  float cmd[N], tau_obs[N];
+  uint32_t overheat[N];
+  // motor number (mark_constants.py order) of local index jl
+  __device__ __forceinline__ static int motor(int leg0, int jl) { return jl < NLM ? (NL == 4 ? jl : 3 * leg0 + jl) : 12 + (jl - NLM); }
+};
+// entry jl of a per-motor array of all 12 leg motors as this lane sees its legs (NL = 1: a select, no dynamic indexing)
+template <int NL>
+__device__ __forceinline__ float legv(const float* a, int leg0, int jl) { return NL == 4 ? a[jl] : pick_leg(a, leg0, jl); }
+template <int NL>
+__device__ __forceinline__ uint32_t legu(const uint32_t* a, int leg0, int jl) {
+  if (NL == 4) return a[jl];
+  const uint32_t lo = leg0 & 1 ? a[3 + jl] : a[jl], hi = leg0 & 1 ? a[9 + jl] : a[6 + jl];
+  return leg0 & 2 ? hi : lo;
+}
+// this lane's share of the counters loaded with the state, and back (lane groups: through the hand-over chunks in LDS)
+template <int NL, bool ARM>
+__device__ __forceinline__ void take_overheat(const EnvState& e, int leg0, MotorSide<NL, ARM>& ms) {
+#pragma unroll
+  for (int jl = 0; jl < 3 * NL; ++jl) ms.overheat[jl] = legu<NL>(e.overheat, leg0, jl);
+#pragma unroll
+  for (int a = 0; a < (ARM ? 6 : 0); ++a) ms.overheat[3 * NL + a] = e.overheat[12 + a];
+}
 
 template <int NM>
 __device__ __forceinline__ void load_env(const float* st, int n, int i, EnvState& e) {
@@ -280,8 +314,9 @@ __device__ __forceinline__ void delay_slots(uint32_t hist, float latency, int n,
 __device__ __forceinline__ float delayed_word(const DevCfg& c, int i, int s0, int s1, float alpha, int w) {
   return (1.0f - alpha) * hist_at(c, i, s0, w) + alpha * hist_at(c, i, s1, w);
 }
-// the controller-facing observation (Rex._control_observation): q, qd, tau_obs, quat, angular velocity
-struct CtrlObs { float q[18], qd[18], tau[18], quat[4], w[3]; };
+// the controller-facing observation (Rex._control_observation): q, qd, tau_obs of the lane's motors (MotorSide's local
+// order), base quaternion, base angular velocity
+template <int N> struct CtrlObs { float q[N], qd[N], tau[N], quat[4], w[3]; };
 
 // terrain of (global env index, episode): the reference regenerates the field on every reset
 // (rex_gym_env.py:347-348); here each episode picks one of the pool entries
@@ -312,88 +347,81 @@ __device__ __forceinline__ Ground env_ground(const DevCfg& c, int i, int gidx, i
   return g;
 }
 
-// Rex.ReceiveObservation (rex.py:726-733): the true observation goes to the front of the history ring
-template <int NM>
-__device__ __forceinline__ void receive_observation(const DevCfg& c, EnvState& e, int i, bool live, const float* tau_obs) {
+// Rex.ReceiveObservation (rex.py:726-733): the true observation goes to the front of the history ring.  `owner`: this
+// lane writes the words of its leg's motors; `live` (one lane per env): the arm's, the base quaternion and angular velocity.
+template <int NM, int NL, bool ARM>
+__device__ __forceinline__ void receive_observation(const DevCfg& c, EnvState& e, int i, bool live, bool owner, int leg0,
+                                                    const MotorSide<NL, ARM>& ms) {
   if (!c.hist) return;
   const int head = ((int)(e.hist & 0xFFu) + 1) % REX_HISTORY_LEN;
   const int len = min((int)((e.hist >> 8) & 0xFFu) + 1, REX_HISTORY_LEN);
   e.hist = (uint32_t)head | ((uint32_t)len << 8);
+  if (owner) {
+#pragma unroll
+    for (int jl = 0; jl < 3 * NL; ++jl) {
+      const int j = MotorSide<NL, ARM>::motor(leg0, jl);
+      hist_at(c, i, head, j) = legv<NL>(e.ph.q, leg0, jl); hist_at(c, i, head, NM + j) = legv<NL>(e.ph.qd, leg0, jl);
+      hist_at(c, i, head, 2 * NM + j) = ms.tau_obs[jl];
+    }
+  }
   if (live) {
 #pragma unroll
-    for (int j = 0; j < NM; ++j) { hist_at(c, i, head, j) = e.ph.q[j]; hist_at(c, i, head, NM + j) = e.ph.qd[j]; hist_at(c, i, head, 2 * NM + j) = tau_obs[j]; }
+    for (int a = 0; a < (ARM ? 6 : 0); ++a) {
+      hist_at(c, i, head, 12 + a) = e.ph.q[12 + a]; hist_at(c, i, head, NM + 12 + a) = e.ph.qd[12 + a];
+      hist_at(c, i, head, 2 * NM + 12 + a) = ms.tau_obs[3 * NL + a];
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) hist_at(c, i, head, 3 * NM + k) = e.ph.quat[k];
 #pragma unroll
     for (int k = 0; k < 3; ++k) hist_at(c, i, head, 3 * NM + 4 + k) = e.ph.ang[k];
   }
+  if (NL == 1) mirror_sync();   // the ring entry has several writers; its readers are other lanes of the group
 }
 
-// Rex.ApplyAction + stepSimulation + ReceiveObservation (rex.py:158-163, 568-641).
-template <bool LANECAP, class SM, class ARMP>
-__device__ __forceinline__ void rex_substep(const DevCfg& c, EnvState& e, int i, bool live, float* cmd, float* tau_obs,
+// Rex.ApplyAction + stepSimulation + ReceiveObservation (rex.py:158-163, 568-641) for the motors this lane carries.
+template <bool LANECAP, int NL, bool ARM, class SM, class ARMP>
+__device__ __forceinline__ void rex_substep(const DevCfg& c, EnvState& e, int i, bool live, bool owner, int leg0, MotorSide<NL, ARM>& ms,
                                             const SM& sm, const Ground& ground, ARMP& armp) {
-  constexpr int NM = ARMP::NM;
-  float tau[18];
+  constexpr int NM = ARMP::NM, N = MotorSide<NL, ARM>::N;
+  float tau[N];
   const float limit = 1.0f / c.dt;  // OVERHEAT_SHUTDOWN_TIME / time_step, rex.py:607
-  float qo[NM], qdo[NM];                        // what the PD loop sees: _GetPDObservation, rex.py:755-759
+  int s0 = 0, s1 = 0;
+  float alpha = 0.0f;
+  if (c.hist) delay_slots(e.hist, c.pd_latency, c.pd_slots, c.pd_alpha, s0, s1, alpha);   // what the PD loop sees: _GetPDObservation, rex.py:755-759
 #pragma unroll
-  for (int j = 0; j < NM; ++j) { qo[j] = e.ph.q[j]; qdo[j] = e.ph.qd[j]; }
-  if (c.hist) {
-    int s0, s1;
-    float alpha;
-    delay_slots(e.hist, c.pd_latency, c.pd_slots, c.pd_alpha, s0, s1, alpha);
-#pragma unroll
-    for (int j = 0; j < NM; ++j) { qo[j] = delayed_word(c, i, s0, s1, alpha, j); qdo[j] = delayed_word(c, i, s0, s1, alpha, NM + j); }
-  }
-#pragma unroll
-  for (int j = 0; j < NM; ++j) {
+  for (int jl = 0; jl < N; ++jl) {
+    const int j = MotorSide<NL, ARM>::motor(leg0, jl);
+    const float qt = jl < 3 * NL ? legv<NL>(e.ph.q, leg0, jl) : e.ph.q[12 + (jl - 3 * NL)];
+    const float qdt = jl < 3 * NL ? legv<NL>(e.ph.qd, leg0, jl) : e.ph.qd[12 + (jl - 3 * NL)];
+    float qo = qt, qdo = qdt;
+    if (c.hist) { qo = delayed_word(c, i, s0, s1, alpha, j); qdo = delayed_word(c, i, s0, s1, alpha, NM + j); }
     float act, obs;
-    motor_torque(cmd[j], qo[j], qdo[j], e.ph.qd[j], c.kp, c.kd, act, obs);
-    uint32_t cnt = e.overheat[j];
+    motor_torque(ms.cmd[jl], qo, qdo, qdt, c.kp, c.kd, act, obs);
+    uint32_t cnt = ms.overheat[jl];
     cnt = fabsf(act) > 2.45f ? min(cnt + 1u, 65535u) : 0u;                      // rex.py:603-606
-    if ((float)cnt > limit) e.motor_en &= ~(1u << j);                           // rex.py:607-608
-    e.overheat[j] = cnt;
-    tau_obs[j] = obs;
-    tau[j] = ((e.motor_en >> j) & 1u) ? act : 0.0f;                             // rex.py:617-623
-  }
-  // mark 'arm', <= 8 envs per wave: the motor-side state of the env waits in LDS while the substep runs (rex_device.h,
-  // REX_MOTOR_PARK_WORDS); one lane of the group writes, all read back
-  constexpr bool kPark = NM == 18 && SM::kEpw <= 8;
-  if constexpr (kPark) {
-    if ((threadIdx.x & 7u) == 0u) {
-#pragma unroll
-      for (int j = 0; j < 18; ++j) { sm.motorf(j) = cmd[j]; sm.motorf(18 + j) = tau_obs[j]; sm.motorf(36 + j) = __uint_as_float(e.overheat[j]); }
-      sm.motorf(54) = e.phi; sm.motorf(55) = __int_as_float(e.last_step); sm.motorf(56) = e.alpha;
-      sm.motorf(57) = e.target; sm.motorf(58) = __int_as_float(e.end_step); sm.motorf(59) = e.aux;
-      sm.motorf(60) = __uint_as_float(e.flags); sm.motorf(61) = __int_as_float(e.steps); sm.motorf(62) = __int_as_float(e.episode);
-      sm.motorf(63) = __uint_as_float(e.motor_en); sm.motorf(64) = __uint_as_float(e.hist);
-    }
-    asm volatile("" ::: "memory");
+    if ((float)cnt > limit) e.motor_en &= ~(1u << j);                           // rex.py:607-608 (lane groups: the lane's own bits;
+    ms.overheat[jl] = cnt;                                                      //  the masks are merged before the state is stored)
+    ms.tau_obs[jl] = obs;
+    tau[jl] = ((e.motor_en >> j) & 1u) ? act : 0.0f;                            // rex.py:617-623
   }
   physics_substep<LANECAP>(e.ph, tau, c.dt, c.max_iterations, c.iterations, c.res_thr, sm, ground, armp, e.sweeps);
-  if constexpr (kPark) {
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int j = 0; j < 18; ++j) { cmd[j] = sm.motorf(j); tau_obs[j] = sm.motorf(18 + j); e.overheat[j] = __float_as_uint(sm.motorf(36 + j)); }
-    e.phi = sm.motorf(54); e.last_step = __float_as_int(sm.motorf(55)); e.alpha = sm.motorf(56);
-    e.target = sm.motorf(57); e.end_step = __float_as_int(sm.motorf(58)); e.aux = sm.motorf(59);
-    e.flags = __float_as_uint(sm.motorf(60)); e.steps = __float_as_int(sm.motorf(61)); e.episode = __float_as_int(sm.motorf(62));
-    e.motor_en = __float_as_uint(sm.motorf(63)); e.hist = __float_as_uint(sm.motorf(64));
-  }
-  receive_observation<NM>(c, e, i, live, tau_obs);
+  receive_observation<NM>(c, e, i, live, owner, leg0, ms);
 }
 
-// Rex._control_observation as the env-level getters see it (delayed by control_latency when the model is on)
-template <int NM>
-__device__ __forceinline__ void control_observation(const DevCfg& c, const EnvState& e, int i, const float* tau_obs, CtrlObs& o) {
+// Rex._control_observation as the env-level getters see it (delayed by control_latency when the model is on), for the
+// motors this lane carries
+template <int NM, int NL, bool ARM>
+__device__ __forceinline__ void control_observation(const DevCfg& c, const EnvState& e, int i, int leg0, const MotorSide<NL, ARM>& ms,
+                                                    CtrlObs<MotorSide<NL, ARM>::N>& o) {
+  constexpr int N = MotorSide<NL, ARM>::N;
   if (c.hist) {
     int s0, s1; float alpha;
     delay_slots(e.hist, c.control_latency, c.control_slots, c.control_alpha, s0, s1, alpha);
 #pragma unroll
-    for (int j = 0; j < NM; ++j) {
-      o.q[j] = delayed_word(c, i, s0, s1, alpha, j); o.qd[j] = delayed_word(c, i, s0, s1, alpha, NM + j);
-      o.tau[j] = delayed_word(c, i, s0, s1, alpha, 2 * NM + j);
+    for (int jl = 0; jl < N; ++jl) {
+      const int j = MotorSide<NL, ARM>::motor(leg0, jl);
+      o.q[jl] = delayed_word(c, i, s0, s1, alpha, j); o.qd[jl] = delayed_word(c, i, s0, s1, alpha, NM + j);
+      o.tau[jl] = delayed_word(c, i, s0, s1, alpha, 2 * NM + j);
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) o.quat[k] = delayed_word(c, i, s0, s1, alpha, 3 * NM + k);
@@ -401,7 +429,11 @@ __device__ __forceinline__ void control_observation(const DevCfg& c, const EnvSt
     for (int k = 0; k < 3; ++k) o.w[k] = delayed_word(c, i, s0, s1, alpha, 3 * NM + 4 + k);
   } else {
 #pragma unroll
-    for (int j = 0; j < NM; ++j) { o.q[j] = e.ph.q[j]; o.qd[j] = e.ph.qd[j]; o.tau[j] = tau_obs[j]; }
+    for (int jl = 0; jl < N; ++jl) {
+      o.q[jl] = jl < 3 * NL ? legv<NL>(e.ph.q, leg0, jl) : e.ph.q[12 + (jl - 3 * NL)];
+      o.qd[jl] = jl < 3 * NL ? legv<NL>(e.ph.qd, leg0, jl) : e.ph.qd[12 + (jl - 3 * NL)];
+      o.tau[jl] = ms.tau_obs[jl];
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) o.quat[k] = e.ph.quat[k];
 #pragma unroll
@@ -410,18 +442,24 @@ __device__ __forceinline__ void control_observation(const DevCfg& c, const EnvSt
 }
 
 // RangeNormalize of the observation (wrappers.py:236-240); bounds are symmetric (rex_gym_env.py:277-278)
-__device__ __forceinline__ void normalize_obs(const DevCfg& c, float* obs) {
-#pragma unroll
-  for (int k = 0; k < 22; ++k) {
-    if (k < c.obs_dim) {
-      const float hi = (k == 2 || k == 3) ? c.obs_hi_rate : c.obs_hi_ang, lo = -hi;
-      obs[k] = 2.0f * (obs[k] - lo) / (hi - lo) - 1.0f;
-    }
-  }
+__device__ __forceinline__ float normalize_obs1(const DevCfg& c, int k, float v) {
+  const float hi = (k == 2 || k == 3) ? c.obs_hi_rate : c.obs_hi_ang, lo = -hi;
+  return 2.0f * (v - lo) / (hi - lo) - 1.0f;
+}
+// one standard normal draw of a getter call site's motor j (blocks of four motors, see gauss4)
+__device__ __forceinline__ float gauss_motor(const DevCfg& c, int gidx, int episode, int step, int site, int j) {
+  float z[4];
+  gauss4(c.seed_lo, c.seed_hi, gidx, episode, step, site + (j >> 2), z);
+  const int k = j & 3;
+  return k == 0 ? z[0] : (k == 1 ? z[1] : (k == 2 ? z[2] : z[3]));
 }
 
-template <int NM>
-__device__ __forceinline__ void env_observation(const DevCfg& c, const CtrlObs& co, float* obs, int gidx = 0, int episode = 0, int step = 0) {
+// _get_observation: obs[0..3] = roll, pitch, roll rate, pitch rate (walk_env.py:356-362); the gallop env appends the motor
+// angles (gallop_env.py:349-356) -- `ang` receives those of the motors this lane carries (MotorSide's local order)
+template <int NM, int N>
+__device__ __forceinline__ void env_observation(const DevCfg& c, const CtrlObs<N>& co, int leg0, float* obs, float* ang,
+                                                int gidx = 0, int episode = 0, int step = 0) {
+  constexpr int NLM = NM == 18 ? N - 6 : N;
   float rpy[3];
   quat_to_euler(co.quat, rpy);
   float wx = co.w[0], wy = co.w[1];
@@ -432,18 +470,17 @@ __device__ __forceinline__ void env_observation(const DevCfg& c, const CtrlObs& 
   }
   obs[0] = rpy[0]; obs[1] = rpy[1]; obs[2] = wx; obs[3] = wy;                       // walk_env.py:356-362
   if (c.task == REX_TASK_GALLOP) {
-    float nz[20];
     const bool noisy = c.noise_on && c.noise[0] > 0.0f;                           // GetMotorAngles: noise, then MapToMinusPiToPi (rex.py:457-468)
-    if (noisy) {
 #pragma unroll
-      for (int b = 0; b < (NM + 3) / 4; ++b) gauss4(c.seed_lo, c.seed_hi, gidx, episode, step, kNzAngle + b, nz + 4 * b);
-    }
-#pragma unroll
-    for (int j = 0; j < NM; ++j) {                                                // MapToMinusPiToPi, rex.py:26-41
-      float a = fmodf(co.q[j] + (noisy ? c.noise[0] * nz[j] : 0.0f), 2.0f * kPi);
+    for (int jl = 0; jl < N; ++jl) {                                              // MapToMinusPiToPi, rex.py:26-41
+      const int j = jl < NLM ? (NLM == 12 ? jl : 3 * leg0 + jl) : 12 + (jl - NLM);
+      float a = fmodf(co.q[jl] + (noisy ? c.noise[0] * gauss_motor(c, gidx, episode, step, kNzAngle, j) : 0.0f), 2.0f * kPi);
       if (a >= kPi) a -= 2.0f * kPi; else if (a < -kPi) a += 2.0f * kPi;
-      obs[4 + j] = a;
+      ang[jl] = a;
     }
+  } else {
+#pragma unroll
+    for (int jl = 0; jl < N; ++jl) ang[jl] = 0.0f;    // a task with a narrower observation leaves the tail of a mixed batch's row 0
   }
 }
 
@@ -507,29 +544,66 @@ __device__ __forceinline__ void env_reset(const DevCfg& c, const float* snap, in
 }
 
 // the env clock `step_counter * time_step` (rex.py:155-156) at env step k, as the double the reference holds
-__device__ __forceinline__ double step_time(const DevCfg& c, int k) { return (double)(k * c.action_repeat) * c.dt_d; }
-// GaitPlanner.loop on the env's planner state: _last_time is the (wall) clock of the env step that latched it, and
-// `_phi >= 0.99` was decided in double when _phi was computed
-__device__ __forceinline__ void env_gait_loop(const DevCfg& c, EnvState& e, int mode, float v, float angle, float w_rot, double T,
-                                              float direction, float* frames) {
-  const bool wrap = (e.flags & REX_F_PHASE_WRAP) != 0;
+__device__ __forceinline__ double step_time(const DevCfg& c, int k) {
+#pragma clang fp contract(off)   // exact double clock arithmetic: no fused multiply-add (rexsim.h, "Clocks")
+  return (double)(k * c.action_repeat) * c.dt_d;
+}
+// What a task's command code asks of the shared controller tail (ONE call site per kernel: the planner + IK code is the
+// bulk of the controller, and every copy of it lengthens a kernel that is already longer than the reach of a short branch).
+// kind 0: the joint targets are already written; 1: GaitPlanner.loop then Kinematics.solve; 2: Kinematics.solve on the
+// default stance frames (RexPosesEnv).
+struct LegCall {
+  int kind, mode;
+  float v, angle, w_rot, direction;
+  double T;
+  float pos[3], orn[3];
+};
+// GaitPlanner.loop + Kinematics.solve on the env's planner state, for the legs this lane carries: the 3 NL joint targets in
+// the motor order (the planner's leg order FR, FL, RR, RL is the motor order FL, FR, RL, RR with the sides swapped:
+// walk_env.py:284-289).  _last_time is the (wall) clock of the env step that latched it, and `_phi >= 0.99` was decided
+// in double when _phi was computed.
+template <int NL>
+__device__ __forceinline__ void env_gait_ik(const DevCfg& c, EnvState& e, int leg0, const LegCall& k, float* cmd) {
+#pragma clang fp contract(off)   // exact double clock arithmetic: no fused multiply-add (rexsim.h, "Clocks")
+  if (k.kind == 0) return;
+  const bool planner = k.kind == 1;
+  const bool wrap = planner && (e.flags & REX_F_PHASE_WRAP) != 0;
   GaitState g{wrap ? 1.0 : 0.0, step_time(c, e.last_step) * c.gait_clock_d, e.alpha};
   if (wrap) e.last_step = e.steps;
-  gait_loop(g, mode, v, angle, w_rot, T, direction, step_time(c, e.steps) * c.gait_clock_d, frames);
-  e.phi = (float)g.phi; e.alpha = g.alpha;
-  e.flags = g.phi >= 0.99 ? (e.flags | REX_F_PHASE_WRAP) : (e.flags & ~REX_F_PHASE_WRAP);
-}
-
-__device__ __forceinline__ void order_signal(const float* ang, float* cmd) {  // FR,FL,RR,RL -> FL,FR,RL,RR
+  const double now = step_time(c, e.steps) * c.gait_clock_d;
+  if constexpr (NL == 4) {
+    float frames[12], ang[12];
+    if (planner) gait_loop(g, k.mode, k.v, k.angle, k.w_rot, k.T, k.direction, now, frames);
+    else {
 #pragma unroll
-  for (int k = 0; k < 3; ++k) { cmd[k] = ang[3 + k]; cmd[3 + k] = ang[k]; cmd[6 + k] = ang[9 + k]; cmd[9 + k] = ang[6 + k]; }
+      for (int l = 0; l < 4; ++l) { frames[3 * l] = gait_bx0(l); frames[3 * l + 1] = gait_by0(l); frames[3 * l + 2] = -kIkHeight; }
+    }
+    ik_solve(k.orn, k.pos, frames, ang);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { cmd[j] = ang[3 + j]; cmd[3 + j] = ang[j]; cmd[6 + j] = ang[9 + j]; cmd[9 + j] = ang[6 + j]; }
+  } else {
+    const int own = leg0 ^ 1;
+    // the arc angle runs through the legs only while the gait turns (or a turn has left it non-zero): decided for the wave
+    const bool chain = __builtin_amdgcn_ballot_w64(planner && (k.w_rot != 0.0f || g.alpha != 0.0f)) != 0;
+    float frame[3] = {gait_bx0(own), gait_by0(own), -kIkHeight};
+    if (planner) gait_loop_leg(g, k.mode, k.v, k.angle, k.w_rot, k.T, k.direction, now, own, chain, frame);
+    ik_solve_leg(k.orn, k.pos, frame, own, cmd);
+  }
+  if (planner) {
+    e.phi = (float)g.phi; e.alpha = g.alpha;
+    e.flags = g.phi >= 0.99 ? (e.flags | REX_F_PHASE_WRAP) : (e.flags & ~REX_F_PHASE_WRAP);
+  }
 }
+// joint j (0..11, motor order) of local index jl
+template <int NL> __device__ __forceinline__ int leg_joint(int leg0, int jl) { return NL == 4 ? jl : 3 * leg0 + jl; }
 
 // RexWalkEnv._transform_action_to_motor_command (walk_env.py:207-324)
-__device__ __forceinline__ void walk_command(const DevCfg& c, EnvState& e, const float* action, float* cmd) {
+template <int NL>
+__device__ __forceinline__ void walk_command(const DevCfg& c, EnvState& e, const float* action, int leg0, float* cmd, LegCall& call) {
+#pragma clang fp contract(off)   // exact double clock arithmetic: no fused multiply-add (rexsim.h, "Clocks")
   if (e.flags & REX_F_STAY_STILL) {
 #pragma unroll
-    for (int j = 0; j < 12; ++j) cmd[j] = init_pose(c, j);
+    for (int jl = 0; jl < 3 * NL; ++jl) cmd[jl] = init_pose(c, leg_joint<NL>(leg0, jl));
     return;
   }
   const double t = step_time(c, e.steps);                                        // rex.py:155-156
@@ -543,7 +617,6 @@ __device__ __forceinline__ void walk_command(const DevCfg& c, EnvState& e, const
     const double p = 0.8 + (double)action[0];
     const float gait_coeff = (0.0 <= t && t <= p) ? (float)t : 1.0f;
     const double period = backwards ? 0.5 : 0.65;
-    const float pos[3] = {backwards ? 0.0f : 0.01f, 0.0f, 0.0f}, orn[3] = {0.0f, 0.0f, 0.0f};
     float step_length = (backwards ? -0.3f : 0.6f) * gait_coeff;
     if (e.flags & REX_F_GOAL_REACHED) {
       const double pb = 0.8 + (double)action[1];
@@ -551,11 +624,7 @@ __device__ __forceinline__ void walk_command(const DevCfg& c, EnvState& e, const
       step_length *= b;
       if (b == 0.0f) e.flags |= REX_F_STAY_STILL;
     }
-    const float direction = step_length < 0.0f ? -1.0f : 1.0f;
-    float frames[12], ang[12];
-    env_gait_loop(c, e, 0, step_length, 0.0f, 0.0f, period, direction, frames);
-    ik_solve(orn, pos, frames, ang);
-    order_signal(ang, cmd);
+    call = LegCall{1, 0, step_length, 0.0f, 0.0f, step_length < 0.0f ? -1.0f : 1.0f, period, {backwards ? 0.0f : 0.01f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
   } else {                                                                       // walk_env.py:292-315
     float l_a = 0.1f, f_a = 0.2f;
     if (e.flags & REX_F_GOAL_REACHED) {
@@ -571,18 +640,26 @@ __device__ __forceinline__ void walk_command(const DevCfg& c, EnvState& e, const
     float sph, cph;
     sincos_fast(2.0f * kPi / 0.125f * (float)t, sph, cph);
     const float le = l_a * cph, fe = f_a * cph;
-    const float pose[12] = {0.f, le + action[0], fe + action[1], 0.f, -le + action[2], -fe + action[3],
-                            0.f, -le + action[4], -fe + action[5], 0.f, le + action[6], fe + action[7]};
 #pragma unroll
-    for (int j = 0; j < 12; ++j) cmd[j] = pose_stand_ol(j) + pose[j];
+    for (int l = 0; l < NL; ++l) {
+      const int m = NL == 4 ? l : leg0;                       // legs 0 and 3 swing against legs 1 and 2; action pair (2m, 2m + 1)
+      const float sg = (m == 0 || m == 3) ? 1.0f : -1.0f;
+      const float a0 = m == 0 ? action[0] : (m == 1 ? action[2] : (m == 2 ? action[4] : action[6]));
+      const float a1 = m == 0 ? action[1] : (m == 1 ? action[3] : (m == 2 ? action[5] : action[7]));
+      cmd[3 * l] = pose_stand_ol(3 * m);
+      cmd[3 * l + 1] = pose_stand_ol(3 * m + 1) + (sg * le + a0);
+      cmd[3 * l + 2] = pose_stand_ol(3 * m + 2) + (sg * fe + a1);
+    }
   }
 }
 
 // RexReactiveEnv._transform_action_to_motor_command (gallop_env.py:212-313)
-__device__ __forceinline__ void gallop_command(const DevCfg& c, EnvState& e, const float* action, float* cmd) {
+template <int NL>
+__device__ __forceinline__ void gallop_command(const DevCfg& c, EnvState& e, const float* action, int leg0, float* cmd, LegCall& call) {
+#pragma clang fp contract(off)   // exact double clock arithmetic: no fused multiply-add (rexsim.h, "Clocks")
   if (e.flags & REX_F_STAY_STILL) {
 #pragma unroll
-    for (int j = 0; j < 12; ++j) cmd[j] = pose_stand(j);                         // rex.initial_pose
+    for (int jl = 0; jl < 3 * NL; ++jl) cmd[jl] = pose_stand(leg_joint<NL>(leg0, jl));   // rex.initial_pose
     return;
   }
   const double t = step_time(c, e.steps);
@@ -594,16 +671,12 @@ __device__ __forceinline__ void gallop_command(const DevCfg& c, EnvState& e, con
   if (c.signal == REX_SIGNAL_IK) {                                               // gallop_env.py:257-285
     const double pg = 1.0 + (double)action[1];
     const float gait_coeff = (0.0 <= t && t <= pg) ? (float)t : 1.0f;
-    const float pos[3] = {0.01f, 0.0f, -0.007f}, orn[3] = {0.0f, 0.0f, 0.0f};
     float step_length = 1.3f * gait_coeff;
     if (e.flags & REX_F_GOAL_REACHED) {
       const double pb = 1.0 + (double)action[0];
       step_length *= (end_t <= t && t <= pb + end_t) ? (float)(1.0 - (t - end_t)) : 0.0f;
     }
-    float frames[12], ang[12];
-    env_gait_loop(c, e, 1, step_length, 0.0f, 0.0f, 0.3, 1.0f, frames);
-    ik_solve(orn, pos, frames, ang);
-    order_signal(ang, cmd);
+    call = LegCall{1, 1, step_length, 0.0f, 0.0f, 1.0f, 0.3, {0.01f, 0.0f, -0.007f}, {0.0f, 0.0f, 0.0f}};
   } else {                                                                       // gallop_env.py:287-304
     float lp[4] = {action[0], action[1], action[2], action[3]};
     if (e.flags & REX_F_GOAL_REACHED) {
@@ -614,36 +687,35 @@ __device__ __forceinline__ void gallop_command(const DevCfg& c, EnvState& e, con
       if (!inside) e.flags |= REX_F_STAY_STILL;   // gallop_env.py:291: `coeff is 0.0`, an identity test (see walk_command)
     }
 #pragma unroll
-    for (int l = 0; l < 4; ++l) {
-      cmd[3 * l] = init_pose(c, 3 * l);
-      cmd[3 * l + 1] = init_pose(c, 3 * l + 1) + (l < 2 ? lp[0] : lp[2]);
-      cmd[3 * l + 2] = init_pose(c, 3 * l + 2) + (l < 2 ? lp[1] : lp[3]);
+    for (int l = 0; l < NL; ++l) {
+      const int m = NL == 4 ? l : leg0;
+      cmd[3 * l] = init_pose(c, 3 * m);
+      cmd[3 * l + 1] = init_pose(c, 3 * m + 1) + (m < 2 ? lp[0] : lp[2]);
+      cmd[3 * l + 2] = init_pose(c, 3 * m + 2) + (m < 2 ? lp[1] : lp[3]);
     }
   }
 }
 
 // RexPosesEnv._signal (poses_env.py:186-225)
-__device__ __forceinline__ void poses_command(const DevCfg& c, EnvState& e, const float* action, float* cmd) {
+__device__ __forceinline__ void poses_command(const DevCfg& c, EnvState& e, const float* action, LegCall& call) {
+#pragma clang fp contract(off)   // exact double clock arithmetic: no fused multiply-add (rexsim.h, "Clocks")
   const double t = step_time(c, e.steps), p = 0.8 + (double)action[0];
   const float coeff = (0.0 <= t && t <= p) ? (float)t : 1.0f;
   const float staged = e.target * coeff;
   const int k = (int)e.aux;
-  const float pos[3] = {0.01f, k == 0 ? staged : 0.0f, k == 1 ? staged : 0.0f};
-  const float orn[3] = {k == 2 ? staged : 0.0f, k == 3 ? staged : 0.0f, k == 4 ? staged : 0.0f};
-  const float frames[12] = {kIkL / 2, -kIkYDist / 2, -kIkHeight, kIkL / 2, kIkYDist / 2, -kIkHeight,
-                            -kIkL / 2, -kIkYDist / 2, -kIkHeight, -kIkL / 2, kIkYDist / 2, -kIkHeight};
-  float ang[12];
-  ik_solve(orn, pos, frames, ang);
-  order_signal(ang, cmd);
+  call = LegCall{2, 0, 0.0f, 0.0f, 0.0f, 1.0f, 1.0, {0.01f, k == 0 ? staged : 0.0f, k == 1 ? staged : 0.0f},
+                 {k == 2 ? staged : 0.0f, k == 3 ? staged : 0.0f, k == 4 ? staged : 0.0f}};
 }
 
 // RexTurnEnv._transform_action_to_motor_command (turn_env.py:239-347)
-__device__ __forceinline__ void turn_command(const DevCfg& c, EnvState& e, const float* ctrl_quat, const float* action, float* cmd, int gidx) {
+template <int NL>
+__device__ __forceinline__ void turn_command(const DevCfg& c, EnvState& e, const float* ctrl_quat, const float* action, int leg0, float* cmd, int gidx, LegCall& call) {
+#pragma clang fp contract(off)   // exact double clock arithmetic: no fused multiply-add (rexsim.h, "Clocks")
   const double t = step_time(c, e.steps);
   if (e.flags & REX_F_STAY_STILL) {
     if (t - step_time(c, e.end_step) >= 1.0) e.flags |= REX_F_ENV_GOAL;          // _terminate_with_delay
 #pragma unroll
-    for (int j = 0; j < 12; ++j) cmd[j] = init_pose(c, j);
+    for (int jl = 0; jl < 3 * NL; ++jl) cmd[jl] = init_pose(c, leg_joint<NL>(leg0, jl));
     return;
   }
   {                                                                              // _check_target_position
@@ -676,29 +748,33 @@ __device__ __forceinline__ void turn_command(const DevCfg& c, EnvState& e, const
     const float coeff = (0.0 <= t && t <= 0.8) ? (float)t : 1.0f;
     float dirv = -0.5f * coeff;
     if (clockwise) dirv = -dirv;
-    const float pos[3] = {0.009f, 0.0f, 0.0f}, orn[3] = {0.0f, 0.0f, 0.0f};
-    float frames[12], ang[12];
-    env_gait_loop(c, e, 0, 0.02f, 0.0f, dirv + action[0], 0.75 + (double)action[1], 1.0f, frames);
-    ik_solve(orn, pos, frames, ang);
-    order_signal(ang, cmd);
+    call = LegCall{1, 0, 0.02f, 0.0f, dirv + action[0], 1.0f, 0.75 + (double)action[1], {0.009f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
   } else {
     const float ext = 0.1f, swing = 0.03f + action[0], swipe = 0.05f + action[1];
     const int ith = ((int)(t / 0.1)) % 2;
     const float ms = clockwise ? swing : -swing;     // right_* = left_* with the swing sign flipped
-    const float first[12] = {swipe, ext, ms, -swipe, ext, -ms, swipe, -ext, -ms, -swipe, -ext, ms};
-    const float second[12] = {-swipe, 0.f, -ms, swipe, 0.f, ms, -swipe, 0.f, ms, swipe, 0.f, -ms};
 #pragma unroll
-    for (int j = 0; j < 12; ++j) cmd[j] = pose_stand_ol(j) + (ith ? second[j] : first[j]);
+    for (int l = 0; l < NL; ++l) {
+      const int m = NL == 4 ? l : leg0;
+      // first pose:  ( swipe,  ext,  ms) (-swipe,  ext, -ms) ( swipe, -ext, -ms) (-swipe, -ext,  ms)
+      // second pose: (-swipe,  0,   -ms) ( swipe,  0,    ms) (-swipe,  0,    ms) ( swipe,  0,   -ms)
+      const float s0 = (m & 1) ? -1.0f : 1.0f, s1 = m < 2 ? 1.0f : -1.0f, s2 = (m == 0 || m == 3) ? 1.0f : -1.0f;
+      cmd[3 * l] = pose_stand_ol(3 * m) + (ith ? -s0 * swipe : s0 * swipe);
+      cmd[3 * l + 1] = pose_stand_ol(3 * m + 1) + (ith ? 0.0f : s1 * ext);
+      cmd[3 * l + 2] = pose_stand_ol(3 * m + 2) + (ith ? -s2 * ms : s2 * ms);
+    }
   }
 }
 
 // RexStandupEnv._signal (standup_env.py:113-120): the 'stand' pose, scaled by a 'brake' overshoot for the first 0.1 s
+template <int NL>
 __device__ __forceinline__ void standup_command(const DevCfg& c, const EnvState& e, const float* action, float* cmd) {
+#pragma clang fp contract(off)   // exact double clock arithmetic: no fused multiply-add (rexsim.h, "Clocks")
   const double t = step_time(c, e.steps);                                  // GetTimeSinceReset, rex.py:155-156
   const float f = t > 0.1 ? 1.0f : (0.1f + action[0]) / ((float)t + 1.0f) + 1.5f;
   const float leg = -0.88643435f * f, foot = 1.30197369f * f;
 #pragma unroll
-  for (int l = 0; l < 4; ++l) { cmd[3 * l] = 0.0f; cmd[3 * l + 1] = leg; cmd[3 * l + 2] = foot; }
+  for (int l = 0; l < NL; ++l) { cmd[3 * l] = 0.0f; cmd[3 * l + 1] = leg; cmd[3 * l + 2] = foot; }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -717,20 +793,25 @@ __global__ __launch_bounds__(REX_WAVE) REX_STEP_KERNEL_ATTR void rex_step_kernel
   // idle SIMDs are free and a wave leaves the PGS sweep loop only when its slowest env has converged (and skips
   // only the legs no env of the wave has in contact), so fewer envs per wave means fewer sweeps and rows per
   // wave.  With EPW <= 16 every env owns a group of LPE = 8 (EPW <= 8) or 4 (EPW = 16) adjacent lanes (for EPW = 4 the
-  // upper 32 lanes repeat the lower 32): the lanes of a group run the same arithmetic on the same state, split the
-  // per-leg and per-row work of a substep between them (rex_device.h) and only lane 0 of the group stores.
+  // upper 32 lanes repeat the lower 32): the lanes of a group hold the same body state and split the work of an
+  // env.step() by LEG -- the controller (Bezier + IK), the motor model, the observation words and the leg factorisation
+  // of a substep are those of the lane's own leg (MotorSide; rex_device.h), the row work of a substep is split by row --
+  // and lane 0 of the group stores the state.
   // MIXED (REX_TASK_MIXED): the envs of a wave may run different tasks -- c_ below is the lane's own view of the config.
   constexpr int NM = ARM ? 18 : 12;   // mark='arm': 6 more motors held at ARM_POSES['rest'] (rex_gym_env.py:347-353)
-  constexpr int kLegF4 = REX_LEG_F4_OF(EPW, ARM);
+  constexpr int kLegF4 = REX_LEG_F4_OF(EPW, ARM, BODY);
   constexpr int kRowsF4 = ARM ? REX_LDS_F4_PER_ENV_ARM_OF(EPW) : REX_ROWS_F4_OF(kLegF4);
   static_assert(!BODY || EPW <= 16, "link-box contact rows: lane-group kernels only");
-  constexpr int kMotorF4 = (ARM && EPW <= 8) ? REX_MOTOR_PARK_F4 : 0;
-  __shared__ float4 lds[(kRowsF4 + (EPW <= 16 ? REX_PARK_F4 : 0) + (BODY ? REX_BODY_F4 : 0) + kMotorF4) * EPW];
+  __shared__ float4 lds[(kRowsF4 + (EPW <= 16 ? REX_PARK_F4 : 0) + (BODY ? REX_BODY_F4 : 0)) * EPW];
   REX_STAMP(t_kernel);
-  if (c.clock && threadIdx.x == 0) atomicMin(&c.clock[0], (unsigned long long)wall_clock64());
+  if (c.clock && threadIdx.x == 0) atomicMin(&c.clock[2 * (blockIdx.x & (REX_CLOCK_WAYS - 1))], (unsigned long long)wall_clock64());
   const int lane = threadIdx.x;
   constexpr int LPE = EPW < 64 ? lanes_per_env(EPW) : 1;     // EPW <= 16: lane = LPE * slot + p (rex_device.h, group layout)
+  constexpr int NL = EPW < 64 ? 1 : 4;                       // legs whose controller / motors a lane carries
+  using MS = MotorSide<NL, ARM>;
   const int slot = (lane / LPE) & (EPW - 1);
+  const int pl = lane & (LPE - 1);                           // lane of the group
+  const int leg0 = NL == 4 ? 0 : (LPE == 8 ? pl >> 1 : pl);  // its leg (motor order FL, FR, RL, RR)
   // Block b runs on XCD b % 8 (observed placement; speed only).  A 64-byte sector of a state word holds 16 envs = 16 / EPW
   // blocks' worth: hand the blocks of one sector to the same XCD, so that one L2 fetches (and writes back) the sector
   // instead of 16 / EPW of them.  A bijection on the full groups of 8 x (16 / EPW) blocks; the tail keeps its order.
@@ -741,11 +822,12 @@ __global__ __launch_bounds__(REX_WAVE) REX_STEP_KERNEL_ATTR void rex_step_kernel
     if (blk < full) { const int xcd = blk & 7, q = blk >> 3; blk = ((q / G) * 8 + xcd) * G + (q % G); }
   }
   const int gi = blk * EPW + slot;
-  const bool live = lane < LPE * EPW && (lane & (LPE - 1)) == 0 && gi < c.n;
+  const bool ingrid = lane < LPE * EPW && gi < c.n;
+  const bool live = ingrid && pl == 0;                       // the lane that stores the env's state
+  const bool owner = ingrid && (LPE != 8 || (pl & 1) == 0);  // the lane that stores its leg's words (8 lanes per env: two carry a leg)
   const int gj = gi < c.n ? gi : c.n - 1;   // tail slots shadow the last env (keeps the wave convergent)
   const int i = c.perm ? c.perm[gj] : gj;   // regrouped batches: the env this slot works on
-  const Lds<EPW, kLegF4, BODY> sm{lds, slot, EPW <= 16 ? lds + kRowsF4 * EPW : nullptr, BODY ? lds + (kRowsF4 + REX_PARK_F4) * EPW : nullptr,
-                                  kMotorF4 ? lds + (kRowsF4 + REX_PARK_F4 + (BODY ? REX_BODY_F4 : 0)) * EPW : nullptr};
+  const Lds<EPW, kLegF4, BODY> sm{lds, slot, EPW <= 16 ? lds + kRowsF4 * EPW : nullptr, BODY ? lds + (kRowsF4 + REX_PARK_F4) * EPW : nullptr};
   typename ArmHook<EPW, ARM>::type armp = ArmHook<EPW, ARM>::make(lds, slot);
 
   DevCfg cmix;                          // MIXED only
@@ -755,6 +837,9 @@ __global__ __launch_bounds__(REX_WAVE) REX_STEP_KERNEL_ATTR void rex_step_kernel
   EnvState e;
   load_env<NM>(state, c.n, i, e);
   e.sweeps = 0;
+  MS ms;
+  take_overheat(e, leg0, ms);
+  const uint32_t motor_en0 = e.motor_en;
   float act[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
@@ -766,12 +851,10 @@ __global__ __launch_bounds__(REX_WAVE) REX_STEP_KERNEL_ATTR void rex_step_kernel
     act[k] = a;
   }
 
-  float cmd[NM];
-  if (ARM) {
 #pragma unroll
-    for (int j = 12; j < NM; ++j) cmd[j] = (float)REXA_REST[j - 12];
-  }
-  if (c_.task == REX_TASK_GALLOP) gallop_command(c_, e, act, cmd);
+  for (int a = 0; a < MS::NA; ++a) ms.cmd[3 * NL + a] = (float)REXA_REST[a];
+  LegCall call{0, 0, 0.0f, 0.0f, 0.0f, 1.0f, 1.0, {0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
+  if (c_.task == REX_TASK_GALLOP) gallop_command<NL>(c_, e, act, leg0, ms.cmd, call);
   else if (c_.task == REX_TASK_TURN) {
     float cq[4] = {e.ph.quat[0], e.ph.quat[1], e.ph.quat[2], e.ph.quat[3]};
     if (c.hist) {
@@ -780,21 +863,36 @@ __global__ __launch_bounds__(REX_WAVE) REX_STEP_KERNEL_ATTR void rex_step_kernel
 #pragma unroll
       for (int k = 0; k < 4; ++k) cq[k] = delayed_word(c, i, s0, s1, alpha, 3 * NM + k);
     }
-    turn_command(c_, e, cq, act, cmd, c.env_index_base + i);
+    turn_command<NL>(c_, e, cq, act, leg0, ms.cmd, c.env_index_base + i, call);
   }
-  else if (c_.task == REX_TASK_POSES) poses_command(c_, e, act, cmd);
-  else if (c_.task == REX_TASK_STANDUP) standup_command(c_, e, act, cmd);
-  else walk_command(c_, e, act, cmd);
+  else if (c_.task == REX_TASK_POSES) poses_command(c_, e, act, call);
+  else if (c_.task == REX_TASK_STANDUP) standup_command<NL>(c_, e, act, ms.cmd);
+  else walk_command<NL>(c_, e, act, leg0, ms.cmd, call);
+  env_gait_ik<NL>(c_, e, leg0, call, ms.cmd);     // the planner + IK tail of the task's command, if it has one
 
-  float tau_obs[NM];
   const Ground ground = env_ground(c, i, c.env_index_base + i, e.episode);
   const int step0 = e.steps, episode0 = e.episode;   // keys of this step's sensor-noise draws
 
   // everything of env.step() after Rex.Step: reward, termination, in-launch reset, observation, stores
-  auto epilogue = [&](bool commit) {
+  auto epilogue = [&](bool commit, bool own) {
+  // ---- the motor bookkeeping of the group's lanes meets again: enable mask, overheat counters ----
+  if constexpr (NL == 1) {
+    const uint32_t cleared = leg_or<LPE>(motor_en0 & ~e.motor_en);     // every lane switched off only its own motors
+    e.motor_en = motor_en0 & ~cleared;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) sm.parkf(REX_PARK_XY, 3 * leg0 + k) = __uint_as_float(ms.overheat[k]);
+    mirror_sync();
+#pragma unroll
+    for (int j = 0; j < 12; ++j) e.overheat[j] = __float_as_uint(sm.parkf(REX_PARK_XY, j));
+  } else {
+#pragma unroll
+    for (int j = 0; j < 12; ++j) e.overheat[j] = ms.overheat[j];
+  }
+#pragma unroll
+  for (int a = 0; a < MS::NA; ++a) e.overheat[12 + a] = ms.overheat[3 * NL + a];
   // ---- reward (rex_gym_env.py:501-542) ----
-  CtrlObs co;
-  control_observation<NM>(c, e, i, tau_obs, co);
+  CtrlObs<MS::N> co;
+  control_observation<NM>(c, e, i, leg0, ms, co);
   float rpy[3], r20, r21, r22;
   quat_to_euler(co.quat, rpy);       // GetBaseOrientation: (delayed) quat -> RPY -> quat, rex.py:530-537
   if (c.noise_on) {                  // sensor noise: the reward's and is_fallen's orientation reads draw separately
@@ -808,14 +906,12 @@ __global__ __launch_bounds__(REX_WAVE) REX_STEP_KERNEL_ATTR void rex_step_kernel
       rp[0] = rpy[0] + c.noise[3] * z[0]; rp[1] = rpy[1] + c.noise[3] * z[1]; rp[2] = rpy[2] + c.noise[3] * z[2];
       euler_to_row2(rp, r20, r21, d0);
     } else euler_to_row2(rpy, r20, r21, r22);
-    float nt[20], nv[20];
 #pragma unroll
-    for (int b = 0; b < (NM + 3) / 4; ++b) {
-      gauss4(c.seed_lo, c.seed_hi, gx, episode0, step0, kNzTorque + b, nt + 4 * b);
-      gauss4(c.seed_lo, c.seed_hi, gx, episode0, step0, kNzVelocity + b, nv + 4 * b);
+    for (int jl = 0; jl < MS::N; ++jl) {   // GetMotorTorques / Velocities
+      const int j = MS::motor(leg0, jl);
+      co.tau[jl] += c.noise[2] * gauss_motor(c, gx, episode0, step0, kNzTorque, j);
+      co.qd[jl] += c.noise[1] * gauss_motor(c, gx, episode0, step0, kNzVelocity, j);
     }
-#pragma unroll
-    for (int j = 0; j < NM; ++j) { co.tau[j] += c.noise[2] * nt[j]; co.qd[j] += c.noise[1] * nv[j]; }   // GetMotorTorques / Velocities
   } else
   euler_to_row2(rpy, r20, r21, r22);
   float x = -e.ph.pos[0];
@@ -830,9 +926,12 @@ __global__ __launch_bounds__(REX_WAVE) REX_STEP_KERNEL_ATTR void rex_step_kernel
   fwd = fminf(fwd, c.fwd_cap);      // rex_gym_env.py:525
   const float drift = -fabsf(e.ph.pos[1]);
   const float shake = -fabsf(r20 + r21);
-  float dp = 0.0f;
+  float dp = 0.0f;                  // GetMotorTorques . GetMotorVelocities: the lane's legs, summed over the group, plus the arm
 #pragma unroll
-  for (int j = 0; j < NM; ++j) dp += co.tau[j] * co.qd[j];   // GetMotorTorques . GetMotorVelocities
+  for (int jl = 0; jl < 3 * NL; ++jl) dp += co.tau[jl] * co.qd[jl];
+  if constexpr (NL == 1) dp = leg_sum<LPE>(dp);
+#pragma unroll
+  for (int a = 0; a < MS::NA; ++a) dp += co.tau[3 * NL + a] * co.qd[3 * NL + a];
   const float energy = -fabsf(dp) * c.dt;
   float reward = c.w_dist * fwd + c_.w_energy * energy + c.w_drift * drift + c.w_shake * shake;
   if (c_.task == REX_TASK_TURN) reward = 0.035f - fabsf(e.ph.pos[0]) - fabsf(e.ph.pos[1]);   // turn_env.py:362-367
@@ -859,9 +958,10 @@ __global__ __launch_bounds__(REX_WAVE) REX_STEP_KERNEL_ATTR void rex_step_kernel
   if (done && c.auto_reset) {
     float seen[7];
     env_reset<NM>(c_, snap, i, commit, c.env_index_base + i, e, seen);
+    take_overheat(e, leg0, ms);
 #pragma unroll
-    for (int j = 0; j < NM; ++j) tau_obs[j] = 0.0f;
-    control_observation<NM>(c, e, i, tau_obs, co);
+    for (int jl = 0; jl < MS::N; ++jl) ms.tau_obs[jl] = 0.0f;
+    control_observation<NM>(c, e, i, leg0, ms, co);
     if (!c.hist) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) co.quat[k] = seen[k];
@@ -870,43 +970,49 @@ __global__ __launch_bounds__(REX_WAVE) REX_STEP_KERNEL_ATTR void rex_step_kernel
     }
   }
 
-  float obs[22];
-  if constexpr (MIXED) {
-#pragma unroll
-    for (int k = 4; k < 22; ++k) obs[k] = 0.0f;    // a task with a narrower observation leaves the tail of its row 0
-  }
-  env_observation<NM>(c_, co, obs, c.env_index_base + i, episode0, step0);
-  if (c.range_normalize) normalize_obs(c, obs);
+  float obs[4], ang[MS::N];
+  env_observation<NM>(c_, co, leg0, obs, ang, c.env_index_base + i, episode0, step0);
+  // an opaque copy of the env index: the store addresses are rebuilt here instead of 54 address pairs being carried
+  // (in AGPRs and scratch) from load_env across the whole kernel
+  int is = i;
+  asm volatile("" : "+v"(is));
   if (commit) {
-    // an opaque copy of the env index: the store addresses are rebuilt here instead of 54 address pairs being carried
-    // (in AGPRs and scratch) from load_env across the whole kernel
-    int is = i;
-    asm volatile("" : "+v"(is));
     store_env<NM>(state, c.n, is, e);
-    for (int k = 0; k < c.obs_dim; ++k) obs_out[(size_t)is * c.obs_dim + k] = obs[k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) obs_out[(size_t)is * c.obs_dim + k] = c.range_normalize ? normalize_obs1(c, k, obs[k]) : obs[k];
     reward_out[is] = reward;
     done_out[is] = done ? 1 : 0;
     if (c.sweeps) c.sweeps[is] = e.sweeps;
-    if (cmd_out) {
+  }
+  // the words of the lane's motors: info['action'] and -- where the row carries motor angles (gallop; a mixed batch with
+  // gallop in it: the other tasks leave them 0) -- its part of the observation row
+  const bool wide = c.obs_dim > 4;
 #pragma unroll
-      for (int j = 0; j < NM; ++j) cmd_out[(size_t)is * NM + j] = cmd[j];
+  for (int jl = 0; jl < MS::N; ++jl) {
+    if (jl < 3 * NL ? own : commit) {
+      const int j = MS::motor(leg0, jl);
+      if (cmd_out) cmd_out[(size_t)is * NM + j] = ms.cmd[jl];
+      if (wide) obs_out[(size_t)is * c.obs_dim + 4 + j] = c.range_normalize && c_.task == REX_TASK_GALLOP ? normalize_obs1(c, 4 + j, ang[jl]) : ang[jl];
     }
   }
   };
 
   if constexpr (!MIXED) {
-    for (int k = 0; k < c.action_repeat; ++k) rex_substep<false>(c, e, i, live, cmd, tau_obs, sm, ground, armp);   // Rex.Step
-    epilogue(live);
+    for (int k = 0; k < c.action_repeat; ++k) rex_substep<false>(c, e, i, live, owner, leg0, ms, sm, ground, armp);   // Rex.Step
+    epilogue(live, owner);
   } else {
     // Rex.Step of tasks with different action_repeat in one wave: every lane runs max_repeat substeps (the substep is
     // full of wave-level operations), an env whose own count is reached finishes its env.step() -- epilogue, stores --
     // before the extra substeps, whose results it never stores
     for (int k = 0; k <= c.max_repeat; ++k) {
-      if (k == c_.action_repeat) epilogue(live);
-      if (k < c.max_repeat) rex_substep<true>(c_, e, i, live && k < c_.action_repeat, cmd, tau_obs, sm, ground, armp);
+      if (k == c_.action_repeat) epilogue(live, owner);
+      if (k < c.max_repeat) {
+        const bool mine = k < c_.action_repeat;
+        rex_substep<true>(c_, e, i, live && mine, owner && mine, leg0, ms, sm, ground, armp);
+      }
     }
   }
-  if (c.clock && threadIdx.x == 0) atomicMax(&c.clock[1], (unsigned long long)wall_clock64());
+  if (c.clock && threadIdx.x == 0) atomicMax(&c.clock[2 * (blockIdx.x & (REX_CLOCK_WAYS - 1)) + 1], (unsigned long long)wall_clock64());
 #ifdef REX_PROF
   if (threadIdx.x == 0 && blockIdx.x < 1024) { g_prof[10 * blockIdx.x + 8] += clock64() - t_kernel; g_prof[10 * blockIdx.x + 9] += 1; }
 #endif
@@ -918,17 +1024,22 @@ template <bool ARM, bool BODY>
 __global__ __launch_bounds__(REX_WAVE) void rex_settle_kernel(DevCfg c, float* __restrict__ snap) {
   constexpr int NM = ARM ? 18 : 12;
   constexpr int EPW = (ARM || BODY) ? 16 : REX_WAVE;   // the arm rows / link-box rows do not fit 64 envs per workgroup in LDS
-  constexpr int kLegF4 = REX_LEG_F4_OF(EPW, ARM);
+  constexpr int kLegF4 = REX_LEG_F4_OF(EPW, ARM, BODY);
   constexpr int kRowsF4 = ARM ? REX_LDS_F4_PER_ENV_ARM_OF(EPW) : REX_ROWS_F4_OF(kLegF4);
   __shared__ float4 lds[(kRowsF4 + (EPW <= 16 ? REX_PARK_F4 : 0) + (BODY ? REX_BODY_F4 : 0)) * EPW];
   constexpr int LPE = EPW < 64 ? lanes_per_env(EPW) : 1;
+  constexpr int NL = EPW < 64 ? 1 : 4;
+  using MS = MotorSide<NL, ARM>;
   const int lane = (int)(threadIdx.x / LPE) & (EPW - 1);
-  const Lds<EPW, kLegF4, BODY> sm{lds, lane, EPW <= 16 ? lds + kRowsF4 * EPW : nullptr, BODY ? lds + (kRowsF4 + REX_PARK_F4) * EPW : nullptr, nullptr};
+  const int pl = (int)threadIdx.x & (LPE - 1);
+  const int leg0 = NL == 4 ? 0 : (LPE == 8 ? pl >> 1 : pl);
+  const Lds<EPW, kLegF4, BODY> sm{lds, lane, EPW <= 16 ? lds + kRowsF4 * EPW : nullptr, BODY ? lds + (kRowsF4 + REX_PARK_F4) * EPW : nullptr};
   typename ArmHook<EPW, ARM>::type armp = ArmHook<EPW, ARM>::make(lds, lane);
   const int nrec = (c.n_terrain > 0 ? c.n_terrain : 1) * c.n_mix;
   const int first = (int)blockIdx.x * EPW + lane;                       // the (terrain, task) record this lane group settles
-  const int rec = (threadIdx.x & (LPE - 1)) == 0 ? first : nrec;        // one lane of the group stores it
   const int t = first < nrec ? first : nrec - 1;
+  const bool keeps = first < nrec && pl == 0;                           // one lane of the group stores it ...
+  const bool owner = first < nrec && (LPE != 8 || (pl & 1) == 0);       // ... and one lane per leg that leg's history words
   const int terr = t / c.n_mix, slot = t % c.n_mix;
   Ground ground{nullptr, 0.0f, 1.0f, 1.0f, kMu, c.geo, c.anchor};
   if (c.n_terrain > 0) { ground.h = c.terrain + (size_t)terr * c.hf_stride; ground.mid = c.terrain_mid[terr]; }
@@ -954,28 +1065,42 @@ __global__ __launch_bounds__(REX_WAVE) void rex_settle_kernel(DevCfg c, float* _
     const int task = slot == 0 ? c.mix_task[0] : (slot == 1 ? c.mix_task[1] : (slot == 2 ? c.mix_task[2] : (slot == 3 ? c.mix_task[3] : c.mix_task[4])));
     cs.iterations = 300 / task_action_repeat(task);
   }
-  const bool keeps = rec < nrec;
   e.hist = (uint32_t)(REX_HISTORY_LEN - 1);
-  float tau_obs[NM];
+  MS ms;
 #pragma unroll
-  for (int j = 0; j < NM; ++j) tau_obs[j] = 0.0f;
+  for (int jl = 0; jl < MS::N; ++jl) { ms.tau_obs[jl] = 0.0f; ms.overheat[jl] = 0u; }
+  const uint32_t motor_en0 = e.motor_en;
   if (c.task != REX_TASK_POSES) {   // RexPosesEnv: base reset() with initial_motor_angles=None skips the motion (rex.py:308)
-    receive_observation<NM>(cs, e, t, keeps, tau_obs);
-    float cmd[NM];
-    if (ARM) {
+    receive_observation<NM>(cs, e, t, keeps, owner, leg0, ms);
 #pragma unroll
-      for (int j = 12; j < NM; ++j) cmd[j] = (float)REXA_REST[j - 12];
+    for (int a = 0; a < MS::NA; ++a) ms.cmd[3 * NL + a] = (float)REXA_REST[a];
+#pragma unroll
+    for (int jl = 0; jl < 3 * NL; ++jl) ms.cmd[jl] = pose_stand(leg_joint<NL>(leg0, jl));
+    for (int k = 0; k < 100 + c.reset_substeps; ++k) {     // one call site: the substep is the bulk of the kernel's code
+      if (k == 100) {                                      // rex.py:315-318 (100 substeps holding 'stand'), then :319-322
+#pragma unroll
+        for (int jl = 0; jl < 3 * NL; ++jl) ms.cmd[jl] = reset_pose(c, leg_joint<NL>(leg0, jl));
+      }
+      rex_substep<true>(cs, e, t, keeps, owner, leg0, ms, sm, ground, armp);
     }
-#pragma unroll
-    for (int j = 0; j < 12; ++j) cmd[j] = pose_stand(j);
-    for (int k = 0; k < 100; ++k) rex_substep<true>(cs, e, t, keeps, cmd, tau_obs, sm, ground, armp);   // rex.py:315-318
-#pragma unroll
-    for (int j = 0; j < 12; ++j) cmd[j] = reset_pose(c, j);
-    for (int k = 0; k < c.reset_substeps; ++k) rex_substep<true>(cs, e, t, keeps, cmd, tau_obs, sm, ground, armp);   // rex.py:319-322
   }
-  receive_observation<NM>(cs, e, t, keeps, tau_obs);                                                           // rex.py:323
+  receive_observation<NM>(cs, e, t, keeps, owner, leg0, ms);                                                   // rex.py:323
   if (!cs.hist) e.hist = 0u;
-  if (keeps) store_env<NM>(snap, nrec, rec, e);
+  if constexpr (NL == 1) {          // the group's lanes hand their motors' bookkeeping to the lane that stores the record
+    const uint32_t cleared = leg_or<LPE>(motor_en0 & ~e.motor_en);
+    e.motor_en = motor_en0 & ~cleared;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) sm.parkf(REX_PARK_XY, 3 * leg0 + k) = __uint_as_float(ms.overheat[k]);
+    mirror_sync();
+#pragma unroll
+    for (int j = 0; j < 12; ++j) e.overheat[j] = __float_as_uint(sm.parkf(REX_PARK_XY, j));
+  } else {
+#pragma unroll
+    for (int j = 0; j < 12; ++j) e.overheat[j] = ms.overheat[j];
+  }
+#pragma unroll
+  for (int a = 0; a < MS::NA; ++a) e.overheat[12 + a] = ms.overheat[3 * NL + a];
+  if (keeps) store_env<NM>(snap, nrec, t, e);
 }
 
 template <int NM>
@@ -994,26 +1119,29 @@ __global__ void rex_reset_kernel(DevCfg c, float* __restrict__ state, const floa
   const DevCfg& c_ = c.task == REX_TASK_MIXED ? cmix : c;
   env_reset<NM>(c_, snap, i, true, c.env_index_base + i, e, seen);
   store_env<NM>(state, c.n, i, e);
-  float obs[22], tz[NM];
+  MotorSide<4, NM == 18> ms;
 #pragma unroll
-  for (int j = 0; j < NM; ++j) tz[j] = 0.0f;
-  CtrlObs co;
-  control_observation<NM>(c, e, i, tz, co);
+  for (int jl = 0; jl < MotorSide<4, NM == 18>::N; ++jl) ms.tau_obs[jl] = 0.0f;
+  CtrlObs<MotorSide<4, NM == 18>::N> co;
+  control_observation<NM>(c, e, i, 0, ms, co);
   if (!c.hist) {
     for (int k = 0; k < 4; ++k) co.quat[k] = seen[k];
     for (int k = 0; k < 3; ++k) co.w[k] = seen[4 + k];
   }
-  for (int k = 4; k < 22; ++k) obs[k] = 0.0f;
-  env_observation<NM>(c_, co, obs, c.env_index_base + i, e.episode, -1);   // reset()'s own reading: its own noise draws
-  if (c.range_normalize) normalize_obs(c, obs);
-  if (obs_out) for (int k = 0; k < c.obs_dim; ++k) obs_out[(size_t)r * c.obs_dim + k] = obs[k];
+  float obs[4], ang[MotorSide<4, NM == 18>::N];
+  env_observation<NM>(c_, co, 0, obs, ang, c.env_index_base + i, e.episode, -1);   // reset()'s own reading: its own noise draws
+  if (!obs_out) return;
+  for (int k = 0; k < 4; ++k) obs_out[(size_t)r * c.obs_dim + k] = c.range_normalize ? normalize_obs1(c, k, obs[k]) : obs[k];
+  if (c.obs_dim > 4) {
+    for (int j = 0; j < NM; ++j)
+      obs_out[(size_t)r * c.obs_dim + 4 + j] = c.range_normalize && c_.task == REX_TASK_GALLOP ? normalize_obs1(c, 4 + j, ang[j]) : ang[j];
+  }
 }
 
 }  // namespace rex
 
 // ---- host side shared by the translation units ----
 #define REX_TIMING_RING 256     /* event pairs of rex_set_timing(2) */
-#define REX_CLOCK_SLOTS 4096    /* device-side (start, end) tick pairs of rex_set_timing(3) */
 struct RexSim {
   RexConfig cfg;
   rex::DevCfg dev;
@@ -1025,7 +1153,7 @@ struct RexSim {
   int timing;
   int have_timing;
   // ring of event pairs around the last REX_TIMING_RING launches: per-launch durations without a host sync in between
-  unsigned long long* d_clock;   // [REX_CLOCK_SLOTS][2] device-side (min start, max end) ticks, rex_set_timing(3)
+  unsigned long long* d_clock;   // [REX_CLOCK_SLOTS][REX_CLOCK_WAYS][2] device-side (min start, max end) ticks, rex_set_timing(3)
   unsigned long long* h_clock;   // host staging of the same (per sim: no buffer is shared between sims or threads)
   int32_t* d_perm;   // regrouping (large batches only): wave slot -> env, and the per-env sweep counts it is sorted by
   int32_t* d_sweeps;

@@ -415,7 +415,7 @@ int rex_step(RexSim* s, const float* d_action, float* d_obs, float* d_reward, ui
     e0 = s->ring0[k]; e1 = s->ring1[k];
   }
   if (s->timing == 3 && s->timed_steps < REX_CLOCK_SLOTS) {   // device-side timestamps: this launch's (min start, max end) slot
-    s->dev.clock = s->d_clock + 2 * s->timed_steps;           // (all slots were primed by rex_set_timing: nothing is copied per
+    s->dev.clock = s->d_clock + 2 * REX_CLOCK_WAYS * s->timed_steps;   // (all slots were primed by rex_set_timing: nothing is copied per
     s->timed_steps++;                                         // launch, the queue stays as full as in an untimed run)
   } else s->dev.clock = nullptr;
   if (s->timing == 1 || s->timing == 2) HIPCHK(hipEventRecord(e0, st));
@@ -448,12 +448,13 @@ int rex_set_timing(RexSim* s, int enable) {
   s->timed_steps = 0;
   if (s->timing == 3) {   // the next REX_CLOCK_SLOTS launches are timed on the device; prime their (min, max) slots
     HIPCHK(hipSetDevice(s->device));
-    if (!s->d_clock) HIPCHK(hipMalloc(&s->d_clock, sizeof(unsigned long long) * 2 * REX_CLOCK_SLOTS));
-    if (!s->h_clock) s->h_clock = (unsigned long long*)malloc(sizeof(unsigned long long) * 2 * REX_CLOCK_SLOTS);
+    const size_t words = (size_t)2 * REX_CLOCK_WAYS * REX_CLOCK_SLOTS;
+    if (!s->d_clock) HIPCHK(hipMalloc(&s->d_clock, sizeof(unsigned long long) * words));
+    if (!s->h_clock) s->h_clock = (unsigned long long*)malloc(sizeof(unsigned long long) * words);
     if (!s->h_clock) return fail(REX_ENOMEM, "rex_set_timing: host buffer%s", "");
-    for (int k = 0; k < REX_CLOCK_SLOTS; ++k) { s->h_clock[2 * k] = ~0ull; s->h_clock[2 * k + 1] = 0ull; }
+    for (size_t k = 0; k < words / 2; ++k) { s->h_clock[2 * k] = ~0ull; s->h_clock[2 * k + 1] = 0ull; }
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpy(s->d_clock, s->h_clock, sizeof(unsigned long long) * 2 * REX_CLOCK_SLOTS, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(s->d_clock, s->h_clock, sizeof(unsigned long long) * words, hipMemcpyHostToDevice));
   }
   return REX_OK;
 }
@@ -468,12 +469,14 @@ int rex_step_times_ms(RexSim* s, float* ms, int max_count) {
   if (s->timing == 3) {
     unsigned long long* ticks = s->h_clock;
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpy(ticks, s->d_clock, sizeof(unsigned long long) * 2 * REX_CLOCK_SLOTS, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(ticks, s->d_clock, sizeof(unsigned long long) * 2 * REX_CLOCK_WAYS * REX_CLOCK_SLOTS, hipMemcpyDeviceToHost));
     int khz = 100000;   // s_memrealtime: constant 100 MHz on gfx9
     (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, s->device);
     for (int j = 0; j < n; ++j) {
-      const int k = (int)(s->timed_steps - n + j);
-      ms[j] = (float)((double)(ticks[2 * k + 1] - ticks[2 * k]) / (double)khz);
+      const unsigned long long* t = ticks + (size_t)2 * REX_CLOCK_WAYS * (size_t)(s->timed_steps - n + j);
+      unsigned long long first = ~0ull, last = 0ull;       // first wave start / last wave end over the launch's tick pairs
+      for (int w = 0; w < REX_CLOCK_WAYS; ++w) { if (t[2 * w] < first) first = t[2 * w]; if (t[2 * w + 1] > last) last = t[2 * w + 1]; }
+      ms[j] = last >= first ? (float)((double)(last - first) / (double)khz) : 0.0f;
     }
     return n;
   }
