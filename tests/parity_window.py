@@ -82,6 +82,7 @@ def window(name, env, steps=200, seed=23, threads=None):
     n, nm = env.num_envs, env.num_motors
     env.reset()
     sq = np.zeros(n); cnt = np.zeros(n); alive = np.ones(n, bool)
+    sq_legs = np.zeros(n)            # the 12 leg joints alone (mark 'arm': its arm joints sit ON their bounds and jitter)
     pos_err = np.zeros(n)
     curve = {}
     for k in range(steps):
@@ -89,14 +90,17 @@ def window(name, env, steps=200, seed=23, threads=None):
         ps = product_state_to_numeric(env.state)
         e = ps[orclib.S_Q:orclib.S_Q + nm] - oq[k]
         sq += np.where(alive, (e * e).mean(0), 0.0); cnt += alive
+        sq_legs += np.where(alive, (e[:12] * e[:12]).mean(0), 0.0)
         pos_err = np.where(alive, np.abs(ps[0:3] - opos[k]).max(0), pos_err)
         if k + 1 in (1, 5, 10, 25, 50, 100, 200) and alive.any():
             a = np.abs(e).max(0)[alive]
             curve[k + 1] = dict(median=float(np.median(a)), p99=float(np.percentile(a, 99)), max=float(a.max()), envs=int(alive.sum()))
         alive &= ~(d.cpu().numpy().astype(bool) | odone[k])      # an episode that ended (fall, goal) leaves the comparison
     rmse = np.sqrt(sq / np.maximum(cnt, 1))
+    legs = np.sqrt(sq_legs / np.maximum(cnt, 1))
     return dict(workload=name, envs=n, window_steps=steps, seed=seed, median_rad=float(np.median(rmse)),
                 p99_rad=float(np.percentile(rmse, 99)), max_rad=float(rmse.max()),
+                leg_joints_median_rad=float(np.median(legs)), leg_joints_p99_rad=float(np.percentile(legs, 99)),
                 base_pos_err_p99_m=float(np.percentile(pos_err, 99)), base_pos_err_max_m=float(pos_err.max()),
                 envs_compared_to_the_end=int(alive.sum()), mean_steps_compared=float(cnt.mean()),
                 abs_error_by_step=curve, against="oracle/rex_oracle.c fp64 (restatement; PyBullet is not installable)")
