@@ -800,7 +800,9 @@ __device__ __forceinline__ void mulT6(const Chol6& C, const float* b, float* x) 
 
 struct PhysState {
   float pos[3], quat[4], lin[3], ang[3];
-  float q[18], qd[18];   // 12 leg motors (+ 6 arm motors for mark='arm'; untouched and optimised away otherwise)
+  // one env per lane: the 12 leg motors in motor order (+ 6 arm motors for mark='arm'; untouched and optimised away otherwise).
+  // Lane groups: slots 0..2 hold the joints of the lane's OWN leg, 12..17 the arm's; 3..11 are never touched.
+  float q[18], qd[18];
 };
 
 struct BaseAccum;
@@ -1220,6 +1222,9 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
     acc.F = mk(0.f, 0.f, mbase * kGravity) + (mbase * dl) * bk.v;
   }
   acc.m += ground.anchor; acc.Io.xx += ground.anchor; acc.Io.yy += ground.anchor; acc.Io.zz += ground.anchor;
+  // the extra branch on the base (mark='arm'; its 6 torques; no-op otherwise) goes FIRST: its recursion is the point of
+  // highest register pressure of the substep, and before the legs neither their factors nor their velocities are live yet
+  armp.pass(bk, s, tau + (SM::kEpw <= 16 ? 3 : 12), dt, acc, ground);
 
   unsigned active = 0;
   PgsX x;
@@ -1230,8 +1235,9 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
   const int mleg = LPE == 8 ? pl >> 1 : pl;                                   // the leg this lane factorises
   LegFactor Lown;   // lane group: the factor of this lane's leg (in registers or parked: REX_LEG_F4_OF)
   if constexpr (kSplitLegs) {
-    const float ql[3] = {pick_leg(s.q, mleg, 0), pick_leg(s.q, mleg, 1), pick_leg(s.q, mleg, 2)};
-    const float qdl[3] = {pick_leg(s.qd, mleg, 0), pick_leg(s.qd, mleg, 1), pick_leg(s.qd, mleg, 2)};
+    // lane groups: a lane carries the joint state of ITS leg only (slots 0..2 of q / qd; PhysState)
+    const float ql[3] = {s.q[0], s.q[1], s.q[2]};
+    const float qdl[3] = {s.qd[0], s.qd[1], s.qd[2]};
     const float tl[3] = {tau[0], tau[1], tau[2]};   // lane groups: `tau` holds the torques of the lane's own leg (then the arm's)
     BaseAccum part;
     part.Io = s33{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -1352,7 +1358,6 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
       }
     }
   }
-  armp.pass(bk, s, tau + (kSplitLegs ? 3 : 12), dt, acc, ground);   // extra branch on the base (mark='arm'; its 6 torques), no-op otherwise
 
   // base articulated inertia A = [[Io, hx],[hx^T, m]] - S, then A = Lc Lc^T
   float A[21];
@@ -1523,15 +1528,9 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
     const float u3 = t3 * L.gi3;
     const float u2 = (t2 - L.g32 * u3) * L.gi2;
     const float u1 = (t1 - L.g21 * u2 - L.g31 * u3) * L.gi1;
-    sm.zc(mleg) = make_float4(clampf(u1, -kMaxCoordVel, kMaxCoordVel), clampf(u2, -kMaxCoordVel, kMaxCoordVel),
-                                  clampf(u3, -kMaxCoordVel, kMaxCoordVel), 0.0f);
-    mirror_sync();
-#pragma unroll
-    for (int k = 0; k < REX_NLEG; ++k) {
-      const float4 u = sm.zc(k);
-      s.qd[3 * k] = u.x; s.qd[3 * k + 1] = u.y; s.qd[3 * k + 2] = u.z;
-    }
-    mirror_sync();   // the next substep's leg pass overwrites these chunks
+    s.qd[0] = clampf(u1, -kMaxCoordVel, kMaxCoordVel); s.qd[1] = clampf(u2, -kMaxCoordVel, kMaxCoordVel);
+    s.qd[2] = clampf(u3, -kMaxCoordVel, kMaxCoordVel);
+    mirror_sync();   // the next substep's leg pass overwrites the z chunks the lanes have just read
   } else {
 #pragma unroll 1
     for (int leg = 0; leg < REX_NLEG; ++leg) {
@@ -1560,7 +1559,7 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
 #pragma unroll
   for (int k = 0; k < 3; ++k) s.pos[k] += dt * s.lin[k];
 #pragma unroll
-  for (int j = 0; j < ARMP::NM; ++j) s.q[j] += dt * s.qd[j];
+  for (int j = 0; j < ARMP::NM; ++j) if (!kSplitLegs || j < 3 || j >= 12) s.q[j] += dt * s.qd[j];   // lane groups: own leg (+ arm)
   {
     const float wn = sqrtf(s.ang[0] * s.ang[0] + s.ang[1] * s.ang[1] + s.ang[2] * s.ang[2]);
     const float angle = wn * dt;

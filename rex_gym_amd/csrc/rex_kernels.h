@@ -84,7 +84,7 @@ struct MotorSide {
 };
 // entry jl of a per-motor array of all 12 leg motors as this lane sees its legs (NL = 1: a select, no dynamic indexing)
 template <int NL>
-__device__ __forceinline__ float legv(const float* a, int leg0, int jl) { return NL == 4 ? a[jl] : pick_leg(a, leg0, jl); }
+__device__ __forceinline__ float legv(const float* a, int leg0, int jl) { (void)leg0; return a[jl]; }   // (lane groups keep their leg in slots 0..2)
 template <int NL>
 __device__ __forceinline__ uint32_t legu(const uint32_t* a, int leg0, int jl) {
   if (NL == 4) return a[jl];
@@ -100,15 +100,20 @@ __device__ __forceinline__ void take_overheat(const EnvState& e, int leg0, Motor
   for (int a = 0; a < (ARM ? 6 : 0); ++a) ms.overheat[3 * NL + a] = e.overheat[12 + a];
 }
 
-template <int NM>
-__device__ __forceinline__ void load_env(const float* st, int n, int i, EnvState& e) {
+// NL = 4: the whole env (one env per lane; reset kernel).  NL = 1 (lane groups): the joint state of leg `leg0` only, into
+// slots 0..2 of q / qd (PhysState), next to the arm's
+template <int NM, int NL = 4>
+__device__ __forceinline__ void load_env(const float* st, int n, int i, EnvState& e, int leg0 = 0) {
   using Y = Lay<NM>;
 #pragma unroll
   for (int k = 0; k < 3; ++k) { e.ph.pos[k] = ldw(st, n, REX_S_POS + k, i); e.ph.lin[k] = ldw(st, n, REX_S_LINVEL + k, i); e.ph.ang[k] = ldw(st, n, REX_S_ANGVEL + k, i); }
 #pragma unroll
   for (int k = 0; k < 4; ++k) e.ph.quat[k] = ldw(st, n, REX_S_QUAT + k, i);
 #pragma unroll
-  for (int j = 0; j < NM; ++j) { e.ph.q[j] = ldw(st, n, Y::Q + j, i); e.ph.qd[j] = ldw(st, n, Y::QD + j, i); }
+  for (int j = 0; j < NM; ++j) {
+    if (NL == 4 || j >= 12) { e.ph.q[j] = ldw(st, n, Y::Q + j, i); e.ph.qd[j] = ldw(st, n, Y::QD + j, i); }
+    else if (j < 3) { e.ph.q[j] = ldw(st, n, Y::Q + 3 * leg0 + j, i); e.ph.qd[j] = ldw(st, n, Y::QD + 3 * leg0 + j, i); }
+  }
   e.phi = ldw(st, n, Y::PHI, i); e.last_step = (int32_t)ldi(st, n, Y::LASTT, i); e.alpha = ldw(st, n, Y::ALPHA, i);
   e.target = ldw(st, n, Y::TARGET, i); e.end_step = (int32_t)ldi(st, n, Y::ENDTIME, i); e.aux = ldw(st, n, Y::AUX, i);
   e.flags = ldi(st, n, Y::FLAGS, i); e.steps = (int32_t)ldi(st, n, Y::STEPS, i); e.episode = (int32_t)ldi(st, n, Y::EPISODE, i);
@@ -121,15 +126,16 @@ __device__ __forceinline__ void load_env(const float* st, int n, int i, EnvState
   }
 }
 
+// q12 / qd12: the 12 leg joints in motor order (lane groups gather them from their lanes first, gather_legs)
 template <int NM>
-__device__ __forceinline__ void store_env(float* st, int n, int i, const EnvState& e) {
+__device__ __forceinline__ void store_env(float* st, int n, int i, const EnvState& e, const float* q12, const float* qd12) {
   using Y = Lay<NM>;
 #pragma unroll
   for (int k = 0; k < 3; ++k) { stw(st, n, REX_S_POS + k, i, e.ph.pos[k]); stw(st, n, REX_S_LINVEL + k, i, e.ph.lin[k]); stw(st, n, REX_S_ANGVEL + k, i, e.ph.ang[k]); }
 #pragma unroll
   for (int k = 0; k < 4; ++k) stw(st, n, REX_S_QUAT + k, i, e.ph.quat[k]);
 #pragma unroll
-  for (int j = 0; j < NM; ++j) { stw(st, n, Y::Q + j, i, e.ph.q[j]); stw(st, n, Y::QD + j, i, e.ph.qd[j]); }
+  for (int j = 0; j < NM; ++j) { stw(st, n, Y::Q + j, i, j < 12 ? q12[j] : e.ph.q[j]); stw(st, n, Y::QD + j, i, j < 12 ? qd12[j] : e.ph.qd[j]); }
   stw(st, n, Y::PHI, i, e.phi); sti(st, n, Y::LASTT, i, (uint32_t)e.last_step); stw(st, n, Y::ALPHA, i, e.alpha);
   stw(st, n, Y::TARGET, i, e.target); sti(st, n, Y::ENDTIME, i, (uint32_t)e.end_step); stw(st, n, Y::AUX, i, e.aux);
   sti(st, n, Y::FLAGS, i, e.flags); sti(st, n, Y::STEPS, i, (uint32_t)e.steps); sti(st, n, Y::EPISODE, i, (uint32_t)e.episode);
@@ -487,13 +493,13 @@ __device__ __forceinline__ void env_observation(const DevCfg& c, const CtrlObs<N
 // RexWalkEnv.reset / RexReactiveEnv.reset ... draws on top of the settled snapshot.  `seen` receives what the robot last
 // observed of its base (quaternion, angular velocity): the settled one -- the turn env teleports the base behind the
 // observation's back (turn_env.py:158-160), and reset() returns that older reading.
-template <int NM>
-__device__ __forceinline__ void env_reset(const DevCfg& c, const float* snap, int i, bool live, int gidx, EnvState& e, float* seen) {
+template <int NM, int NL = 4>
+__device__ __forceinline__ void env_reset(const DevCfg& c, const float* snap, int i, bool live, int gidx, EnvState& e, float* seen, int leg0 = 0) {
   const int32_t episode = e.episode + 1;
   const float alpha = e.alpha;   // the env keeps one GaitPlanner for life: its arc angle survives reset() (gait_planner.py:76-85)
   const int nrec = (c.n_terrain > 0 ? c.n_terrain : 1) * c.n_mix;
   const int rec = (c.n_terrain > 0 ? terrain_index(c, gidx, episode) : 0) * c.n_mix + (c.n_mix > 1 ? mix_slot(c, c.task) : 0);
-  load_env<NM>(snap, nrec, rec, e);   // settled on this episode's terrain (under this env's task)
+  load_env<NM, NL>(snap, nrec, rec, e, leg0);   // settled on this episode's terrain (under this env's task)
   if (c.hist) {   // the deque as the reset motion left it: its last 100 observations, ring position included (e.hist)
     if (live) {
       const float* ring = snap + (size_t)Lay<NM>::WORDS * nrec;
@@ -777,6 +783,28 @@ __device__ __forceinline__ void standup_command(const DevCfg& c, const EnvState&
   for (int l = 0; l < NL; ++l) { cmd[3 * l] = 0.0f; cmd[3 * l + 1] = leg; cmd[3 * l + 2] = foot; }
 }
 
+// The joint states and overheat counters of an env, in motor order, for the lane that stores the state.  Lane groups: every
+// lane hands in its own leg's through LDS (rows 0..2 of the contact-row region, idle outside a substep; a substep rewrites
+// them from scratch); one env per lane: already there.  Also fills e.overheat (all motors).
+template <int NL, int LPE, bool ARM, class SM>
+__device__ __forceinline__ void gather_legs(const SM& sm, int leg0, EnvState& e, const MotorSide<NL, ARM>& ms, float* q12, float* qd12) {
+  if constexpr (NL == 1) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      sm.rowf(0, 3 * leg0 + k) = e.ph.q[k]; sm.rowf(1, 3 * leg0 + k) = e.ph.qd[k];
+      sm.rowf(2, 3 * leg0 + k) = __uint_as_float(ms.overheat[k]);
+    }
+    mirror_sync();
+#pragma unroll
+    for (int j = 0; j < 12; ++j) { q12[j] = sm.rowf(0, j); qd12[j] = sm.rowf(1, j); e.overheat[j] = __float_as_uint(sm.rowf(2, j)); }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 12; ++j) { q12[j] = e.ph.q[j]; qd12[j] = e.ph.qd[j]; e.overheat[j] = ms.overheat[j]; }
+  }
+#pragma unroll
+  for (int a = 0; a < (ARM ? 6 : 0); ++a) e.overheat[12 + a] = ms.overheat[3 * NL + a];
+}
+
 // ------------------------------------------------------------------------------------------
 #ifndef REX_STEP_KERNEL_ATTR
 #define REX_STEP_KERNEL_ATTR          /* developer experiments: e.g. -DREX_STEP_KERNEL_ATTR='__attribute__((amdgpu_waves_per_eu(2,2)))' */
@@ -835,7 +863,7 @@ __global__ __launch_bounds__(REX_WAVE) REX_STEP_KERNEL_ATTR void rex_step_kernel
   const DevCfg& c_ = MIXED ? cmix : c;
 
   EnvState e;
-  load_env<NM>(state, c.n, i, e);
+  load_env<NM, NL>(state, c.n, i, e, leg0);
   e.sweeps = 0;
   MS ms;
   take_overheat(e, leg0, ms);
@@ -875,21 +903,11 @@ __global__ __launch_bounds__(REX_WAVE) REX_STEP_KERNEL_ATTR void rex_step_kernel
 
   // everything of env.step() after Rex.Step: reward, termination, in-launch reset, observation, stores
   auto epilogue = [&](bool commit, bool own) {
-  // ---- the motor bookkeeping of the group's lanes meets again: enable mask, overheat counters ----
+  // ---- the motor bookkeeping of the group's lanes meets again: the enable mask (the counters and joint states follow at the store) ----
   if constexpr (NL == 1) {
     const uint32_t cleared = leg_or<LPE>(motor_en0 & ~e.motor_en);     // every lane switched off only its own motors
     e.motor_en = motor_en0 & ~cleared;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) sm.parkf(REX_PARK_XY, 3 * leg0 + k) = __uint_as_float(ms.overheat[k]);
-    mirror_sync();
-#pragma unroll
-    for (int j = 0; j < 12; ++j) e.overheat[j] = __float_as_uint(sm.parkf(REX_PARK_XY, j));
-  } else {
-#pragma unroll
-    for (int j = 0; j < 12; ++j) e.overheat[j] = ms.overheat[j];
   }
-#pragma unroll
-  for (int a = 0; a < MS::NA; ++a) e.overheat[12 + a] = ms.overheat[3 * NL + a];
   // ---- reward (rex_gym_env.py:501-542) ----
   CtrlObs<MS::N> co;
   control_observation<NM>(c, e, i, leg0, ms, co);
@@ -957,7 +975,7 @@ __global__ __launch_bounds__(REX_WAVE) REX_STEP_KERNEL_ATTR void rex_step_kernel
   if (done) e.flags |= REX_F_DONE;
   if (done && c.auto_reset) {
     float seen[7];
-    env_reset<NM>(c_, snap, i, commit, c.env_index_base + i, e, seen);
+    env_reset<NM, NL>(c_, snap, i, commit, c.env_index_base + i, e, seen, leg0);
     take_overheat(e, leg0, ms);
 #pragma unroll
     for (int jl = 0; jl < MS::N; ++jl) ms.tau_obs[jl] = 0.0f;
@@ -976,8 +994,10 @@ __global__ __launch_bounds__(REX_WAVE) REX_STEP_KERNEL_ATTR void rex_step_kernel
   // (in AGPRs and scratch) from load_env across the whole kernel
   int is = i;
   asm volatile("" : "+v"(is));
+  float q12[12], qd12[12];
+  gather_legs<NL, LPE>(sm, leg0, e, ms, q12, qd12);
   if (commit) {
-    store_env<NM>(state, c.n, is, e);
+    store_env<NM>(state, c.n, is, e, q12, qd12);
 #pragma unroll
     for (int k = 0; k < 4; ++k) obs_out[(size_t)is * c.obs_dim + k] = c.range_normalize ? normalize_obs1(c, k, obs[k]) : obs[k];
     reward_out[is] = reward;
@@ -1048,7 +1068,7 @@ __global__ __launch_bounds__(REX_WAVE) void rex_settle_kernel(DevCfg c, float* _
   e.ph.pos[2] = c.init_z;
   e.ph.quat[3] = 1.0f;
 #pragma unroll
-  for (int j = 0; j < 12; ++j) e.ph.q[j] = pose_stand(j);       // ResetPose: INIT_POSES[pose_id = 'stand']
+  for (int jl = 0; jl < 3 * NL; ++jl) e.ph.q[jl] = pose_stand(leg_joint<NL>(leg0, jl));       // ResetPose: INIT_POSES[pose_id = 'stand']
   if (ARM) {                                                     // ResetPose: arm motors at ARM_POSES['rest'] (rex.py:371-373)
 #pragma unroll
     for (int j = 12; j < NM; ++j) e.ph.q[j] = (float)REXA_REST[j - 12];
@@ -1089,18 +1109,10 @@ __global__ __launch_bounds__(REX_WAVE) void rex_settle_kernel(DevCfg c, float* _
   if constexpr (NL == 1) {          // the group's lanes hand their motors' bookkeeping to the lane that stores the record
     const uint32_t cleared = leg_or<LPE>(motor_en0 & ~e.motor_en);
     e.motor_en = motor_en0 & ~cleared;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) sm.parkf(REX_PARK_XY, 3 * leg0 + k) = __uint_as_float(ms.overheat[k]);
-    mirror_sync();
-#pragma unroll
-    for (int j = 0; j < 12; ++j) e.overheat[j] = __float_as_uint(sm.parkf(REX_PARK_XY, j));
-  } else {
-#pragma unroll
-    for (int j = 0; j < 12; ++j) e.overheat[j] = ms.overheat[j];
   }
-#pragma unroll
-  for (int a = 0; a < MS::NA; ++a) e.overheat[12 + a] = ms.overheat[3 * NL + a];
-  if (keeps) store_env<NM>(snap, nrec, t, e);
+  float q12[12], qd12[12];
+  gather_legs<NL, LPE>(sm, leg0, e, ms, q12, qd12);
+  if (keeps) store_env<NM>(snap, nrec, t, e, q12, qd12);
 }
 
 template <int NM>
@@ -1118,7 +1130,7 @@ __global__ void rex_reset_kernel(DevCfg c, float* __restrict__ state, const floa
   if (c.task == REX_TASK_MIXED) mixed_config(c, c.env_index_base + i, cmix);
   const DevCfg& c_ = c.task == REX_TASK_MIXED ? cmix : c;
   env_reset<NM>(c_, snap, i, true, c.env_index_base + i, e, seen);
-  store_env<NM>(state, c.n, i, e);
+  store_env<NM>(state, c.n, i, e, e.ph.q, e.ph.qd);
   MotorSide<4, NM == 18> ms;
 #pragma unroll
   for (int jl = 0; jl < MotorSide<4, NM == 18>::N; ++jl) ms.tau_obs[jl] = 0.0f;

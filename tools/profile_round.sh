@@ -1,16 +1,18 @@
 #!/bin/bash
-# Run on the GPU box (gpurun): rocprofv3 kernel stats + two PMC passes (HBM read / write bytes) of bench.py for one
-# workload.  usage: tools/profile_round.sh TAG [bench.py workload flags ...]   -> gpurun_out/TAG_*
+# Run on the GPU box (gpurun): rocprofv3 kernel stats + three PMC passes (HBM read bytes, HBM write bytes, SQ issue / wait
+# cycles next to GRBM_GUI_ACTIVE) of bench.py for one workload.  Counters are collected in their own passes, with
+# --kernel-trace only.   usage: tools/profile_round.sh TAG [bench.py workload flags ...]   -> gpurun_out/TAG_*
 TAG=$1; shift
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_prof -- python $GRAFT_REPO_ROOT/bench.py --steps 400 --warmup 50 --no-cpu-baseline --no-walking-workload "$@" > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_bench_under_rocprof.json 2>/dev/null
-for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_$C -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 50 --no-cpu-baseline --no-walking-workload "$@" > /dev/null 2>&1
-done
+B="--no-cpu-baseline --no-walking-workload --no-gather"
+rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_prof -- python $GRAFT_REPO_ROOT/bench.py --steps 400 --warmup 50 $B "$@" > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_bench_under_rocprof.json 2>/dev/null
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_FETCH_SIZE -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 50 $B "$@" > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_WRITE_SIZE -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 50 $B "$@" > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --kernel-trace -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_SQ -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 50 $B "$@" > /dev/null 2>&1
 cd $GRAFT_REPO_ROOT
 python tools/rocprof_stats.py $(find gpurun_out/${TAG}_prof -name "*_results.db" | head -1) --skip 1550 | head -4
-python tools/rocprof_pmc.py $(find gpurun_out/${TAG}_pmc_FETCH_SIZE -name "*_results.db" | head -1) $(find gpurun_out/${TAG}_pmc_WRITE_SIZE -name "*_results.db" | head -1)
-rm -rf gpurun_out/${TAG}_prof gpurun_out/${TAG}_pmc_FETCH_SIZE gpurun_out/${TAG}_pmc_WRITE_SIZE   # the databases are tens of MB: gpurun copies back <= 64 MiB
+python tools/rocprof_pmc.py $(find gpurun_out/${TAG}_pmc_FETCH_SIZE -name "*_results.db" | head -1) $(find gpurun_out/${TAG}_pmc_WRITE_SIZE -name "*_results.db" | head -1) $(find gpurun_out/${TAG}_pmc_SQ -name "*_results.db" | head -1)
+rm -rf gpurun_out/${TAG}_prof gpurun_out/${TAG}_pmc_FETCH_SIZE gpurun_out/${TAG}_pmc_WRITE_SIZE gpurun_out/${TAG}_pmc_SQ   # the databases are tens of MB: gpurun copies back <= 64 MiB
