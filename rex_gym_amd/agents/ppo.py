@@ -277,6 +277,7 @@ class PPOAgent:
         self.policy_opt = torch.optim.Adam(self.net.policy_parameters(), lr=cfg.policy_lr, eps=1e-8)
         self.value_opt = torch.optim.Adam(self.net.value_parameters(), lr=cfg.value_lr, eps=1e-8)
         self.sync_gradients = sync_gradients
+        self._full_episodes_unpolled, self._warned_unpolled = 0, False
         self.last = None
         self.updates = 0
         self.log = []
@@ -323,8 +324,17 @@ class PPOAgent:
                 mem[dst] = epi[use]
             self.memory_length[dst] = self.episode_length[use].clamp(max=self.cfg.max_length)
             self.memory_index += k
-        if self.memory_index >= self.cfg.update_every and not self._distributed():
-            return self._training()
+        if self.memory_index >= self.cfg.update_every:
+            if not self._distributed():
+                return self._training()
+            # multi-rank learner: the update is collective and runs from train_if_all_full(), which the caller's loop has to
+            # poll (train() does); a custom loop that never does would silently stop learning
+            self._full_episodes_unpolled += int(indices.numel())
+            if self._full_episodes_unpolled > 4 * self.cfg.update_every and not self._warned_unpolled:
+                import warnings
+                warnings.warn("PPOAgent(sync_gradients=True): the memory is full but train_if_all_full() has not been called; "
+                              "poll it at the same loop positions on every rank (agents.ppo.train does)")
+                self._warned_unpolled = True
         return None
 
     def _distributed(self):
@@ -340,6 +350,7 @@ class PPOAgent:
             return None
         full = torch.tensor([1.0 if self.memory_index >= self.cfg.update_every else 0.0], device=self.device)
         torch.distributed.all_reduce(full, op=torch.distributed.ReduceOp.MIN)
+        self._full_episodes_unpolled = 0
         if float(full) < 1.0:
             return None
         self.observ_filter.merge_ranks()      # the ranks' filters have seen different envs: one filter from here on
@@ -436,6 +447,14 @@ def train(env, agent, steps, training=True, sync_poll=8):
     tensors; auto_reset must be off: finished envs are reset here, by index, as simulate() does).
     Returns the mean score (undiscounted episode reward) and length of the episodes that ended."""
     dev = agent.device
+    if training and agent._distributed():
+        # the update decision is collective (train_if_all_full): every rank must poll at the same loop positions, i.e. run
+        # the same number of steps with the same poll period -- checked once here, where a mismatch would otherwise block
+        # a rank in an all-reduce for ever
+        want = torch.tensor([float(steps), -float(steps), float(sync_poll), -float(sync_poll)], device=dev)
+        torch.distributed.all_reduce(want, op=torch.distributed.ReduceOp.MAX)
+        if want[0] != -want[1] or want[2] != -want[3]:
+            raise ValueError("train(): every rank of a sync_gradients learner must pass the same `steps` and `sync_poll`")
     observ = env.reset().to(dev).clone()
     agent.begin_episode(torch.arange(agent.n, device=dev))
     score = torch.zeros(agent.n, device=dev)
