@@ -56,6 +56,16 @@ class _EnvView:
         return self._batch.state[:, self.index].clone()
 
 
+class StepOut:
+    """Output tensors of a step, validated once (RexBatchEnv.bind_out): the tensors and their device pointers."""
+    __slots__ = ("obs", "reward", "done", "done_bool", "p_obs", "p_reward", "p_done")
+
+    def __init__(self, obs, reward, done, torch):
+        self.obs, self.reward, self.done = obs, reward, done
+        self.done_bool = done if done.dtype == torch.bool else done.view(torch.bool)
+        self.p_obs, self.p_reward, self.p_done = obs.data_ptr(), reward.data_ptr(), done.data_ptr()
+
+
 class RexBatchEnv:
     metadata = {"render.modes": []}
 
@@ -204,6 +214,8 @@ class RexBatchEnv:
             _lib.check(self._L.rex_create(ctypes.byref(cfg), self.device.index, self.state.data_ptr(),
                                           self._stream_ptr(), ctypes.byref(handle)), "rex_create")
         self._h = handle
+        self._own_out = StepOut(self._obs, self._reward, self._done, torch)
+        self._p_cmd, self._info = self._cmd.data_ptr(), {"action": self._cmd}
         self._needs_reset = True
         from .rex_knobs import RexKnobs
         self.rex = RexKnobs(self)
@@ -370,13 +382,19 @@ class RexBatchEnv:
             if bool(rows.any()):
                 i = int(torch.nonzero(rows)[0])
                 raise ValueError(f"Invalid action at index {i}: {a[i].tolist()}")
-        obs, reward, done = (self._obs, self._reward, self._done) if out is None else out
-        if out is not None:
-            for t, shape, dt in ((obs, (self.num_envs, self.obs_dim), (torch.float32,)), (reward, (self.num_envs,), (torch.float32,)),
-                                 (done, (self.num_envs,), (torch.uint8, torch.bool))):
-                if tuple(t.shape) != shape or t.dtype not in dt or not t.is_contiguous() or t.device != self.device:
-                    raise ValueError(f"out tensors must be contiguous on {self.device}: obs {(self.num_envs, self.obs_dim)} float32, "
-                                     f"reward {(self.num_envs,)} float32, done {(self.num_envs,)} uint8 / bool")
-        _lib.check(self._L.rex_step(self._h, a.data_ptr(), obs.data_ptr(), reward.data_ptr(),
-                                    done.data_ptr(), self._cmd.data_ptr(), self._stream_ptr()), "rex_step")
-        return obs, reward, done if done.dtype == torch.bool else done.view(torch.bool), {"action": self._cmd}
+        if out is None:
+            out = self._own_out
+        elif not isinstance(out, StepOut):
+            out = self.bind_out(*out)
+        _lib.check(self._L.rex_step(self._h, a.data_ptr(), out.p_obs, out.p_reward, out.p_done, self._p_cmd, self._stream_ptr()), "rex_step")
+        return out.obs, out.reward, out.done_bool, self._info
+
+    def bind_out(self, obs, reward, done):
+        """Validate a set of output tensors once (`step(..., out=...)`): returns a StepOut that a loop can pass again and again."""
+        torch = self._torch
+        for t, shape, dt in ((obs, (self.num_envs, self.obs_dim), (torch.float32,)), (reward, (self.num_envs,), (torch.float32,)),
+                             (done, (self.num_envs,), (torch.uint8, torch.bool))):
+            if tuple(t.shape) != shape or t.dtype not in dt or not t.is_contiguous() or t.device != self.device:
+                raise ValueError(f"out tensors must be contiguous on {self.device}: obs {(self.num_envs, self.obs_dim)} float32, "
+                                 f"reward {(self.num_envs,)} float32, done {(self.num_envs,)} uint8 / bool")
+        return StepOut(obs, reward, done, torch)

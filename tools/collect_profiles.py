@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Turn the files tools/final_round.sh left in gpurun_out/ into the tracked summaries under profiles/:
+    python tools/collect_profiles.py TAG
+-> profiles/TAG_bench.json, TAG_bench_driver_cmd.json, TAG_bench_2rank_gloo_1gpu.json, TAG_bench_configs.md,
+   TAG_kernel_stats_and_pmc.md, and the workloads' entries of profiles/traffic.json (HBM bytes per launch, issue fraction)."""
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
+for name in ("bench.json", "bench_driver_cmd.json", "bench_2rank_gloo_1gpu.json"):
+    src = os.path.join(G, f"{tag}_{name}")
+    if os.path.exists(src):
+        lines = [l for l in open(src).read().splitlines() if l.strip().startswith("{")]
+        with open(os.path.join(P, f"{tag}_{name}"), "w") as f:
+            f.write(lines[-1] + "\n")
+rows = []
+src = os.path.join(G, f"{tag}_bench_configs.jsonl")
+if os.path.exists(src):
+    with open(os.path.join(P, f"{tag}_bench_configs.md"), "w") as f:
+        f.write(f"# {tag} -- bench.py lines of the other workloads (tools/bench_configs.sh: --steps 1000 --warmup 100 after the 1 500-step pre-roll), MI355X, 1 GPU\n\n")
+        f.write("| workload | env-steps/s | ms / step | kernel ms (device timestamps over the timed launches) |\n|---|---|---|---|\n")
+        for l in open(src):
+            try:
+                d = json.loads(l)
+            except ValueError:
+                continue
+            f.write(f"| {d['config']['workload'].split(', dt 1 ms')[0]} | {d['value'] / 1e6:.2f} M | {d['ms_per_step']:.4f} | {d['roofline']['kernel_ms']:.4f} |\n")
+KEYS = {"walk4096": "walk-ik/plane/base/4096", "walk262144": "walk-ik/plane/base/262144", "arm4096": "walk-ik/plane/arm/4096",
+        "mixedarm2048": "mixed-ik/plane/arm/2048", "gallop8192": "gallop-ol/plane/base/8192", "turnhf4096": "turn-ik/random/base/4096",
+        "poses4096": "poses-ik/plane/base/4096"}
+ALGO = {"walk4096": 541 * 4096, "walk262144": 541 * 262144, "arm4096": 661 * 4096, "mixedarm2048": 749 * 2048, "gallop8192": 581 * 8192,
+        "turnhf4096": 621 * 4096, "poses4096": 537 * 4096}
+traffic_path = os.path.join(P, "traffic.json")
+traffic = json.load(open(traffic_path))
+out = [f"# {tag} -- rocprofv3 kernel trace + PMC passes of bench.py per workload (tools/profile_round.sh), MI355X\n",
+       "Each workload: `rocprofv3 --kernel-trace --stats` (steady = launches after the 1 550th), then three separate `--pmc` passes "
+       "(FETCH_SIZE; WRITE_SIZE; SQ_* with GRBM_GUI_ACTIVE).  FETCH_SIZE / WRITE_SIZE in KB as gfx950 reports them (4-byte-per-lane word "
+       "loads: no correction known, MI355X_MICROARCH.md); issue fraction = 4 x SQ_ACTIVE_INST_VALU / (32 SIMDs x GRBM_GUI_ACTIVE) per shader "
+       "engine: the share of SIMD cycles that issue a VALU instruction.\n",
+       "| workload | kernel | avg us (steady) | min | max | scratch B | FETCH KB | WRITE KB | HBM MB / launch | algorithmic MB | ratio | VALU issue fraction | WAIT_ANY / WAVE_CYCLES |",
+       "|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
+for f in sorted(glob.glob(os.path.join(G, f"{tag}_profile_*.txt"))):
+    name = os.path.basename(f)[len(tag) + 9:-4]
+    txt = open(f).read()
+    stats = [l for l in txt.splitlines() if l.startswith("| `_ZN3rex15rex_step")]
+    js = [l for l in txt.splitlines() if l.startswith('{"')]
+    if not stats or not js:
+        continue
+    d = json.loads(js[-1]); g = lambda k: d.get(k, {}).get("avg_steady")
+    st = [c.strip() for c in stats[0].split("|")]
+    mb = (g("FETCH_SIZE") + g("WRITE_SIZE")) * 1e3 / 1e6
+    frac = 4 * g("SQ_ACTIVE_INST_VALU") / (32 * g("GRBM_GUI_ACTIVE"))
+    kern = st[1].split("rex_step_kernelI")[1].split("EEv")[0].replace("Lb0", "0").replace("Lb1", "1").replace("Li", "").replace("E", ",")
+    out.append(f"| {KEYS.get(name, name)} | `<{kern}>` | {st[5]} | {st[6]} | {st[7]} | {st[-2]} | {g('FETCH_SIZE'):.1f} | {g('WRITE_SIZE'):.1f} | {mb:.2f} | "
+               f"{ALGO[name] / 1e6:.2f} | {mb / (ALGO[name] / 1e6):.2f} | {frac:.3f} | {g('SQ_WAIT_ANY') / g('SQ_WAVE_CYCLES'):.3f} |")
+    traffic[KEYS.get(name, name)] = {"bytes_per_launch": int(mb * 1e6), "fetch_kb": round(g("FETCH_SIZE"), 1), "write_kb": round(g("WRITE_SIZE"), 1),
+                                     "issue_frac": round(frac, 4), "kernel_us_steady": float(st[5]), "source": f"profiles/{tag}_kernel_stats_and_pmc.md"}
+with open(os.path.join(P, f"{tag}_kernel_stats_and_pmc.md"), "w") as f:
+    f.write("\n".join(out) + "\n")
+with open(traffic_path, "w") as f:
+    json.dump(traffic, f, indent=2)
+print("\n".join(out[3:]))
