@@ -904,9 +904,12 @@ template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
 constexpr int kDppXor1 = 0xB1;         // quad_perm [1,0,3,2]
 constexpr int kDppXor2 = 0x4E;         // quad_perm [2,3,0,1]
 constexpr int kDppHalfMirror = 0x141;  // row_half_mirror: lane i of 8 reads lane 7 - i (the other quad)
+constexpr int kDppShr1 = 0x111;        // row_shr:1: lane i of a row of 16 reads lane i - 1 (lane 0: 0)
 // sum over the lanes of a group, every lane holding a distinct addend
 template <int LPE>
 __device__ __forceinline__ float group_sum(float v) {
@@ -934,6 +937,33 @@ __device__ __forceinline__ float pick_leg(const float* a, int m, int j) {   // a
   const float lo = m & 1 ? a[3 + j] : a[j], hi = m & 1 ? a[9 + j] : a[6 + j];
   return m & 2 ? hi : lo;
 }
+// A value held in an accumulation register across a region that needs every VGPR (the sweep loop): the compiler spills
+// to AGPRs by itself, but by its own weights -- at 16 envs per wave it kept the substep's bystanders (the base Cholesky
+// factor, the body state) in VGPRs and put a quarter of the loop's row slices into AGPRs, one v_accvgpr_read per use.
+__device__ __forceinline__ float to_agpr(float v) { float a; asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(a) : "v"(v)); return a; }
+__device__ __forceinline__ float from_agpr(float a) { float v; asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a)); return v; }
+__device__ __forceinline__ void hold(float& x) { x = to_agpr(x); }
+__device__ __forceinline__ void take(float& x) { x = from_agpr(x); }
+__device__ __forceinline__ void hold(uint32_t& x) { x = __builtin_bit_cast(uint32_t, to_agpr(__builtin_bit_cast(float, x))); }
+__device__ __forceinline__ void take(uint32_t& x) { x = __builtin_bit_cast(uint32_t, from_agpr(__builtin_bit_cast(float, x))); }
+__device__ __forceinline__ void hold(int32_t& x) { x = __builtin_bit_cast(int32_t, to_agpr(__builtin_bit_cast(float, x))); }
+__device__ __forceinline__ void take(int32_t& x) { x = __builtin_bit_cast(int32_t, from_agpr(__builtin_bit_cast(float, x))); }
+template <int N> __device__ __forceinline__ void hold(uint32_t (&x)[N]) {
+#pragma unroll
+  for (int k = 0; k < N; ++k) hold(x[k]);
+}
+template <int N> __device__ __forceinline__ void take(uint32_t (&x)[N]) {
+#pragma unroll
+  for (int k = 0; k < N; ++k) take(x[k]);
+}
+template <int N> __device__ __forceinline__ void hold(float (&x)[N]) {
+#pragma unroll
+  for (int k = 0; k < N; ++k) x[k] = to_agpr(x[k]);
+}
+template <int N> __device__ __forceinline__ void take(float (&x)[N]) {
+#pragma unroll
+  for (int k = 0; k < N; ++k) x[k] = from_agpr(x[k]);
+}
 // LDS rows / parked factors written by one lane of a group are read by the others: order the accesses of the wave
 __device__ __forceinline__ void mirror_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
 
@@ -948,7 +978,28 @@ __device__ __forceinline__ void mirror_sync() { __builtin_amdgcn_fence(__ATOMIC_
 // turn), which leaves fma - fma - clamp - subtract on the dependent chain.  Joint-limit rows come first, as in Bullet,
 // group by group and skipped while no env of the wave has a bound in reach.  Contact rows out of reach have invd = 0,
 // produce zero impulses and are not skipped: a static row sequence is what lets the pipeline run.
+#ifdef REX_PROF
+__device__ long long g_prof[10 * 1024];  // per block: cycle counters of the sections of physics_substep (+ [8] whole kernel, [9] launches)
+__device__ long long g_prof2[8 * 1024];  // per block: inside pgs_dv: [0] set-up, [1] sweep loop, [2] hand-back
+#define REX_STAMP(var) const long long var = clock64()
+#else
+#define REX_STAMP(var)
+#endif
+// per-variant code shape of the sweep loop (pgs_dv), chosen by measurement (tools/ab_libs.sh)
+#ifndef REX_FINISH_UNROLL
+#define REX_FINISH_UNROLL(EPW, BLOCK) (BLOCK)
+#endif
+#ifndef REX_HOLD_ACROSS_SWEEPS
+#define REX_HOLD_ACROSS_SWEEPS(EPW, ARM, BODY, MIXED) false
+#endif
+#ifndef REX_ROW_FENCE
+#define REX_ROW_FENCE(EPW) false
+#endif
+#ifndef REX_PAIRED_SWEEPS
+#define REX_PAIRED_SWEEPS(EPW, ARM, BODY, MIXED) ((EPW) <= 8 && !(BODY) && !(MIXED))
+#endif
 __device__ __forceinline__ constexpr int crow_leg(int r) { return r < REX_NPOINT ? r / 2 : (r - REX_NPOINT) / 4; }
+__device__ __forceinline__ int crow_leg_rt(int r) { return r < REX_NPOINT ? r >> 1 : (r - REX_NPOINT) >> 2; }   // (a lane's own row index)
 
 template <int NY, int EPW>
 struct DvLane {
@@ -989,7 +1040,11 @@ __device__ __forceinline__ void pgs_dv(const SM& sm, ARMP& armp, PgsX& x, int p,
                                        unsigned bgroups, float mu, int iterations, int lane_iterations, float thr, int& nsweeps, int& lane_sweeps) {
   constexpr int EPW = SM::kEpw, NY = (6 + LPE - 1) / LPE;
   constexpr int kRow = REX_ROW_F4 * EPW * 16;   // bytes from a row to the next
+  constexpr bool kRowFence = REX_ROW_FENCE(EPW);
+  constexpr bool kPairedSweeps = REX_PAIRED_SWEEPS(EPW, ARMP::NM > 12, SM::kBody, LANECAP);
+  REX_STAMP(t_dv0);
   DvLane<NY, EPW> ln;
+  int okt;                  // byte offset of the lane's target word in row 0
   float ys[NY], zs[REX_NLEG];
   {
     const float yv[6] = {x.y01.x, x.y01.y, x.y23.x, x.y23.y, x.y45.x, x.y45.y};
@@ -1005,6 +1060,7 @@ __device__ __forceinline__ void pgs_dv(const SM& sm, ARMP& armp, PgsX& x, int p,
     }
     const int f = p < 3 ? 6 + p : 11;
     ln.oz = ((f >> 2) * EPW + sm.slot) * 16 + (f & 3) * 4;
+    okt = (2 * EPW + sm.slot) * 16 + (p == 0 ? 1 : 3) * 4;
 #pragma unroll
     for (int l = 0; l < REX_NLEG; ++l) zs[l] = sm.zf(l, p < 3 ? p : 3);
   }
@@ -1035,13 +1091,11 @@ __device__ __forceinline__ void pgs_dv(const SM& sm, ARMP& armp, PgsX& x, int p,
     for (int i = 0; i < NY; ++i) Jy[r][i] = ln.ld(sm, r * kRow + ln.oy[i]);
     Jz[r] = ln.ld(sm, r * kRow + ln.oz);
     Ki[r] = sm.rowf(r, 10);
-    // chunk 2 .y holds invd * target; rows out of reach have invd = 0 and never move, whatever their target
-    // (storing the plain target instead, to save this reciprocal, measured 1.7 % SLOWER: scheduling)
-    Kt[r] = (p == 0 && Ki[r] > 0.0f) ? -sm.rowf(r, 9) * __builtin_amdgcn_rcpf(Ki[r]) : 0.0f;
+    Kt[r] = ln.ld(sm, r * kRow + okt);   // chunk 2 .y holds -target (0 for a row out of reach): lane 0; the others read the 0 in .w
   }
-
+  REX_STAMP(t_dv1);
   bool running = true;
-  for (int it = 0; it < iterations; ++it) {
+  auto sweep = [&](const auto& li, auto& lo, int it) __attribute__((always_inline)) {
     ++nsweeps;
     if (running) {
       ++lane_sweeps;
@@ -1062,7 +1116,7 @@ __device__ __forceinline__ void pgs_dv(const SM& sm, ARMP& armp, PgsX& x, int p,
 #pragma unroll
           for (int i = 0; i < NY; ++i) part = fmaf(jy[i], ys[i], part);
           const float vel = group_sum<LPE>(part);
-          const float nl = fmaxf(fmaf(-c2.z, vel, lam[r] + c2.y), 0.0f);
+          const float nl = fmaxf(fmaf(-c2.z, vel, lam[r] + c2.y), 0.0f);   // (in place, also when the contact rows alternate)
           const float dl = nl - lam[r];
           lam[r] = nl;
           worst = fmaxf(worst, fmaf(-thr, c2.z, fabsf(dl)));
@@ -1099,13 +1153,13 @@ __device__ __forceinline__ void pgs_dv(const SM& sm, ARMP& armp, PgsX& x, int p,
         for (int r = 0; r < REX_NCROW; ++r) {
           const int L = crow_leg(r);
           const float sum = fmaf(cpl[r], dlp, S);
-          float nl = fmaf(-Ki[r], sum, lam[r]);
+          float nl = fmaf(-Ki[r], sum, li[r]);
           if (r < REX_NPOINT) nl = fmaxf(nl, 0.0f);
           else {
-            const float lm = mu * lam[(r - REX_NPOINT) / 2];
+            const float lm = mu * lo[(r - REX_NPOINT) / 2];
             nl = __builtin_amdgcn_fmed3f(nl, -lm, lm);
           }
-          const float dl = nl - lam[r];
+          const float dl = nl - li[r];
           if (r + 1 < REX_NCROW) {   // group sum of the next row over x as it stands before this row's step
             float part = fmaf(Jz[r + 1], zs[crow_leg(r + 1)], Kt[r + 1]);
 #pragma unroll
@@ -1113,11 +1167,12 @@ __device__ __forceinline__ void pgs_dv(const SM& sm, ARMP& armp, PgsX& x, int p,
             S = group_sum<LPE>(part);
           }
           worst = fmaxf(worst, fmaf(-thr, Ki[r], fabsf(dl)));   // |dl| / invd > thr: Bullet's velocity residual
-          lam[r] = nl;
+          lo[r] = nl;
           dlp = dl;
 #pragma unroll
           for (int i = 0; i < NY; ++i) ys[i] = fmaf(Jy[r][i], dl, ys[i]);
           zs[L] = fmaf(Jz[r], dl, zs[L]);
+          if constexpr (kRowFence) __builtin_amdgcn_sched_barrier(0);
         }
       }
       if constexpr (SM::kBody) {
@@ -1147,9 +1202,23 @@ __device__ __forceinline__ void pgs_dv(const SM& sm, ARMP& armp, PgsX& x, int p,
       // (the per-lane cap is compiled in for mixed-task batches only: even as a scalar condition it lengthens the loop's
       // back edge enough to cost 2.3 % of a step)
       running = LANECAP ? (worst > 0.0f && it + 1 < lane_iterations) : worst > 0.0f;
+    }             // (a lane that has stopped never sweeps again: what it leaves in `lo` is never read)
+  };
+  if constexpr (kPairedSweeps) {
+    float lamB[REX_NCROW];
+    for (int it = 0; it < iterations; it += 2) {
+      sweep(lam, lamB, it);
+      if (__builtin_amdgcn_ballot_w64(running) == 0 || it + 1 >= iterations) break;
+      sweep(lamB, lam, it + 1);
+      if (__builtin_amdgcn_ballot_w64(running) == 0) break;
     }
-    if (__builtin_amdgcn_ballot_w64(running) == 0) break;
+  } else {
+    for (int it = 0; it < iterations; ++it) {
+      sweep(lam, lam, it);
+      if (__builtin_amdgcn_ballot_w64(running) == 0) break;
+    }
   }
+  REX_STAMP(t_dv2);
   // hand the components back: every lane needs the whole of x for the back-substitution
 #pragma unroll
   for (int i = 0; i < NY; ++i) { const int k = p + i * LPE; sm.parkf(REX_PARK_XY, k < 6 ? k : 7) = ys[i]; }
@@ -1164,6 +1233,12 @@ __device__ __forceinline__ void pgs_dv(const SM& sm, ARMP& armp, PgsX& x, int p,
     for (int l = 0; l < REX_NLEG; ++l) { const float4 z = sm.zc(l); x.z01[l] = v2{z.x, z.y}; x.z2[l] = z.z; }
   }
   armp.dv_gather();
+#ifdef REX_PROF
+  if (threadIdx.x == 0 && blockIdx.x < 1024) {
+    long long* p2 = g_prof2 + 8 * blockIdx.x;
+    p2[0] += t_dv1 - t_dv0; p2[1] += t_dv2 - t_dv1; p2[2] += clock64() - t_dv2;
+  }
+#endif
 }
 
 // The restated pybullet.stepSimulation for one env: tau is held for this substep (one env per lane: the 12 leg torques in
@@ -1176,12 +1251,6 @@ __device__ __forceinline__ void rotate_leg(T* a) {   // 12-entry per-joint array
   a[9] = t0; a[10] = t1; a[11] = t2;
 }
 
-#ifdef REX_PROF
-__device__ long long g_prof[10 * 1024];  // per block: cycle counters of the sections of physics_substep (+ [8] whole kernel, [9] launches)
-#define REX_STAMP(var) const long long var = clock64()
-#else
-#define REX_STAMP(var)
-#endif
 template <bool LANECAP, class SM, class ARMP>
 __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float dt, int iterations, int lane_iterations,
                                                 float sqrt_res_thr, const SM& sm, const Ground& ground, ARMP& armp, int& lane_sweeps) {
@@ -1395,17 +1464,70 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
   // finish the rows: whiten the base part, inverse diagonal (0 disables an inactive point)
   armp.finish(Lc);
   const bool any_limit = __builtin_amdgcn_ballot_w64(((active >> REX_NPOINT) & 0xFFFu) != 0) != 0;   // bits 8..19: the 12 leg joints
-  for (int r = pl; r < (any_limit ? REX_NROW : REX_NCROW); r += kSplitLegs ? LPE : 1) {   // lane p: rows p, p + LPE, ...
-    float4 c0 = sm.row(r, 0), c1 = sm.row(r, 1), c2 = sm.row(r, 2);
+  auto finish_row = [&](int r, float (&gw)[6], float4& c1, float4& c2, bool contact_dv) __attribute__((always_inline)) {
+    const float4 c0 = sm.row(r, 0);
+    c1 = sm.row(r, 1); c2 = sm.row(r, 2);
     const float g[6] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y};
-    float gw[6];
     fwd6(Lc, g, gw);
     const float diag = gw[0] * gw[0] + gw[1] * gw[1] + gw[2] * gw[2] + gw[3] * gw[3] + gw[4] * gw[4] + gw[5] * gw[5] +
                        c1.z * c1.z + c1.w * c1.w + c2.x * c2.x;
     const float invd = c2.z != 0.0f ? __builtin_amdgcn_rcpf(diag) : 0.0f;
     sm.row(r, 0) = make_float4(gw[0], gw[1], gw[2], gw[3]);
     sm.row(r, 1) = make_float4(gw[4], gw[5], c1.z, c1.w);
-    sm.row(r, 2) = make_float4(c2.x, c2.y * invd, invd, kSplitLegs ? 0.0f : diag);   // .w = 0: see pgs_dv
+    // .y: what the sweep adds to a row's velocity: invd * target for the rows solved one by one (joint limits; all rows of
+    // the one-env-per-lane layout), the plain -target (0 when the row is out of reach) for the pipelined contact rows of a
+    // lane group (pgs_dv: the group sum is then vel - target); .w = 0 there: the word of the lanes that own no component
+    c2.y = contact_dv ? (c2.z != 0.0f ? -c2.y : 0.0f) : c2.y * invd;
+    sm.row(r, 2) = make_float4(c2.x, c2.y, invd, kSplitLegs ? 0.0f : diag);
+  };
+  if constexpr (kSplitLegs) {
+    // lane p finishes the contact rows [kBlock p, kBlock (p + 1)): consecutive rows meet in one lane, and the couplings of
+    // consecutive rows A(r, r-1) = J~_r . J~_(r-1) the pipelined sweep needs (pgs_dv) come out of its registers; the row
+    // before a block's first comes from the lane below (DPP row_shr:1; row 0 has no predecessor: lane 0 gets zeros or
+    // another env's row, and writes 0)
+    constexpr int kBlock = REX_NCROW / LPE;
+    float fg[6], fz[3];       // the block's first row: whitened base part, leg part
+    float pg[6], pz[3];       // the row before the current one
+    int pleg = -1;
+    constexpr int kUnroll = REX_FINISH_UNROLL(EPW, kBlock);
+#pragma unroll kUnroll
+    for (int k = 0; k < kBlock; ++k) {
+      const int r = kBlock * pl + k;
+      float gw[6]; float4 c1, c2;
+      finish_row(r, gw, c1, c2, true);
+      const float z[3] = {c1.z, c1.w, c2.x};
+      if (k > 0) {
+        float cp = crow_leg_rt(r) == pleg ? z[0] * pz[0] + z[1] * pz[1] + z[2] * pz[2] : 0.0f;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) cp = fmaf(gw[q], pg[q], cp);
+        sm.parkf(REX_PARK_CPL, r) = cp;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) fg[q] = gw[q];
+        fz[0] = z[0]; fz[1] = z[1]; fz[2] = z[2];
+      }
+#pragma unroll
+      for (int q = 0; q < 6; ++q) pg[q] = gw[q];
+      pz[0] = z[0]; pz[1] = z[1]; pz[2] = z[2];
+      pleg = crow_leg_rt(r);
+    }
+    {
+      // the block's last row goes to the lane above (the DPP moves are wave-wide: every lane shifts)
+      const int r0 = kBlock * pl;
+      // (every shift outside any condition, the leg test as a factor: inside `same leg ? ... : 0` the compiler branches, and
+      // a DPP move executed under a lane mask reads 0 from the lanes the mask has switched off)
+      const float nz0 = dpp_f<kDppShr1>(pz[0]), nz1 = dpp_f<kDppShr1>(pz[1]), nz2 = dpp_f<kDppShr1>(pz[2]);
+      const float same = crow_leg_rt(r0) == dpp_i<kDppShr1>(pleg) ? 1.0f : 0.0f;
+      float cp = same * (fz[0] * nz0 + fz[1] * nz1 + fz[2] * nz2);
+#pragma unroll
+      for (int q = 0; q < 6; ++q) cp = fmaf(fg[q], dpp_f<kDppShr1>(pg[q]), cp);
+      sm.parkf(REX_PARK_CPL, r0) = pl == 0 ? 0.0f : cp;
+    }
+    if (any_limit) {
+      for (int r = REX_NCROW + pl; r < REX_NROW; r += LPE) { float gw[6]; float4 c1, c2; finish_row(r, gw, c1, c2, false); }
+    }
+  } else {
+    for (int r = 0; r < (any_limit ? REX_NROW : REX_NCROW); ++r) { float gw[6]; float4 c1, c2; finish_row(r, gw, c1, c2, false); }
   }
 
   // bit 0: the base group has rows in reach of some env of the wave; bit 1 + leg / 5 + leg: the leg's first / second slot holds a
@@ -1470,20 +1592,21 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
   REX_STAMP(t_pgs0);
   int nsweeps = 0;
   if constexpr (kSplitLegs) {
-    mirror_sync();
-    // couplings of consecutive contact rows, A(r, r-1) = J~_r . J~_(r-1): lane p takes rows 1 + p, 1 + p + LPE, ...
-    for (int r = 1 + pl; r < REX_NCROW; r += LPE) {
-      const float4 a0 = sm.row(r, 0), a1 = sm.row(r, 1), a2 = sm.row(r, 2);
-      const float4 b0 = sm.row(r - 1, 0), b1 = sm.row(r - 1, 1), b2 = sm.row(r - 1, 2);
-      const int La = r < REX_NPOINT ? r >> 1 : (r - REX_NPOINT) >> 2, Lb = r - 1 < REX_NPOINT ? (r - 1) >> 1 : (r - 1 - REX_NPOINT) >> 2;
-      float cp = La == Lb ? a1.z * b1.z + a1.w * b1.w + a2.x * b2.x : 0.0f;
-      cp += a0.x * b0.x + a0.y * b0.y + a0.z * b0.z + a0.w * b0.w + a1.x * b1.x + a1.y * b1.y;
-      sm.parkf(REX_PARK_CPL, r) = cp;
-    }
-    if (pl == 0) sm.parkf(REX_PARK_CPL, 0) = 0.0f;
-    mirror_sync();
     const bool lim[4] = {lim0, lim1, lim2, lim3};
+    constexpr bool kHold = REX_HOLD_ACROSS_SWEEPS(EPW, ARMP::NM > 12, SM::kBody, LANECAP);
+    if constexpr (kHold) {
+      hold(Lc.l); hold(Lc.di);
+      hold(s.pos); hold(s.quat); hold(s.lin); hold(s.ang);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { hold(s.q[k]); hold(s.qd[k]); }
+    }
     pgs_dv<LPE, LANECAP>(sm, armp, x, pl, lim, any0 || any1 || any2 || any3, bgroups, ground.mu, iterations, lane_iterations, sqrt_res_thr, nsweeps, lane_sweeps);
+    if constexpr (kHold) {
+      take(Lc.l); take(Lc.di);
+      take(s.pos); take(s.quat); take(s.lin); take(s.ang);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { take(s.q[k]); take(s.qd[k]); }
+    }
   } else {
     // one env per lane (EPW = 64): every lane carries the whole of x, row by row from LDS
     bool running = true;

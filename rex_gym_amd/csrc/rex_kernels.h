@@ -410,7 +410,17 @@ __device__ __forceinline__ void rex_substep(const DevCfg& c, EnvState& e, int i,
     ms.tau_obs[jl] = obs;
     tau[jl] = ((e.motor_en >> j) & 1u) ? act : 0.0f;                            // rex.py:617-623
   }
+  // (the env's words that only sit through the physics: out of the way of the sweep loop, see to_agpr)
+  constexpr bool kHold = REX_HOLD_ACROSS_SWEEPS(SM::kEpw, ARM, SM::kBody, LANECAP) && NL == 1;
+  if constexpr (kHold) {
+    hold(e.phi); hold(e.alpha); hold(e.target); hold(e.aux); hold(e.last_step); hold(e.end_step); hold(e.flags); hold(e.steps);
+    hold(e.episode); hold(e.motor_en); hold(e.hist); hold(ms.cmd); hold(ms.tau_obs); hold(ms.overheat);
+  }
   physics_substep<LANECAP>(e.ph, tau, c.dt, c.max_iterations, c.iterations, c.res_thr, sm, ground, armp, e.sweeps);
+  if constexpr (kHold) {
+    take(e.phi); take(e.alpha); take(e.target); take(e.aux); take(e.last_step); take(e.end_step); take(e.flags); take(e.steps);
+    take(e.episode); take(e.motor_en); take(e.hist); take(ms.cmd); take(ms.tau_obs); take(ms.overheat);
+  }
   receive_observation<NM>(c, e, i, live, owner, leg0, ms);
 }
 
@@ -898,6 +908,7 @@ __global__ __launch_bounds__(REX_WAVE) REX_STEP_KERNEL_ATTR void rex_step_kernel
   else walk_command<NL>(c_, e, act, leg0, ms.cmd, call);
   env_gait_ik<NL>(c_, e, leg0, call, ms.cmd);     // the planner + IK tail of the task's command, if it has one
 
+  REX_STAMP(t_command);
   const Ground ground = env_ground(c, i, c.env_index_base + i, e.episode);
   const int step0 = e.steps, episode0 = e.episode;   // keys of this step's sensor-noise draws
 
@@ -1019,7 +1030,14 @@ __global__ __launch_bounds__(REX_WAVE) REX_STEP_KERNEL_ATTR void rex_step_kernel
 
   if constexpr (!MIXED) {
     for (int k = 0; k < c.action_repeat; ++k) rex_substep<false>(c, e, i, live, owner, leg0, ms, sm, ground, armp);   // Rex.Step
+    REX_STAMP(t_substeps);
     epilogue(live, owner);
+#ifdef REX_PROF
+    if (threadIdx.x == 0 && blockIdx.x < 1024) {
+      long long* p2 = g_prof2 + 8 * blockIdx.x;
+      p2[3] += t_command - t_kernel; p2[4] += t_substeps - t_command; p2[5] += clock64() - t_substeps;
+    }
+#endif
   } else {
     // Rex.Step of tasks with different action_repeat in one wave: every lane runs max_repeat substeps (the substep is
     // full of wave-level operations), an env whose own count is reached finishes its env.step() -- epilogue, stores --

@@ -26,6 +26,7 @@ from rex_gym_amd import RexBatchEnv, _lib
 
 L = _lib.lib()
 L.rex_debug_prof.argtypes = [ctypes.c_void_p, ctypes.c_int]
+L.rex_debug_prof2.argtypes = [ctypes.c_void_p, ctypes.c_int]
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 n = int(args[0]) if args else 4096
 mark = "arm" if "--arm" in sys.argv else "base"
@@ -46,11 +47,15 @@ acts = [torch.rand((n, env.action_dim), device="cuda") * (-2 * _lo) + _lo for _ 
 def window(steps, label):
     torch.cuda.synchronize()
     L.rex_debug_prof(None, 1)
+    L.rex_debug_prof2(None, 1)
     for k in range(steps):
         env.step(acts[k % 8])
     torch.cuda.synchronize()
     out = np.zeros((1024, 10), np.int64)
     L.rex_debug_prof(out.ctypes.data, 0)
+    out2 = np.zeros((1024, 8), np.int64)
+    L.rex_debug_prof2(out2.ctypes.data, 0)
+    out2 = out2[out[:, 4] > 0].astype(float)
     out = out[out[:, 4] > 0].astype(float)
     pgs, sw, tot, fin, sub, legs, chol = (out[:, i] for i in (0, 1, 2, 3, 4, 6, 7))
     rest = tot - pgs - fin - legs - chol
@@ -63,6 +68,13 @@ def window(steps, label):
     print("  cycles/substep: total %.0f (slowest workgroup %.0f) = legs %.0f + base chol %.0f + finish rows %.0f + pgs %.0f "
           "+ back-subst/integrate %.0f" % (np.mean(tot / sub), np.max(tot / sub), np.mean(legs / sub), np.mean(chol / sub),
                                            np.mean(fin / sub), np.mean(pgs / sub), np.mean(rest / sub)))
+    if out2[:, 4].sum() > 0:
+        print("  step = load + command (planner, IK) %.0f + substeps (motors, physics, observation ring) %.0f + reward / done / reset / observation / stores %.0f" %
+              tuple(np.mean(out2[:, k] / out[:, 9]) for k in (3, 4, 5)))
+    if out2[:, 1].sum() > 0:     # lane-group kernels: inside the pgs section
+        su, lp, hb = (np.mean(out2[:, k] / sub) for k in range(3))
+        print("  pgs = row couplings %.0f + sweep set-up %.0f + sweep loop %.0f (%.0f per sweep) + hand-back %.0f" %
+              (np.mean(pgs / sub) - su - lp - hb, su, lp, out2[:, 1].sum() / sw.sum(), hb))
 
 
 window(20, "first 20 steps after reset")
