@@ -44,6 +44,11 @@
 /* small-batch waves (EPW <= 16) only: chunks 0..1 the whitened base velocity y on its way to / from the lanes that own
    its components (pgs_dv), 2..7 the couplings A(r, r-1) of consecutive contact rows */
 #define REX_PARK_F4 8
+/* 16 envs per wave, mark 'base' ("pair layout", physics_substep / pgs_dv): 6 more chunks, the inverse diagonals of the 24
+   contact rows, whose word in the row makes room for a zero */
+#define REX_PAIR_LAYOUT(EPW, ARM) ((EPW) == 16 && !(ARM))
+#define REX_PARK_F4_OF(EPW, ARM) (REX_PAIR_LAYOUT(EPW, ARM) ? 14 : REX_PARK_F4)
+#define REX_PARK_KI 8
 /* link-box contact rows (RexConfig.body_contacts): 12 point slots -- 0..3 the base group (base + chassis boxes), 4 + 2 L + k
    leg L's boxes -- with a normal row (index slot) and two friction rows (12 + 2 slot + d) each, 3 chunks per row like the
    toe rows, in their own LDS region behind the hand-over chunks; lane groups only */
@@ -990,13 +995,13 @@ __device__ long long g_prof2[8 * 1024];  // per block: inside pgs_dv: [0] set-up
 #define REX_FINISH_UNROLL(EPW, BLOCK) (BLOCK)
 #endif
 #ifndef REX_HOLD_ACROSS_SWEEPS
-#define REX_HOLD_ACROSS_SWEEPS(EPW, ARM, BODY, MIXED) false
+#define REX_HOLD_ACROSS_SWEEPS(EPW, ARM, BODY, MIXED) ((EPW) == 16 && !(ARM))
 #endif
 #ifndef REX_ROW_FENCE
 #define REX_ROW_FENCE(EPW) false
 #endif
 #ifndef REX_PAIRED_SWEEPS
-#define REX_PAIRED_SWEEPS(EPW, ARM, BODY, MIXED) ((EPW) <= 8 && !(BODY) && !(MIXED))
+#define REX_PAIRED_SWEEPS(EPW, ARM, BODY, MIXED) (!(BODY) && !(MIXED) && ((EPW) <= 8 || !(ARM)))
 #endif
 __device__ __forceinline__ constexpr int crow_leg(int r) { return r < REX_NPOINT ? r / 2 : (r - REX_NPOINT) / 4; }
 __device__ __forceinline__ int crow_leg_rt(int r) { return r < REX_NPOINT ? r >> 1 : (r - REX_NPOINT) >> 2; }   // (a lane's own row index)
@@ -1045,6 +1050,9 @@ __device__ __forceinline__ void pgs_dv(const SM& sm, ARMP& armp, PgsX& x, int p,
   REX_STAMP(t_dv0);
   DvLane<NY, EPW> ln;
   int okt;                  // byte offset of the lane's target word in row 0
+  int opair = 0, ozc = 0;   // pair layout: of the lane's (y_p, y_(p+4)) word and of its leg component in a contact row
+  constexpr bool kPairLayout = REX_PAIR_LAYOUT(EPW, ARMP::NM > 12);
+  static_assert(!kPairLayout || (LPE == 4 && NY == 2), "pair layout: 4 lanes per env");
   float ys[NY], zs[REX_NLEG];
   {
     const float yv[6] = {x.y01.x, x.y01.y, x.y23.x, x.y23.y, x.y45.x, x.y45.y};
@@ -1061,6 +1069,11 @@ __device__ __forceinline__ void pgs_dv(const SM& sm, ARMP& armp, PgsX& x, int p,
     const int f = p < 3 ? 6 + p : 11;
     ln.oz = ((f >> 2) * EPW + sm.slot) * 16 + (f & 3) * 4;
     okt = (2 * EPW + sm.slot) * 16 + (p == 0 ? 1 : 3) * 4;
+    if constexpr (kPairLayout) {   // contact rows: (g0 g4 g1 g5) (g2 0 g3 0) (z0 z1 z2 -target); word 5 is a zero
+      opair = ((p >> 1) * EPW + sm.slot) * 16 + (p & 1) * 8;
+      ozc = ((p < 3 ? 2 : 1) * EPW + sm.slot) * 16 + (p < 3 ? p : 1) * 4;
+      okt = ((p == 0 ? 2 : 1) * EPW + sm.slot) * 16 + (p == 0 ? 3 : 1) * 4;
+    }
 #pragma unroll
     for (int l = 0; l < REX_NLEG; ++l) zs[l] = sm.zf(l, p < 3 ? p : 3);
   }
@@ -1087,11 +1100,24 @@ __device__ __forceinline__ void pgs_dv(const SM& sm, ARMP& armp, PgsX& x, int p,
   float Jy[REX_NCROW][NY], Jz[REX_NCROW], Kt[REX_NCROW], Ki[REX_NCROW];
 #pragma unroll
   for (int r = 0; r < REX_NCROW; ++r) {
+    if constexpr (kPairLayout) {
+      const float2 v = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(sm.p) + r * kRow + opair);
+      Jy[r][0] = v.x; Jy[r][NY - 1] = v.y;
+      Jz[r] = ln.ld(sm, r * kRow + ozc);
+    } else {
 #pragma unroll
-    for (int i = 0; i < NY; ++i) Jy[r][i] = ln.ld(sm, r * kRow + ln.oy[i]);
-    Jz[r] = ln.ld(sm, r * kRow + ln.oz);
-    Ki[r] = sm.rowf(r, 10);
-    Kt[r] = ln.ld(sm, r * kRow + okt);   // chunk 2 .y holds -target (0 for a row out of reach): lane 0; the others read the 0 in .w
+      for (int i = 0; i < NY; ++i) Jy[r][i] = ln.ld(sm, r * kRow + ln.oy[i]);
+      Jz[r] = ln.ld(sm, r * kRow + ln.oz);
+      Ki[r] = sm.rowf(r, 10);
+    }
+    Kt[r] = ln.ld(sm, r * kRow + okt);   // -target (0 for a row out of reach): lane 0; the others read a zero word of the row
+  }
+  if constexpr (kPairLayout) {
+#pragma unroll
+    for (int c = 0; c < REX_NCROW / 4; ++c) {
+      const float4 v = sm.park(REX_PARK_KI + c);
+      Ki[4 * c] = v.x; Ki[4 * c + 1] = v.y; Ki[4 * c + 2] = v.z; Ki[4 * c + 3] = v.w;
+    }
   }
   REX_STAMP(t_dv1);
   bool running = true;
@@ -1464,6 +1490,7 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
   // finish the rows: whiten the base part, inverse diagonal (0 disables an inactive point)
   armp.finish(Lc);
   const bool any_limit = __builtin_amdgcn_ballot_w64(((active >> REX_NPOINT) & 0xFFFu) != 0) != 0;   // bits 8..19: the 12 leg joints
+  constexpr bool kPairLayout = REX_PAIR_LAYOUT(SM::kEpw, ARMP::NM > 12);
   auto finish_row = [&](int r, float (&gw)[6], float4& c1, float4& c2, bool contact_dv) __attribute__((always_inline)) {
     const float4 c0 = sm.row(r, 0);
     c1 = sm.row(r, 1); c2 = sm.row(r, 2);
@@ -1472,6 +1499,16 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
     const float diag = gw[0] * gw[0] + gw[1] * gw[1] + gw[2] * gw[2] + gw[3] * gw[3] + gw[4] * gw[4] + gw[5] * gw[5] +
                        c1.z * c1.z + c1.w * c1.w + c2.x * c2.x;
     const float invd = c2.z != 0.0f ? __builtin_amdgcn_rcpf(diag) : 0.0f;
+    if (kPairLayout && contact_dv) {
+      // 4 lanes per env, lane p owns y_p and y_(p+4): the two meet in one 8-byte word of the row -- a lane's slice of the row
+      // is born as a register pair (what the packed multiply-adds of the sweep take; read as two words the compiler pairs
+      // the loads by row and copies every value into a second register).  (g0 g4 g1 g5) (g2 0 g3 0) (z0 z1 z2 -target)
+      sm.row(r, 0) = make_float4(gw[0], gw[4], gw[1], gw[5]);
+      sm.row(r, 1) = make_float4(gw[2], 0.0f, gw[3], 0.0f);
+      sm.row(r, 2) = make_float4(c1.z, c1.w, c2.x, c2.z != 0.0f ? -c2.y : 0.0f);
+      sm.parkf(REX_PARK_KI, r) = invd;
+      return;
+    }
     sm.row(r, 0) = make_float4(gw[0], gw[1], gw[2], gw[3]);
     sm.row(r, 1) = make_float4(gw[4], gw[5], c1.z, c1.w);
     // .y: what the sweep adds to a row's velocity: invd * target for the rows solved one by one (joint limits; all rows of

@@ -840,7 +840,7 @@ __global__ __launch_bounds__(REX_WAVE) REX_STEP_KERNEL_ATTR void rex_step_kernel
   constexpr int kLegF4 = REX_LEG_F4_OF(EPW, ARM, BODY);
   constexpr int kRowsF4 = ARM ? REX_LDS_F4_PER_ENV_ARM_OF(EPW) : REX_ROWS_F4_OF(kLegF4);
   static_assert(!BODY || EPW <= 16, "link-box contact rows: lane-group kernels only");
-  __shared__ float4 lds[(kRowsF4 + (EPW <= 16 ? REX_PARK_F4 : 0) + (BODY ? REX_BODY_F4 : 0)) * EPW];
+  __shared__ float4 lds[(kRowsF4 + (EPW <= 16 ? REX_PARK_F4_OF(EPW, ARM) : 0) + (BODY ? REX_BODY_F4 : 0)) * EPW];
   REX_STAMP(t_kernel);
   if (c.clock && threadIdx.x == 0) atomicMin(&c.clock[2 * (blockIdx.x & (REX_CLOCK_WAYS - 1))], (unsigned long long)wall_clock64());
   const int lane = threadIdx.x;
@@ -865,7 +865,7 @@ __global__ __launch_bounds__(REX_WAVE) REX_STEP_KERNEL_ATTR void rex_step_kernel
   const bool owner = ingrid && (LPE != 8 || (pl & 1) == 0);  // the lane that stores its leg's words (8 lanes per env: two carry a leg)
   const int gj = gi < c.n ? gi : c.n - 1;   // tail slots shadow the last env (keeps the wave convergent)
   const int i = c.perm ? c.perm[gj] : gj;   // regrouped batches: the env this slot works on
-  const Lds<EPW, kLegF4, BODY> sm{lds, slot, EPW <= 16 ? lds + kRowsF4 * EPW : nullptr, BODY ? lds + (kRowsF4 + REX_PARK_F4) * EPW : nullptr};
+  const Lds<EPW, kLegF4, BODY> sm{lds, slot, EPW <= 16 ? lds + kRowsF4 * EPW : nullptr, BODY ? lds + (kRowsF4 + REX_PARK_F4_OF(EPW, ARM)) * EPW : nullptr};
   typename ArmHook<EPW, ARM>::type armp = ArmHook<EPW, ARM>::make(lds, slot);
 
   DevCfg cmix;                          // MIXED only
@@ -1064,14 +1064,14 @@ __global__ __launch_bounds__(REX_WAVE) void rex_settle_kernel(DevCfg c, float* _
   constexpr int EPW = (ARM || BODY) ? 16 : REX_WAVE;   // the arm rows / link-box rows do not fit 64 envs per workgroup in LDS
   constexpr int kLegF4 = REX_LEG_F4_OF(EPW, ARM, BODY);
   constexpr int kRowsF4 = ARM ? REX_LDS_F4_PER_ENV_ARM_OF(EPW) : REX_ROWS_F4_OF(kLegF4);
-  __shared__ float4 lds[(kRowsF4 + (EPW <= 16 ? REX_PARK_F4 : 0) + (BODY ? REX_BODY_F4 : 0)) * EPW];
+  __shared__ float4 lds[(kRowsF4 + (EPW <= 16 ? REX_PARK_F4_OF(EPW, ARM) : 0) + (BODY ? REX_BODY_F4 : 0)) * EPW];
   constexpr int LPE = EPW < 64 ? lanes_per_env(EPW) : 1;
   constexpr int NL = EPW < 64 ? 1 : 4;
   using MS = MotorSide<NL, ARM>;
   const int lane = (int)(threadIdx.x / LPE) & (EPW - 1);
   const int pl = (int)threadIdx.x & (LPE - 1);
   const int leg0 = NL == 4 ? 0 : (LPE == 8 ? pl >> 1 : pl);
-  const Lds<EPW, kLegF4, BODY> sm{lds, lane, EPW <= 16 ? lds + kRowsF4 * EPW : nullptr, BODY ? lds + (kRowsF4 + REX_PARK_F4) * EPW : nullptr};
+  const Lds<EPW, kLegF4, BODY> sm{lds, lane, EPW <= 16 ? lds + kRowsF4 * EPW : nullptr, BODY ? lds + (kRowsF4 + REX_PARK_F4_OF(EPW, ARM)) * EPW : nullptr};
   typename ArmHook<EPW, ARM>::type armp = ArmHook<EPW, ARM>::make(lds, lane);
   const int nrec = (c.n_terrain > 0 ? c.n_terrain : 1) * c.n_mix;
   const int first = (int)blockIdx.x * EPW + lane;                       // the (terrain, task) record this lane group settles
