@@ -842,6 +842,9 @@ __global__ __launch_bounds__(REX_WAVE) REX_STEP_KERNEL_ATTR void rex_step_kernel
   static_assert(!BODY || EPW <= 16, "link-box contact rows: lane-group kernels only");
   __shared__ float4 lds[(kRowsF4 + (EPW <= 16 ? REX_PARK_F4_OF(EPW, ARM) : 0) + (BODY ? REX_BODY_F4 : 0)) * EPW];
   REX_STAMP(t_kernel);
+#ifdef REX_PROF
+  const long long t_wall = (long long)wall_clock64();
+#endif
   if (c.clock && threadIdx.x == 0) atomicMin(&c.clock[2 * (blockIdx.x & (REX_CLOCK_WAYS - 1))], (unsigned long long)wall_clock64());
   const int lane = threadIdx.x;
   constexpr int LPE = EPW < 64 ? lanes_per_env(EPW) : 1;     // EPW <= 16: lane = LPE * slot + p (rex_device.h, group layout)
@@ -1052,7 +1055,11 @@ __global__ __launch_bounds__(REX_WAVE) REX_STEP_KERNEL_ATTR void rex_step_kernel
   }
   if (c.clock && threadIdx.x == 0) atomicMax(&c.clock[2 * (blockIdx.x & (REX_CLOCK_WAYS - 1)) + 1], (unsigned long long)wall_clock64());
 #ifdef REX_PROF
-  if (threadIdx.x == 0 && blockIdx.x < 1024) { g_prof[10 * blockIdx.x + 8] += clock64() - t_kernel; g_prof[10 * blockIdx.x + 9] += 1; }
+  if (threadIdx.x == 0 && blockIdx.x < 1024) {
+    g_prof[10 * blockIdx.x + 8] += clock64() - t_kernel; g_prof[10 * blockIdx.x + 9] += 1;
+    g_prof2[8 * blockIdx.x + 6] += (long long)wall_clock64() - t_wall;   // the 100 MHz counter over the same span: calibrates clock64()
+    g_prof2[8 * blockIdx.x + 7] = t_wall;                                // when this block of the LAST launch started
+  }
 #endif
 }
 

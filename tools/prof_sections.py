@@ -68,6 +68,15 @@ def window(steps, label):
     print("  cycles/substep: total %.0f (slowest workgroup %.0f) = legs %.0f + base chol %.0f + finish rows %.0f + pgs %.0f "
           "+ back-subst/integrate %.0f" % (np.mean(tot / sub), np.max(tot / sub), np.mean(legs / sub), np.mean(chol / sub),
                                            np.mean(fin / sub), np.mean(pgs / sub), np.mean(rest / sub)))
+    if out2[:, 7].sum() > 0:     # start times of the blocks of the last launch (10 ns ticks), its own length from the same counter
+        st = out2[:, 7] - out2[:, 7].min()
+        dur = out2[:, 6] / out[:, 9]
+        print("  last launch: block starts spread over %.1f us (median %.1f, p90 %.1f); a block runs %.1f us (mean; max %.1f); "
+              "latest end %.1f us after the first start" % (st.max() / 100, np.median(st) / 100, np.percentile(st, 90) / 100,
+                                                          dur.mean() / 100, dur.max() / 100, (st + dur).max() / 100))
+    if out2[:, 6].sum() > 0:
+        print("  clock64() ticks per 10 ns tick of the constant 100 MHz counter over the kernel: %.2f  (a clock64 tick = %.3f ns)" %
+              (out[:, 8].sum() / out2[:, 6].sum(), 10.0 * out2[:, 6].sum() / out[:, 8].sum()))
     if out2[:, 4].sum() > 0:
         print("  step = load + command (planner, IK) %.0f + substeps (motors, physics, observation ring) %.0f + reward / done / reset / observation / stores %.0f" %
               tuple(np.mean(out2[:, k] / out[:, 9]) for k in (3, 4, 5)))
