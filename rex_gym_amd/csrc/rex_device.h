@@ -991,8 +991,13 @@ __device__ long long g_prof2[8 * 1024];  // per block: inside pgs_dv: [0] set-up
 #define REX_STAMP(var)
 #endif
 // per-variant code shape of the sweep loop (pgs_dv), chosen by measurement (tools/ab_libs.sh)
+/* mark 'arm' at 16 envs per wave (every register taken, 300-600 B of scratch): the row keeps invd * target and the sweep
+   set-up divides it out again row by row (a branch and an LDS round trip each) -- slower set-up, fewer values in flight */
+#ifndef REX_TARGET_BY_DIVISION
+#define REX_TARGET_BY_DIVISION(EPW, ARM) ((EPW) == 16 && (ARM))
+#endif
 #ifndef REX_FINISH_UNROLL
-#define REX_FINISH_UNROLL(EPW, BLOCK) (BLOCK)
+#define REX_FINISH_UNROLL(EPW, ARM, BLOCK) ((EPW) == 16 && (ARM) ? 1 : (BLOCK))   /* mark 'arm' at 16 envs per wave spills: rolled there */
 #endif
 #ifndef REX_HOLD_ACROSS_SWEEPS
 #define REX_HOLD_ACROSS_SWEEPS(EPW, ARM, BODY, MIXED) ((EPW) == 16 && !(ARM))
@@ -1110,7 +1115,8 @@ __device__ __forceinline__ void pgs_dv(const SM& sm, ARMP& armp, PgsX& x, int p,
       Jz[r] = ln.ld(sm, r * kRow + ln.oz);
       Ki[r] = sm.rowf(r, 10);
     }
-    Kt[r] = ln.ld(sm, r * kRow + okt);   // -target (0 for a row out of reach): lane 0; the others read a zero word of the row
+    if constexpr (REX_TARGET_BY_DIVISION(EPW, ARMP::NM > 12)) Kt[r] = (p == 0 && Ki[r] > 0.0f) ? -sm.rowf(r, 9) * __builtin_amdgcn_rcpf(Ki[r]) : 0.0f;
+    else Kt[r] = ln.ld(sm, r * kRow + okt);   // -target (0 for a row out of reach): lane 0; the others read a zero word of the row
   }
   if constexpr (kPairLayout) {
 #pragma unroll
@@ -1514,7 +1520,7 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
     // .y: what the sweep adds to a row's velocity: invd * target for the rows solved one by one (joint limits; all rows of
     // the one-env-per-lane layout), the plain -target (0 when the row is out of reach) for the pipelined contact rows of a
     // lane group (pgs_dv: the group sum is then vel - target); .w = 0 there: the word of the lanes that own no component
-    c2.y = contact_dv ? (c2.z != 0.0f ? -c2.y : 0.0f) : c2.y * invd;
+    c2.y = contact_dv && !REX_TARGET_BY_DIVISION(SM::kEpw, ARMP::NM > 12) ? (c2.z != 0.0f ? -c2.y : 0.0f) : c2.y * invd;
     sm.row(r, 2) = make_float4(c2.x, c2.y, invd, kSplitLegs ? 0.0f : diag);
   };
   if constexpr (kSplitLegs) {
@@ -1526,7 +1532,7 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
     float fg[6], fz[3];       // the block's first row: whitened base part, leg part
     float pg[6], pz[3];       // the row before the current one
     int pleg = -1;
-    constexpr int kUnroll = REX_FINISH_UNROLL(EPW, kBlock);
+    constexpr int kUnroll = REX_FINISH_UNROLL(EPW, ARMP::NM > 12, kBlock);
 #pragma unroll kUnroll
     for (int k = 0; k < kBlock; ++k) {
       const int r = kBlock * pl + k;
