@@ -1002,9 +1002,6 @@ __device__ long long g_prof2[8 * 1024];  // per block: inside pgs_dv: [0] set-up
 #ifndef REX_HOLD_ACROSS_SWEEPS
 #define REX_HOLD_ACROSS_SWEEPS(EPW, ARM, BODY, MIXED) ((EPW) == 16 && !(ARM))
 #endif
-#ifndef REX_ROW_FENCE
-#define REX_ROW_FENCE(EPW) false
-#endif
 #ifndef REX_PAIRED_SWEEPS
 #define REX_PAIRED_SWEEPS(EPW, ARM, BODY, MIXED) (!(BODY) && !(MIXED) && ((EPW) <= 8 || !(ARM)))
 #endif
@@ -1050,7 +1047,6 @@ __device__ __forceinline__ void pgs_dv(const SM& sm, ARMP& armp, PgsX& x, int p,
                                        unsigned bgroups, float mu, int iterations, int lane_iterations, float thr, int& nsweeps, int& lane_sweeps) {
   constexpr int EPW = SM::kEpw, NY = (6 + LPE - 1) / LPE;
   constexpr int kRow = REX_ROW_F4 * EPW * 16;   // bytes from a row to the next
-  constexpr bool kRowFence = REX_ROW_FENCE(EPW);
   constexpr bool kPairedSweeps = REX_PAIRED_SWEEPS(EPW, ARMP::NM > 12, SM::kBody, LANECAP);
   REX_STAMP(t_dv0);
   DvLane<NY, EPW> ln;
@@ -1207,7 +1203,6 @@ __device__ __forceinline__ void pgs_dv(const SM& sm, ARMP& armp, PgsX& x, int p,
 #pragma unroll
           for (int i = 0; i < NY; ++i) ys[i] = fmaf(Jy[r][i], dl, ys[i]);
           zs[L] = fmaf(Jz[r], dl, zs[L]);
-          if constexpr (kRowFence) __builtin_amdgcn_sched_barrier(0);
         }
       }
       if constexpr (SM::kBody) {
