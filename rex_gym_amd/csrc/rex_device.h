@@ -974,18 +974,21 @@ __device__ __forceinline__ void mirror_sync() { __builtin_amdgcn_fence(__ATOMIC_
 
 // ---- the sweep loop of a lane group (EPW <= 16): velocity form with the whitened velocity DISTRIBUTED over the lanes ----
 // Lane p of a group owns component p (+ LPE, ...) of the base part y and component p of every leg's part z_L (lanes
-// that own none read the zero in chunk 2 .w of a row and never change).  A row is then: one or two scalar LDS reads of
-// the lane's components of J~, that many FMAs, a DPP sum over the group, the clamp (every lane, redundantly) and that
-// many FMAs for x += J~ dl -- 17 instructions against 21 + three 16-byte LDS reads per row when every lane carries the
-// whole of x, with no per-substep solver set-up, and it takes any row (contact, joint limit, arm limit) alike.
+// that own none read a zero word of the row and never change).  A row is then: one or two FMAs over the lane's components
+// of J~, a DPP sum over the group, the clamp (every lane, redundantly) and that many FMAs for x += J~ dl -- 13 instructions
+// in the contact loop against 21 + three 16-byte LDS reads per row when every lane carries the whole of x, and it takes
+// any row (contact, joint limit, arm limit) alike.  A lane's slice of the 24 contact rows is read from LDS once per substep.
 // The 24 contact rows run software-pipelined: the group sum of row r+1 is taken over x as it stands BEFORE row r is
-// solved and corrected by A(r+1, r) dl_r (cpl[], one 9-term inner product per row and substep, computed by the lanes in
-// turn), which leaves fma - fma - clamp - subtract on the dependent chain.  Joint-limit rows come first, as in Bullet,
-// group by group and skipped while no env of the wave has a bound in reach.  Contact rows out of reach have invd = 0,
-// produce zero impulses and are not skipped: a static row sequence is what lets the pipeline run.
+// solved and corrected by A(r+1, r) dl_r (cpl[]: one 9-term inner product per row and substep, out of the registers of
+// the lane that finishes the rows, physics_substep), which leaves fma - fma - clamp - subtract on the dependent chain.
+// Joint-limit rows come first, as in Bullet, behind one wave-uniform test (out of line: no env of a wave has a bound
+// in reach in 97-100 % of the substeps).  Contact rows out of reach have invd = 0, produce zero impulses and are not
+// skipped: a static row sequence is what lets the pipeline run.  What an instruction costs a lone wave here, and the
+// formulations that were measured and dropped: DESIGN.md section 5, profiles/r03_microbench.md.
 #ifdef REX_PROF
 __device__ long long g_prof[10 * 1024];  // per block: cycle counters of the sections of physics_substep (+ [8] whole kernel, [9] launches)
-__device__ long long g_prof2[8 * 1024];  // per block: inside pgs_dv: [0] set-up, [1] sweep loop, [2] hand-back
+__device__ long long g_prof2[8 * 1024];  // per block: inside pgs_dv: [0] set-up, [1] sweep loop, [2] hand-back; of the kernel: [3] load + command,
+                                         // [4] substeps, [5] epilogue, [6] the 100 MHz counter over the kernel, [7] start of the last launch
 #define REX_STAMP(var) const long long var = clock64()
 #else
 #define REX_STAMP(var)
@@ -999,9 +1002,13 @@ __device__ long long g_prof2[8 * 1024];  // per block: inside pgs_dv: [0] set-up
 #ifndef REX_FINISH_UNROLL
 #define REX_FINISH_UNROLL(EPW, ARM, BLOCK) ((EPW) == 16 && (ARM) ? 1 : (BLOCK))   /* mark 'arm' at 16 envs per wave spills: rolled there */
 #endif
+/* the substep's bystanders (base Cholesky factor, body state, the env's words) parked in AGPRs around the sweeps by hand
+   (to_agpr): where the loop's row slices need every VGPR -- 4 lanes per env, two base components per lane */
 #ifndef REX_HOLD_ACROSS_SWEEPS
 #define REX_HOLD_ACROSS_SWEEPS(EPW, ARM, BODY, MIXED) ((EPW) == 16 && !(ARM))
 #endif
+/* contact impulses alternating between two register sets, sweeps in pairs: not where it measured slower (link-box rows,
+   mixed tasks with their per-lane sweep cap, mark 'arm' at 16 envs per wave) */
 #ifndef REX_PAIRED_SWEEPS
 #define REX_PAIRED_SWEEPS(EPW, ARM, BODY, MIXED) (!(BODY) && !(MIXED) && ((EPW) <= 8 || !(ARM)))
 #endif
