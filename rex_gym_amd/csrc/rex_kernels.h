@@ -1194,6 +1194,7 @@ struct RexSim {
   unsigned long long* h_clock;   // host staging of the same (per sim: no buffer is shared between sims or threads)
   int32_t* d_perm;   // regrouping (large batches only): wave slot -> env, and the per-env sweep counts it is sorted by
   int32_t* d_sweeps;
+  int32_t* d_regroup;   // [chunks][64] bin counts / start offsets of the many-workgroup sort + its completion counter
   hipEvent_t ring0[REX_TIMING_RING], ring1[REX_TIMING_RING];
   long long timed_steps;
   int words;   // per-env state words of the config's mark

@@ -21,6 +21,50 @@ __global__ __launch_bounds__(1024) void rex_regroup_kernel(int n, int bin_width,
   __syncthreads();
   for (int i = t; i < n; i += 1024) perm[atomicAdd(&base[63 - min(sweeps[i] / bin_width, 63)], 1)] = i;
 }
+// The same sort over many workgroups (the one-workgroup kernel above takes 0.3 ms for 262 144 envs: a tenth of their step):
+// workgroup b counts its REX_REGROUP_CHUNK envs per bin; the last workgroup to finish turns the counts into start offsets
+// (bins in order, workgroups in order inside a bin: the permutation is the one-workgroup kernel's up to the order inside a
+// bin); a second launch scatters.
+#define REX_REGROUP_CHUNK 1024
+__device__ __forceinline__ int regroup_bin(int sweeps, int bin_width) { return 63 - min(sweeps / bin_width, 63); }
+__global__ __launch_bounds__(256) void rex_regroup_count_kernel(int n, int bin_width, const int32_t* __restrict__ sweeps, int32_t* __restrict__ counts,
+                                                                unsigned* __restrict__ done) {
+  __shared__ int hist[64];
+  __shared__ bool last;
+  const int t = threadIdx.x, b = blockIdx.x, nb = gridDim.x;
+  if (t < 64) hist[t] = 0;
+  __syncthreads();
+  for (int k = t; k < REX_REGROUP_CHUNK; k += 256) {
+    const int i = b * REX_REGROUP_CHUNK + k;
+    if (i < n) atomicAdd(&hist[regroup_bin(sweeps[i], bin_width)], 1);
+  }
+  __syncthreads();
+  if (t < 64) counts[b * 64 + t] = hist[t];
+  __threadfence();
+  __syncthreads();
+  if (t == 0) last = atomicAdd(done, 1u) == (unsigned)nb - 1u;
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  // counts[b][bin] -> first slot of workgroup b's envs of that bin
+  __shared__ int total[64], first[64];
+  if (t < 64) { int acc = 0; for (int k = 0; k < nb; ++k) acc += counts[k * 64 + t]; total[t] = acc; }
+  __syncthreads();
+  if (t == 0) { int acc = 0; for (int k = 0; k < 64; ++k) { first[k] = acc; acc += total[k]; } *done = 0u; }
+  __syncthreads();
+  if (t < 64) { int acc = first[t]; for (int k = 0; k < nb; ++k) { const int c = counts[k * 64 + t]; counts[k * 64 + t] = acc; acc += c; } }
+}
+__global__ __launch_bounds__(256) void rex_regroup_scatter_kernel(int n, int bin_width, const int32_t* __restrict__ sweeps, const int32_t* __restrict__ counts,
+                                                                  int32_t* __restrict__ perm) {
+  __shared__ int cursor[64];
+  const int t = threadIdx.x, b = blockIdx.x;
+  if (t < 64) cursor[t] = counts[b * 64 + t];
+  __syncthreads();
+  for (int k = t; k < REX_REGROUP_CHUNK; k += 256) {
+    const int i = b * REX_REGROUP_CHUNK + k;
+    if (i < n) perm[atomicAdd(&cursor[regroup_bin(sweeps[i], bin_width)], 1)] = i;
+  }
+}
 __global__ void rex_iota_kernel(int n, int32_t* __restrict__ perm, int32_t* __restrict__ sweeps) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) { perm[i] = i; sweeps[i] = 0; }
@@ -254,7 +298,7 @@ int rex_create(const RexConfig* cfg, int device, float* d_state, void* stream, R
   d.pose_index = cfg->pose_index; d.pose_value = cfg->pose_value;
   d.range_normalize = cfg->range_normalize;
   d.terrain = nullptr; d.terrain_mid = nullptr; d.n_terrain = 0; d.body_params = nullptr;
-  d.perm = nullptr; d.sweeps = nullptr; s->d_perm = nullptr; s->d_sweeps = nullptr; d.clock = nullptr; s->d_clock = nullptr; s->h_clock = nullptr;
+  d.perm = nullptr; d.sweeps = nullptr; s->d_perm = nullptr; s->d_sweeps = nullptr; s->d_regroup = nullptr; d.clock = nullptr; s->d_clock = nullptr; s->h_clock = nullptr;
   d.geo = rex::HfGeom{256, 20.0f, 20.0f, 127.5f, 127.5f, 254.999f, 254.999f}; d.hf_stride = 65536;   /* model/terrain.py:32-54 */
   d.init_z = cfg->init_height > 0.0f ? cfg->init_height : rex::kInitZ;
   d.anchor = 0.0f;
@@ -284,15 +328,20 @@ int rex_create(const RexConfig* cfg, int device, float* d_state, void* stream, R
   d.dt_d = as_written(cfg->sim_time_step);
   d.gait_clock_d = cfg->gait_clock_scale > 0.0f ? as_written(cfg->gait_clock_scale) : 1.0;
   {
-    // Regrouping (opt-in: REX_REGROUP=1) can pay once a SIMD runs several waves one after the other -- below that the launch
-    // ends with its slowest wave whatever the grouping.  Measured on MI355X (profiles/r02_regroup.md): +10 % on the walking
-    // workload (gait clock 1.5, sweep counts 0.96 correlated from step to step), -11 % on the falling one (0.52), where the
-    // scattered state access and the sort cost more than the 18 % of sweeps the grouping can save.
+    // Regrouping (REX_REGROUP=1 / 0 overrides) can pay once a SIMD runs several waves one after the other -- below that the
+    // launch ends with its slowest wave whatever the grouping.  Measured on MI355X: round 2, one-workgroup sort
+    // (profiles/r02_regroup.md): +10 % on the walking workload (gait clock 1.5, sweep counts 0.96 correlated from step to
+    // step), -11 % on the falling one (0.52).  Round 3, many-workgroup sort, falling workload: the step kernel -9 % at
+    // 262 144 envs and -5 % at 65 536; with the sort's two launches +5.4 % (132.9 -> 140.1 M env-steps/s) and +0.9 % on
+    // the whole step.  On by default from 262 144 envs.
     const char* ov = getenv("REX_REGROUP");
-    const bool want = ov ? atoi(ov) != 0 : false;
+    const bool want = ov ? atoi(ov) != 0 : cfg->num_envs >= 262144;
     if (want) {
       hipError_t e2 = hipMalloc(&s->d_perm, sizeof(int32_t) * (size_t)cfg->num_envs);
       if (e2 == hipSuccess) e2 = hipMalloc(&s->d_sweeps, sizeof(int32_t) * (size_t)cfg->num_envs);
+      const int chunks = (cfg->num_envs + REX_REGROUP_CHUNK - 1) / REX_REGROUP_CHUNK;
+      if (e2 == hipSuccess) e2 = hipMalloc(&s->d_regroup, sizeof(int32_t) * ((size_t)chunks * 64 + 1));
+      if (e2 == hipSuccess) e2 = hipMemsetAsync(s->d_regroup, 0, sizeof(int32_t) * ((size_t)chunks * 64 + 1), (hipStream_t)stream);
       if (e2 != hipSuccess) { delete s; return fail(REX_ENOMEM, "hipMalloc(regroup): %s", hipGetErrorString(e2)); }
       hipLaunchKernelGGL(rex::rex_iota_kernel, dim3((cfg->num_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, cfg->num_envs, s->d_perm, s->d_sweeps);
       d.perm = s->d_perm; d.sweeps = s->d_sweeps;
@@ -378,6 +427,7 @@ int rex_destroy(RexSim* s) {
   free(s->h_clock);
   if (s->d_perm) (void)hipFree(s->d_perm);
   if (s->d_sweeps) (void)hipFree(s->d_sweeps);
+  if (s->d_regroup) (void)hipFree(s->d_regroup);
   (void)hipEventDestroy(s->ev0);
   (void)hipEventDestroy(s->ev1);
   for (int k = 0; k < REX_TIMING_RING; ++k) if (s->ring0[k]) { (void)hipEventDestroy(s->ring0[k]); (void)hipEventDestroy(s->ring1[k]); }
@@ -425,9 +475,16 @@ int rex_step(RexSim* s, const float* d_action, float* d_obs, float* d_reward, ui
     for (int k = 1; k < repeat; ++k) launch_step(s, blocks, st, d_action, d_obs, d_reward, d_done, d_motor_cmd);
   }
   HIPCHK(hipGetLastError());
-  if (s->d_perm)   // next step's grouping from this step's sweep counts (stream-ordered behind the step)
-    hipLaunchKernelGGL(rex::rex_regroup_kernel, dim3(1), dim3(1024), 0, st, s->cfg.num_envs, (s->dev.max_repeat * s->dev.max_iterations + 63) / 64,
-                       s->d_sweeps, s->d_perm);
+  if (s->d_perm) {   // next step's grouping from this step's sweep counts (stream-ordered behind the step)
+    const int n = s->cfg.num_envs, width = (s->dev.max_repeat * s->dev.max_iterations + 63) / 64;
+    const int chunks = (n + REX_REGROUP_CHUNK - 1) / REX_REGROUP_CHUNK;
+    if (chunks <= 4) hipLaunchKernelGGL(rex::rex_regroup_kernel, dim3(1), dim3(1024), 0, st, n, width, s->d_sweeps, s->d_perm);
+    else {
+      unsigned* done = reinterpret_cast<unsigned*>(s->d_regroup + (size_t)chunks * 64);
+      hipLaunchKernelGGL(rex::rex_regroup_count_kernel, dim3(chunks), dim3(256), 0, st, n, width, s->d_sweeps, s->d_regroup, done);
+      hipLaunchKernelGGL(rex::rex_regroup_scatter_kernel, dim3(chunks), dim3(256), 0, st, n, width, s->d_sweeps, s->d_regroup, s->d_perm);
+    }
+  }
   if (s->timing == 1 || s->timing == 2) { HIPCHK(hipEventRecord(e1, st)); s->have_timing = 1; if (s->timing == 2) s->timed_steps++; }
   return REX_OK;
 }
