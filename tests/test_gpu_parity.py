@@ -1299,7 +1299,7 @@ def test_link_box_rows_change_nothing_while_no_box_touches_the_ground(torch):
     a.close(); b.close()
 
 
-@pytest.mark.parametrize("n", [3000, 9000])    # the one-workgroup sort (<= 4 096 envs) and the many-workgroup one (ragged last chunk)
+@pytest.mark.parametrize("n", [3000, 9000, 70000])    # the one-workgroup sort (<= 4 096 envs) and the many-workgroup one (9 and 69 chunks, ragged last chunk)
 def test_regrouped_batch_is_bit_identical(torch, monkeypatch, n):
     """REX_REGROUP=1: envs are regrouped into waves by the solver sweeps of the previous step; the wave slot -> env
     permutation changes every step, an env's results must not."""
