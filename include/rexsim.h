@@ -297,6 +297,14 @@ REX_API int rex_gait_loop(int n, int mode, double* d_planner, const double* d_pa
  * the batch size; the environment variable REX_ENVS_PER_WAVE overrides (tests run every variant through it). */
 REX_API int rex_envs_per_wave(const RexSim* sim);
 
+/* How a REX_TASK_MIXED batch is laid out over the wavefronts of the step kernel (host-only, no GPU needed).  An env of a
+ * mixed batch keeps the task drawn for it for life, so the library decides once which envs share a wave: chunks of
+ * neighbouring envs, sorted by task inside a chunk, every task's run padded to whole waves -- a wave then runs ONE task
+ * (wave-uniform action_repeat / sweep cap / action box / reward weights) and the chunks' workgroups are dealt to the XCDs.
+ * slots[blk * envs_per_wave + k] = env of slot k of workgroup blk (-1: padding), tasks[blk] = that workgroup's task.
+ * Returns the number of workgroups (pass NULL buffers to size them), or a negative error. */
+REX_API int rex_mixed_slot_map(const RexConfig* cfg, int envs_per_wave, int32_t* slots, int32_t* tasks, int max_blocks);
+
 /* Solver sweeps every env ran in the last rex_step (summed over its substeps), int32 [num_envs] copied to the caller's
  * device buffer -- the key a batch created under REX_REGROUP=1 is regrouped into waves by (opt-in). */
 REX_API int rex_get_sweeps(RexSim* sim, int32_t* d_out, void* stream);

@@ -69,6 +69,7 @@ _SIGS = {
     "rex_gait_loop": ([ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                        ctypes.c_void_p], ctypes.c_int),
     "rex_envs_per_wave": ([ctypes.c_void_p], ctypes.c_int),
+    "rex_mixed_slot_map": ([ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int], ctypes.c_int),
     "rex_get_sweeps": ([ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p], ctypes.c_int),
     "rex_step_times_ms": ([ctypes.c_void_p, ctypes.POINTER(ctypes.c_float), ctypes.c_int], ctypes.c_int),
     "rex_last_error": ([], ctypes.c_char_p),

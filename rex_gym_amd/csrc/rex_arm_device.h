@@ -327,6 +327,9 @@ struct ArmChain {
   __device__ __forceinline__ int foff(int f) const { return ((REX_ARM_BASE_F4 + REX_ARM_PARK_F4 + (f >> 2)) * EPW + sma.slot) * 16 + (f & 3) * 4; }
   __device__ __forceinline__ float ldb(int off) const { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(sma.p) + off); }
   __device__ __forceinline__ float& parkf(int f) const { return reinterpret_cast<float*>(&sma.park(f >> 2))[f & 3]; }
+  // the diagonal word of limit row k: written by finish(), read by the one-env-per-lane sweep only -- a free word per row
+  // for the lane groups once the rows are finished (physics_substep parks bystanders of the sweep loop there)
+  __device__ __forceinline__ float& spare(int k) const { return sma.row(k, 3).z; }
   template <int LPE>
   __device__ __forceinline__ void dv_begin(int p) {
     constexpr int NY = (6 + LPE - 1) / LPE;

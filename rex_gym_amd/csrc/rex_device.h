@@ -205,7 +205,9 @@ struct BaseKin {
 // (vertex coordinate = x * inv_cx + off_x, clamped to [0, max_x]).  The reference's random terrain: 256, 20, 127.5, 254.999.
 struct HfGeom { int nx; float inv_cx, inv_cy, off_x, off_y, max_x, max_y; };
 struct Ground {
-  const float* h; float mid;
+  // the heightfield pool (wave-uniform; nullptr: plane only) and this env's field in it as a 32-bit element offset: one
+  // register instead of an address pair carried through the whole step, and "is there a field" is a scalar test
+  const float* h; unsigned off; float mid;
   // per-env domain randomisation (Rex.SetBaseMasses / SetLegMasses, rex.py:659-692: masses only -- Bullet keeps the
   // inertia tensors computed at load time; plus the foot friction coefficient)
   float base_mass_scale, leg_mass_scale, mu;
@@ -224,7 +226,8 @@ __device__ __forceinline__ void ground_query(const Ground& g, float x, float y, 
   float fx = fminf(fmaxf(x * q.inv_cx + q.off_x, 0.0f), q.max_x), fy = fminf(fmaxf(y * q.inv_cy + q.off_y, 0.0f), q.max_y);
   const int i = (int)fx, j = (int)fy;
   const float u = fx - (float)i, v = fy - (float)j;
-  const float h00 = g.h[j * q.nx + i], h10 = g.h[j * q.nx + i + 1], h01 = g.h[(j + 1) * q.nx + i], h11 = g.h[(j + 1) * q.nx + i + 1];
+  const unsigned o = g.off + (unsigned)(j * q.nx + i);
+  const float h00 = g.h[o], h10 = g.h[o + 1u], h01 = g.h[o + (unsigned)q.nx], h11 = g.h[o + (unsigned)q.nx + 1u];
   float hh, gx, gy;
   if (u + v <= 1.0f) { hh = h00 + u * (h10 - h00) + v * (h01 - h00); gx = (h10 - h00) * q.inv_cx; gy = (h01 - h00) * q.inv_cy; }
   else { hh = h11 + (1.0f - u) * (h01 - h11) + (1.0f - v) * (h10 - h11); gx = (h11 - h01) * q.inv_cx; gy = (h11 - h10) * q.inv_cy; }
@@ -931,6 +934,10 @@ __device__ __forceinline__ float leg_sum(float v) {
   if (LPE == 8) v += dpp_f<kDppHalfMirror>(v);
   return v;
 }
+// lane `own` (0..3, a constant after unrolling) of every quad hands its value to the quad: quad_perm [own, own, own, own]
+__device__ __forceinline__ float quad_bcast(float v, int own) {
+  return own == 0 ? dpp_f<0x00>(v) : (own == 1 ? dpp_f<0x55>(v) : (own == 2 ? dpp_f<0xAA>(v) : dpp_f<0xFF>(v)));
+}
 template <int LPE>
 __device__ __forceinline__ unsigned leg_or(unsigned v) {   // over ALL lanes of the group (with LPE = 8 each lane of a leg sets its own point)
   v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, kDppXor1, 0xF, 0xF, true);
@@ -1009,6 +1016,14 @@ __device__ long long g_prof2[8 * 1024];  // per block: inside pgs_dv: [0] set-up
 #endif
 /* contact impulses alternating between two register sets, sweeps in pairs: not where it measured slower (link-box rows,
    mixed tasks with their per-lane sweep cap, mark 'arm' at 16 envs per wave) */
+/* the base Cholesky factor parked in the free target words of the friction rows during the sweeps (physics_substep) */
+#ifndef REX_PARK_IN_ROWS
+#define REX_PARK_IN_ROWS(EPW, ARM) ((EPW) == 16 && (ARM) ? 7 : 0)   /* bit 0: the factor's triangle, 1: its diagonal, 2: the body state */
+#endif
+/* joint-limit impulses held by one lane of the group each (pgs_dv): where every register counts */
+#ifndef REX_LIMIT_IMPULSE_BY_LANE
+#define REX_LIMIT_IMPULSE_BY_LANE(EPW, ARM) ((EPW) == 16 && (ARM))
+#endif
 #ifndef REX_PAIRED_SWEEPS
 #define REX_PAIRED_SWEEPS(EPW, ARM, BODY, MIXED) (!(BODY) && !(MIXED) && ((EPW) <= 8 || !(ARM)))
 #endif
@@ -1049,9 +1064,12 @@ __device__ __forceinline__ void body_row(const SM& sm, const LN& ln, int bodyoff
   if (leg >= 0) zs[leg] = fmaf(jz, dl, zs[leg]);
 }
 
-template <int LPE, bool LANECAP, class SM, class ARMP>
+// `cpl_free`: called once the couplings have been read into registers -- their six LDS chunks are idle until the next
+// substep's row finishing, and physics_substep parks bystanders of the sweep loop there where registers are short
+template <int LPE, bool LANECAP, class SM, class ARMP, class F>
 __device__ __forceinline__ void pgs_dv(const SM& sm, ARMP& armp, PgsX& x, int p, const bool (&lim)[4], bool any_contact,
-                                       unsigned bgroups, float mu, int iterations, int lane_iterations, float thr, int& nsweeps, int& lane_sweeps) {
+                                       unsigned bgroups, float mu, int iterations, int lane_iterations, float thr, int& nsweeps, int& lane_sweeps,
+                                       const F& cpl_free) {
   constexpr int EPW = SM::kEpw, NY = (6 + LPE - 1) / LPE;
   constexpr int kRow = REX_ROW_F4 * EPW * 16;   // bytes from a row to the next
   constexpr bool kPairedSweeps = REX_PAIRED_SWEEPS(EPW, ARMP::NM > 12, SM::kBody, LANECAP);
@@ -1092,9 +1110,13 @@ __device__ __forceinline__ void pgs_dv(const SM& sm, ARMP& armp, PgsX& x, int p,
     const float4 v = sm.park(REX_PARK_CPL + c);
     cpl[4 * c] = v.x; cpl[4 * c + 1] = v.y; cpl[4 * c + 2] = v.z; cpl[4 * c + 3] = v.w;
   }
-  float lam[REX_NROW];
+  cpl_free();
+  constexpr bool kLimLamByLane = REX_LIMIT_IMPULSE_BY_LANE(EPW, ARMP::NM > 12);
+  static_assert(!kLimLamByLane || LPE == 4, "limit impulses by lane: 4 lanes per env");
+  float lam[kLimLamByLane ? REX_NCROW : REX_NROW];
 #pragma unroll
-  for (int r = 0; r < REX_NROW; ++r) lam[r] = 0.0f;
+  for (int r = 0; r < (kLimLamByLane ? REX_NCROW : REX_NROW); ++r) lam[r] = 0.0f;
+  float laml[3] = {0.0f, 0.0f, 0.0f};
   float lamb[SM::kBody ? REX_NBROW : 1];
   int bodyoff = 0;
   if constexpr (SM::kBody) {
@@ -1105,7 +1127,8 @@ __device__ __forceinline__ void pgs_dv(const SM& sm, ARMP& armp, PgsX& x, int p,
   // this lane's slice of the 24 contact rows, read once per substep: its components of J~, invd, and -target in lane 0
   // of the group (0 elsewhere): the addend of the lane's first product, so that the group sum is vel - target and the
   // impulse step is one fma, nl = lam - invd (vel - target)
-  float Jy[REX_NCROW][NY], Jz[REX_NCROW], Kt[REX_NCROW], Ki[REX_NCROW];
+  // (only the 8 normal rows have a target -- emit_rows gives the friction rows none: 16 registers and LDS reads less)
+  float Jy[REX_NCROW][NY], Jz[REX_NCROW], Kt[REX_NPOINT], Ki[REX_NCROW];
 #pragma unroll
   for (int r = 0; r < REX_NCROW; ++r) {
     if constexpr (kPairLayout) {
@@ -1118,8 +1141,10 @@ __device__ __forceinline__ void pgs_dv(const SM& sm, ARMP& armp, PgsX& x, int p,
       Jz[r] = ln.ld(sm, r * kRow + ln.oz);
       Ki[r] = sm.rowf(r, 10);
     }
-    if constexpr (REX_TARGET_BY_DIVISION(EPW, ARMP::NM > 12)) Kt[r] = (p == 0 && Ki[r] > 0.0f) ? -sm.rowf(r, 9) * __builtin_amdgcn_rcpf(Ki[r]) : 0.0f;
-    else Kt[r] = ln.ld(sm, r * kRow + okt);   // -target (0 for a row out of reach): lane 0; the others read a zero word of the row
+    if (r < REX_NPOINT) {
+      if constexpr (REX_TARGET_BY_DIVISION(EPW, ARMP::NM > 12)) Kt[r] = (p == 0 && Ki[r] > 0.0f) ? -sm.rowf(r, 9) * __builtin_amdgcn_rcpf(Ki[r]) : 0.0f;
+      else Kt[r] = ln.ld(sm, r * kRow + okt);   // -target (0 for a row out of reach): lane 0; the others read a zero word of the row
+    }
   }
   if constexpr (kPairLayout) {
 #pragma unroll
@@ -1154,9 +1179,20 @@ __device__ __forceinline__ void pgs_dv(const SM& sm, ARMP& armp, PgsX& x, int p,
 #pragma unroll
           for (int i = 0; i < NY; ++i) part = fmaf(jy[i], ys[i], part);
           const float vel = group_sum<LPE>(part);
-          const float nl = fmaxf(fmaf(-c2.z, vel, lam[r] + c2.y), 0.0f);   // (in place, also when the contact rows alternate)
-          const float dl = nl - lam[r];
-          lam[r] = nl;
+          float dl;
+          if constexpr (kLimLamByLane) {
+            // the impulse of limit row 3 l + k lives in lane (3 l + k) % 4 of the group only (three registers instead of
+            // twelve): every lane evaluates the step on the register of that index, the owner's result goes round (one DPP
+            // broadcast inside the quad), the owner keeps the new impulse.  Two more instructions on a row that is rarely run.
+            const int own = (3 * l + k) & 3, idx = (3 * l + k) >> 2;   // (constants once the loops are unrolled)
+            const float nlo = fmaxf(fmaf(-c2.z, vel, laml[idx] + c2.y), 0.0f);
+            dl = quad_bcast(nlo - laml[idx], own);
+            laml[idx] = p == own ? nlo : laml[idx];
+          } else {
+            const float nl = fmaxf(fmaf(-c2.z, vel, lam[r] + c2.y), 0.0f);   // (in place, also when the contact rows alternate)
+            dl = nl - lam[r];
+            lam[r] = nl;
+          }
           worst = fmaxf(worst, fmaf(-thr, c2.z, fabsf(dl)));
 #pragma unroll
           for (int i = 0; i < NY; ++i) ys[i] = fmaf(jy[i], dl, ys[i]);
@@ -1199,7 +1235,7 @@ __device__ __forceinline__ void pgs_dv(const SM& sm, ARMP& armp, PgsX& x, int p,
           }
           const float dl = nl - li[r];
           if (r + 1 < REX_NCROW) {   // group sum of the next row over x as it stands before this row's step
-            float part = fmaf(Jz[r + 1], zs[crow_leg(r + 1)], Kt[r + 1]);
+            float part = r + 1 < REX_NPOINT ? fmaf(Jz[r + 1], zs[crow_leg(r + 1)], Kt[r + 1]) : Jz[r + 1] * zs[crow_leg(r + 1)];
 #pragma unroll
             for (int i = 0; i < NY; ++i) part = fmaf(Jy[r + 1][i], ys[i], part);
             S = group_sum<LPE>(part);
@@ -1648,7 +1684,47 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
 #pragma unroll
       for (int k = 0; k < 3; ++k) { hold(s.q[k]); hold(s.qd[k]); }
     }
-    pgs_dv<LPE, LANECAP>(sm, armp, x, pl, lim, any0 || any1 || any2 || any3, bgroups, ground.mu, iterations, lane_iterations, sqrt_res_thr, nsweeps, lane_sweeps);
+    // mark 'arm' at 16 envs per wave has no register left (512 taken, LDS full at four workgroups per CU) -- but a friction
+    // row has no target: word 9 of its 16 rows is free once the rows are finished (pgs_dv reads the targets of the 8 normal
+    // rows only).  The base Cholesky factor -- identical in the lanes of a group, needed again by the back-substitution --
+    // waits there during the sweeps.
+    constexpr int kRowParkBits = REX_PARK_IN_ROWS(EPW, ARMP::NM > 12);
+    constexpr bool kRowPark = (kRowParkBits & 1) != 0, kRowParkDi = (kRowParkBits & 2) != 0, kRowParkBody = (kRowParkBits & 4) != 0;
+    if constexpr (kRowPark) {
+#pragma unroll
+      for (int k = 0; k < 15; ++k) sm.rowf(REX_NPOINT + k, 9) = Lc.l[k];
+      sm.rowf(REX_NPOINT + 15, 9) = Lc.di[0];
+    }
+    if constexpr (kRowParkDi) {
+#pragma unroll
+      for (int k = 1; k < 6; ++k) armp.spare(k) = Lc.di[k];   // (and the diagonal words of the arm limit rows, which the lane groups' sweep does not read)
+    }
+    // ... and what the integrator still needs of the body state (base position and orientation, the arm's joint angles:
+    // identical in the lanes of a group; the velocities are rewritten by the back-substitution) in the chunks of the row
+    // couplings, which pgs_dv holds in registers during the sweeps (cpl_free)
+    auto park_body = [&]() __attribute__((always_inline)) {
+      if constexpr (kRowParkBody) {
+        sm.park(REX_PARK_CPL + 0) = make_float4(s.pos[0], s.pos[1], s.pos[2], s.quat[0]);
+        sm.park(REX_PARK_CPL + 1) = make_float4(s.quat[1], s.quat[2], s.quat[3], s.q[12]);
+        sm.park(REX_PARK_CPL + 2) = make_float4(s.q[13], s.q[14], s.q[15], s.q[16]);
+        sm.parkf(REX_PARK_CPL + 3, 0) = s.q[17];
+      }
+    };
+    pgs_dv<LPE, LANECAP>(sm, armp, x, pl, lim, any0 || any1 || any2 || any3, bgroups, ground.mu, iterations, lane_iterations, sqrt_res_thr, nsweeps, lane_sweeps, park_body);
+    if constexpr (kRowParkBody) {
+      const float4 a = sm.park(REX_PARK_CPL + 0), b = sm.park(REX_PARK_CPL + 1), c = sm.park(REX_PARK_CPL + 2);
+      s.pos[0] = a.x; s.pos[1] = a.y; s.pos[2] = a.z; s.quat[0] = a.w; s.quat[1] = b.x; s.quat[2] = b.y; s.quat[3] = b.z; s.q[12] = b.w;
+      s.q[13] = c.x; s.q[14] = c.y; s.q[15] = c.z; s.q[16] = c.w; s.q[17] = sm.parkf(REX_PARK_CPL + 3, 0);
+    }
+    if constexpr (kRowPark) {
+#pragma unroll
+      for (int k = 0; k < 15; ++k) Lc.l[k] = sm.rowf(REX_NPOINT + k, 9);
+      Lc.di[0] = sm.rowf(REX_NPOINT + 15, 9);
+    }
+    if constexpr (kRowParkDi) {
+#pragma unroll
+      for (int k = 1; k < 6; ++k) Lc.di[k] = armp.spare(k);
+    }
     if constexpr (kHold) {
       take(Lc.l); take(Lc.di);
       take(s.pos); take(s.quat); take(s.lin); take(s.ang);

@@ -78,7 +78,17 @@ template <int NL, bool ARM>
 struct MotorSide {
   static constexpr int NLM = 3 * NL, NA = ARM ? 6 : 0, N = NLM + NA;
   float cmd[N], tau_obs[N];
-  uint32_t overheat[N];
+  // overheat counters (<= 65 535, rex.py:601-608), two to a register: they only sit through the solver sweeps, where every
+  // register counts (mark 'arm': 5 instead of 9)
+  uint32_t overheat2[(N + 1) / 2];
+  __device__ __forceinline__ uint32_t heat(int jl) const { return (jl & 1) ? overheat2[jl >> 1] >> 16 : overheat2[jl >> 1] & 0xFFFFu; }
+  __device__ __forceinline__ void set_heat(int jl, uint32_t v) {
+    overheat2[jl >> 1] = (jl & 1) ? (overheat2[jl >> 1] & 0xFFFFu) | (v << 16) : (overheat2[jl >> 1] & 0xFFFF0000u) | v;
+  }
+  __device__ __forceinline__ void clear_heat() {
+#pragma unroll
+    for (int k = 0; k < (N + 1) / 2; ++k) overheat2[k] = 0u;
+  }
   // motor number (mark_constants.py order) of local index jl
   __device__ __forceinline__ static int motor(int leg0, int jl) { return jl < NLM ? (NL == 4 ? jl : 3 * leg0 + jl) : 12 + (jl - NLM); }
 };
@@ -94,10 +104,11 @@ __device__ __forceinline__ uint32_t legu(const uint32_t* a, int leg0, int jl) {
 // this lane's share of the counters loaded with the state, and back (lane groups: through the hand-over chunks in LDS)
 template <int NL, bool ARM>
 __device__ __forceinline__ void take_overheat(const EnvState& e, int leg0, MotorSide<NL, ARM>& ms) {
+  ms.clear_heat();
 #pragma unroll
-  for (int jl = 0; jl < 3 * NL; ++jl) ms.overheat[jl] = legu<NL>(e.overheat, leg0, jl);
+  for (int jl = 0; jl < 3 * NL; ++jl) ms.set_heat(jl, legu<NL>(e.overheat, leg0, jl));
 #pragma unroll
-  for (int a = 0; a < (ARM ? 6 : 0); ++a) ms.overheat[3 * NL + a] = e.overheat[12 + a];
+  for (int a = 0; a < (ARM ? 6 : 0); ++a) ms.set_heat(3 * NL + a, e.overheat[12 + a]);
 }
 
 // NL = 4: the whole env (one env per lane; reset kernel).  NL = 1 (lane groups): the joint state of leg `leg0` only, into
@@ -242,6 +253,10 @@ struct DevCfg {
   // large batches: envs are regrouped into waves by the solver sweeps they needed in the previous step (a wave sweeps
   // until the slowest of its envs has converged): wave slot k works on env perm[k]; sweeps[i] = this step's count of env i
   const int32_t* perm; int32_t* sweeps;
+  // REX_TASK_MIXED: the task-sorted slot map (host: build_task_slots).  An env keeps its task for life, so the waves are
+  // made of envs of ONE task: slot_env[blk * EPW + slot] = env of that wave slot (-1: padding), block_task[blk] = the
+  // task of workgroup blk's envs -- the per-task constants are then wave-uniform (SGPRs), not per-lane registers
+  const int32_t* slot_env; const int32_t* block_task;
   // rex_set_timing(3): device-side launch duration -- every workgroup folds its start / end wall-clock tick (100 MHz
   // constant clock, s_memrealtime) into clock[0] (min) / clock[1] (max); nullptr otherwise
   unsigned long long* clock;
@@ -274,15 +289,16 @@ __device__ __forceinline__ int mixed_task_of(const DevCfg& c, int gidx) {
 }
 
 // this env's view of the config in a REX_TASK_MIXED batch: its task and the per-task constants that go with it
-__device__ __forceinline__ void mixed_config(const DevCfg& c, int gidx, DevCfg& cm) {
+__device__ __forceinline__ void mixed_config_of_task(const DevCfg& c, int task, DevCfg& cm) {
   cm = c;
-  cm.task = mixed_task_of(c, gidx);
+  cm.task = task;
   cm.action_repeat = task_action_repeat(cm.task);
   cm.iterations = 300 / cm.action_repeat;                       // rex_gym_env.py:25,184
   const float b = task_action_bound(cm.task, c.signal);
   cm.act_lo = -b; cm.act_hi = b;
   cm.w_energy = task_energy_weight(cm.task);
 }
+__device__ __forceinline__ void mixed_config(const DevCfg& c, int gidx, DevCfg& cm) { mixed_config_of_task(c, mixed_task_of(c, gidx), cm); }
 // snapshot record of (terrain, task): one settled robot per terrain and -- in a mixed batch -- per task of the mix
 // (the reset motion runs under the task's own numSolverIterations)
 __device__ __forceinline__ int mix_slot(const DevCfg& c, int task) {
@@ -330,7 +346,7 @@ __device__ __forceinline__ int terrain_index(const DevCfg& c, int gidx, int epis
   return (int)(((uint32_t)gidx + 977u * (uint32_t)episode) % (uint32_t)c.n_terrain);
 }
 __device__ __forceinline__ Ground env_ground(const DevCfg& c, int i, int gidx, int episode) {
-  Ground g{nullptr, 0.0f, 1.0f, 1.0f, kMu, c.geo, c.anchor};
+  Ground g{nullptr, 0u, 0.0f, 1.0f, 1.0f, kMu, c.geo, c.anchor};
   if (c.body_params) {
     g.base_mass_scale = c.body_params[i]; g.leg_mass_scale = c.body_params[(size_t)c.n + i]; g.mu = c.body_params[2 * (size_t)c.n + i];
   }
@@ -347,7 +363,7 @@ __device__ __forceinline__ Ground env_ground(const DevCfg& c, int i, int gidx, i
   }
   if (c.n_terrain > 0) {
     const int t = terrain_index(c, gidx, episode);
-    g.h = c.terrain + (size_t)t * c.hf_stride;
+    g.h = c.terrain; g.off = (unsigned)t * (unsigned)c.hf_stride;   // (rex_set_heightfield: k fields x stride < 2^31)
     g.mid = c.terrain_mid[t];
   }
   return g;
@@ -403,10 +419,10 @@ __device__ __forceinline__ void rex_substep(const DevCfg& c, EnvState& e, int i,
     if (c.hist) { qo = delayed_word(c, i, s0, s1, alpha, j); qdo = delayed_word(c, i, s0, s1, alpha, NM + j); }
     float act, obs;
     motor_torque(ms.cmd[jl], qo, qdo, qdt, c.kp, c.kd, act, obs);
-    uint32_t cnt = ms.overheat[jl];
+    uint32_t cnt = ms.heat(jl);
     cnt = fabsf(act) > 2.45f ? min(cnt + 1u, 65535u) : 0u;                      // rex.py:603-606
     if ((float)cnt > limit) e.motor_en &= ~(1u << j);                           // rex.py:607-608 (lane groups: the lane's own bits;
-    ms.overheat[jl] = cnt;                                                      //  the masks are merged before the state is stored)
+    ms.set_heat(jl, cnt);                                                       //  the masks are merged before the state is stored)
     ms.tau_obs[jl] = obs;
     tau[jl] = ((e.motor_en >> j) & 1u) ? act : 0.0f;                            // rex.py:617-623
   }
@@ -414,12 +430,12 @@ __device__ __forceinline__ void rex_substep(const DevCfg& c, EnvState& e, int i,
   constexpr bool kHold = REX_HOLD_ACROSS_SWEEPS(SM::kEpw, ARM, SM::kBody, LANECAP) && NL == 1;
   if constexpr (kHold) {
     hold(e.phi); hold(e.alpha); hold(e.target); hold(e.aux); hold(e.last_step); hold(e.end_step); hold(e.flags); hold(e.steps);
-    hold(e.episode); hold(e.motor_en); hold(e.hist); hold(ms.cmd); hold(ms.tau_obs); hold(ms.overheat);
+    hold(e.episode); hold(e.motor_en); hold(e.hist); hold(ms.cmd); hold(ms.tau_obs); hold(ms.overheat2);
   }
   physics_substep<LANECAP>(e.ph, tau, c.dt, c.max_iterations, c.iterations, c.res_thr, sm, ground, armp, e.sweeps);
   if constexpr (kHold) {
     take(e.phi); take(e.alpha); take(e.target); take(e.aux); take(e.last_step); take(e.end_step); take(e.flags); take(e.steps);
-    take(e.episode); take(e.motor_en); take(e.hist); take(ms.cmd); take(ms.tau_obs); take(ms.overheat);
+    take(e.episode); take(e.motor_en); take(e.hist); take(ms.cmd); take(ms.tau_obs); take(ms.overheat2);
   }
   receive_observation<NM>(c, e, i, live, owner, leg0, ms);
 }
@@ -802,17 +818,17 @@ __device__ __forceinline__ void gather_legs(const SM& sm, int leg0, EnvState& e,
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       sm.rowf(0, 3 * leg0 + k) = e.ph.q[k]; sm.rowf(1, 3 * leg0 + k) = e.ph.qd[k];
-      sm.rowf(2, 3 * leg0 + k) = __uint_as_float(ms.overheat[k]);
+      sm.rowf(2, 3 * leg0 + k) = __uint_as_float(ms.heat(k));
     }
     mirror_sync();
 #pragma unroll
     for (int j = 0; j < 12; ++j) { q12[j] = sm.rowf(0, j); qd12[j] = sm.rowf(1, j); e.overheat[j] = __float_as_uint(sm.rowf(2, j)); }
   } else {
 #pragma unroll
-    for (int j = 0; j < 12; ++j) { q12[j] = e.ph.q[j]; qd12[j] = e.ph.qd[j]; e.overheat[j] = ms.overheat[j]; }
+    for (int j = 0; j < 12; ++j) { q12[j] = e.ph.q[j]; qd12[j] = e.ph.qd[j]; e.overheat[j] = ms.heat(j); }
   }
 #pragma unroll
-  for (int a = 0; a < (ARM ? 6 : 0); ++a) e.overheat[12 + a] = ms.overheat[3 * NL + a];
+  for (int a = 0; a < (ARM ? 6 : 0); ++a) e.overheat[12 + a] = ms.heat(3 * NL + a);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -857,22 +873,34 @@ __global__ __launch_bounds__(REX_WAVE) REX_STEP_KERNEL_ATTR void rex_step_kernel
   // blocks' worth: hand the blocks of one sector to the same XCD, so that one L2 fetches (and writes back) the sector
   // instead of 16 / EPW of them.  A bijection on the full groups of 8 x (16 / EPW) blocks; the tail keeps its order.
   int blk = (int)blockIdx.x;
-  if constexpr (EPW < 16) {
-    constexpr int G = 16 / EPW;
-    const int full = ((int)gridDim.x / (8 * G)) * (8 * G);
-    if (blk < full) { const int xcd = blk & 7, q = blk >> 3; blk = ((q / G) * 8 + xcd) * G + (q % G); }
+  int gi, i;
+  bool ingrid;
+  DevCfg cmix;                          // MIXED only
+  if constexpr (MIXED) {
+    // the task-sorted slot map (host: build_task_slots) places the envs: a wave holds envs of one task out of one chunk of
+    // neighbouring envs, and the chunks' workgroups are dealt to the XCDs by the map itself
+    const int first = c.slot_env[blk * EPW];                 // wave-uniform (scalar load)
+    if (first < 0) return;                                   // a padding workgroup of the map
+    gi = c.slot_env[blk * EPW + slot];
+    ingrid = lane < LPE * EPW && gi >= 0;
+    i = gi >= 0 ? gi : first;                                // padding slots shadow the wave's first env (keeps the wave convergent)
+    mixed_config_of_task(c, c.block_task[blk], cmix);        // wave-uniform: the task's constants stay in SGPRs
+    cmix.max_repeat = cmix.action_repeat; cmix.max_iterations = cmix.iterations;
+  } else {
+    if constexpr (EPW < 16) {
+      constexpr int G = 16 / EPW;
+      const int full = ((int)gridDim.x / (8 * G)) * (8 * G);
+      if (blk < full) { const int xcd = blk & 7, q = blk >> 3; blk = ((q / G) * 8 + xcd) * G + (q % G); }
+    }
+    gi = blk * EPW + slot;
+    ingrid = lane < LPE * EPW && gi < c.n;
+    const int gj = gi < c.n ? gi : c.n - 1;   // tail slots shadow the last env (keeps the wave convergent)
+    i = c.perm ? c.perm[gj] : gj;             // regrouped batches: the env this slot works on
   }
-  const int gi = blk * EPW + slot;
-  const bool ingrid = lane < LPE * EPW && gi < c.n;
   const bool live = ingrid && pl == 0;                       // the lane that stores the env's state
   const bool owner = ingrid && (LPE != 8 || (pl & 1) == 0);  // the lane that stores its leg's words (8 lanes per env: two carry a leg)
-  const int gj = gi < c.n ? gi : c.n - 1;   // tail slots shadow the last env (keeps the wave convergent)
-  const int i = c.perm ? c.perm[gj] : gj;   // regrouped batches: the env this slot works on
   const Lds<EPW, kLegF4, BODY> sm{lds, slot, EPW <= 16 ? lds + kRowsF4 * EPW : nullptr, BODY ? lds + (kRowsF4 + REX_PARK_F4_OF(EPW, ARM)) * EPW : nullptr};
   typename ArmHook<EPW, ARM>::type armp = ArmHook<EPW, ARM>::make(lds, slot);
-
-  DevCfg cmix;                          // MIXED only
-  if constexpr (MIXED) mixed_config(c, c.env_index_base + i, cmix);
   const DevCfg& c_ = MIXED ? cmix : c;
 
   EnvState e;
@@ -1031,28 +1059,16 @@ __global__ __launch_bounds__(REX_WAVE) REX_STEP_KERNEL_ATTR void rex_step_kernel
   }
   };
 
-  if constexpr (!MIXED) {
-    for (int k = 0; k < c.action_repeat; ++k) rex_substep<false>(c, e, i, live, owner, leg0, ms, sm, ground, armp);   // Rex.Step
-    REX_STAMP(t_substeps);
-    epilogue(live, owner);
+  // Rex.Step (a REX_TASK_MIXED wave runs one task: c_ is its wave-uniform view of the config)
+  for (int k = 0; k < c_.action_repeat; ++k) rex_substep<false>(c_, e, i, live, owner, leg0, ms, sm, ground, armp);
+  REX_STAMP(t_substeps);
+  epilogue(live, owner);
 #ifdef REX_PROF
-    if (threadIdx.x == 0 && blockIdx.x < 1024) {
-      long long* p2 = g_prof2 + 8 * blockIdx.x;
-      p2[3] += t_command - t_kernel; p2[4] += t_substeps - t_command; p2[5] += clock64() - t_substeps;
-    }
-#endif
-  } else {
-    // Rex.Step of tasks with different action_repeat in one wave: every lane runs max_repeat substeps (the substep is
-    // full of wave-level operations), an env whose own count is reached finishes its env.step() -- epilogue, stores --
-    // before the extra substeps, whose results it never stores
-    for (int k = 0; k <= c.max_repeat; ++k) {
-      if (k == c_.action_repeat) epilogue(live, owner);
-      if (k < c.max_repeat) {
-        const bool mine = k < c_.action_repeat;
-        rex_substep<true>(c_, e, i, live && mine, owner && mine, leg0, ms, sm, ground, armp);
-      }
-    }
+  if (threadIdx.x == 0 && blockIdx.x < 1024) {
+    long long* p2 = g_prof2 + 8 * blockIdx.x;
+    p2[3] += t_command - t_kernel; p2[4] += t_substeps - t_command; p2[5] += clock64() - t_substeps;
   }
+#endif
   if (c.clock && threadIdx.x == 0) atomicMax(&c.clock[2 * (blockIdx.x & (REX_CLOCK_WAYS - 1)) + 1], (unsigned long long)wall_clock64());
 #ifdef REX_PROF
   if (threadIdx.x == 0 && blockIdx.x < 1024) {
@@ -1086,8 +1102,8 @@ __global__ __launch_bounds__(REX_WAVE) void rex_settle_kernel(DevCfg c, float* _
   const bool keeps = first < nrec && pl == 0;                           // one lane of the group stores it ...
   const bool owner = first < nrec && (LPE != 8 || (pl & 1) == 0);       // ... and one lane per leg that leg's history words
   const int terr = t / c.n_mix, slot = t % c.n_mix;
-  Ground ground{nullptr, 0.0f, 1.0f, 1.0f, kMu, c.geo, c.anchor};
-  if (c.n_terrain > 0) { ground.h = c.terrain + (size_t)terr * c.hf_stride; ground.mid = c.terrain_mid[terr]; }
+  Ground ground{nullptr, 0u, 0.0f, 1.0f, 1.0f, kMu, c.geo, c.anchor};
+  if (c.n_terrain > 0) { ground.h = c.terrain; ground.off = (unsigned)terr * (unsigned)c.hf_stride; ground.mid = c.terrain_mid[terr]; }
   EnvState e;
   memset(&e, 0, sizeof(e));
   e.ph.pos[2] = c.init_z;
@@ -1113,7 +1129,8 @@ __global__ __launch_bounds__(REX_WAVE) void rex_settle_kernel(DevCfg c, float* _
   e.hist = (uint32_t)(REX_HISTORY_LEN - 1);
   MS ms;
 #pragma unroll
-  for (int jl = 0; jl < MS::N; ++jl) { ms.tau_obs[jl] = 0.0f; ms.overheat[jl] = 0u; }
+  for (int jl = 0; jl < MS::N; ++jl) ms.tau_obs[jl] = 0.0f;
+  ms.clear_heat();
   const uint32_t motor_en0 = e.motor_en;
   if (c.task != REX_TASK_POSES) {   // RexPosesEnv: base reset() with initial_motor_angles=None skips the motion (rex.py:308)
     receive_observation<NM>(cs, e, t, keeps, owner, leg0, ms);
@@ -1198,6 +1215,9 @@ struct RexSim {
   hipEvent_t ring0[REX_TIMING_RING], ring1[REX_TIMING_RING];
   long long timed_steps;
   int words;   // per-env state words of the config's mark
+  int32_t* d_slot_env;   // REX_TASK_MIXED: the task-sorted slot map (DevCfg::slot_env / block_task) and its workgroup count
+  int32_t* d_block_task;
+  int mixed_blocks;
 };
 
 // launchers, one per variant group (each in its own translation unit)

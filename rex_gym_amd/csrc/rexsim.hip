@@ -4,6 +4,7 @@
 // The step and settle kernels are instantiated in rex_step_*.hip / rex_settle.hip (rex_kernels.h); this file holds the
 // C ABI, the reset kernel and the small kernels (regrouping, controller-only entry points).
 #include "rex_kernels.h"
+#include <vector>
 
 namespace rex {
 
@@ -255,6 +256,59 @@ static size_t snapshot_floats(const RexSim* s, int nrec) {
   return (size_t)nrec * ((size_t)s->words + (ring ? (size_t)REX_HISTORY_LEN * (size_t)s->dev.hist_words : 0));
 }
 
+// ---- REX_TASK_MIXED: the task-sorted slot map ----
+// An env of a mixed batch keeps the task drawn for it (rex::mixed_task_of: one Philox block keyed by the seed and the global
+// env index) for its whole life, so which envs share a wave is decided ONCE: the envs are cut into chunks of neighbouring
+// indices (their state words share 64-byte sectors), a chunk's envs are sorted by task, every task's run is padded to whole
+// waves, and the chunks' workgroups are dealt to the XCDs (workgroup b runs on XCD b % 8) so that one L2 fetches a chunk's
+// sectors.  The step kernel then runs waves of ONE task: action_repeat, sweep cap, action box and reward weight are
+// wave-uniform, a 5-substep wave does not sit through gallop's sixth substep, and the kernel is the single-task kernel.
+static void host_philox4x32(uint32_t* c, uint32_t k0, uint32_t k1) {   // rex::philox4x32 on the host
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+static int host_mixed_task_of(const rex::DevCfg& d, int gidx) {      // rex::mixed_task_of on the host
+  uint32_t ctr[4] = {0xFFFFFFFFu, (uint32_t)gidx, 2u, 0u};
+  host_philox4x32(ctr, d.seed_lo, d.seed_hi);
+  return d.mix_task[ctr[0] % (uint32_t)d.n_mix];
+}
+// slots[blk * epw + k] = env of wave slot k of workgroup blk (-1: padding), tasks[blk] = the workgroup's task
+// returns the number of workgroups that hold envs (the others leave at once)
+static int task_slot_map(const rex::DevCfg& d, int epw, std::vector<int32_t>& slots, std::vector<int32_t>& tasks) {
+  const int n = d.n;
+  // 8 m chunks of whole sectors (m per XCD), each at most 64 waves' worth: padding <= (epw - 1) slots per task and chunk
+  const int m = (n + 8 * 64 * epw - 1) / (8 * 64 * epw);
+  const int chunk = ((n + 8 * m - 1) / (8 * m) + 15) / 16 * 16;
+  const int nchunks = (n + chunk - 1) / chunk;
+  std::vector<std::vector<int32_t>> xs(8), xt(8);    // per XCD: its workgroups' slots and tasks
+  for (int c = 0; c < nchunks; ++c) {
+    std::vector<int32_t>& s = xs[c & 7];
+    for (int k = 0; k < d.n_mix; ++k) {
+      const size_t before = s.size();
+      for (int i = c * chunk; i < n && i < (c + 1) * chunk; ++i)
+        if (host_mixed_task_of(d, d.env_index_base + i) == d.mix_task[k]) s.push_back(i);
+      while ((s.size() - before) % (size_t)epw) s.push_back(-1);
+      for (size_t b = before / epw; b < s.size() / epw; ++b) xt[c & 7].push_back(d.mix_task[k]);
+    }
+  }
+  size_t rounds = 0, busy = 0;
+  for (int x = 0; x < 8; ++x) { busy += xt[x].size(); if (xt[x].size() > rounds) rounds = xt[x].size(); }
+  slots.assign(rounds * 8 * (size_t)epw, -1);
+  tasks.assign(rounds * 8, d.mix_task[0]);
+  for (int x = 0; x < 8; ++x)
+    for (size_t j = 0; j < xt[x].size(); ++j) {
+      const size_t b = 8 * j + (size_t)x;
+      tasks[b] = xt[x][j];
+      for (int k = 0; k < epw; ++k) slots[b * epw + k] = xs[x][j * epw + k];
+    }
+  while (!tasks.empty() && slots[(tasks.size() - 1) * epw] < 0) { tasks.pop_back(); slots.resize(tasks.size() * epw); }   // trailing padding workgroups
+  return (int)busy;
+}
+
 int rex_create(const RexConfig* cfg, int device, float* d_state, void* stream, RexSim** out) {
   if (!out || !d_state) return fail(REX_EINVAL, "rex_create: null pointer%s", "");
   int rc = validate(cfg);
@@ -290,9 +344,10 @@ int rex_create(const RexConfig* cfg, int device, float* d_state, void* stream, R
     d.max_repeat = 0;
     for (int k = 0; k < d.n_mix; ++k) { d.mix_task[k] = ts[k]; const int r = rex::task_action_repeat(ts[k]); if (r > d.max_repeat) d.max_repeat = r; }
     for (int k = d.n_mix; k < 5; ++k) d.mix_task[k] = ts[0];
-    d.action_repeat = d.max_repeat;          // per-env values replace these inside the mixed kernel
+    d.action_repeat = d.max_repeat;          // per-task values replace these inside the mixed kernel (wave by wave)
     d.iterations = d.max_iterations = 60;
   }
+  d.slot_env = nullptr; d.block_task = nullptr; s->d_slot_env = nullptr; s->d_block_task = nullptr; s->mixed_blocks = 0;
   d.mass_lo = cfg->mass_scale_lo; d.mass_hi = cfg->mass_scale_hi; d.mu_lo = cfg->friction_lo; d.mu_hi = cfg->friction_hi;
   s->words = rex_state_words(cfg);
   d.pose_index = cfg->pose_index; d.pose_value = cfg->pose_value;
@@ -335,7 +390,7 @@ int rex_create(const RexConfig* cfg, int device, float* d_state, void* stream, R
     // 262 144 envs and -5 % at 65 536; with the sort's two launches +5.4 % (132.9 -> 140.1 M env-steps/s) and +0.9 % on
     // the whole step.  On by default from 262 144 envs.
     const char* ov = getenv("REX_REGROUP");
-    const bool want = ov ? atoi(ov) != 0 : cfg->num_envs >= 262144;
+    const bool want = (ov ? atoi(ov) != 0 : cfg->num_envs >= 262144) && cfg->task != REX_TASK_MIXED;   // (a mixed batch is placed by its task-sorted slot map)
     if (want) {
       hipError_t e2 = hipMalloc(&s->d_perm, sizeof(int32_t) * (size_t)cfg->num_envs);
       if (e2 == hipSuccess) e2 = hipMalloc(&s->d_sweeps, sizeof(int32_t) * (size_t)cfg->num_envs);
@@ -347,8 +402,22 @@ int rex_create(const RexConfig* cfg, int device, float* d_state, void* stream, R
       d.perm = s->d_perm; d.sweeps = s->d_sweeps;
     }
   }
+  if (cfg->task == REX_TASK_MIXED) {
+    std::vector<int32_t> slots, tasks;
+    int busy = task_slot_map(d, s->epw, slots, tasks);
+    // up to 1 024 workgroups the launch is one wave per SIMD; the padding of the map must not push it into a second round
+    const bool pinned = getenv("REX_ENVS_PER_WAVE") != nullptr;
+    while (!pinned && s->epw < 16 && busy > 1024) { s->epw *= 2; busy = task_slot_map(d, s->epw, slots, tasks); }
+    s->mixed_blocks = (int)tasks.size();
+    hipError_t e2 = hipMalloc(&s->d_slot_env, sizeof(int32_t) * slots.size());
+    if (e2 == hipSuccess) e2 = hipMalloc(&s->d_block_task, sizeof(int32_t) * tasks.size());
+    if (e2 == hipSuccess) e2 = hipMemcpy(s->d_slot_env, slots.data(), sizeof(int32_t) * slots.size(), hipMemcpyHostToDevice);
+    if (e2 == hipSuccess) e2 = hipMemcpy(s->d_block_task, tasks.data(), sizeof(int32_t) * tasks.size(), hipMemcpyHostToDevice);
+    if (e2 != hipSuccess) { (void)hipFree(s->d_slot_env); (void)hipFree(s->d_block_task); delete s; return fail(REX_ENOMEM, "task slot map: %s", hipGetErrorString(e2)); }
+    d.slot_env = s->d_slot_env; d.block_task = s->d_block_task;
+  }
   hipError_t e = hipMalloc(&s->d_snap, sizeof(float) * snapshot_floats(s, d.n_mix));
-  if (e != hipSuccess) { delete s; return fail(REX_ENOMEM, "hipMalloc(snapshot): %s", hipGetErrorString(e)); }
+  if (e != hipSuccess) { (void)hipFree(s->d_slot_env); (void)hipFree(s->d_block_task); delete s; return fail(REX_ENOMEM, "hipMalloc(snapshot): %s", hipGetErrorString(e)); }
   (void)hipEventCreate(&s->ev0);
   (void)hipEventCreate(&s->ev1);
   for (int k = 0; k < REX_TIMING_RING; ++k) { s->ring0[k] = nullptr; s->ring1[k] = nullptr; }
@@ -359,7 +428,7 @@ int rex_create(const RexConfig* cfg, int device, float* d_state, void* stream, R
   if (e == hipSuccess) e = hipMemsetAsync(d_state, 0, sizeof(float) * (size_t)s->words * cfg->num_envs, st);
   if (e == hipSuccess) e = hipStreamSynchronize(st);
   if (e != hipSuccess) {
-    (void)hipFree(s->d_snap);
+    (void)hipFree(s->d_snap); (void)hipFree(s->d_slot_env); (void)hipFree(s->d_block_task);
     delete s;
     return fail(REX_EHIP, "settle kernel: %s", hipGetErrorString(e));
   }
@@ -386,7 +455,7 @@ static int install_terrain(RexSim* s, const float* d_heights, const float* d_mid
 }
 
 int rex_set_terrain(RexSim* s, const float* d_heights, const float* d_mids, int k, void* stream) {
-  if (!s || k < 0 || (k > 0 && (!d_heights || !d_mids))) return fail(REX_EINVAL, "rex_set_terrain: bad arguments%s", "");
+  if (!s || k < 0 || k >= 32768 || (k > 0 && (!d_heights || !d_mids))) return fail(REX_EINVAL, "rex_set_terrain: bad arguments (0 <= k < 32768 fields)%s", "");
   s->dev.geo = rex::HfGeom{256, 20.0f, 20.0f, 127.5f, 127.5f, 254.999f, 254.999f};   /* 256 x 256 vertices, 5 cm cells, centred */
   s->dev.hf_stride = 65536;
   return install_terrain(s, d_heights, d_mids, k, stream);
@@ -396,6 +465,7 @@ int rex_set_heightfield(RexSim* s, const float* d_heights, const float* d_mids, 
                         float origin_x, float origin_y, void* stream) {
   if (!s || k <= 0 || !d_heights || !d_mids || nx < 2 || ny < 2 || !(cell_x > 0.0f) || !(cell_y > 0.0f) || (long long)nx * ny > (1ll << 26))
     return fail(REX_EINVAL, "rex_set_heightfield: bad arguments%s", "");
+  if ((long long)k * nx * ny >= (1ll << 31)) return fail(REX_EINVAL, "rex_set_heightfield: the pool (k fields of nx * ny heights) must stay below 2^31 floats%s", "");
   rex::HfGeom g;
   g.nx = nx; g.inv_cx = 1.0f / cell_x; g.inv_cy = 1.0f / cell_y;
   g.off_x = 0.5f * (float)(nx - 1) - origin_x * g.inv_cx; g.off_y = 0.5f * (float)(ny - 1) - origin_y * g.inv_cy;
@@ -428,6 +498,8 @@ int rex_destroy(RexSim* s) {
   if (s->d_perm) (void)hipFree(s->d_perm);
   if (s->d_sweeps) (void)hipFree(s->d_sweeps);
   if (s->d_regroup) (void)hipFree(s->d_regroup);
+  if (s->d_slot_env) (void)hipFree(s->d_slot_env);
+  if (s->d_block_task) (void)hipFree(s->d_block_task);
   (void)hipEventDestroy(s->ev0);
   (void)hipEventDestroy(s->ev1);
   for (int k = 0; k < REX_TIMING_RING; ++k) if (s->ring0[k]) { (void)hipEventDestroy(s->ring0[k]); (void)hipEventDestroy(s->ring1[k]); }
@@ -457,7 +529,7 @@ int rex_step(RexSim* s, const float* d_action, float* d_obs, float* d_reward, ui
   if (!s || !d_action || !d_obs || !d_reward || !d_done) return fail(REX_EINVAL, "rex_step: null pointer%s", "");
   HIPCHK(hipSetDevice(s->device));
   hipStream_t st = (hipStream_t)stream;
-  const int blocks = (s->cfg.num_envs + s->epw - 1) / s->epw;
+  const int blocks = s->d_slot_env ? s->mixed_blocks : (s->cfg.num_envs + s->epw - 1) / s->epw;
   hipEvent_t e0 = s->ev0, e1 = s->ev1;
   if (s->timing == 2) {
     const int k = (int)(s->timed_steps % REX_TIMING_RING);
@@ -475,6 +547,8 @@ int rex_step(RexSim* s, const float* d_action, float* d_obs, float* d_reward, ui
     for (int k = 1; k < repeat; ++k) launch_step(s, blocks, st, d_action, d_obs, d_reward, d_done, d_motor_cmd);
   }
   HIPCHK(hipGetLastError());
+  // (the timed span is the step kernel's: the regrouping launches below are not part of it)
+  if (s->timing == 1 || s->timing == 2) { HIPCHK(hipEventRecord(e1, st)); s->have_timing = 1; if (s->timing == 2) s->timed_steps++; }
   if (s->d_perm) {   // next step's grouping from this step's sweep counts (stream-ordered behind the step)
     const int n = s->cfg.num_envs, width = (s->dev.max_repeat * s->dev.max_iterations + 63) / 64;
     const int chunks = (n + REX_REGROUP_CHUNK - 1) / REX_REGROUP_CHUNK;
@@ -485,8 +559,27 @@ int rex_step(RexSim* s, const float* d_action, float* d_obs, float* d_reward, ui
       hipLaunchKernelGGL(rex::rex_regroup_scatter_kernel, dim3(chunks), dim3(256), 0, st, n, width, s->d_sweeps, s->d_regroup, s->d_perm);
     }
   }
-  if (s->timing == 1 || s->timing == 2) { HIPCHK(hipEventRecord(e1, st)); s->have_timing = 1; if (s->timing == 2) s->timed_steps++; }
   return REX_OK;
+}
+
+int rex_mixed_slot_map(const RexConfig* cfg, int envs_per_wave, int32_t* slots, int32_t* tasks, int max_blocks) {
+  if (validate(cfg)) return REX_EINVAL;
+  if (cfg->task != REX_TASK_MIXED || (envs_per_wave != 4 && envs_per_wave != 8 && envs_per_wave != 16))
+    return fail(REX_EINVAL, "rex_mixed_slot_map: a REX_TASK_MIXED config and 4, 8 or 16 envs per wave%s", "");
+  rex::DevCfg d;
+  memset(&d, 0, sizeof d);
+  d.n = cfg->num_envs; d.env_index_base = cfg->env_index_base; d.seed_lo = (uint32_t)cfg->seed; d.seed_hi = (uint32_t)(cfg->seed >> 32);
+  int ts[5];
+  d.n_mix = mix_tasks(cfg, ts);
+  for (int k = 0; k < 5; ++k) d.mix_task[k] = ts[k < d.n_mix ? k : 0];
+  std::vector<int32_t> sl, tk;
+  task_slot_map(d, envs_per_wave, sl, tk);
+  if (slots && tasks) {
+    if ((int)tk.size() > max_blocks) return fail(REX_EINVAL, "rex_mixed_slot_map: buffers too small%s", "");
+    memcpy(slots, sl.data(), sizeof(int32_t) * sl.size());
+    memcpy(tasks, tk.data(), sizeof(int32_t) * tk.size());
+  }
+  return (int)tk.size();
 }
 
 int rex_envs_per_wave(const RexSim* s) { return s ? s->epw : REX_EINVAL; }

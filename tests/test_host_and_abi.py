@@ -203,3 +203,48 @@ def test_config_validation_happens_before_any_device_call():
     cfg.energy_weight = 0.01
     assert lib.rex_create(ctypes.byref(cfg), 0, ctypes.cast(dummy, ctypes.c_void_p), None, ctypes.byref(out)) == -1
     assert b"energy_weight" in lib.rex_last_error()
+
+
+@pytest.mark.parametrize("n,epw,base,seed", [(96, 4, 0, 4), (2048, 4, 0, 0), (2048, 4, 6144, 0), (5000, 8, 0, 4), (16384, 16, 0, 0), (1, 4, 0, 1), (37, 16, 5, 2)])
+def test_mixed_batch_slot_map_places_every_env_once_in_waves_of_one_task(L, n, epw, base, seed):
+    """BASELINE configs[4] (per-env mixed tasks): the host decides once which envs of a REX_TASK_MIXED batch share a wave
+    (rex_mixed_slot_map, host-only).  Every env sits in exactly one slot; a workgroup's envs all run the workgroup's task,
+    which is the task the env's own Philox draw gives it (the draw the oracle and RexBatchEnv.task_ids make); the envs of a
+    workgroup come out of one chunk of neighbouring indices (their state words share sectors); workgroup b of a chunk dealt
+    to XCD x has b % 8 == x; padding stays below one wave per (chunk, task)."""
+    from rex_gym_amd.envs.philox import philox4x32
+    lib = L.lib()
+    cfg = L.RexConfig()
+    assert lib.rex_default_config(L.TASKS["mixed"], L.SIGNALS["ik"], n, ctypes.byref(cfg)) == 0
+    cfg.seed = seed; cfg.env_index_base = base; cfg.mark = 1
+    nb = lib.rex_mixed_slot_map(ctypes.byref(cfg), epw, None, None, 0)
+    assert nb > 0
+    slots = np.full(nb * epw, -7, np.int32); tasks = np.full(nb, -7, np.int32)
+    assert lib.rex_mixed_slot_map(ctypes.byref(cfg), epw, slots.ctypes.data_as(ctypes.c_void_p), tasks.ctypes.data_as(ctypes.c_void_p), nb) == nb
+    assert lib.rex_mixed_slot_map(ctypes.byref(cfg), epw, slots.ctypes.data_as(ctypes.c_void_p), tasks.ctypes.data_as(ctypes.c_void_p), nb - 1) < 0
+    assert lib.rex_mixed_slot_map(ctypes.byref(cfg), 5, None, None, 0) < 0
+    real = slots[slots >= 0]
+    assert sorted(real.tolist()) == list(range(n))                     # every env exactly once
+    assert set(slots[slots < 0].tolist()) <= {-1}
+    g = np.arange(n, dtype=np.uint32) + np.uint32(base)
+    out = philox4x32(np.stack([np.full_like(g, 0xFFFFFFFF), g, np.full_like(g, 2), np.zeros_like(g)]), np.uint32(seed), np.uint32(0))
+    mix = np.array([L.TASKS["walk"], L.TASKS["gallop"], L.TASKS["turn"]], np.int32)    # task_mix bits, ascending
+    want = mix[(out[0] % np.uint32(3)).astype(np.int64)]
+    grid = slots.reshape(nb, epw)
+    busy = 0
+    for b in range(nb):
+        envs = grid[b][grid[b] >= 0]
+        if envs.size == 0:
+            continue
+        busy += 1
+        assert grid[b][0] >= 0                                           # the slot the padding slots shadow
+        assert (want[envs] == tasks[b]).all()
+        assert envs.max() - envs.min() < 64 * epw + 16                   # one chunk
+    m = -(-n // (8 * 64 * epw))
+    chunk = (-(-n // (8 * m)) + 15) // 16 * 16
+    nchunks = -(-n // chunk)
+    assert busy * epw - n <= nchunks * 3 * (epw - 1)
+    for b in range(nb):                                                  # chunk c goes to XCD c % 8
+        envs = grid[b][grid[b] >= 0]
+        if envs.size:
+            assert (envs[0] // chunk) % 8 == b % 8
