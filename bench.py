@@ -2,6 +2,7 @@
 """bench.py -- env-steps/sec of the batched Rex walk-IK hot path on MI355X (BASELINE.json metric).
 
   python bench.py --gpus 1 --steps 2000 --warmup 200
+  python bench.py --gpus N --steps K --warmup W            (N > 1: starts its own N ranks, one per GPU, under torch.distributed.run)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -9,8 +10,9 @@ A "step" is ONE launch of rex_step_kernel = one env.step() of every env of the s
 (controller + 5 x [motor model + restated stepSimulation with 60 PGS iterations] + reward/done/obs,
 with in-launch auto-reset), writing its observation / reward / done into slice t of a rollout segment.
 Workload = BASELINE.json configs[1]: 4 096 Rex envs per GPU, walk-IK, flat plane, random actions
-U(-0.4, 0.4) from a pre-generated pool that is resident in HBM before the timed region (weak scaling:
-4 096 envs on every GPU, independent shards, no data-path collective).  With N > 1 every rank all-gathers
+U(-0.4, 0.4) drawn afresh for every step -- one device-side draw per 25-step rollout segment on
+the launch stream, inside the timed region -- (weak scaling: 4 096 envs on every GPU, independent shards, no
+data-path collective).  With N > 1 every rank all-gathers
 its finished 25-step segment to all ranks (RCCL over xGMI: the learner hand-off, the design's only
 collective) while the next segment is stepped; the line reports the throughput with it (`value`) and
 without it.  `--config 3|4|5` runs BASELINE.json's other configs at their TOTAL sizes divided over the
@@ -97,7 +99,10 @@ def cpu_baseline(task="walk", signal="ik", mark="base", n=ENVS_PER_GPU, cores=No
     return {"value": n * steps / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
             "sample": f"{n} envs x {steps} steps {task}-{signal.upper()} ({mark} mark), oracle/rex_oracle.c fp32 build, OpenMP "
                       f"over envs on {threads} thread(s) of the {usable_cores()} CPUs this container is granted "
-                      f"({dt:.1f} s); CPU restatement, not PyBullet (pybullet is not installable here)"}
+                      f"({dt:.1f} s); CPU restatement, not PyBullet (pybullet is not installable here).  SURVEY 8(d) baseline (iii), the "
+                      "reference's own pure-Python controller (GaitPlanner.loop + Kinematics.solve + 5 x MotorModel.convert_to_torque), "
+                      "needs /root/reference and cannot run on the GPU box: 1 134 control steps/s on one core of the build container "
+                      "(DESIGN.md section 6, round-1 record)"}
 
 
 def orclib_mark(mark):
@@ -162,9 +167,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU, rendezvous on 127.0.0.1) -- the same
+        # command line under torch.distributed.run; rank 0 prints the one JSON line
+        import socket
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                                  "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus} "
+                         "(or without it: bench.py starts its own ranks)")
     scaling = "weak"
     if args.config is not None:
         c = CONFIGS[args.config]
@@ -204,8 +218,14 @@ def main():
     lo = torch.as_tensor(env.action_space.low, device=dev).minimum(torch.as_tensor(env.action_space.high, device=dev)).float()
     hi = torch.as_tensor(env.action_space.low, device=dev).maximum(torch.as_tensor(env.action_space.high, device=dev)).float()
     T = max(1, args.gather_every)
-    pool = (torch.rand((T, n, env.action_dim), device=dev, generator=gen) * (hi - lo) + lo).contiguous()   # one rollout segment of actions
-    assert bool(((pool >= lo) & (pool <= hi)).all())
+
+    def draw_actions(buf):
+        """a rollout segment of fresh actions, uniform over the env's Box: U[0, 1) scaled into [lo, hi) on the launch stream"""
+        torch.rand(buf.shape, device=dev, generator=gen, out=buf)
+        return buf.mul_(hi - lo).add_(lo)
+
+    pool = draw_actions(torch.empty((T, n, env.action_dim), device=dev))
+    assert bool(((pool >= lo) & (pool <= hi)).all())     # by construction; checked once on a drawn segment
     env.reset()
     # pre-roll (untimed, outside --warmup): right after a synchronous reset every env is in the same episode phase and
     # the solver converges quickly; the number reported is the steady state a training run sees
@@ -229,12 +249,13 @@ def main():
     # T steps the finished segment is all-gathered to all ranks (the learner hand-off, sharding.gather_rollout) while the
     # next segment fills the other buffer: the collective runs on RCCL's stream, the steps keep the compute stream busy.
     seg = [dict(obs=torch.zeros((T, n, env.obs_dim), device=dev), reward=torch.zeros((T, n), device=dev),
-                done=torch.zeros((T, n), dtype=torch.uint8, device=dev), action=pool) for _ in range(2)]
+                done=torch.zeros((T, n), dtype=torch.uint8, device=dev), action=draw_actions(torch.empty_like(pool))) for _ in range(2)]
     seg_bytes = sum(v.numel() * v.element_size() for v in seg[0].values())
     do_gather = not args.no_gather
 
     # (slices and their device pointers are taken once, outside the timed loops: nothing but the launch is left per step)
     acts = [pool[t] for t in range(T)]
+    sacts = [[s["action"][t] for t in range(T)] for s in seg]
     outs = [[env.bind_out(s["obs"][t], s["reward"][t], s["done"][t]) for t in range(T)] for s in seg]
 
     def run(steps, gather):
@@ -242,9 +263,11 @@ def main():
         step = env.step
         for k in range(steps):
             b, t = (k // T) & 1, k % T
-            if t == 0 and pending[b] is not None:
-                pending[b].wait(); pending[b] = None         # this buffer's previous segment has left before it is overwritten
-            step(acts[t], outs[b][t])
+            if t == 0:
+                if pending[b] is not None:
+                    pending[b].wait(); pending[b] = None     # this buffer's previous segment has left before it is overwritten
+                draw_actions(seg[b]["action"])               # fresh actions for every step of the segment
+            step(sacts[b][t], outs[b][t])
             if gather and t == T - 1:
                 pending[b] = gather_rollout(seg[b], async_op=True, slot=b)
         for p in pending:
@@ -350,6 +373,11 @@ def main():
         env2.close()
 
     task_name = "mixed" if args.mixed else args.task
+    ranks_seen = dist.get_world_size() if dist is not None else 1
+    try:
+        rccl_version = ".".join(str(v) for v in torch.cuda.nccl.version())       # torch's "nccl" on ROCm is RCCL
+    except Exception:
+        rccl_version = None
     if rank == 0:
         total_envs = n * world
         value = total_envs * args.steps / elapsed
@@ -366,7 +394,8 @@ def main():
                                    f"{'link-box rows (ground + self collision) on, ' if body_contacts else ''}"
                                    f"dt 1 ms x {repeat} substeps, <= {sweeps} PGS sweeps "
                                    "(Bullet residual threshold 1e-7), auto-reset, episode cap 2000, uniform random actions "
-                                   f"over the env's action Box (pool validated against the Box before the timed region); {PREROLL_STEPS} "
+                                   f"over the env's action Box drawn afresh for every step (one device-side draw per {T}-step segment on the "
+                                   f"launch stream, inside the timed region); {PREROLL_STEPS} "
                                    "untimed pre-roll steps with staggered resets before --warmup (stationary episode-age mix); every step "
                                    f"writes obs / reward / done into a {T}-step rollout segment" +
                                    (f", all-gathered to all {world} ranks every {T} steps (RCCL, overlapped with the next segment)" if gather_info else ""),
@@ -385,6 +414,8 @@ def main():
                          "valu_tflops_est": ALGO_FLOP_PER_ENV_STEP * n / (kernel_ms * 1e-3) / 1e12,
                          "valu_frac": ALGO_FLOP_PER_ENV_STEP * n / (kernel_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS},
             "finite": finite,
+            # what the process group itself reports: proof that the collective library saw all ranks of a multi-GPU run
+            "n_ranks_seen": ranks_seen, "backend": args.backend if world > 1 else None, "rccl_version": rccl_version,
         }
         if gather_info:
             out["rollout_gather"] = gather_info

@@ -136,7 +136,8 @@ def main(argv=None):
     p.add_argument("--seed", type=int, default=0)
     args = p.parse_args(argv)
     from ..envs import RexBatchEnv
-    env = RexBatchEnv(args.num_envs, task=args.env, signal_type=args.signal_type, seed=args.seed)
+    # (PolicyPlayer.play steps the bare env, policy_player.py:44-56: BatchEnv's per-step Box test -- a host sync per step here -- is not in that loop)
+    env = RexBatchEnv(args.num_envs, task=args.env, signal_type=args.signal_type, seed=args.seed, check_actions=False)
     policy = SimplePPOPolicy(env, args.checkpoint)
     total, length, ended = play(env, policy, args.max_steps)
     x = env.state[0].float()

@@ -124,6 +124,7 @@ __device__ __forceinline__ void load_env(const float* st, int n, int i, EnvState
   for (int j = 0; j < NM; ++j) {
     if (NL == 4 || j >= 12) { e.ph.q[j] = ldw(st, n, Y::Q + j, i); e.ph.qd[j] = ldw(st, n, Y::QD + j, i); }
     else if (j < 3) { e.ph.q[j] = ldw(st, n, Y::Q + 3 * leg0 + j, i); e.ph.qd[j] = ldw(st, n, Y::QD + 3 * leg0 + j, i); }
+    else { e.ph.q[j] = 0.0f; e.ph.qd[j] = 0.0f; }   // lane groups never touch slots 3..11: a read of one would at least be deterministic
   }
   e.phi = ldw(st, n, Y::PHI, i); e.last_step = (int32_t)ldi(st, n, Y::LASTT, i); e.alpha = ldw(st, n, Y::ALPHA, i);
   e.target = ldw(st, n, Y::TARGET, i); e.end_step = (int32_t)ldi(st, n, Y::ENDTIME, i); e.aux = ldw(st, n, Y::AUX, i);

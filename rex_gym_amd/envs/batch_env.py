@@ -366,22 +366,22 @@ class RexBatchEnv:
             if a.shape != (self.num_envs, self.action_dim):
                 raise ValueError(f"actions must have shape {(self.num_envs, self.action_dim)}, got {tuple(a.shape)}")
             a = a.contiguous()
-        if self.check_actions:
-            # BatchEnv.step: `if not env.action_space.contains(action): raise ValueError` for every env (agents/tools/
-            # batch_env.py:76-79), in the Box's own dtype (float32).  Behind the folded ClipAction the space is unbounded
-            # (wrappers.py:254-259): only non-finite actions are invalid.  The verdict is read back from the device, i.e. one
-            # host synchronisation per step, as in the reference; throughput loops that have validated their actions
-            # beforehand pass check_actions=False.
-            bad = ~torch.isfinite(a)
-            if not self.config.range_normalize:
-                if self._act_lo is None:
-                    self._act_lo = torch.as_tensor(np.minimum(self.action_space.low, self.action_space.high).astype(np.float32), device=self.device)
-                    self._act_hi = torch.as_tensor(np.maximum(self.action_space.low, self.action_space.high).astype(np.float32), device=self.device)
-                bad |= (a < self._act_lo) | (a > self._act_hi)
-            rows = bad.any(dim=1)
-            if bool(rows.any()):
-                i = int(torch.nonzero(rows)[0])
-                raise ValueError(f"Invalid action at index {i}: {a[i].tolist()}")
+            if self.check_actions:
+                # BatchEnv.step: `if not env.action_space.contains(action): raise ValueError` for every env (agents/tools/
+                # batch_env.py:76-79), in the Box's own dtype (float32).  Behind the folded ClipAction the space is unbounded
+                # (wrappers.py:254-259): only non-finite actions are invalid.  The verdict is read back from the device, i.e. one
+                # host synchronisation per step, as in the reference (issued on the env's own stream, behind the staging copy
+                # above); throughput loops that have validated their actions beforehand pass check_actions=False.
+                bad = ~torch.isfinite(a)
+                if not self.config.range_normalize:
+                    if self._act_lo is None:
+                        self._act_lo = torch.as_tensor(np.minimum(self.action_space.low, self.action_space.high).astype(np.float32), device=self.device)
+                        self._act_hi = torch.as_tensor(np.maximum(self.action_space.low, self.action_space.high).astype(np.float32), device=self.device)
+                    bad |= (a < self._act_lo) | (a > self._act_hi)
+                rows = bad.any(dim=1)
+                if bool(rows.any()):
+                    i = int(torch.nonzero(rows)[0])
+                    raise ValueError(f"Invalid action at index {i}: {a[i].tolist()}")
         if out is None:
             out = self._own_out
         elif not isinstance(out, StepOut):

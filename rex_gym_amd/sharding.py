@@ -61,12 +61,32 @@ class RolloutGather:
             for name, buf in self._bufs.items():
                 t, n = self._shapes[name][0], self._shapes[name][1]
                 # [world, T, n, ...] -> [T, world * n, ...]: global env index = rank * n + local index
-                out[name] = buf.view(self._world, *self._shapes[name]).transpose(0, 1).reshape(t, self._world * n, *self._shapes[name][2:])
+                o = buf.view(self._world, *self._shapes[name]).transpose(0, 1).reshape(t, self._world * n, *self._shapes[name][2:])
+                # (T == 1, or one rank: the reshape is a view of the cached receive buffer, which the next gather on this slot
+                #  overwrites -- the caller gets its own tensor, as it does whenever the reshape had to copy)
+                out[name] = o.clone() if o.data_ptr() == buf.data_ptr() else o
             self._out = out
         return self._out
 
 
 _GATHER_BUFFERS = {}
+
+
+def clear_gather_buffers():
+    """Drop the cached receive buffers of gather_rollout (e.g. before a process group is destroyed, or when a run changes its
+    segment shape for good)."""
+    _GATHER_BUFFERS.clear()
+
+
+def _group_key(group):
+    """cache key of a process group: its ranks (an id() can be handed to a new group once the old one is gone)"""
+    import torch.distributed as dist
+    if group is None:
+        return "world"
+    try:
+        return tuple(dist.get_process_group_ranks(group))
+    except Exception:
+        return id(group)
 
 
 def gather_rollout(segment, group=None, always=False, async_op=False, slot=0):
@@ -93,7 +113,7 @@ def gather_rollout(segment, group=None, always=False, async_op=False, slot=0):
         t = t.contiguous()
         src = t.cpu() if (via_host and t.is_cuda) else t
         wire = src.view(torch.uint8) if src.dtype == torch.bool else src       # bool travels as bytes
-        key = (name, tuple(wire.shape), wire.dtype, str(wire.device), slot, id(group))
+        key = (name, tuple(wire.shape), wire.dtype, str(wire.device), slot, _group_key(group))
         buf = _GATHER_BUFFERS.get(key)
         if buf is None:
             # rank-major along dim 0 ([world * T, N_local, ...]): the concatenated form every backend's all_gather_into_tensor takes

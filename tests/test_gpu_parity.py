@@ -747,16 +747,17 @@ def test_bench_two_ranks_gather_rollout_segments(torch):
     the line reports the hand-off's bytes and time next to the throughput with and without it."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    port = 29300 + os.getpid() % 500
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "50", "--warmup", "25",
+    # the plain spelling the driver uses: bench.py starts its own two ranks (torch.distributed.run, rendezvous on 127.0.0.1)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "50", "--warmup", "25",
                           "--config", "3", "--envs-per-gpu", "1024", "--backend", "gloo", "--no-cpu-baseline"],
-                         capture_output=True, text=True, timeout=900, cwd=root)
+                         capture_output=True, text=True, timeout=900, cwd=root, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["envs_total"] == 2048 and d["finite"]
+    assert d["n_ranks_seen"] == 2 and d["backend"] == "gloo"                     # what the process group itself reports
     g = d["rollout_gather"]
     # gallop-OL: obs 16 x 4 + action 4 x 4 + reward 4 + done 1 = 85 B per env-step (SURVEY 8e)
     assert g["every_steps"] == 25 and g["bytes_per_env_step"] == 85 and g["segment_bytes_per_rank"] == 85 * 25 * 1024
