@@ -39,9 +39,9 @@ traffic_path = os.path.join(P, "traffic.json")
 traffic = json.load(open(traffic_path))
 out = [f"# {tag} -- rocprofv3 kernel trace + PMC passes of bench.py per workload (tools/profile_round.sh), MI355X\n",
        "Each workload: `rocprofv3 --kernel-trace --stats` (steady = launches after the 1 550th), then three separate `--pmc` passes "
-       "(FETCH_SIZE; WRITE_SIZE; SQ_* with GRBM_GUI_ACTIVE).  FETCH_SIZE / WRITE_SIZE in KB as gfx950 reports them (4-byte-per-lane word "
-       "loads: no correction known, MI355X_MICROARCH.md); issue fraction = 4 x SQ_ACTIVE_INST_VALU / (32 SIMDs x GRBM_GUI_ACTIVE) per shader "
-       "engine: the share of SIMD cycles that issue a VALU instruction.\n",
+       "(FETCH_SIZE; WRITE_SIZE; SQ_* with GRBM_GUI_ACTIVE).  FETCH_SIZE / WRITE_SIZE in KiB as gfx950 reports them (calibrated on this kernel's 4-byte-per-lane word "
+       "loads: true bytes, profiles/r04_hbm_counter_calibration.md); issue fraction = 4 x SQ_ACTIVE_INST_VALU / (32 SIMDs x GRBM_GUI_ACTIVE) per shader "
+       "engine: the share of SIMD cycles in which the VALU is busy (a wave64 fma keeps it busy ~2 cycles, a DPP add ~9: profiles/r04_microbench.md).\n",
        "| workload | kernel | avg us (steady) | min | max | scratch B | FETCH KB | WRITE KB | HBM MB / launch | algorithmic MB | ratio | VALU issue fraction | WAIT_ANY / WAVE_CYCLES |",
        "|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
 for f in sorted(glob.glob(os.path.join(G, f"{tag}_profile_*.txt"))):
@@ -53,7 +53,7 @@ for f in sorted(glob.glob(os.path.join(G, f"{tag}_profile_*.txt"))):
         continue
     d = json.loads(js[-1]); g = lambda k: d.get(k, {}).get("avg_steady")
     st = [c.strip() for c in stats[0].split("|")]
-    mb = (g("FETCH_SIZE") + g("WRITE_SIZE")) * 1e3 / 1e6
+    mb = (g("FETCH_SIZE") + g("WRITE_SIZE")) * 1024 / 1e6   # both counters are in KiB and exact for this access pattern (profiles/r04_hbm_counter_calibration.md)
     frac = 4 * g("SQ_ACTIVE_INST_VALU") / (32 * g("GRBM_GUI_ACTIVE"))
     kern = st[1].split("rex_step_kernelI")[1].split("EEv")[0].replace("Lb0", "0").replace("Lb1", "1").replace("Li", "").replace("E", ",")
     out.append(f"| {KEYS.get(name, name)} | `<{kern}>` | {st[5]} | {st[6]} | {st[7]} | {st[-2]} | {g('FETCH_SIZE'):.1f} | {g('WRITE_SIZE'):.1f} | {mb:.2f} | "
