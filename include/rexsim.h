@@ -236,6 +236,18 @@ REX_API int rex_set_heightfield(RexSim* sim, const float* d_heights, const float
  * the ones computed at load.  NULL restores (1, 1, 0.5). */
 REX_API int rex_set_body_params(RexSim* sim, const float* d_params);
 
+/* Debug: trace the discrete events of the restated stepSimulation.  d_trace: caller-owned device buffer uint32 [3][num_envs]
+ * (NULL switches the trace off, the default; the caller zeroes it).  While set, every substep folds into word [0][i] of env i
+ * which toe points are within the contact breaking distance, the heightfield facet under each of them (under the toe end's
+ * centre and under the contact point, and the branch btPlaneSpace1 takes for its friction directions), and which joint / arm
+ * bounds are reached -- and every control step the controller's flags and gait latches; into word [1][i] the env's solver sweep
+ * count; into word [2][i] the same events as [0] without the arm's bounds (mark arm commands three arm joints beyond their
+ * bounds: those rows switch with the last bit of the joint angle).  The words are chained hashes: two runs (or this library and the CPU oracle, which folds the same words the same
+ * way) agree on an env's word exactly as long as they took every such decision alike -- what separates their trajectories
+ * then is continuous round-off, not a contact that switched.  One read-modify-write of three words per substep; off in
+ * production and in bench.py. */
+REX_API int rex_set_event_trace(RexSim* sim, uint32_t* d_trace);
+
 /* Observation-history ring for the latency model (Rex._observation_history, deque(maxlen=100) of 43-vectors:
  * q, qd, observed torque, base quaternion, base angular velocity; model/rex.py:122,717-763).  d_history: caller-owned
  * device buffer of REX_HISTORY_LEN * REX_HISTORY_WORDS (_ARM for mark 'arm': 61-vectors) * num_envs float32, laid out

@@ -687,8 +687,10 @@ typedef struct { int nx, ny; real inv_cx, inv_cy, off_x, off_y, max_x, max_y; } 
 static const HfGeom HF_RANDOM = {HF_N, HF_N, (real)20.0, (real)20.0, (real)127.5, (real)127.5, (real)254.999, (real)254.999};   /* model/terrain.py:32-54 */
 typedef struct { const float* h; real mid; real base_mass_scale, leg_mass_scale, mu; int has_params; int body_contacts; HfGeom geo; int fixed_base; } Ground;
 
-static void ground_query(const Ground* g, real x, real y, real* height, real n[3]) {
+/* fid (event trace): the facet the point stands on -- 1 + 2 (cell index) + (upper triangle); 0 where the plane is on top */
+static void ground_query_f(const Ground* g, real x, real y, real* height, real n[3], uint32_t* fid) {
   n[0] = 0; n[1] = 0; n[2] = 1; *height = 0;
+  *fid = 0;
   if (!g || !g->h) return;
   const HfGeom* q = &g->geo;
   real fx = x * q->inv_cx + q->off_x, fy = y * q->inv_cy + q->off_y;
@@ -703,7 +705,24 @@ static void ground_query(const Ground* g, real x, real y, real* height, real n[3
   if (hh <= 0) return;                      /* the plane is on top here */
   real inv = 1 / sqrt(gx * gx + gy * gy + 1);
   *height = hh; n[0] = -gx * inv; n[1] = -gy * inv; n[2] = inv;
+  *fid = 1u + 2u * (uint32_t)(j * q->nx + i) + (u + v <= 1 ? 0u : 1u);
 }
+static void ground_query(const Ground* g, real x, real y, real* height, real n[3]) { uint32_t fid; ground_query_f(g, x, y, height, n, &fid); }
+
+/* ---- event trace (orc_set_event_trace; the kernels fold the same words the same way, rex_set_event_trace in include/rexsim.h):
+ * per substep, which toe points are within the breaking distance, the heightfield facet under each of them (under the end
+ * centre and under the contact point), which joint / arm bounds are reached -> one chained hash per env; the solver sweep
+ * counts -> a second one.  Thread-local: set by env_step for the env it is stepping. ---- */
+static __thread uint32_t* TR_EVENTS = 0;
+static __thread uint32_t* TR_SWEEPS = 0;
+static __thread uint32_t* TR_LEG_EVENTS = 0;   /* the events without the arm's bounds */
+static __thread uint32_t TR_STEP_SWEEPS = 0;   /* sweeps of the current env.step() so far */
+static uint32_t trace_point(int p, uint32_t f0, uint32_t f1) {
+  uint32_t m = f0 * 0x9E3779B1u + f1 * 0x85EBCA77u + (uint32_t)(p + 1) * 0xC2B2AE3Du;
+  m ^= m >> 15; m *= 0x2C1B3C6Du; m ^= m >> 12;
+  return m;
+}
+static uint32_t trace_mix(uint32_t h, uint32_t w) { h = (h ^ w) * 0x01000193u; return h ^ (h >> 13); }
 
 /* btPlaneSpace1 */
 static void plane_space(const real n[3], real p[3], real q[3]) {
@@ -819,6 +838,7 @@ static void physics_substep(Phys* s, const real tau[NJ], real dt, int iterations
   real PtDist[MAX_POINTS];
   memset(PtSelf, 0, sizeof(PtSelf));
   const real rad = (real)REX_TOE_RADIUS + P_MARGIN;
+  uint32_t tr_active = 0, tr_facets = 0, tr_arm = 0;
   for (int l = 0; l < REX_NLEG; ++l) {
     int kb = REX_TOE_BODY[l];
     real ctr[3] = {(real)REX_TOE_CENTER[l][0], (real)REX_TOE_CENTER[l][1], (real)REX_TOE_CENTER[l][2]};
@@ -831,8 +851,9 @@ static void physics_substep(Phys* s, const real tau[NJ], real dt, int iterations
     for (int e = 0; e < 2; ++e) {
       real sgn = e == 0 ? (real)-1 : (real)1;
       real ce[3], n0[3], h0;
+      uint32_t fid0, fid1;
       for (int k = 0; k < 3; ++k) ce[k] = cw[k] + sgn * (real)REX_TOE_HALFLEN * aw[k];
-      ground_query(ground, ce[0], ce[1], &h0, n0);
+      ground_query_f(ground, ce[0], ce[1], &h0, n0, &fid0);
       real na = dot3(n0, aw);
       real dv[3] = {n0[0] - na * aw[0], n0[1] - na * aw[1], n0[2] - na * aw[2]};
       real dn = sqrt(dot3(dv, dv));
@@ -846,9 +867,10 @@ static void physics_substep(Phys* s, const real tau[NJ], real dt, int iterations
         for (int k = 0; k < 3; ++k) dir[k] = cos(ang) * u[k] + sin(ang) * t[k];
         real P[3], n[3], h;
         for (int k = 0; k < 3; ++k) P[k] = a == 0 ? ce[k] - rad * inv * dv[k] : ce[k] + rad * dir[k];   /* a == 0: the lowest line itself */
-        ground_query(ground, P[0], P[1], &h, n);
+        ground_query_f(ground, P[0], P[1], &h, n, &fid1);
         real dist = (P[2] - h) * n[2];
         if (dist < P_BREAKING) {
+          if (a == 0) { tr_active |= 1u << (2 * l + e); if (ground && ground->h) tr_facets ^= trace_point(2 * l + e, fid0, fid1 | (fabs(n[2]) > (real)0.7071067811865475244 ? 0x80000000u : 0u)); }   /* bit 31: the branch plane_space takes */
           memcpy(PtP[npoint], P, sizeof(P));
           memcpy(PtN[npoint], n, sizeof(n));
           PtBody[npoint] = kb;
@@ -991,6 +1013,7 @@ static void physics_substep(Phys* s, const real tau[NJ], real dt, int iterations
     real gap = lower ? lo_gap : hi_gap;
     if (gap >= LIMIT_ACTIVATION) continue;
     if (P_LIMIT_EXACT && gap > 0) continue;   /* btMultiBodyJointLimitConstraint skips a row while its bound is not reached */
+    if (j < 12) tr_active |= 1u << (8 + j); else tr_arm |= 1u << (j - 12);
     Row* r = &rows[nrow++];
     real sgn = lower ? (real)1 : (real)-1;
     for (int k = 0; k < NDOF; ++k) r->J[k] = 0;
@@ -1075,10 +1098,16 @@ static void physics_substep(Phys* s, const real tau[NJ], real dt, int iterations
     /* btSequentialImpulseConstraintSolver::solveGroupCacheFriendlyIterations: leave the sweep loop once
      * the residual is below m_leastSquaresResidualThreshold (PyBullet default 1e-7) */
     if (DBG_STATS) ++DBG_SWEEPS;
+    ++TR_STEP_SWEEPS;
     if (worst <= residual_threshold) { if (DBG_STATS) DBG_HIST[it < 63 ? it : 63]++; break; }
     if (DBG_STATS && it == iterations - 1) DBG_HIST[63]++;
   }
   if (DBG_STATS) ++DBG_SUBSTEPS;
+  if (TR_EVENTS) {
+    *TR_EVENTS = trace_mix(trace_mix(trace_mix(*TR_EVENTS, tr_active), tr_facets), tr_arm);
+    *TR_SWEEPS = trace_mix(*TR_SWEEPS, TR_STEP_SWEEPS);
+    *TR_LEG_EVENTS = trace_mix(trace_mix(*TR_LEG_EVENTS, tr_active), tr_facets);
+  }
   if (DBG_STATS) {   /* census: legs with a toe point within the breaking distance / legs that carry a normal impulse */
     int act[REX_NLEG] = {0}, load[REX_NLEG] = {0};
     for (int p = 0; p < toe_points; ++p) {
@@ -1186,6 +1215,7 @@ typedef struct {
   float* mids;    /* [K] */
   Env* terrain_snapshot;
   float* body_params; /* [3][N] or NULL */
+  uint32_t* trace;    /* orc_set_event_trace: caller-owned [3][N] or NULL */
 } Orc;
 
 /* ---- REX_TASK_MIXED: env g runs one task of the mix for its whole life, drawn from its own Philox stream ---- */
@@ -1732,6 +1762,8 @@ static void env_step(Orc* o, int idx, const real* action_in, real* obs, real* re
   const RexConfig* c = &cfg_env;
   Env* e = &o->envs[idx];
   e->nz_gidx = c->env_index_base + idx; e->nz_episode = e->episode; e->nz_step = e->steps;
+  TR_EVENTS = o->trace ? o->trace + idx : 0; TR_SWEEPS = o->trace ? o->trace + o->cfg.num_envs + idx : 0; TR_STEP_SWEEPS = 0;
+  TR_LEG_EVENTS = o->trace ? o->trace + 2 * (size_t)o->cfg.num_envs + idx : 0;
   real cmd[NJ], leg_cmd[12];
   real action[8];
   {
@@ -1746,8 +1778,14 @@ static void env_step(Orc* o, int idx, const real* action_in, real* obs, real* re
   }
   env_command(c, e, action, leg_cmd);
   full_command(leg_cmd, cmd);
+  if (TR_EVENTS) {   /* the controller's discrete decisions of this step: goal / brake / hold flags, gait latches */
+    const uint32_t w = trace_mix(e->flags, (uint32_t)e->last_step * 65537u + (uint32_t)e->end_step);
+    *TR_EVENTS = trace_mix(*TR_EVENTS, w);
+    *TR_LEG_EVENTS = trace_mix(*TR_LEG_EVENTS, w);
+  }
   Ground ground = env_ground(o, idx, e->episode);
   for (int k = 0; k < c->action_repeat; ++k) rex_substep(c, e, cmd, &ground);    /* Rex.Step, rex.py:158-163 */
+  TR_EVENTS = 0; TR_SWEEPS = 0; TR_LEG_EVENTS = 0;   /* (the reset motion of an auto-reset below is not part of the trace: the kernels restore a snapshot) */
   if (c->task == REX_TASK_TURN) *reward = (real)0.035 - fabs(e->ph.pos[0]) - fabs(e->ph.pos[1]);  /* turn_env.py:362-367 */
   else if (c->task == REX_TASK_POSES) { *reward = 1; for (int j = 0; j < NJ; ++j) (void)e->tau_obs[j]; } /* poses_env.py:267-269 */
   else if (c->task == REX_TASK_STANDUP) {                                /* standup_env.py:150-166, target (0, 0, 0.21) */
@@ -1799,6 +1837,8 @@ ORC_API void* orc_create(const RexConfig* cfg) {
   for (int k = 0; k < o->n_mix; ++k) { RexConfig ct = task_cfg(o, o->mix_task[k]); settle(o, &o->snapshot[k], &g0, &ct); }
   return o;
 }
+/* event trace: trace = caller-owned uint32 [3][num_envs] (NULL: off), updated by orc_step as the kernels update theirs */
+ORC_API void orc_set_event_trace(void* h, uint32_t* trace) { ((Orc*)h)->trace = trace; }
 ORC_API void orc_set_body_params(void* h, const float* params) {
   Orc* o = (Orc*)h;
   free(o->body_params); o->body_params = 0;

@@ -68,6 +68,7 @@ _SIGS = {
                          ctypes.c_int),
     "rex_gait_loop": ([ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                        ctypes.c_void_p], ctypes.c_int),
+    "rex_set_event_trace": ([ctypes.c_void_p, ctypes.c_void_p], ctypes.c_int),
     "rex_envs_per_wave": ([ctypes.c_void_p], ctypes.c_int),
     "rex_mixed_slot_map": ([ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int], ctypes.c_int),
     "rex_get_sweeps": ([ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p], ctypes.c_int),

@@ -23,6 +23,9 @@ LIB_PATH = os.environ.get("REX_LIB_PATH") or os.path.join(PKG_DIR, "librexsim_hi
 GROUPS = {"rex_step_base.hip": "base", "rex_step_arm.hip": "arm", "rex_step_mixed_base.hip": "mixed_base",
           "rex_step_mixed_arm.hip": "mixed_arm", "rex_step_body.hip": "body", "rex_settle_base.hip": "base", "rex_settle_arm.hip": "arm"}
 SOURCES = ["rexsim.hip"] + sorted(GROUPS)
+# the step translation units are compiled a second time with -DREX_TU_TRACE=1: the kernel instantiations with the event trace
+# (rex_set_event_trace, a debug aid of the parity tests) compiled in -- the product kernels carry none of it
+TRACE_SOURCES = sorted(f for f in GROUPS if f.startswith("rex_step_"))
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h"))   # every header the sources can include
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden"]
 
@@ -51,8 +54,8 @@ _STUB = """// stub of a variant group left out of a developer build (REX_BUILD_O
 """
 
 
-def _stub_source(tu):
-    name = tu[:-4]
+def _stub_source(tu, trace=False):
+    name = tu[:-4] + ("_trace" if trace else "")
     if name.startswith("rex_step_"):
         sig = "void rex_launch_%s(RexSim*, int, hipStream_t, const float*, float*, float*, uint8_t*, float*)" % name[4:]
     else:
@@ -74,20 +77,26 @@ def build(force=False, verbose=False, lib_path=None, defines=(), unity=False, on
             uni = os.path.join(tmp, "unity.hip")
             with open(uni, "w") as f:
                 f.write("".join('#include "%s"\n' % os.path.join(CSRC, s) for s in SOURCES))
+                f.write("#undef REX_TU_TRACE\n#undef REX_STEP_LAUNCHER\n#undef REX_LAUNCH_STEP\n#define REX_TU_TRACE 1\n"
+                        "#define REX_STEP_LAUNCHER(group) rex_launch_step_##group##_trace\n"
+                        "#define REX_LAUNCH_STEP(EPW, ARM, MIXED, BODY) hipLaunchKernelGGL((rex::rex_step_kernel<EPW, ARM, MIXED, BODY, true>), "
+                        "dim3(blocks), dim3(REX_WAVE), 0, st, s->dev, s->d_state, s->d_snap, a, o, r, d, m)\n")
+                f.write("".join('#include "%s"\n' % os.path.join(CSRC, s) for s in TRACE_SOURCES))
             cmd = [hipcc] + flags + ["-shared", uni, "-o", lib_path]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
             return lib_path
         jobs_list = []
-        for s in SOURCES:
+        for s, trace in [(s, False) for s in SOURCES] + [(s, True) for s in TRACE_SOURCES]:
             src = os.path.join(CSRC, s)
+            tag = "_trace" if trace else ""
             if keep is not None and s in GROUPS and GROUPS[s] not in keep:
-                src = os.path.join(tmp, "stub_" + s)
+                src = os.path.join(tmp, "stub_" + s[:-4] + tag + ".hip")
                 with open(src, "w") as f:
-                    f.write(_stub_source(s))
-            obj = os.path.join(tmp, s[:-4] + ".o")
-            jobs_list.append(([hipcc] + flags + ["-c", src, "-o", obj], obj))
+                    f.write(_stub_source(s, trace))
+            obj = os.path.join(tmp, s[:-4] + tag + ".o")
+            jobs_list.append(([hipcc] + flags + (["-DREX_TU_TRACE=1"] if trace else []) + ["-c", src, "-o", obj], obj))
 
         def run(job):
             if verbose:

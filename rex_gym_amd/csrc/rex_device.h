@@ -22,6 +22,7 @@
 
 #include "../../include/rexsim.h"
 #include "rex_model_gen.h"
+#include "rex_arm_model_gen.h"
 
 #define REX_WAVE 64
 #define REX_NPOINT 8                  /* 2 toe-cylinder end points per foot */
@@ -38,7 +39,9 @@
    -- and in the link-box kernels of mark 'base': with the factor held in registers across the sweep loop those kernels
    (140 KB of code, 450 registers) came out of hipcc 7.2 with the joint velocities of the back-substitution wrong although
    no link-box row was in reach (same source minus the never-executed candidate search: correct), round 3. */
+#ifndef REX_LEG_F4_OF
 #define REX_LEG_F4_OF(EPW, ARM, BODY) ((((EPW) <= 8 && !((BODY) && !(ARM))) || ((EPW) <= 16 && (ARM))) ? 1 : REX_LEG_F4)
+#endif
 #define REX_ROWS_F4_OF(LEGF4) (REX_NROW * REX_ROW_F4 + REX_NLEG * (LEGF4))   /* rows + leg chunks: 136 (2.2 KB) or 112 */
 #define REX_LDS_F4_PER_ENV REX_ROWS_F4_OF(REX_LEG_F4)
 /* small-batch waves (EPW <= 16) only: chunks 0..1 the whitened base velocity y on its way to / from the lanes that own
@@ -220,8 +223,10 @@ constexpr float kRackAnchor = 1.0e9f;
 constexpr float kSelfMargin = 0.001f;   // a corner is a candidate from 1 mm before it enters the other box (oracle: SELF_MARGIN)
 constexpr float kSelfMu = 0.25f;   // btManifoldResult::calculateCombinedFriction: 0.5 x 0.5, the URDF default of both links
 // (every division by the cell size is a multiplication by its inverse, here and in the oracle)
-__device__ __forceinline__ void ground_query(const Ground& g, float x, float y, float& height, f3& n) {
+// `fid` (event trace only): the facet the point stands on -- 1 + 2 (cell index) + (upper triangle), 0 where the plane is on top
+__device__ __forceinline__ void ground_query(const Ground& g, float x, float y, float& height, f3& n, unsigned& fid) {
   n = f3{0.f, 0.f, 1.f}; height = 0.0f;
+  fid = 0u;
   const HfGeom& q = g.geo;
   float fx = fminf(fmaxf(x * q.inv_cx + q.off_x, 0.0f), q.max_x), fy = fminf(fmaxf(y * q.inv_cy + q.off_y, 0.0f), q.max_y);
   const int i = (int)fx, j = (int)fy;
@@ -235,8 +240,23 @@ __device__ __forceinline__ void ground_query(const Ground& g, float x, float y, 
   if (hh > 0.0f) {
     const float inv = rsqrtf(gx * gx + gy * gy + 1.0f);
     height = hh; n = f3{-gx * inv, -gy * inv, inv};
+    fid = 1u + 2u * (unsigned)(j * q.nx + i) + (u + v <= 1.0f ? 0u : 1u);
   }
 }
+// ---- event trace (debug; rex_set_event_trace): the discrete events of a substep folded into one word per env, the same way
+// in oracle/rex_oracle.c -- which toe points are in reach, which facet of the heightfield each of them stands on (under the
+// end centre and under the contact point), which joint / arm bounds are reached.  Two runs whose words agree took every
+// discrete decision of the contact set-up alike; what is left between them is continuous round-off.
+__device__ __forceinline__ void ground_query(const Ground& g, float x, float y, float& height, f3& n) {
+  unsigned fid;
+  ground_query(g, x, y, height, n, fid);
+}
+__device__ __forceinline__ unsigned trace_point(int p, unsigned f0, unsigned f1) {
+  unsigned m = f0 * 0x9E3779B1u + f1 * 0x85EBCA77u + (unsigned)(p + 1) * 0xC2B2AE3Du;
+  m ^= m >> 15; m *= 0x2C1B3C6Du; m ^= m >> 12;
+  return m;
+}
+__device__ __forceinline__ unsigned trace_mix(unsigned h, unsigned w) { h = (h ^ w) * 0x01000193u; return h ^ (h >> 13); }
 // btPlaneSpace1
 __device__ __forceinline__ void plane_space(f3 n, f3& p, f3& q) {
   if (fabsf(n.z) > 0.7071067811865475244f) {
@@ -303,7 +323,8 @@ __device__ __forceinline__ int tri(int i, int j) { return i * (i + 1) / 2 + j; }
 template <class SM>
 __device__ __forceinline__ void leg_pass(int leg, const BaseKin& bk, const float* __restrict__ q, const float* __restrict__ qd,
                                          const float* __restrict__ tau, float dt, LegFactor& L, BaseAccum& acc,
-                                         const SM& sm, unsigned& active_mask, const Ground& ground, int esel = -1) {
+                                         const SM& sm, unsigned& active_mask, const Ground& ground, int esel, bool tracing, unsigned& facets) {
+  // facets (event trace, `tracing`: wave-uniform): ^= trace_point of every toe point in reach
   static_assert(REX_LEG_SX[0] == -1 && REX_LEG_SX[1] == -1 && REX_LEG_SX[2] == 1 && REX_LEG_SX[3] == 1, "leg mirror table");
   static_assert(REX_LEG_SY[0] == -1 && REX_LEG_SY[1] == 1 && REX_LEG_SY[2] == -1 && REX_LEG_SY[3] == 1, "leg mirror table");
   const float SX = leg < 2 ? -1.0f : 1.0f, SY = (leg & 1) ? 1.0f : -1.0f;
@@ -504,15 +525,20 @@ __device__ __forceinline__ void leg_pass(int leg, const BaseKin& bk, const float
       const f3 ce = tc + sg * aw;
       f3 n0, nrm, t1, t2;
       float h0, h;
-      ground_query(ground, bk.px + ce.x, bk.py + ce.y, h0, n0);
+      unsigned fid0 = 0u, fid1 = 0u;
+      ground_query(ground, bk.px + ce.x, bk.py + ce.y, h0, n0, fid0);
       const float na = dot(n0, aw);
       const f3 dv = n0 - na * aw;
       const float dn2 = dot(dv, dv);
       const float inv = dn2 > 1e-18f ? rsqrtf(dn2) : 0.0f;
       const f3 P = ce - (kToeRad * inv) * dv;
-      ground_query(ground, bk.px + P.x, bk.py + P.y, h, nrm);
+      ground_query(ground, bk.px + P.x, bk.py + P.y, h, nrm, fid1);
       plane_space(nrm, t1, t2);
-      emit_rows(e, P, (bk.height + P.z - h) * nrm.z, nrm, t1, t2);
+      const float dist = (bk.height + P.z - h) * nrm.z;
+      emit_rows(e, P, dist, nrm, t1, t2);
+      // (bit 31: which branch btPlaneSpace1 took for the friction directions of this normal -- with a friction pyramid the
+      //  tangent frame is part of the problem, and |n.z| crosses 0.7071 on a 45-degree facet)
+      if (tracing && dist < kBreaking) facets ^= trace_point(2 * leg + e, fid0, fid1 | (fabsf(nrm.z) > 0.7071067811865475244f ? 0x80000000u : 0u));
     }
   }
 
@@ -945,6 +971,13 @@ __device__ __forceinline__ unsigned leg_or(unsigned v) {   // over ALL lanes of 
   if (LPE == 8) v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, kDppHalfMirror, 0xF, 0xF, true);
   return v;
 }
+template <int LPE>
+__device__ __forceinline__ unsigned group_xor(unsigned v) {  // xor over the lanes of the group (event trace)
+  v ^= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, kDppXor1, 0xF, 0xF, true);
+  v ^= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, kDppXor2, 0xF, 0xF, true);
+  if (LPE == 8) v ^= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, kDppHalfMirror, 0xF, 0xF, true);
+  return v;
+}
 __device__ __forceinline__ float pick_leg(const float* a, int m, int j) {   // a[3 m + j] with a per-lane m, no scratch
   const float lo = m & 1 ? a[3 + j] : a[j], hi = m & 1 ? a[9 + j] : a[6 + j];
   return m & 2 ? hi : lo;
@@ -1324,9 +1357,12 @@ __device__ __forceinline__ void rotate_leg(T* a) {   // 12-entry per-joint array
   a[9] = t0; a[10] = t1; a[11] = t2;
 }
 
-template <bool LANECAP, class SM, class ARMP>
+template <bool LANECAP, bool TRACE, class SM, class ARMP>
 __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float dt, int iterations, int lane_iterations,
-                                                float sqrt_res_thr, const SM& sm, const Ground& ground, ARMP& armp, int& lane_sweeps) {
+                                                float sqrt_res_thr, const SM& sm, const Ground& ground, ARMP& armp, int& lane_sweeps,
+                                                unsigned* trace = nullptr, int trace_n = 0, int env = 0, bool live = false) {
+  // TRACE (the kernel instantiations launched while rex_set_event_trace is on; the product kernels carry none of it): `trace` =
+  // the event trace buffer [3][trace_n]; `live`: this lane stores env's words
   // lane_sweeps: += the solver sweeps THIS env ran (the host regroups large batches by it, rex_regroup_kernel)
   // `iterations`: wave-uniform sweep cap; `lane_iterations` <= iterations: this env's own cap (they differ only in a batch
   // that mixes tasks with different numSolverIterations, REX_TASK_MIXED)
@@ -1368,7 +1404,7 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
   // highest register pressure of the substep, and before the legs neither their factors nor their velocities are live yet
   armp.pass(bk, s, tau + (SM::kEpw <= 16 ? 3 : 12), dt, acc, ground);
 
-  unsigned active = 0;
+  unsigned active = 0, facets = 0;
   PgsX x;
   constexpr int EPW = SM::kEpw;
   constexpr bool kSplitLegs = EPW <= 16;          // group layout: LPE lanes per env
@@ -1389,7 +1425,7 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
     for (int k = 0; k < 21; ++k) part.S[k] = 0.0f;
 #pragma unroll
     for (int k = 0; k < 6; ++k) part.bz[k] = 0.0f;
-    leg_pass(mleg, bk, ql, qdl, tl, dt, Lown, part, sm, active, ground, LPE == 8 ? (pl & 1) : -1);
+    leg_pass(mleg, bk, ql, qdl, tl, dt, Lown, part, sm, active, ground, LPE == 8 ? (pl & 1) : -1, TRACE, facets);
     if constexpr (SM::kLegF4 == 1) sm.zc(mleg) = make_float4(Lown.z[0], Lown.z[1], Lown.z[2], 0.0f);
     else leg_park(sm, mleg, Lown);
     active = leg_or<LPE>(active);
@@ -1410,7 +1446,7 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
       // the current leg always sits in slots 0..2: q / qd / tau are rotated by one leg per iteration,
       // which keeps every register index static inside the rolled loop
       LegFactor L;
-      leg_pass(leg, bk, s.q, s.qd, tau, dt, L, acc, sm, active, ground);
+      leg_pass(leg, bk, s.q, s.qd, tau, dt, L, acc, sm, active, ground, -1, TRACE, facets);
       leg_park(sm, leg, L);
       rotate_leg(s.q); rotate_leg(s.qd); rotate_leg(tau);
     }
@@ -1421,6 +1457,19 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
     x.z01[k] = v2{zc.x, zc.y}; x.z2[k] = zc.z;
   }
   REX_STAMP(t_legs);
+  if constexpr (TRACE) {   // the substep's discrete events (rex_set_event_trace): one read-modify-write of the env's word, debug runs only
+    if constexpr (kSplitLegs) facets = group_xor<LPE>(facets);
+    unsigned arm_mask = 0;
+    if constexpr (ARMP::NM > 12) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k)
+        if (fminf(s.q[12 + k] - (float)REXA_LOWER[k], (float)REXA_UPPER[k] - s.q[12 + k]) <= kLimitActivation) arm_mask |= 1u << k;
+    }
+    if (live) {
+      trace[env] = trace_mix(trace_mix(trace_mix(trace[env], active & 0xFFFFFu), facets), arm_mask);
+      trace[2 * trace_n + env] = trace_mix(trace_mix(trace[2 * trace_n + env], active & 0xFFFFFu), facets);   // the same without the arm's bounds
+    }
+  }
   if constexpr (SM::kBody) {
     // link-box contact rows of the base group: base_link and the two chassis boxes (rex.urdf:15-33,63-108), the four
     // deepest penetrating corners of their ground-facing faces.  Every lane of the group computes (and writes) the same rows.
@@ -1758,6 +1807,7 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
     }
   }
   REX_STAMP(t_pgs1);
+  if constexpr (TRACE) { if (live) trace[trace_n + env] = trace_mix(trace[trace_n + env], (unsigned)lane_sweeps); }   // (cumulative over the env.step())
   y[0] = x.y01.x; y[1] = x.y01.y; y[2] = x.y23.x; y[3] = x.y23.y; y[4] = x.y45.x; y[5] = x.y45.y;
 
   // back to generalized velocities: nu0 = Lc^-T y ;  qd_f = G^-T (z_f - Bw_f nu0)

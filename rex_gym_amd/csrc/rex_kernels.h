@@ -258,6 +258,10 @@ struct DevCfg {
   // made of envs of ONE task: slot_env[blk * EPW + slot] = env of that wave slot (-1: padding), block_task[blk] = the
   // task of workgroup blk's envs -- the per-task constants are then wave-uniform (SGPRs), not per-lane registers
   const int32_t* slot_env; const int32_t* block_task;
+  // rex_set_event_trace (debug; nullptr: off): [3][n] words per env -- [0] the chained hash of every substep's discrete events
+  // (toe points in reach, their heightfield facets, joint / arm bounds reached), [1] of the solver sweep counts, [2] as [0]
+  // without the arm's bounds
+  unsigned* trace;
   // rex_set_timing(3): device-side launch duration -- every workgroup folds its start / end wall-clock tick (100 MHz
   // constant clock, s_memrealtime) into clock[0] (min) / clock[1] (max); nullptr otherwise
   unsigned long long* clock;
@@ -402,7 +406,7 @@ __device__ __forceinline__ void receive_observation(const DevCfg& c, EnvState& e
 }
 
 // Rex.ApplyAction + stepSimulation + ReceiveObservation (rex.py:158-163, 568-641) for the motors this lane carries.
-template <bool LANECAP, int NL, bool ARM, class SM, class ARMP>
+template <bool LANECAP, bool TRACE, int NL, bool ARM, class SM, class ARMP>
 __device__ __forceinline__ void rex_substep(const DevCfg& c, EnvState& e, int i, bool live, bool owner, int leg0, MotorSide<NL, ARM>& ms,
                                             const SM& sm, const Ground& ground, ARMP& armp) {
   constexpr int NM = ARMP::NM, N = MotorSide<NL, ARM>::N;
@@ -433,7 +437,7 @@ __device__ __forceinline__ void rex_substep(const DevCfg& c, EnvState& e, int i,
     hold(e.phi); hold(e.alpha); hold(e.target); hold(e.aux); hold(e.last_step); hold(e.end_step); hold(e.flags); hold(e.steps);
     hold(e.episode); hold(e.motor_en); hold(e.hist); hold(ms.cmd); hold(ms.tau_obs); hold(ms.overheat2);
   }
-  physics_substep<LANECAP>(e.ph, tau, c.dt, c.max_iterations, c.iterations, c.res_thr, sm, ground, armp, e.sweeps);
+  physics_substep<LANECAP, TRACE>(e.ph, tau, c.dt, c.max_iterations, c.iterations, c.res_thr, sm, ground, armp, e.sweeps, c.trace, c.n, i, live);
   if constexpr (kHold) {
     take(e.phi); take(e.alpha); take(e.target); take(e.aux); take(e.last_step); take(e.end_step); take(e.flags); take(e.steps);
     take(e.episode); take(e.motor_en); take(e.hist); take(ms.cmd); take(ms.tau_obs); take(ms.overheat2);
@@ -839,7 +843,7 @@ __device__ __forceinline__ void gather_legs(const SM& sm, int leg0, EnvState& e,
 #ifndef REX_FAST_EPW
 #define REX_FAST_EPW 4
 #endif
-template <int EPW, bool ARM, bool MIXED, bool BODY>
+template <int EPW, bool ARM, bool MIXED, bool BODY, bool TRACE = false>
 __global__ __launch_bounds__(REX_WAVE) REX_STEP_KERNEL_ATTR void rex_step_kernel(DevCfg c, float* __restrict__ state, const float* __restrict__ snap,
                                                             const float* __restrict__ action, float* __restrict__ obs_out,
                                                             float* __restrict__ reward_out, uint8_t* __restrict__ done_out,
@@ -939,6 +943,13 @@ __global__ __launch_bounds__(REX_WAVE) REX_STEP_KERNEL_ATTR void rex_step_kernel
   else if (c_.task == REX_TASK_STANDUP) standup_command<NL>(c_, e, act, ms.cmd);
   else walk_command<NL>(c_, e, act, leg0, ms.cmd, call);
   env_gait_ik<NL>(c_, e, leg0, call, ms.cmd);     // the planner + IK tail of the task's command, if it has one
+  if constexpr (TRACE) {   // rex_set_event_trace: the controller's discrete decisions of this step (goal / brake / hold flags, gait latches)
+    if (live) {
+      const unsigned w = trace_mix(e.flags, (unsigned)e.last_step * 65537u + (unsigned)e.end_step);
+      c.trace[i] = trace_mix(c.trace[i], w);
+      c.trace[2 * c.n + i] = trace_mix(c.trace[2 * c.n + i], w);
+    }
+  }
 
   REX_STAMP(t_command);
   const Ground ground = env_ground(c, i, c.env_index_base + i, e.episode);
@@ -1061,7 +1072,7 @@ __global__ __launch_bounds__(REX_WAVE) REX_STEP_KERNEL_ATTR void rex_step_kernel
   };
 
   // Rex.Step (a REX_TASK_MIXED wave runs one task: c_ is its wave-uniform view of the config)
-  for (int k = 0; k < c_.action_repeat; ++k) rex_substep<false>(c_, e, i, live, owner, leg0, ms, sm, ground, armp);
+  for (int k = 0; k < c_.action_repeat; ++k) rex_substep<false, TRACE>(c_, e, i, live, owner, leg0, ms, sm, ground, armp);
   REX_STAMP(t_substeps);
   epilogue(live, owner);
 #ifdef REX_PROF
@@ -1122,6 +1133,7 @@ __global__ __launch_bounds__(REX_WAVE) void rex_settle_kernel(DevCfg c, float* _
   DevCfg cs = c;
   cs.hist = (c.pd_latency > 0.0f || c.control_latency > 0.0f) ? snap + (size_t)Lay<NM>::WORDS * nrec : nullptr;
   cs.n = nrec;
+  cs.trace = nullptr;   // (the event trace belongs to the envs, not to the snapshot records)
   if (c.n_mix > 1) {   // the reset motion of this record's task: its own sweep cap (rex_gym_env.py:184) -- a per-lane cap, the
     // records of a wave belong to different tasks (rex_substep<true>: the wave sweeps to max_iterations, a lane to its own)
     const int task = slot == 0 ? c.mix_task[0] : (slot == 1 ? c.mix_task[1] : (slot == 2 ? c.mix_task[2] : (slot == 3 ? c.mix_task[3] : c.mix_task[4])));
@@ -1144,7 +1156,7 @@ __global__ __launch_bounds__(REX_WAVE) void rex_settle_kernel(DevCfg c, float* _
 #pragma unroll
         for (int jl = 0; jl < 3 * NL; ++jl) ms.cmd[jl] = reset_pose(c, leg_joint<NL>(leg0, jl));
       }
-      rex_substep<true>(cs, e, t, keeps, owner, leg0, ms, sm, ground, armp);
+      rex_substep<true, false>(cs, e, t, keeps, owner, leg0, ms, sm, ground, armp);
     }
   }
   receive_observation<NM>(cs, e, t, keeps, owner, leg0, ms);                                                   // rex.py:323
@@ -1227,11 +1239,26 @@ void rex_launch_step_arm(RexSim* s, int blocks, hipStream_t st, const float* a, 
 void rex_launch_step_mixed_base(RexSim* s, int blocks, hipStream_t st, const float* a, float* o, float* r, uint8_t* d, float* m);
 void rex_launch_step_mixed_arm(RexSim* s, int blocks, hipStream_t st, const float* a, float* o, float* r, uint8_t* d, float* m);
 void rex_launch_step_body(RexSim* s, int blocks, hipStream_t st, const float* a, float* o, float* r, uint8_t* d, float* m);
+void rex_launch_step_base_trace(RexSim* s, int blocks, hipStream_t st, const float* a, float* o, float* r, uint8_t* d, float* m);
+void rex_launch_step_arm_trace(RexSim* s, int blocks, hipStream_t st, const float* a, float* o, float* r, uint8_t* d, float* m);
+void rex_launch_step_mixed_base_trace(RexSim* s, int blocks, hipStream_t st, const float* a, float* o, float* r, uint8_t* d, float* m);
+void rex_launch_step_mixed_arm_trace(RexSim* s, int blocks, hipStream_t st, const float* a, float* o, float* r, uint8_t* d, float* m);
+void rex_launch_step_body_trace(RexSim* s, int blocks, hipStream_t st, const float* a, float* o, float* r, uint8_t* d, float* m);
 void rex_launch_settle_base(RexSim* s, int nrec, hipStream_t st, float* snap);   // <false, *>
 void rex_launch_settle_arm(RexSim* s, int nrec, hipStream_t st, float* snap);    // <true, *>
 
+// Every step translation unit is compiled twice (rex_gym_amd/build.py): as it is -- the product kernels -- and with
+// -DREX_TU_TRACE=1, the instantiations with the event trace compiled in (rex_set_event_trace; launcher names end in _trace)
+#ifndef REX_TU_TRACE
+#define REX_TU_TRACE 0
+#endif
+#if REX_TU_TRACE
+#define REX_STEP_LAUNCHER(group) rex_launch_step_##group##_trace
+#else
+#define REX_STEP_LAUNCHER(group) rex_launch_step_##group
+#endif
 #define REX_LAUNCH_STEP(EPW, ARM, MIXED, BODY)                                                                                  \
-  hipLaunchKernelGGL((rex::rex_step_kernel<EPW, ARM, MIXED, BODY>), dim3(blocks), dim3(REX_WAVE), 0, st, s->dev, s->d_state, s->d_snap, \
+  hipLaunchKernelGGL((rex::rex_step_kernel<EPW, ARM, MIXED, BODY, REX_TU_TRACE != 0>), dim3(blocks), dim3(REX_WAVE), 0, st, s->dev, s->d_state, s->d_snap, \
                      a, o, r, d, m)
 #define REX_LAUNCH_BY_EPW(ARM, MIXED, BODY)                                           \
   do {                                                                                \

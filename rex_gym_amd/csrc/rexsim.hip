@@ -347,6 +347,7 @@ int rex_create(const RexConfig* cfg, int device, float* d_state, void* stream, R
     d.action_repeat = d.max_repeat;          // per-task values replace these inside the mixed kernel (wave by wave)
     d.iterations = d.max_iterations = 60;
   }
+  d.trace = nullptr;
   d.slot_env = nullptr; d.block_task = nullptr; s->d_slot_env = nullptr; s->d_block_task = nullptr; s->mixed_blocks = 0;
   d.mass_lo = cfg->mass_scale_lo; d.mass_hi = cfg->mass_scale_hi; d.mu_lo = cfg->friction_lo; d.mu_hi = cfg->friction_hi;
   s->words = rex_state_words(cfg);
@@ -480,6 +481,12 @@ int rex_set_history(RexSim* s, float* d_history) {
   // without a latency the delayed observation IS the newest one (rex.py:744-745): the ring is not needed, and the
   // snapshot holds none to restore from
   s->dev.hist = (s->cfg.pd_latency > 0.0f || s->cfg.control_latency > 0.0f) ? d_history : nullptr;
+  return REX_OK;
+}
+
+int rex_set_event_trace(RexSim* s, uint32_t* d_trace) {
+  if (!s) return fail(REX_EINVAL, "rex_set_event_trace: null sim%s", "");
+  s->dev.trace = d_trace;
   return REX_OK;
 }
 
@@ -685,6 +692,13 @@ REX_API int rex_debug_prof2(long long* out, int reset) {   /* the sections of th
 
 static void launch_step(RexSim* s, int blocks, hipStream_t st, const float* a, float* o, float* r, uint8_t* d, float* m) {
   const bool arm = s->cfg.mark == REX_MARK_ARM;
+  if (s->dev.trace) {   // rex_set_event_trace: the instantiations with the event trace compiled in (debug runs)
+    if (s->cfg.task == REX_TASK_MIXED) { if (arm) rex_launch_step_mixed_arm_trace(s, blocks, st, a, o, r, d, m); else rex_launch_step_mixed_base_trace(s, blocks, st, a, o, r, d, m); }
+    else if (s->cfg.body_contacts) rex_launch_step_body_trace(s, blocks, st, a, o, r, d, m);
+    else if (arm) rex_launch_step_arm_trace(s, blocks, st, a, o, r, d, m);
+    else rex_launch_step_base_trace(s, blocks, st, a, o, r, d, m);
+    return;
+  }
   if (s->cfg.task == REX_TASK_MIXED) {   // lane groups only (rex_create caps the envs per wave at 16)
     if (arm) rex_launch_step_mixed_arm(s, blocks, st, a, o, r, d, m); else rex_launch_step_mixed_base(s, blocks, st, a, o, r, d, m);
   } else if (s->cfg.body_contacts) rex_launch_step_body(s, blocks, st, a, o, r, d, m);   // link-box contact rows: 4 or 8 envs per wave (rex_create caps it)

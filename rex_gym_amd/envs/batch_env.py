@@ -292,6 +292,20 @@ class RexBatchEnv:
         except Exception:
             pass
 
+    def set_event_trace(self, enable=True):
+        """Debug (rex_set_event_trace): fold the discrete events of every physics substep -- toe points in reach, the heightfield
+        facets under them, joint / arm bounds reached -- into a chained hash per env, and the solver sweep counts into a second
+        one, and the events without the arm's bounds into a third.  Returns the device tensor uint32-as-int32 [3, num_envs] the launches
+        update (zeroed here); False switches it off."""
+        torch = self._torch
+        if not enable:
+            _lib.check(self._L.rex_set_event_trace(self._h, None), "rex_set_event_trace")
+            self._trace = None
+            return None
+        self._trace = torch.zeros((3, self.num_envs), dtype=torch.int32, device=self.device)
+        _lib.check(self._L.rex_set_event_trace(self._h, self._trace.data_ptr()), "rex_set_event_trace")
+        return self._trace
+
     def set_timing(self, enable=True):
         """True / 1: time the last launch (last_step_ms); 2: a ring of the last 256 launches, no sync in between (step_times_ms)."""
         _lib.check(self._L.rex_set_timing(self._h, int(enable)), "rex_set_timing")

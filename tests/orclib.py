@@ -195,6 +195,17 @@ class OracleEnv:
         self.o.lib.orc_env_command(self.h, int(idx), self.o._p(a), self.o._p(cmd))
         return cmd
 
+    def set_event_trace(self, enable=True):
+        """uint32 [3, n] array the oracle's steps update: [0] chained hash of every substep's discrete events, [1] of the sweep
+        counts, [2] the events without the arm's bounds (orc_set_event_trace; the kernels fold the same words, RexBatchEnv.set_event_trace).  False: off."""
+        if not enable:
+            self.o.lib.orc_set_event_trace(self.h, None)
+            self._trace = None
+            return None
+        self._trace = np.zeros((3, self.n), np.uint32)
+        self.o.lib.orc_set_event_trace(self.h, self._trace.ctypes.data_as(ctypes.c_void_p))
+        return self._trace
+
     def set_body_params(self, params):
         params = np.ascontiguousarray(params, np.float32)
         assert params.shape == (3, self.n)

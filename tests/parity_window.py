@@ -48,13 +48,17 @@ _TRAJ = {}
 
 def oracle_trajectory(name, env, steps, seed, threads=None, keep_states=(40, 120)):
     """fp64 oracle rollout of the workload from reset (cached: the kernel variants of a workload share it):
-    actions [steps, n, A] float32, q [steps, nm, n] float64, done [steps, n], full states at `keep_states`."""
+    actions [steps, n, A] float32, q [steps, nm, n] float64, done [steps, n], full states at `keep_states`, and the event
+    trace after every step, uint32 [steps, 3, n] (chained hashes of the discrete events / of the sweep counts / of the events
+    without the arm's bounds), with its value BEFORE each of the `keep_states` steps (a single step replayed from such a state
+    starts its chain there)."""
     key = (name, env.num_envs, steps, seed)
     if key not in _TRAJ:
         orc = oracle_for(env)
         if threads:
             orc.o.lib.orc_set_threads(int(threads))
         orc.reset()
+        otrace = orc.set_event_trace(True)
         lo, hi = action_box(env)
         rng = np.random.RandomState(seed)
         acts = rng.uniform(lo, hi, (steps, env.num_envs, env.action_dim)).astype(np.float32)
@@ -62,15 +66,18 @@ def oracle_trajectory(name, env, steps, seed, threads=None, keep_states=(40, 120
         q = np.zeros((steps, nm, env.num_envs))
         pos = np.zeros((steps, 3, env.num_envs))
         done = np.zeros((steps, env.num_envs), bool)
-        states = {}
+        trace = np.zeros((steps, 3, env.num_envs), np.uint32)
+        states, pre_trace = {}, {}
         for k in range(steps):
             if k in keep_states:
                 states[k] = orc.get_state()
+                pre_trace[k] = otrace.copy()
             _, _, d, _ = orc.step(acts[k])
             st = orc.get_state()
             q[k], pos[k], done[k] = st[orclib.S_Q:orclib.S_Q + nm], st[0:3], d
+            trace[k] = otrace
         orc.close()
-        _TRAJ[key] = (acts, q, pos, done, states)
+        _TRAJ[key] = (acts, q, pos, done, states, (trace, pre_trace))
     return _TRAJ[key]
 
 
@@ -78,18 +85,30 @@ def window(name, env, steps=200, seed=23, threads=None):
     """Run the window on `env` (freshly created with `seed`; its episode counters must be 0) -> record dict."""
     import torch
     from helpers import product_state_to_numeric
-    acts, oq, opos, odone, _ = oracle_trajectory(name, env, steps, seed, threads)
+    acts, oq, opos, odone, _, (otrace, _pre) = oracle_trajectory(name, env, steps, seed, threads)
     n, nm = env.num_envs, env.num_motors
     env.reset()
+    ktrace = env.set_event_trace(True)
+    same_events = np.ones(n, bool)      # the env's event sequence has been the oracle's so far (chained hash equal)
+    same_sweeps = np.ones(n, bool)      # ... and so have its solver sweep counts
+    same_leg_events = np.ones(n, bool)  # the event sequence without the arm's bounds (mark arm)
+    first_div = np.full(n, -1)          # control step at which the event sequences parted (while both episodes ran)
     sq = np.zeros(n); cnt = np.zeros(n); alive = np.ones(n, bool)
+    sq_same = np.zeros(n); cnt_same = np.zeros(n)     # the same sums over the steps up to which the env's events were the oracle's
     sq_legs = np.zeros(n)            # the 12 leg joints alone (mark 'arm': its arm joints sit ON their bounds and jitter)
     pos_err = np.zeros(n)
     curve = {}
     for k in range(steps):
         _, _, d, _ = env.step(torch.as_tensor(acts[k], device=env.device))
         ps = product_state_to_numeric(env.state)
+        kt = ktrace.cpu().numpy().view(np.uint32)
+        ev_eq, sw_eq = kt[0] == otrace[k, 0], kt[1] == otrace[k, 1]
+        same_leg_events &= (kt[2] == otrace[k, 2]) | ~alive
+        first_div = np.where(alive & same_events & ~ev_eq, k, first_div)
+        same_events &= ev_eq | ~alive; same_sweeps &= sw_eq | ~alive
         e = ps[orclib.S_Q:orclib.S_Q + nm] - oq[k]
         sq += np.where(alive, (e * e).mean(0), 0.0); cnt += alive
+        sq_same += np.where(alive & same_events, (e * e).mean(0), 0.0); cnt_same += alive & same_events
         sq_legs += np.where(alive, (e[:12] * e[:12]).mean(0), 0.0)
         pos_err = np.where(alive, np.abs(ps[0:3] - opos[k]).max(0), pos_err)
         if k + 1 in (1, 5, 10, 25, 50, 100, 200) and alive.any():
@@ -98,7 +117,28 @@ def window(name, env, steps=200, seed=23, threads=None):
         alive &= ~(d.cpu().numpy().astype(bool) | odone[k])      # an episode that ended (fall, goal) leaves the comparison
     rmse = np.sqrt(sq / np.maximum(cnt, 1))
     legs = np.sqrt(sq_legs / np.maximum(cnt, 1))
-    return dict(workload=name, envs=n, window_steps=steps, seed=seed, median_rad=float(np.median(rmse)),
+    env.set_event_trace(False)
+
+    def stats(x):
+        return dict(envs=int(x.size), median_rad=float(np.median(x)), p99_rad=float(np.percentile(x, 99)), max_rad=float(x.max())) if x.size else dict(envs=0)
+    hist_edges = [0, 1, 2, 5, 10, 25, 50, 100, 200, 10 ** 9]
+    div = first_div[first_div >= 0]
+    events = dict(
+        what="per env and substep: toe points within the breaking distance, the heightfield facet under each of them (end centre "
+             "and contact point), joint and arm bounds reached -- chained hash, HIP path vs fp64 oracle, compared after every "
+             "control step while both episodes run (rex_set_event_trace / orc_set_event_trace)",
+        share_same_event_sequence=float(same_events.mean()),
+        share_same_events_and_sweep_counts=float((same_events & same_sweeps).mean()),
+        share_same_events_without_arm_bounds=float(same_leg_events.mean()),
+        leg_joints_rmse_same_events_without_arm_bounds=stats(legs[same_leg_events]),
+        joint_rmse_same_events=stats(rmse[same_events]), joint_rmse_other_events=stats(rmse[~same_events]),
+        # every env, over the control steps up to which its event sequence was still the oracle's (mark arm: no env keeps it for
+        # the whole window -- its arm joints sit ON their bounds --, all of them keep it for a while)
+        joint_rmse_until_first_divergence=dict(stats(np.sqrt(sq_same[cnt_same > 0] / cnt_same[cnt_same > 0])), mean_steps=float(cnt_same.mean())),
+        leg_joints_rmse_same_events=stats(legs[same_events]),
+        first_divergence_step_histogram={f"[{a}, {b})" if b < 10 ** 9 else f">= {a}": int(((div >= a) & (div < b)).sum())
+                                         for a, b in zip(hist_edges[:-1], hist_edges[1:])})
+    return dict(events=events, workload=name, envs=n, window_steps=steps, seed=seed, median_rad=float(np.median(rmse)),
                 p99_rad=float(np.percentile(rmse, 99)), max_rad=float(rmse.max()),
                 leg_joints_median_rad=float(np.median(legs)), leg_joints_p99_rad=float(np.percentile(legs, 99)),
                 base_pos_err_p99_m=float(np.percentile(pos_err, 99)), base_pos_err_max_m=float(pos_err.max()),

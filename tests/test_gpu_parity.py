@@ -1092,6 +1092,16 @@ _PARITY_BOUNDS = {
     "walk_ik_gait_clock_1.5_4096": (8e-6, 1.6e-4, 3.2e-3),  # 2.5-3.7e-6  3.8-7.7e-5       1.2-1.6e-3
 }
 _MEETS_THE_BAR_AT_P99 = {"walk_ik_4096", "gallop_ol_8192", "walk_ik_gait_clock_1.5_4096"}
+# Share of the envs whose event sequence over the 200-step window (toe points in reach, heightfield facets, joint / arm bounds
+# reached, substep by substep: rex_set_event_trace) equals the fp64 oracle's -- lower bounds at ~0.8 x measured.  On that subset
+# the joint RMSE meets BASELINE.json's 1e-3 rad at the 99th percentile in EVERY workload (heightfield: p99 7.8e-5, max 7.8e-4):
+# what misses the bar in the table above is envs in which float32 took a discrete decision the other way, not drift.  Mark arm
+# keeps no env: its three arm joints sit ON their bounds and the limit rows switch with the last bit in every env within ~25
+# steps (its single steps from common states are split the same way above: same events -> 2e-4 rad).
+_SINGLE_STEP_SAME_EVENTS_RAD = {"walk_ik_4096": 2e-4, "gallop_ol_8192": 2e-4, "turn_ik_heightfield_4096": 1, "mixed_arm_2048": 1,
+                                "walk_ik_gait_clock_1.5_4096": 2e-4}
+_SAME_EVENTS_SHARE = {"walk_ik_4096": 0.95, "gallop_ol_8192": 0.97, "turn_ik_heightfield_4096": 0.33, "mixed_arm_2048": 0.0,
+                      "walk_ik_gait_clock_1.5_4096": 0.9}
 
 
 @pytest.mark.parametrize("epw", [4, 8, 16, 64])
@@ -1117,17 +1127,30 @@ def test_every_kernel_variant_against_the_oracle_at_baseline_sizes(torch, name, 
     steps, seed = 200, 23
     env = pw.make_env(name, seed=seed)
     assert env._L.rex_envs_per_wave(env._h) == epw
-    acts, oq, opos, odone, ostates = pw.oracle_trajectory(name, env, steps, seed)
+    acts, oq, opos, odone, ostates, (otrace, pre_trace) = pw.oracle_trajectory(name, env, steps, seed)
     nm = env.num_motors
-    # --- single steps from common states
+    # --- single steps from common states, with the event trace on: the envs whose step took every discrete decision of the
+    #     contact set-up as the oracle's did (same toe points in reach, same facets, same bounds reached in every substep) are
+    #     held to the round-off tolerance WITHOUT exception; the quantile bounds below are for the others
+    single = []
     for k0, st in ostates.items():
         env.reset()
         env.state.copy_(numeric_to_product_state(st, torch, env.state.device))
+        kt = env.set_event_trace(True)
+        kt.copy_(torch.from_numpy(pre_trace[k0].view(np.int32)))      # the oracle's chain before this step
         env.step(torch.as_tensor(acts[k0], device="cuda"))
+        same = (kt.cpu().numpy().view(np.uint32)[0] == otrace[k0, 0])
+        env.set_event_trace(False)
         ps = product_state_to_numeric(env.state)
         live = ~odone[k0]
         eq = np.abs(ps[orclib.S_Q:orclib.S_Q + nm] - oq[k0])[:, live]
         ep = np.abs(ps[0:3] - opos[k0])[:, live]
+        sm = same[live]
+        single.append(dict(from_step=k0, envs=int(live.sum()), same_events=int(sm.sum()),
+                           joint_err_max_same_events=float(eq[:, sm].max()) if sm.any() else None,
+                           joint_err_max_other_events=float(eq[:, ~sm].max()) if (~sm).any() else None))
+        assert sm.mean() >= (0.5 if "arm" in name else 0.97), (epw, k0, sm.mean())
+        assert eq[:, sm].max() <= _SINGLE_STEP_SAME_EVENTS_RAD[name] and ep[:, sm].max() <= 2e-4, (epw, k0, eq[:, sm].max(), ep[:, sm].max())
         if "heightfield" in name:
             # a toe point within float32 resolution of a triangle edge of the field (45-degree facets between the 2 x 2
             # blocks) takes the neighbouring facet's normal in one of the two precisions: a jump of several 1e-3 rad for
@@ -1148,13 +1171,23 @@ def test_every_kernel_variant_against_the_oracle_at_baseline_sizes(torch, name, 
     env.state.zero_()
     rec = pw.window(name, env, steps=steps, seed=seed)
     rec["envs_per_wave"] = epw
+    rec["single_steps_from_common_states"] = single
     os.makedirs(os.path.join(os.path.dirname(__file__), "..", "gpurun_out"), exist_ok=True)
-    with open(os.path.join(os.path.dirname(__file__), "..", "gpurun_out", "r03_parity.jsonl"), "a") as f:
+    with open(os.path.join(os.path.dirname(__file__), "..", "gpurun_out", "r04_parity.jsonl"), "a") as f:
         f.write(json.dumps(rec) + "\n")
     print(json.dumps(rec))
     med, p99, mx = _PARITY_BOUNDS[name]
     assert rec["median_rad"] <= 1e-3 and (name not in _MEETS_THE_BAR_AT_P99 or rec["p99_rad"] <= 1e-3), rec      # BASELINE.json's bar
     assert rec["median_rad"] <= med and rec["p99_rad"] <= p99 and rec["max_rad"] <= mx, rec
+    # the envs whose whole 200-step event sequence was the oracle's: BASELINE.json's bar at the 99th percentile, every workload
+    ev = rec["events"]
+    share = _SAME_EVENTS_SHARE[name]
+    assert ev["share_same_event_sequence"] >= share, ev
+    if share > 0:
+        assert ev["joint_rmse_same_events"]["p99_rad"] <= 1e-3 and ev["joint_rmse_same_events"]["median_rad"] <= 2e-5, ev
+    # ... and every env, for as long as its event sequence is the oracle's (mark arm: 5-10 control steps, then a bound row switches)
+    u = ev["joint_rmse_until_first_divergence"]
+    assert u["envs"] >= 0.95 * env.num_envs and u["p99_rad"] <= 1e-3, ev
     env.close()
 
 
