@@ -1207,6 +1207,7 @@ __global__ void rex_reset_kernel(DevCfg c, float* __restrict__ state, const floa
 
 }  // namespace rex
 
+namespace rex { struct MixRegions { int32_t n_mix, bins_per_task, base[5]; }; }   // base[k]: first slot of task slot k's region of the slot map
 // ---- host side shared by the translation units ----
 #define REX_TIMING_RING 256     /* event pairs of rex_set_timing(2) */
 struct RexSim {
@@ -1231,6 +1232,8 @@ struct RexSim {
   int32_t* d_slot_env;   // REX_TASK_MIXED: the task-sorted slot map (DevCfg::slot_env / block_task) and its workgroup count
   int32_t* d_block_task;
   int mixed_blocks;
+  int32_t* d_class;      // a regrouped mixed batch: task slot of every env (rexsim.hip, rex_regroup_mixed_*), and its regions
+  rex::MixRegions mix_regions;
 };
 
 // launchers, one per variant group (each in its own translation unit)

@@ -66,6 +66,56 @@ __global__ __launch_bounds__(256) void rex_regroup_scatter_kernel(int n, int bin
     if (i < n) perm[atomicAdd(&cursor[regroup_bin(sweeps[i], bin_width)], 1)] = i;
   }
 }
+// Regrouping of a REX_TASK_MIXED batch: every task of the mix owns a STATIC region of the slot map (whole waves; the envs keep
+// their task for life, so the region sizes and its padding slots never change); inside its region a task's envs are sorted by
+// the sweeps of their last step, most first -- the waves of a large mixed batch then hold envs that need about the same number
+// of sweeps, and the waves that exceed one round of the machine are the short ones.  Bins: 64 / n_mix sweep bins per task.
+__device__ __forceinline__ int regroup_bin_mixed(int sweeps, int bin_width, int cls, int w) { return cls * w + (w - 1 - min(sweeps / bin_width, w - 1)); }
+__global__ __launch_bounds__(256) void rex_regroup_mixed_count_kernel(int n, int bin_width, MixRegions mr, const int32_t* __restrict__ cls,
+                                                                      const int32_t* __restrict__ sweeps, int32_t* __restrict__ counts,
+                                                                      unsigned* __restrict__ done) {
+  __shared__ int hist[64];
+  __shared__ bool last;
+  const int t = threadIdx.x, b = blockIdx.x, nb = gridDim.x;
+  if (t < 64) hist[t] = 0;
+  __syncthreads();
+  for (int k = t; k < REX_REGROUP_CHUNK; k += 256) {
+    const int i = b * REX_REGROUP_CHUNK + k;
+    if (i < n) atomicAdd(&hist[regroup_bin_mixed(sweeps[i], bin_width, cls[i], mr.bins_per_task)], 1);
+  }
+  __syncthreads();
+  if (t < 64) counts[b * 64 + t] = hist[t];
+  __threadfence();
+  __syncthreads();
+  if (t == 0) last = atomicAdd(done, 1u) == (unsigned)nb - 1u;
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  __shared__ int total[64], first[64];
+  if (t < 64) { int acc = 0; for (int k = 0; k < nb; ++k) acc += counts[k * 64 + t]; total[t] = acc; }
+  __syncthreads();
+  if (t == 0) {
+    for (int c = 0; c < mr.n_mix; ++c) {   // a task's bins fill its own region from its first slot
+      int acc = mr.base[c];
+      for (int k = 0; k < mr.bins_per_task; ++k) { first[c * mr.bins_per_task + k] = acc; acc += total[c * mr.bins_per_task + k]; }
+    }
+    *done = 0u;
+  }
+  __syncthreads();
+  if (t < mr.n_mix * mr.bins_per_task) { int acc = first[t]; for (int k = 0; k < nb; ++k) { const int c = counts[k * 64 + t]; counts[k * 64 + t] = acc; acc += c; } }
+}
+__global__ __launch_bounds__(256) void rex_regroup_mixed_scatter_kernel(int n, int bin_width, MixRegions mr, const int32_t* __restrict__ cls,
+                                                                        const int32_t* __restrict__ sweeps, const int32_t* __restrict__ counts,
+                                                                        int32_t* __restrict__ slot_env) {
+  __shared__ int cursor[64];
+  const int t = threadIdx.x, b = blockIdx.x;
+  if (t < 64) cursor[t] = counts[b * 64 + t];
+  __syncthreads();
+  for (int k = t; k < REX_REGROUP_CHUNK; k += 256) {
+    const int i = b * REX_REGROUP_CHUNK + k;
+    if (i < n) slot_env[atomicAdd(&cursor[regroup_bin_mixed(sweeps[i], bin_width, cls[i], mr.bins_per_task)], 1)] = i;
+  }
+}
 __global__ void rex_iota_kernel(int n, int32_t* __restrict__ perm, int32_t* __restrict__ sweeps) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) { perm[i] = i; sweeps[i] = 0; }
@@ -309,6 +359,27 @@ static int task_slot_map(const rex::DevCfg& d, int epw, std::vector<int32_t>& sl
   return (int)busy;
 }
 
+// The layout a regrouped mixed batch starts from (and keeps the shape of): task slot k's envs in index order in ONE region of
+// whole waves per task, regions in the order of the mix; cls[i] = task slot of env i, base[k] = first slot of region k.
+static void task_region_map(const rex::DevCfg& d, int epw, std::vector<int32_t>& slots, std::vector<int32_t>& tasks, std::vector<int32_t>& cls,
+                            int32_t base[5]) {
+  cls.resize((size_t)d.n);
+  for (int i = 0; i < d.n; ++i) {
+    const int t = host_mixed_task_of(d, d.env_index_base + i);
+    int k = 0;
+    for (int j = 1; j < d.n_mix; ++j) if (d.mix_task[j] == t) k = j;
+    cls[i] = k;
+  }
+  slots.clear(); tasks.clear();
+  for (int k = 0; k < 5; ++k) base[k] = 0;
+  for (int k = 0; k < d.n_mix; ++k) {
+    base[k] = (int32_t)slots.size();
+    for (int i = 0; i < d.n; ++i) if (cls[i] == k) slots.push_back(i);
+    while (slots.size() % (size_t)epw) slots.push_back(-1);
+    while (tasks.size() < slots.size() / epw) tasks.push_back(d.mix_task[k]);
+  }
+}
+
 int rex_create(const RexConfig* cfg, int device, float* d_state, void* stream, RexSim** out) {
   if (!out || !d_state) return fail(REX_EINVAL, "rex_create: null pointer%s", "");
   int rc = validate(cfg);
@@ -348,7 +419,7 @@ int rex_create(const RexConfig* cfg, int device, float* d_state, void* stream, R
     d.iterations = d.max_iterations = 60;
   }
   d.trace = nullptr;
-  d.slot_env = nullptr; d.block_task = nullptr; s->d_slot_env = nullptr; s->d_block_task = nullptr; s->mixed_blocks = 0;
+  d.slot_env = nullptr; d.block_task = nullptr; s->d_slot_env = nullptr; s->d_block_task = nullptr; s->mixed_blocks = 0; s->d_class = nullptr;
   d.mass_lo = cfg->mass_scale_lo; d.mass_hi = cfg->mass_scale_hi; d.mu_lo = cfg->friction_lo; d.mu_hi = cfg->friction_hi;
   s->words = rex_state_words(cfg);
   d.pose_index = cfg->pose_index; d.pose_value = cfg->pose_value;
@@ -409,8 +480,26 @@ int rex_create(const RexConfig* cfg, int device, float* d_state, void* stream, R
     // up to 1 024 workgroups the launch is one wave per SIMD; the padding of the map must not push it into a second round
     const bool pinned = getenv("REX_ENVS_PER_WAVE") != nullptr;
     while (!pinned && s->epw < 16 && busy > 1024) { s->epw *= 2; busy = task_slot_map(d, s->epw, slots, tasks); }
+    // More workgroups than the machine holds at once (1 024: one wave per SIMD): the batch is regrouped by sweep counts every
+    // step (REX_REGROUP=0 / 1 overrides) -- regions of whole waves per task, sorted inside.  Measured at 16 384 mark-arm envs,
+    // 16 envs per wave: the padding of the chunked map is a second round of full-length waves; sorted, the late waves are the short ones.
+    const char* ov = getenv("REX_REGROUP");
+    const bool regroup = ov ? atoi(ov) != 0 : busy > 1024;
+    std::vector<int32_t> cls;
+    if (regroup) task_region_map(d, s->epw, slots, tasks, cls, s->mix_regions.base);
     s->mixed_blocks = (int)tasks.size();
     hipError_t e2 = hipMalloc(&s->d_slot_env, sizeof(int32_t) * slots.size());
+    if (regroup) {
+      const int chunks = (cfg->num_envs + REX_REGROUP_CHUNK - 1) / REX_REGROUP_CHUNK;
+      s->mix_regions.n_mix = d.n_mix; s->mix_regions.bins_per_task = 64 / d.n_mix;
+      if (e2 == hipSuccess) e2 = hipMalloc(&s->d_class, sizeof(int32_t) * cls.size());
+      if (e2 == hipSuccess) e2 = hipMemcpy(s->d_class, cls.data(), sizeof(int32_t) * cls.size(), hipMemcpyHostToDevice);
+      if (e2 == hipSuccess) e2 = hipMalloc(&s->d_sweeps, sizeof(int32_t) * (size_t)cfg->num_envs);
+      if (e2 == hipSuccess) e2 = hipMemset(s->d_sweeps, 0, sizeof(int32_t) * (size_t)cfg->num_envs);
+      if (e2 == hipSuccess) e2 = hipMalloc(&s->d_regroup, sizeof(int32_t) * ((size_t)chunks * 64 + 1));
+      if (e2 == hipSuccess) e2 = hipMemset(s->d_regroup, 0, sizeof(int32_t) * ((size_t)chunks * 64 + 1));
+      d.sweeps = s->d_sweeps;
+    }
     if (e2 == hipSuccess) e2 = hipMalloc(&s->d_block_task, sizeof(int32_t) * tasks.size());
     if (e2 == hipSuccess) e2 = hipMemcpy(s->d_slot_env, slots.data(), sizeof(int32_t) * slots.size(), hipMemcpyHostToDevice);
     if (e2 == hipSuccess) e2 = hipMemcpy(s->d_block_task, tasks.data(), sizeof(int32_t) * tasks.size(), hipMemcpyHostToDevice);
@@ -507,6 +596,7 @@ int rex_destroy(RexSim* s) {
   if (s->d_regroup) (void)hipFree(s->d_regroup);
   if (s->d_slot_env) (void)hipFree(s->d_slot_env);
   if (s->d_block_task) (void)hipFree(s->d_block_task);
+  if (s->d_class) (void)hipFree(s->d_class);
   (void)hipEventDestroy(s->ev0);
   (void)hipEventDestroy(s->ev1);
   for (int k = 0; k < REX_TIMING_RING; ++k) if (s->ring0[k]) { (void)hipEventDestroy(s->ring0[k]); (void)hipEventDestroy(s->ring1[k]); }
@@ -556,6 +646,13 @@ int rex_step(RexSim* s, const float* d_action, float* d_obs, float* d_reward, ui
   HIPCHK(hipGetLastError());
   // (the timed span is the step kernel's: the regrouping launches below are not part of it)
   if (s->timing == 1 || s->timing == 2) { HIPCHK(hipEventRecord(e1, st)); s->have_timing = 1; if (s->timing == 2) s->timed_steps++; }
+  if (s->d_class) {   // a regrouped mixed batch: every task's region sorted by this step's sweep counts for the next step
+    const int n = s->cfg.num_envs, width = (s->dev.max_repeat * s->dev.max_iterations + s->mix_regions.bins_per_task - 1) / s->mix_regions.bins_per_task;
+    const int chunks = (n + REX_REGROUP_CHUNK - 1) / REX_REGROUP_CHUNK;
+    unsigned* done = reinterpret_cast<unsigned*>(s->d_regroup + (size_t)chunks * 64);
+    hipLaunchKernelGGL(rex::rex_regroup_mixed_count_kernel, dim3(chunks), dim3(256), 0, st, n, width, s->mix_regions, s->d_class, s->d_sweeps, s->d_regroup, done);
+    hipLaunchKernelGGL(rex::rex_regroup_mixed_scatter_kernel, dim3(chunks), dim3(256), 0, st, n, width, s->mix_regions, s->d_class, s->d_sweeps, s->d_regroup, s->d_slot_env);
+  }
   if (s->d_perm) {   // next step's grouping from this step's sweep counts (stream-ordered behind the step)
     const int n = s->cfg.num_envs, width = (s->dev.max_repeat * s->dev.max_iterations + 63) / 64;
     const int chunks = (n + REX_REGROUP_CHUNK - 1) / REX_REGROUP_CHUNK;

@@ -1357,6 +1357,34 @@ def test_regrouped_batch_is_bit_identical(torch, monkeypatch, n):
     assert torch.equal(outs["0"][1], outs["1"][1])
 
 
+@pytest.mark.parametrize("n,epw", [(700, 4), (5000, 16)])    # one chunk of the count / scatter pair and five, ragged
+def test_regrouped_mixed_batch_is_bit_identical(torch, monkeypatch, n, epw):
+    """A REX_TASK_MIXED batch under REX_REGROUP=1: every task owns a static region of whole waves of the slot map and is
+    sorted inside it by the solver sweeps of the previous step (rex_regroup_mixed_*); against the chunked static map
+    (REX_REGROUP=0) the waves change every step, an env's results must not -- through falls, in-launch resets and the
+    per-reset mass / friction draws."""
+    from rex_gym_amd import RexMixedBatchEnv
+    kw = dict(mark="arm", seed=6, auto_reset=True, max_episode_steps=30, mass_scale_range=(0.8, 1.2), friction_range=(0.25, 0.625))
+    outs = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("REX_REGROUP", flag)
+        monkeypatch.setenv("REX_ENVS_PER_WAVE", str(epw))
+        env = RexMixedBatchEnv(n, **kw)
+        env.reset()
+        g = torch.Generator(device="cuda"); g.manual_seed(5)
+        rec = []
+        for k in range(45):
+            a = torch.rand((n, 2), device="cuda", generator=g) * 0.02 - 0.01
+            o, r, d, info = env.step(a)
+            rec.append((o.clone(), r.clone(), d.clone(), info["action"].clone()))
+        outs[flag] = (rec, env.state.clone())
+        env.close()
+    assert sum(int(x[2].sum()) for x in outs["0"][0]) >= n       # every env ended an episode
+    for (o0, r0, d0, c0), (o1, r1, d1, c1) in zip(outs["0"][0], outs["1"][0]):
+        assert torch.equal(o0, o1) and torch.equal(r0, r1) and torch.equal(d0, d1) and torch.equal(c0, c1)
+    assert torch.equal(outs["0"][1], outs["1"][1])
+
+
 @pytest.mark.parametrize("task,signal,mark", [("walk", "ik", "base"), ("turn", "ik", "base"), ("gallop", "ol", "arm")])
 def test_on_rack_debug_mode_against_the_oracle(torch, task, signal, mark):
     """on_rack=True (loadURDF(useFixedBase=True) at [0, 0, 1], rex.py:269-287): the base stays exactly where the rack holds
