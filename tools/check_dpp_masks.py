@@ -30,6 +30,7 @@ def compile_group(g):
 with ThreadPoolExecutor(4) as ex:
     list(ex.map(compile_group, groups))
 bad = 0
+bad_cross = 0
 for g in groups:
     s = open(os.path.join(OUT, f"rex_{g}-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
     for m in re.finditer(r"^(_ZN3rex\S*kernel\S*):", s, re.M):
@@ -37,9 +38,52 @@ for g in groups:
         lines = [l.strip().split(";")[0].strip() for l in body.split("\n")]
         lines = [l for l in lines if l]
         idx = [i for i, l in enumerate(lines) if "row_shr:1" in l]
-        if not idx:
-            continue
-        masked = [l for l in lines[idx[0]:idx[-1]] if re.match(r"s_\w+\s+exec", l) or "saveexec" in l]
-        print(f"{g:16s} {m.group(1)[:60]:60s} shifts {len(idx):3d}  exec writes among them: {len(masked)}")
-        bad += len(masked)
+        # (2) round 4: EVERY cross-lane instruction of the kernel (DPP, ds_swizzle, ds_bpermute, readlane, permlane) must run
+        # with the full EXEC mask -- a lane the mask has switched off contributes 0 (or stale data) to its neighbours' sums.
+        # EXEC is followed along the instruction stream the way the structurizer lays it out: s_and[n2]_saveexec / v_cmpx /
+        # s_and[n2]_b64 exec narrow it (the saved mask's register pair goes on a stack), `s_or_b64 exec, exec, s[a:b]` widens
+        # it again down to that pair.  Uniform branches (s_cbranch_scc / vcc) leave EXEC alone.
+        # A divergent `if` is laid out as  s_and_saveexec_b64 sX, cond ; [s_xor_b64 ...] ; s_cbranch_execz L ; <then-block> ; L: s_or_b64 exec, exec, sY
+        # (an else-block the same way after s_xor_b64 exec / s_andn2_saveexec); a divergent loop narrows EXEC with s_andn2_b64
+        # exec and leaves through s_cbranch_execnz.  Every instruction between a narrowing and the label its guard branch
+        # names runs under a partial mask.
+        labels = {l[:-1]: i for i, l in enumerate(lines) if l.endswith(":")}
+        stack, under = [], []      # stack of labels at which the innermost narrowed regions end ("?" = until the next EXEC restore)
+        for k, l in enumerate(lines):
+            if l.endswith(":"):
+                lab = l[:-1]
+                while lab in stack:
+                    stack.pop()
+                continue
+            if re.match(r"s_\w+_saveexec_b64", l) or re.match(r"s_(?:and|andn2|xor)_b64\s+exec,\s*exec", l) or l.startswith("v_cmpx"):
+                tgt = "?"
+                for nxt in lines[k + 1:k + 6]:          # the guard branch follows within a few instructions
+                    mm = re.match(r"s_cbranch_execn?z\s+(\S+)", nxt)
+                    if mm:
+                        tgt = mm.group(1) if labels.get(mm.group(1), -1) > k else "?"   # (a loop's back edge: narrowed until the restore behind it)
+                        break
+                    if nxt.endswith(":") or nxt.startswith("s_branch") or nxt.startswith("s_cbranch"):
+                        break
+                stack.append(tgt)
+                continue
+            if re.match(r"s_(?:or_b64\s+exec,\s*exec|mov_b64\s+exec)", l):
+                while stack and stack[-1] == "?":
+                    stack.pop()
+                continue
+            # (v_readlane / v_writelane -- the compiler's SGPR spills -- ignore EXEC; v_readfirstlane reads the first ACTIVE lane)
+            if stack and (("_dpp" in l.split()[0]) or re.match(r"(ds_swizzle|ds_bpermute|ds_permute|v_permlane)", l)):
+                under.append(l)
+        if idx:
+            masked = [l for l in lines[idx[0]:idx[-1]] if re.match(r"s_\w+\s+exec", l) or "saveexec" in l]
+            print(f"{g:16s} {m.group(1)[:60]:60s} shifts {len(idx):3d}  exec writes among them: {len(masked)}")
+            bad += len(masked)
+        ncross = sum(1 for l in lines if "_dpp" in l.split()[0] or re.match(r"(ds_swizzle|ds_bpermute|ds_permute|v_permlane)", l))
+        print(f"{g:16s} {m.group(1)[:60]:60s} cross-lane instructions {ncross:4d}  under a narrowed EXEC: {len(under)}")
+        for l in under[:4]:
+            print("      ", l)
+        bad_cross += len(under)
+# (informational: the sweep loop runs under the per-env `running` mask, which is uniform inside a lane group -- DPP sums inside a
+#  group are exact under it.  The list is for review after a source change: a cross-lane instruction under a mask that is NOT
+#  uniform per lane group is the round-3 bug.)
+print("total cross-lane instructions under a narrowed EXEC (review list, not an error):", bad_cross)
 sys.exit(1 if bad else 0)
