@@ -45,6 +45,15 @@ def _worker(rank, world, port, q):
     assert sh.num_envs == 4 and sh.env_index_base == 4 * rank
     _, seg, _ = _rollout(sh.num_envs, sh.env_index_base, 8, seed=7)
     full = gather_rollout({k: torch.from_numpy(v.astype(np.float32)) for k, v in seg.items()})
+    # a one-step segment: the gathered [T = 1, world * n, ...] tensor would be a VIEW of the cached receive buffer -- the caller
+    # must still own what it got when the next gather on the same slot arrives
+    from rex_gym_amd.sharding import clear_gather_buffers
+    a1 = gather_rollout({"x": torch.full((1, 4, 2), float(rank))})
+    keep = a1["x"].clone()
+    a2 = gather_rollout({"x": torch.full((1, 4, 2), float(rank) + 10.0)})
+    assert torch.equal(a1["x"], keep) and torch.equal(a2["x"], keep + 10.0), "a gathered segment was overwritten by the next gather"
+    assert torch.equal(keep[0, :4], torch.zeros(4, 2)) and torch.equal(keep[0, 4:], torch.ones(4, 2))      # global env order
+    clear_gather_buffers()
     q.put((rank, {k: v.numpy() for k, v in full.items()}))
     dist.barrier()
     dist.destroy_process_group()

@@ -38,17 +38,18 @@ ALGO = {"walk4096": 541 * 4096, "walk262144": 541 * 262144, "arm4096": 661 * 409
 traffic_path = os.path.join(P, "traffic.json")
 traffic = json.load(open(traffic_path))
 out = [f"# {tag} -- rocprofv3 kernel trace + PMC passes of bench.py per workload (tools/profile_round.sh), MI355X\n",
-       "Each workload: `rocprofv3 --kernel-trace --stats` (steady = launches after the 1 550th), then three separate `--pmc` passes "
+       "Each workload: `rocprofv3 --kernel-trace --stats` (launches 1 550 .. 1 949 of the step kernel: the 400 timed launches of that bench.py run), then three separate `--pmc` passes "
        "(FETCH_SIZE; WRITE_SIZE; SQ_* with GRBM_GUI_ACTIVE).  FETCH_SIZE / WRITE_SIZE in KiB as gfx950 reports them (calibrated on this kernel's 4-byte-per-lane word "
        "loads: true bytes, profiles/r04_hbm_counter_calibration.md); issue fraction = 4 x SQ_ACTIVE_INST_VALU / (32 SIMDs x GRBM_GUI_ACTIVE) per shader "
        "engine: the share of SIMD cycles in which the VALU is busy (a wave64 fma keeps it busy ~2 cycles, a DPP add ~9: profiles/r04_microbench.md).\n",
-       "| workload | kernel | avg us (steady) | min | max | scratch B | FETCH KB | WRITE KB | HBM MB / launch | algorithmic MB | ratio | VALU issue fraction | WAIT_ANY / WAVE_CYCLES |",
-       "|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
+       "| workload | kernel | avg us (rocprofv3, the 400 timed launches) | bench.py kernel_ms x 1000 (device timestamps, same launches) | min | max | scratch B | FETCH KiB | WRITE KiB | HBM MB / launch | algorithmic MB | ratio | VALU busy fraction | WAIT_ANY / WAVE_CYCLES |",
+       "|---|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
 for f in sorted(glob.glob(os.path.join(G, f"{tag}_profile_*.txt"))):
     name = os.path.basename(f)[len(tag) + 9:-4]
     txt = open(f).read()
     stats = [l for l in txt.splitlines() if l.startswith("| `_ZN3rex15rex_step")]
-    js = [l for l in txt.splitlines() if l.startswith('{"')]
+    js = [l for l in txt.splitlines() if l.startswith('{"') and "bench_kernel_ms_same_launches" not in l]
+    same = [json.loads(l) for l in txt.splitlines() if l.startswith('{"bench_kernel_ms_same_launches"')]
     if not stats or not js:
         continue
     d = json.loads(js[-1]); g = lambda k: d.get(k, {}).get("avg_steady")
@@ -56,7 +57,7 @@ for f in sorted(glob.glob(os.path.join(G, f"{tag}_profile_*.txt"))):
     mb = (g("FETCH_SIZE") + g("WRITE_SIZE")) * 1024 / 1e6   # both counters are in KiB and exact for this access pattern (profiles/r04_hbm_counter_calibration.md)
     frac = 4 * g("SQ_ACTIVE_INST_VALU") / (32 * g("GRBM_GUI_ACTIVE"))
     kern = st[1].split("rex_step_kernelI")[1].split("EEv")[0].replace("Lb0", "0").replace("Lb1", "1").replace("Li", "").replace("E", ",")
-    out.append(f"| {KEYS.get(name, name)} | `<{kern}>` | {st[5]} | {st[6]} | {st[7]} | {st[-2]} | {g('FETCH_SIZE'):.1f} | {g('WRITE_SIZE'):.1f} | {mb:.2f} | "
+    out.append(f"| {KEYS.get(name, name)} | `<{kern}>` | {st[5]} | {same[-1]['bench_kernel_ms_same_launches'] * 1e3 if same else float('nan'):.1f} | {st[6]} | {st[7]} | {st[-2]} | {g('FETCH_SIZE'):.1f} | {g('WRITE_SIZE'):.1f} | {mb:.2f} | "
                f"{ALGO[name] / 1e6:.2f} | {mb / (ALGO[name] / 1e6):.2f} | {frac:.3f} | {g('SQ_WAIT_ANY') / g('SQ_WAVE_CYCLES'):.3f} |")
     traffic[KEYS.get(name, name)] = {"bytes_per_launch": int(mb * 1e6), "fetch_kb": round(g("FETCH_SIZE"), 1), "write_kb": round(g("WRITE_SIZE"), 1),
                                      "issue_frac": round(frac, 4), "kernel_us_steady": float(st[5]), "source": f"profiles/{tag}_kernel_stats_and_pmc.md"}
