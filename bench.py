@@ -10,8 +10,8 @@ A "step" is ONE launch of rex_step_kernel = one env.step() of every env of the s
 (controller + 5 x [motor model + restated stepSimulation with 60 PGS iterations] + reward/done/obs,
 with in-launch auto-reset), writing its observation / reward / done into slice t of a rollout segment.
 Workload = BASELINE.json configs[1]: 4 096 Rex envs per GPU, walk-IK, flat plane, random actions
-U(-0.4, 0.4) drawn afresh for every step -- one device-side draw per 25-step rollout segment on
-the launch stream, inside the timed region -- (weak scaling: 4 096 envs on every GPU, independent shards, no
+U(-0.4, 0.4) drawn afresh for every step -- one device-side draw (one kernel) per 25-step rollout
+segment on the launch stream, inside the timed region, a segment ahead of its use -- (weak scaling: 4 096 envs on every GPU, independent shards, no
 data-path collective).  With N > 1 every rank all-gathers
 its finished 25-step segment to all ranks (RCCL over xGMI: the learner hand-off, the design's only
 collective) while the next segment is stepped; the line reports the throughput with it (`value`) and
@@ -219,10 +219,16 @@ def main():
     hi = torch.as_tensor(env.action_space.low, device=dev).maximum(torch.as_tensor(env.action_space.high, device=dev)).float()
     T = max(1, args.gather_every)
 
+    span = (hi - lo).contiguous()
+    one_box = bool((lo == lo[0]).all() and (hi == hi[0]).all())      # every dimension of the env's Box has the same bounds (all five envs)
+    lo0, hi0 = float(lo[0]), float(hi[0])
+
     def draw_actions(buf):
-        """a rollout segment of fresh actions, uniform over the env's Box: U[0, 1) scaled into [lo, hi) on the launch stream"""
+        """a rollout segment of fresh actions, uniform over the env's Box, drawn on the launch stream: one kernel"""
+        if one_box:
+            return buf.uniform_(lo0, hi0, generator=gen)
         torch.rand(buf.shape, device=dev, generator=gen, out=buf)
-        return buf.mul_(hi - lo).add_(lo)
+        return buf.mul_(span).add_(lo)
 
     pool = draw_actions(torch.empty((T, n, env.action_dim), device=dev))
     assert bool(((pool >= lo) & (pool <= hi)).all())     # by construction; checked once on a drawn segment
@@ -258,18 +264,25 @@ def main():
     sacts = [[s["action"][t] for t in range(T)] for s in seg]
     outs = [[env.bind_out(s["obs"][t], s["reward"][t], s["done"][t]) for t in range(T)] for s in seg]
 
+    clock = [0]     # steps taken through run() so far: the segments continue across the warm-up / timed / untimed calls
+
     def run(steps, gather):
         pending = [None, None]
         step = env.step
-        for k in range(steps):
+        for k in range(clock[0], clock[0] + steps):
             b, t = (k // T) & 1, k % T
-            if t == 0:
-                if pending[b] is not None:
-                    pending[b].wait(); pending[b] = None     # this buffer's previous segment has left before it is overwritten
-                draw_actions(seg[b]["action"])               # fresh actions for every step of the segment
+            if t == 0 and pending[b] is not None:
+                pending[b].wait(); pending[b] = None         # this buffer's previous segment has left before it is overwritten
             step(sacts[b][t], outs[b][t])
-            if gather and t == T - 1:
-                pending[b] = gather_rollout(seg[b], async_op=True, slot=b)
+            if t == T - 1:
+                if gather:
+                    pending[b] = gather_rollout(seg[b], async_op=True, slot=b)
+                # fresh actions for every step: the OTHER buffer's next segment is drawn now, behind this
+                # segment's last launch (its previous segment was handed over one segment ago)
+                if pending[b ^ 1] is not None:
+                    pending[b ^ 1].wait(); pending[b ^ 1] = None
+                draw_actions(seg[b ^ 1]["action"])
+        clock[0] += steps
         for p in pending:
             if p is not None:
                 p.wait()
@@ -322,7 +335,7 @@ def main():
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev0.record(torch.cuda.current_stream(dev))
     for k in range(m):
-        env.step(acts[k % T])
+        env.step(acts[k % T])      # (launch-rate probe: one pre-drawn segment of actions, recycled)
     ev1.record(torch.cuda.current_stream(dev))
     ev1.synchronize()
     launch_ms = ev0.elapsed_time(ev1) / m
