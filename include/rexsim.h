@@ -314,6 +314,8 @@ REX_API int rex_envs_per_wave(const RexSim* sim);
  * neighbouring envs, sorted by task inside a chunk, every task's run padded to whole waves -- a wave then runs ONE task
  * (wave-uniform action_repeat / sweep cap / action box / reward weights) and the chunks' workgroups are dealt to the XCDs.
  * slots[blk * envs_per_wave + k] = env of slot k of workgroup blk (-1: padding), tasks[blk] = that workgroup's task.
+ * (A batch that needs more workgroups than one round of the machine holds is instead regrouped every step: one region of whole
+ * waves per task, sorted inside by the solver sweeps of the last step; the per-wave rule -- one task -- is the same.)
  * Returns the number of workgroups (pass NULL buffers to size them), or a negative error. */
 REX_API int rex_mixed_slot_map(const RexConfig* cfg, int envs_per_wave, int32_t* slots, int32_t* tasks, int max_blocks);
 

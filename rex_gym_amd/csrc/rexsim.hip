@@ -469,7 +469,7 @@ int rex_create(const RexConfig* cfg, int device, float* d_state, void* stream, R
       const int chunks = (cfg->num_envs + REX_REGROUP_CHUNK - 1) / REX_REGROUP_CHUNK;
       if (e2 == hipSuccess) e2 = hipMalloc(&s->d_regroup, sizeof(int32_t) * ((size_t)chunks * 64 + 1));
       if (e2 == hipSuccess) e2 = hipMemsetAsync(s->d_regroup, 0, sizeof(int32_t) * ((size_t)chunks * 64 + 1), (hipStream_t)stream);
-      if (e2 != hipSuccess) { delete s; return fail(REX_ENOMEM, "hipMalloc(regroup): %s", hipGetErrorString(e2)); }
+      if (e2 != hipSuccess) { (void)rex_destroy(s); return fail(REX_ENOMEM, "hipMalloc(regroup): %s", hipGetErrorString(e2)); }   // (rex_destroy frees whatever was allocated: RexSim starts zeroed)
       hipLaunchKernelGGL(rex::rex_iota_kernel, dim3((cfg->num_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, cfg->num_envs, s->d_perm, s->d_sweeps);
       d.perm = s->d_perm; d.sweeps = s->d_sweeps;
     }
@@ -503,11 +503,11 @@ int rex_create(const RexConfig* cfg, int device, float* d_state, void* stream, R
     if (e2 == hipSuccess) e2 = hipMalloc(&s->d_block_task, sizeof(int32_t) * tasks.size());
     if (e2 == hipSuccess) e2 = hipMemcpy(s->d_slot_env, slots.data(), sizeof(int32_t) * slots.size(), hipMemcpyHostToDevice);
     if (e2 == hipSuccess) e2 = hipMemcpy(s->d_block_task, tasks.data(), sizeof(int32_t) * tasks.size(), hipMemcpyHostToDevice);
-    if (e2 != hipSuccess) { (void)hipFree(s->d_slot_env); (void)hipFree(s->d_block_task); delete s; return fail(REX_ENOMEM, "task slot map: %s", hipGetErrorString(e2)); }
+    if (e2 != hipSuccess) { (void)rex_destroy(s); return fail(REX_ENOMEM, "task slot map: %s", hipGetErrorString(e2)); }
     d.slot_env = s->d_slot_env; d.block_task = s->d_block_task;
   }
   hipError_t e = hipMalloc(&s->d_snap, sizeof(float) * snapshot_floats(s, d.n_mix));
-  if (e != hipSuccess) { (void)hipFree(s->d_slot_env); (void)hipFree(s->d_block_task); delete s; return fail(REX_ENOMEM, "hipMalloc(snapshot): %s", hipGetErrorString(e)); }
+  if (e != hipSuccess) { (void)rex_destroy(s); return fail(REX_ENOMEM, "hipMalloc(snapshot): %s", hipGetErrorString(e)); }
   (void)hipEventCreate(&s->ev0);
   (void)hipEventCreate(&s->ev1);
   for (int k = 0; k < REX_TIMING_RING; ++k) { s->ring0[k] = nullptr; s->ring1[k] = nullptr; }
@@ -518,8 +518,7 @@ int rex_create(const RexConfig* cfg, int device, float* d_state, void* stream, R
   if (e == hipSuccess) e = hipMemsetAsync(d_state, 0, sizeof(float) * (size_t)s->words * cfg->num_envs, st);
   if (e == hipSuccess) e = hipStreamSynchronize(st);
   if (e != hipSuccess) {
-    (void)hipFree(s->d_snap); (void)hipFree(s->d_slot_env); (void)hipFree(s->d_block_task);
-    delete s;
+    (void)rex_destroy(s);
     return fail(REX_EHIP, "settle kernel: %s", hipGetErrorString(e));
   }
   *out = s;
@@ -597,8 +596,8 @@ int rex_destroy(RexSim* s) {
   if (s->d_slot_env) (void)hipFree(s->d_slot_env);
   if (s->d_block_task) (void)hipFree(s->d_block_task);
   if (s->d_class) (void)hipFree(s->d_class);
-  (void)hipEventDestroy(s->ev0);
-  (void)hipEventDestroy(s->ev1);
+  if (s->ev0) (void)hipEventDestroy(s->ev0);
+  if (s->ev1) (void)hipEventDestroy(s->ev1);
   for (int k = 0; k < REX_TIMING_RING; ++k) if (s->ring0[k]) { (void)hipEventDestroy(s->ring0[k]); (void)hipEventDestroy(s->ring1[k]); }
   delete s;
   return REX_OK;
