@@ -254,7 +254,7 @@ struct DevCfg {
   // large batches: envs are regrouped into waves by the solver sweeps they needed in the previous step (a wave sweeps
   // until the slowest of its envs has converged): wave slot k works on env perm[k]; sweeps[i] = this step's count of env i
   const int32_t* perm; int32_t* sweeps;
-  // REX_TASK_MIXED: the task-sorted slot map (host: build_task_slots).  An env keeps its task for life, so the waves are
+  // REX_TASK_MIXED: the task-sorted slot map (host: task_slot_map / task_region_map in rexsim.hip).  An env keeps its task for life, so the waves are
   // made of envs of ONE task: slot_env[blk * EPW + slot] = env of that wave slot (-1: padding), block_task[blk] = the
   // task of workgroup blk's envs -- the per-task constants are then wave-uniform (SGPRs), not per-lane registers
   const int32_t* slot_env; const int32_t* block_task;
@@ -856,7 +856,8 @@ __global__ __launch_bounds__(REX_WAVE) REX_STEP_KERNEL_ATTR void rex_step_kernel
   // env.step() by LEG -- the controller (Bezier + IK), the motor model, the observation words and the leg factorisation
   // of a substep are those of the lane's own leg (MotorSide; rex_device.h), the row work of a substep is split by row --
   // and lane 0 of the group stores the state.
-  // MIXED (REX_TASK_MIXED): the envs of a wave may run different tasks -- c_ below is the lane's own view of the config.
+  // MIXED (REX_TASK_MIXED): the envs of a batch run different tasks, the envs of a WAVE one (the host's slot map sorts them): c_
+  // below is the wave's view of the config, its per-task constants wave-uniform.
   constexpr int NM = ARM ? 18 : 12;   // mark='arm': 6 more motors held at ARM_POSES['rest'] (rex_gym_env.py:347-353)
   constexpr int kLegF4 = REX_LEG_F4_OF(EPW, ARM, BODY);
   constexpr int kRowsF4 = ARM ? REX_LDS_F4_PER_ENV_ARM_OF(EPW) : REX_ROWS_F4_OF(kLegF4);
@@ -882,7 +883,7 @@ __global__ __launch_bounds__(REX_WAVE) REX_STEP_KERNEL_ATTR void rex_step_kernel
   bool ingrid;
   DevCfg cmix;                          // MIXED only
   if constexpr (MIXED) {
-    // the task-sorted slot map (host: build_task_slots) places the envs: a wave holds envs of one task out of one chunk of
+    // the task-sorted slot map (host: task_slot_map / task_region_map in rexsim.hip) places the envs: a wave holds envs of one task out of one chunk of
     // neighbouring envs, and the chunks' workgroups are dealt to the XCDs by the map itself
     const int first = c.slot_env[blk * EPW];                 // wave-uniform (scalar load)
     if (first < 0) return;                                   // a padding workgroup of the map
