@@ -113,7 +113,7 @@ def joint_rmse_vs_oracle(workload, kwargs, n=256, steps=200, seed=11):
     """Half of BASELINE.json's metric ("joint RMSE vs PyBullet"): PyBullet cannot run here, so this is the HIP path
     against the fp64 oracle -- `n` envs of the bench workload from reset, the same random actions, `steps` control steps
     (1 s of robot time); per env the RMSE over time and joints of (q_hip - q_oracle), median / p99 / max over the envs
-    (tests/parity_window.py; the full-size windows of every BASELINE config are in profiles/r03_parity.json)."""
+    (tests/parity_window.py; the full-size windows of every BASELINE config are in profiles/r04_parity.json, split by the event trace)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch
     import parity_window as pw

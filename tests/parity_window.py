@@ -7,7 +7,7 @@ max over the envs.  The workloads are BASELINE.json's configs[1..4] at their per
 workload (gait clock 1.5: the robot does not fall, so the whole window counts).
 
 TEST INFRASTRUCTURE: imported by tests/test_gpu_parity.py, by bench.py's reported `joint_rmse_vs_oracle` and by
-tools/parity_report.py (profiles/r03_parity.json); never by the product.
+tools/parity_report.py (profiles/r04_parity.json); never by the product.
 """
 import numpy as np
 

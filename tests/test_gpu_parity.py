@@ -1075,7 +1075,7 @@ def test_rollout_gather_runs_on_rccl(torch):
 
 # ------------------------------------------------------------------ every kernel variant against the oracle, at BASELINE sizes
 # per-env joint RMSE over the 200-step window against the fp64 oracle: (median, p99, max) bounds = 2 x the values measured
-# on MI355X (profiles/r03_parity.json); BASELINE.json's bar is 1e-3 rad
+# on MI355X (profiles/r03_parity.json, unchanged in profiles/r04_parity.json); BASELINE.json's bar is 1e-3 rad
 _PARITY_BOUNDS = {
     # measured (4 / 8 / 16 / 64 envs per wave):      median            p99               max
     "walk_ik_4096": (6e-6, 5e-4, 4e-3),                # 1.5-2.9e-6      1.4-2.4e-4        1.2-1.8e-3
@@ -1117,7 +1117,7 @@ def test_every_kernel_variant_against_the_oracle_at_baseline_sizes(torch, name, 
         window -- 99th percentile <= 1e-3 rad (BASELINE.json's bar) and median / p99 / max within twice the measured
         values.  Contact dynamics amplify fp32 round-off (a toe that touches down one substep apart is a transient of
         ~1e-2 rad), so the max is looser than the median; the divergence curve goes to gpurun_out/ for
-        profiles/r03_parity.json."""
+        profiles/r04_parity.json (tools/parity_report.py), with the event-trace split of the window."""
     import json
     import os
     import parity_window as pw
