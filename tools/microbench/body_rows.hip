@@ -151,6 +151,51 @@ __global__ __launch_bounds__(64) void k_list_sgpr(float* out, const int* __restr
   if (lane == 0 && blockIdx.x == 0) ticks[0] = t1 - t0;
 }
 
+// D: C with the list where the step kernel would have it -- in scalar registers for real (a kernel argument by value; C's local copy
+//    was re-read from memory by the compiler): no memory load on the way to the next row's LDS addresses
+struct RowList { int r[NROWS + 1]; };
+__global__ __launch_bounds__(64) void k_list_args(float* out, RowList L, int n, int nnormal, int sweeps, long long* ticks) {
+  __shared__ float4 rows[NROWS * 3 * EPW];
+  __shared__ float lamL[NROWS * EPW], limL[NROWS * EPW];
+  const int lane = threadIdx.x, slot = (lane >> 3) & 3, p = lane & 7;
+  fill(rows, lamL, limL, lane);
+  const char* base = reinterpret_cast<const char*>(rows);
+  const int oy = (((p < 6 ? p : 11) >> 2) * EPW + slot) * 16 + ((p < 6 ? p : 11) & 3) * 4;
+  const int oz = (((p < 3 ? 6 + p : 11) >> 2) * EPW + slot) * 16 + ((p < 3 ? 6 + p : 11) & 3) * 4;
+  float ys = 0.01f * p, z0 = 0.1f, z1 = 0.2f, z2 = 0.3f, z3 = 0.4f, worst = 0.0f;
+  const long long t0 = clock64();
+  for (int it = 0; it < sweeps; ++it) {
+    float jy = ldsf(base, L.r[0] * ROWB + oy), jz = ldsf(base, L.r[0] * ROWB + oz);
+    float4 c2 = rows[(L.r[0] * 3 + 2) * EPW + slot];
+    float lam = lamL[L.r[0] * EPW + slot], lim = limL[L.r[0] * EPW + slot];
+#pragma unroll
+    for (int i = 0; i < NROWS; ++i) {
+      if (i >= n) break;                                                  // wave-uniform
+      const int r = L.r[i], rn = L.r[i + 1];
+      const float jyn = ldsf(base, rn * ROWB + oy), jzn = ldsf(base, rn * ROWB + oz);
+      const float4 c2n = rows[(rn * 3 + 2) * EPW + slot];
+      const float lamn = lamL[rn * EPW + slot], limn = limL[rn * EPW + slot];
+      const int leg = (r >> 1) & 3;
+      const float zl = leg == 0 ? z0 : (leg == 1 ? z1 : (leg == 2 ? z2 : z3));
+      const float vel = group_sum8(fmaf(jy, ys, jz * zl));
+      float nl = fmaf(-c2.z, vel, lam + c2.y);
+      const bool normal = i < nnormal;
+      nl = normal ? fmaxf(nl, 0.0f) : __builtin_amdgcn_fmed3f(nl, -lim, lim);
+      const float dl = nl - lam;
+      lamL[r * EPW + slot] = nl;
+      if (normal) limL[(nnormal + 2 * i) * EPW + slot] = 0.5f * nl;
+      worst = fmaxf(worst, fmaf(-1e-4f, c2.z, fabsf(dl)));
+      ys = fmaf(jy, dl, ys);
+      const float zn = fmaf(jz, dl, zl);
+      z0 = leg == 0 ? zn : z0; z1 = leg == 1 ? zn : z1; z2 = leg == 2 ? zn : z2; z3 = leg == 3 ? zn : z3;
+      jy = jyn; jz = jzn; c2 = c2n; lam = lamn; lim = limn;
+    }
+  }
+  const long long t1 = clock64();
+  out[blockIdx.x * 64 + lane] = ys + z0 + z1 + z2 + z3 + worst;
+  if (lane == 0 && blockIdx.x == 0) ticks[0] = t1 - t0;
+}
+
 int main() {
   float* out; long long* ticks; int* list; long long h;
   (void)hipMalloc(&out, 1024 * 64 * 4); (void)hipMalloc(&ticks, 16); (void)hipMalloc(&list, 64 * 4);
@@ -169,6 +214,10 @@ int main() {
     for (int rep = 0; rep < 2; ++rep) { k_list_sgpr<<<1024, 64>>>(out, list, n, n / 3, sweeps, ticks); (void)hipDeviceSynchronize(); }
     (void)hipMemcpy(&h, ticks, 8, hipMemcpyDeviceToHost);
     printf("C the same with the list in scalar registers, loop unrolled : %2d occupied rows: %.1f cycles per row\n", n, (double)h / sweeps / n);
+    RowList rl; for (int i = 0; i <= NROWS; ++i) rl.r[i] = i < n ? i : n - 1;
+    for (int rep = 0; rep < 2; ++rep) { k_list_args<<<1024, 64>>>(out, rl, n, n / 3, sweeps, ticks); (void)hipDeviceSynchronize(); }
+    (void)hipMemcpy(&h, ticks, 8, hipMemcpyDeviceToHost);
+    printf("D the list as a kernel argument (scalar registers), loop unrolled : %2d occupied rows: %.1f cycles per row\n", n, (double)h / sweeps / n);
   }
   return 0;
 }
