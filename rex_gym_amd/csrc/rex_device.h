@@ -1073,28 +1073,36 @@ struct DvLane {
 };
 
 // one Gauss-Seidel step of a link-box contact row, straight from LDS (like the joint-limit rows): row r of the body
-// region; leg < 0: a base-group row (no leg part)
+// region; leg < 0: a base-group row (no leg part).  Split into the LDS reads of a lane's slice of the row and the step itself,
+// so that inside a group of rows the slice of the NEXT row is read while the current one is solved (round 4: the three reads
+// right before their use cost a lone wave 170 cycles a row in isolation, one row ahead 91 -- tools/microbench/body_rows.hip,
+// profiles/r04_microbench.md; the arithmetic and its order are unchanged, the results bit-identical).
+template <int NY> struct BodySlice { float jy[NY]; float jz; float4 c2; };
 template <int LPE, int NY, class SM, class LN>
-__device__ __forceinline__ void body_row(const SM& sm, const LN& ln, int bodyoff, int r, int leg, float* ys, float* zs, float& lam, float lim,
-                                         bool friction, float& worst, float thr) {
+__device__ __forceinline__ BodySlice<NY> body_load(const SM& sm, const LN& ln, int bodyoff, int r, bool leg_part) {
   constexpr int kRow = REX_ROW_F4 * SM::kEpw * 16;
-  float jy[NY];
+  BodySlice<NY> s;
 #pragma unroll
-  for (int i = 0; i < NY; ++i) jy[i] = ln.ld(sm, bodyoff + r * kRow + ln.oy[i]);
-  const float jz = leg >= 0 ? ln.ld(sm, bodyoff + r * kRow + ln.oz) : 0.0f;
-  const float4 c2 = sm.brow(r, 2);
-  float part = leg >= 0 ? jz * zs[leg] : 0.0f;
+  for (int i = 0; i < NY; ++i) s.jy[i] = ln.ld(sm, bodyoff + r * kRow + ln.oy[i]);
+  s.jz = leg_part ? ln.ld(sm, bodyoff + r * kRow + ln.oz) : 0.0f;
+  s.c2 = sm.brow(r, 2);
+  return s;
+}
+template <int LPE, int NY>
+__device__ __forceinline__ void body_solve(const BodySlice<NY>& s, int leg, float* ys, float* zs, float& lam, float lim, bool friction, float& worst,
+                                           float thr) {
+  float part = leg >= 0 ? s.jz * zs[leg] : 0.0f;
 #pragma unroll
-  for (int i = 0; i < NY; ++i) part = fmaf(jy[i], ys[i], part);
+  for (int i = 0; i < NY; ++i) part = fmaf(s.jy[i], ys[i], part);
   const float vel = group_sum<LPE>(part);
-  float nl = fmaf(-c2.z, vel, friction ? lam : lam + c2.y);   // (.y of a friction row is its coefficient, not a target)
+  float nl = fmaf(-s.c2.z, vel, friction ? lam : lam + s.c2.y);   // (.y of a friction row is its coefficient, not a target)
   nl = friction ? __builtin_amdgcn_fmed3f(nl, -lim, lim) : fmaxf(nl, 0.0f);
   const float dl = nl - lam;
   lam = nl;
-  worst = fmaxf(worst, fmaf(-thr, c2.z, fabsf(dl)));
+  worst = fmaxf(worst, fmaf(-thr, s.c2.z, fabsf(dl)));
 #pragma unroll
-  for (int i = 0; i < NY; ++i) ys[i] = fmaf(jy[i], dl, ys[i]);
-  if (leg >= 0) zs[leg] = fmaf(jz, dl, zs[leg]);
+  for (int i = 0; i < NY; ++i) ys[i] = fmaf(s.jy[i], dl, ys[i]);
+  if (leg >= 0) zs[leg] = fmaf(s.jz, dl, zs[leg]);
 }
 
 // `cpl_free`: called once the couplings have been read into registers -- their six LDS chunks are idle until the next
@@ -1237,14 +1245,24 @@ __device__ __forceinline__ void pgs_dv(const SM& sm, ARMP& armp, PgsX& x, int p,
         // link-box normals (among the normals they come before the toe points: the toe rows stay one pipelined block)
         // one branch per GROUP (wave-uniform), its rows in one block: the row loads of a group issue together
         if (bgroups & 1u) {
+          BodySlice<NY> cur = body_load<LPE, NY>(sm, ln, bodyoff, 0, false);
 #pragma unroll
-          for (int sl = 0; sl < 4; ++sl) body_row<LPE, NY>(sm, ln, bodyoff, sl, -1, ys, zs, lamb[sl], 0.0f, false, worst, thr);
+          for (int sl = 0; sl < 4; ++sl) {
+            BodySlice<NY> nxt = cur;
+            if (sl + 1 < 4) nxt = body_load<LPE, NY>(sm, ln, bodyoff, sl + 1, false);      // read while row sl is solved
+            body_solve<LPE, NY>(cur, -1, ys, zs, lamb[sl], 0.0f, false, worst, thr);
+            cur = nxt;
+          }
         }
 #pragma unroll
         for (int l = 0; l < REX_NLEG; ++l) {
           if (!((bgroups >> (1 + l)) & 1u)) continue;       // (a second slot is never filled before the first)
-          body_row<LPE, NY>(sm, ln, bodyoff, 4 + 2 * l, l, ys, zs, lamb[4 + 2 * l], 0.0f, false, worst, thr);
-          if ((bgroups >> (5 + l)) & 1u) body_row<LPE, NY>(sm, ln, bodyoff, 5 + 2 * l, l, ys, zs, lamb[5 + 2 * l], 0.0f, false, worst, thr);
+          const bool two = ((bgroups >> (5 + l)) & 1u) != 0;
+          const BodySlice<NY> a = body_load<LPE, NY>(sm, ln, bodyoff, 4 + 2 * l, true);
+          BodySlice<NY> b = a;
+          if (two) b = body_load<LPE, NY>(sm, ln, bodyoff, 5 + 2 * l, true);
+          body_solve<LPE, NY>(a, l, ys, zs, lamb[4 + 2 * l], 0.0f, false, worst, thr);
+          if (two) body_solve<LPE, NY>(b, l, ys, zs, lamb[5 + 2 * l], 0.0f, false, worst, thr);
         }
       }
       if (any_contact) {
@@ -1284,24 +1302,37 @@ __device__ __forceinline__ void pgs_dv(const SM& sm, ARMP& armp, PgsX& x, int p,
       if constexpr (SM::kBody) {
         // link-box friction pairs: after the toe friction rows; the coefficient of a slot sits in its first friction row
         // (ground: the env's foot friction; link against link: kSelfMu)
+        // (the friction rows of a group are contiguous: rows 12 + 2 slot and 13 + 2 slot; the coefficient of a slot is word .y of its
+        //  FIRST friction row; each row's slice is read while the row before it is solved)
         if (bgroups & 1u) {
+          BodySlice<NY> cur = body_load<LPE, NY>(sm, ln, bodyoff, REX_NBSLOT, false);
+          float coef = 0.0f;
 #pragma unroll
-          for (int sl = 0; sl < 4; ++sl) {
-            const float lm = sm.brow(REX_NBSLOT + 2 * sl, 2).y * lamb[sl];
-            body_row<LPE, NY>(sm, ln, bodyoff, REX_NBSLOT + 2 * sl, -1, ys, zs, lamb[REX_NBSLOT + 2 * sl], lm, true, worst, thr);
-            body_row<LPE, NY>(sm, ln, bodyoff, REX_NBSLOT + 2 * sl + 1, -1, ys, zs, lamb[REX_NBSLOT + 2 * sl + 1], lm, true, worst, thr);
+          for (int k = 0; k < 8; ++k) {
+            const int sl = k >> 1;
+            BodySlice<NY> nxt = cur;
+            if (k + 1 < 8) nxt = body_load<LPE, NY>(sm, ln, bodyoff, REX_NBSLOT + k + 1, false);
+            if ((k & 1) == 0) coef = cur.c2.y;
+            body_solve<LPE, NY>(cur, -1, ys, zs, lamb[REX_NBSLOT + k], coef * lamb[sl], true, worst, thr);
+            cur = nxt;
           }
         }
 #pragma unroll
         for (int l = 0; l < REX_NLEG; ++l) {
           if (!((bgroups >> (1 + l)) & 1u)) continue;
+          const bool two = ((bgroups >> (5 + l)) & 1u) != 0;
+          const int r0 = REX_NBSLOT + 2 * (4 + 2 * l);                                   // first friction row of the leg's first slot
+          BodySlice<NY> cur = body_load<LPE, NY>(sm, ln, bodyoff, r0, true);
+          float coef = 0.0f;
 #pragma unroll
-          for (int k = 0; k < 2; ++k) {
-            if (k == 1 && !((bgroups >> (5 + l)) & 1u)) continue;
-            const int sl = 4 + 2 * l + k;
-            const float lm = sm.brow(REX_NBSLOT + 2 * sl, 2).y * lamb[sl];
-            body_row<LPE, NY>(sm, ln, bodyoff, REX_NBSLOT + 2 * sl, l, ys, zs, lamb[REX_NBSLOT + 2 * sl], lm, true, worst, thr);
-            body_row<LPE, NY>(sm, ln, bodyoff, REX_NBSLOT + 2 * sl + 1, l, ys, zs, lamb[REX_NBSLOT + 2 * sl + 1], lm, true, worst, thr);
+          for (int j = 0; j < 4; ++j) {
+            if (j >= 2 && !two) break;                                                    // wave-uniform
+            const int sl = 4 + 2 * l + (j >> 1);
+            BodySlice<NY> nxt = cur;
+            if (j + 1 < 2 || (j + 1 < 4 && two)) nxt = body_load<LPE, NY>(sm, ln, bodyoff, r0 + j + 1, true);
+            if ((j & 1) == 0) coef = cur.c2.y;
+            body_solve<LPE, NY>(cur, l, ys, zs, lamb[r0 + j], coef * lamb[sl], true, worst, thr);
+            cur = nxt;
           }
         }
       }
