@@ -1078,6 +1078,10 @@ struct DvLane {
 // right before their use cost a lone wave 170 cycles a row in isolation, one row ahead 91 -- tools/microbench/body_rows.hip,
 // profiles/r04_microbench.md; the arithmetic and its order are unchanged, the results bit-identical).
 template <int NY> struct BodySlice { float jy[NY]; float jz; float4 c2; };
+// The reads of the NEXT row are issued, then this: nothing may be scheduled across it.  Without it the machine scheduler sinks the
+// reads back to their first use, behind the current row's group sum (round 5: the ISA of the round-4 form had every row's three
+// ds_reads right in front of its own DPP adds again, and the step kernel measured no faster than with the reads at their use).
+__device__ __forceinline__ void prefetch_fence() { __builtin_amdgcn_sched_barrier(0); }
 template <int LPE, int NY, class SM, class LN>
 __device__ __forceinline__ BodySlice<NY> body_load(const SM& sm, const LN& ln, int bodyoff, int r, bool leg_part) {
   constexpr int kRow = REX_ROW_F4 * SM::kEpw * 16;
@@ -1197,6 +1201,14 @@ __device__ __forceinline__ void pgs_dv(const SM& sm, ARMP& armp, PgsX& x, int p,
   REX_STAMP(t_dv1);
   const bool any_lim = lim[0] || lim[1] || lim[2] || lim[3];
   bool running = true;
+  auto lim_load = [&](int r) __attribute__((always_inline)) {   // this lane's slice of joint-limit row r (rows REX_NCROW.. of the toe region)
+    BodySlice<NY> sl;
+#pragma unroll
+    for (int i = 0; i < NY; ++i) sl.jy[i] = ln.ld(sm, r * kRow + ln.oy[i]);
+    sl.jz = ln.ld(sm, r * kRow + ln.oz);
+    sl.c2 = sm.row(r, 2);
+    return sl;
+  };
   auto sweep = [&](const auto& li, auto& lo, int it) __attribute__((always_inline)) {
     ++nsweeps;
     if (running) {
@@ -1208,17 +1220,17 @@ __device__ __forceinline__ void pgs_dv(const SM& sm, ARMP& armp, PgsX& x, int p,
       for (int l = 0; l < REX_NLEG; ++l) {
         if (__builtin_expect(!any_lim, 1)) break;  // wave-uniform
         if (!lim[l]) continue;                     // wave-uniform
+        // (the three rows of a leg: the slice of row k + 1 is read from LDS while row k is solved, as the link-box rows do)
+        BodySlice<NY> cur = lim_load(REX_NCROW + 3 * l);
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
           const int r = REX_NCROW + 3 * l + k;
-          float jy[NY];
+          BodySlice<NY> nxt = cur;
+          if (k + 1 < 3) { nxt = lim_load(r + 1); prefetch_fence(); }
+          const float4 c2 = cur.c2;
+          float part = cur.jz * zs[l];
 #pragma unroll
-          for (int i = 0; i < NY; ++i) jy[i] = ln.ld(sm, r * kRow + ln.oy[i]);
-          const float jz = ln.ld(sm, r * kRow + ln.oz);
-          const float4 c2 = sm.row(r, 2);
-          float part = jz * zs[l];
-#pragma unroll
-          for (int i = 0; i < NY; ++i) part = fmaf(jy[i], ys[i], part);
+          for (int i = 0; i < NY; ++i) part = fmaf(cur.jy[i], ys[i], part);
           const float vel = group_sum<LPE>(part);
           float dl;
           if constexpr (kLimLamByLane) {
@@ -1236,8 +1248,9 @@ __device__ __forceinline__ void pgs_dv(const SM& sm, ARMP& armp, PgsX& x, int p,
           }
           worst = fmaxf(worst, fmaf(-thr, c2.z, fabsf(dl)));
 #pragma unroll
-          for (int i = 0; i < NY; ++i) ys[i] = fmaf(jy[i], dl, ys[i]);
-          zs[l] = fmaf(jz, dl, zs[l]);
+          for (int i = 0; i < NY; ++i) ys[i] = fmaf(cur.jy[i], dl, ys[i]);
+          zs[l] = fmaf(cur.jz, dl, zs[l]);
+          cur = nxt;
         }
       }
       armp.template dv_sweep<LPE, NY>(ys, worst, thr);
@@ -1249,7 +1262,7 @@ __device__ __forceinline__ void pgs_dv(const SM& sm, ARMP& armp, PgsX& x, int p,
 #pragma unroll
           for (int sl = 0; sl < 4; ++sl) {
             BodySlice<NY> nxt = cur;
-            if (sl + 1 < 4) nxt = body_load<LPE, NY>(sm, ln, bodyoff, sl + 1, false);      // read while row sl is solved
+            if (sl + 1 < 4) { nxt = body_load<LPE, NY>(sm, ln, bodyoff, sl + 1, false); prefetch_fence(); }      // read while row sl is solved
             body_solve<LPE, NY>(cur, -1, ys, zs, lamb[sl], 0.0f, false, worst, thr);
             cur = nxt;
           }
@@ -1260,7 +1273,7 @@ __device__ __forceinline__ void pgs_dv(const SM& sm, ARMP& armp, PgsX& x, int p,
           const bool two = ((bgroups >> (5 + l)) & 1u) != 0;
           const BodySlice<NY> a = body_load<LPE, NY>(sm, ln, bodyoff, 4 + 2 * l, true);
           BodySlice<NY> b = a;
-          if (two) b = body_load<LPE, NY>(sm, ln, bodyoff, 5 + 2 * l, true);
+          if (two) { b = body_load<LPE, NY>(sm, ln, bodyoff, 5 + 2 * l, true); prefetch_fence(); }
           body_solve<LPE, NY>(a, l, ys, zs, lamb[4 + 2 * l], 0.0f, false, worst, thr);
           if (two) body_solve<LPE, NY>(b, l, ys, zs, lamb[5 + 2 * l], 0.0f, false, worst, thr);
         }
@@ -1311,7 +1324,7 @@ __device__ __forceinline__ void pgs_dv(const SM& sm, ARMP& armp, PgsX& x, int p,
           for (int k = 0; k < 8; ++k) {
             const int sl = k >> 1;
             BodySlice<NY> nxt = cur;
-            if (k + 1 < 8) nxt = body_load<LPE, NY>(sm, ln, bodyoff, REX_NBSLOT + k + 1, false);
+            if (k + 1 < 8) { nxt = body_load<LPE, NY>(sm, ln, bodyoff, REX_NBSLOT + k + 1, false); prefetch_fence(); }
             if ((k & 1) == 0) coef = cur.c2.y;
             body_solve<LPE, NY>(cur, -1, ys, zs, lamb[REX_NBSLOT + k], coef * lamb[sl], true, worst, thr);
             cur = nxt;
@@ -1329,7 +1342,7 @@ __device__ __forceinline__ void pgs_dv(const SM& sm, ARMP& armp, PgsX& x, int p,
             if (j >= 2 && !two) break;                                                    // wave-uniform
             const int sl = 4 + 2 * l + (j >> 1);
             BodySlice<NY> nxt = cur;
-            if (j + 1 < 2 || (j + 1 < 4 && two)) nxt = body_load<LPE, NY>(sm, ln, bodyoff, r0 + j + 1, true);
+            if (j + 1 < 2 || (j + 1 < 4 && two)) { nxt = body_load<LPE, NY>(sm, ln, bodyoff, r0 + j + 1, true); prefetch_fence(); }
             if ((j & 1) == 0) coef = cur.c2.y;
             body_solve<LPE, NY>(cur, l, ys, zs, lamb[r0 + j], coef * lamb[sl], true, worst, thr);
             cur = nxt;

@@ -7,7 +7,7 @@ max over the envs.  The workloads are BASELINE.json's configs[1..4] at their per
 workload (gait clock 1.5: the robot does not fall, so the whole window counts).
 
 TEST INFRASTRUCTURE: imported by tests/test_gpu_parity.py, by bench.py's reported `joint_rmse_vs_oracle` and by
-tools/parity_report.py (profiles/r04_parity.json); never by the product.
+tools/parity_report.py (profiles/r05_parity.json); never by the product.
 """
 import numpy as np
 
@@ -81,14 +81,81 @@ def oracle_trajectory(name, env, steps, seed, threads=None, keep_states=(40, 120
     return _TRAJ[key]
 
 
-def window(name, env, steps=200, seed=23, threads=None):
-    """Run the window on `env` (freshly created with `seed`; its episode counters must be 0) -> record dict."""
+_FLOOR = {}
+
+
+def float32_floor(name, env, steps=200, seed=23, threads=None):
+    """The FLOAT32 FLOOR of the window: the oracle's own fp32 build against its fp64 build, same envs, same actions, same
+    statistics as `window` (cached per workload).  What float32 arithmetic costs on this workload whatever the implementation:
+    the bound the whole-batch figures of the HIP path are held against where BASELINE.json's 1e-3 rad is below the floor itself."""
+    key = (name, env.num_envs, steps, seed)
+    if key not in _FLOOR:
+        acts, oq, _opos, odone, _, (otrace, _pre) = oracle_trajectory(name, env, steps, seed, threads)
+        orc = oracle_for(env, np.float32)
+        if threads:
+            orc.o.lib.orc_set_threads(int(threads))
+        orc.reset()
+        t32 = orc.set_event_trace(True)
+        n, nm = env.num_envs, env.num_motors
+        sq = np.zeros(n); cnt = np.zeros(n); alive = np.ones(n, bool); same = np.ones(n, bool)
+        sq_same = np.zeros(n); cnt_same = np.zeros(n)
+        for k in range(steps):
+            _, _, d, _ = orc.step(acts[k])
+            e = orc.get_state()[orclib.S_Q:orclib.S_Q + nm] - oq[k]
+            same &= (t32[0] == otrace[k, 0]) | ~alive
+            sq += np.where(alive, (e * e).mean(0), 0.0); cnt += alive
+            sq_same += np.where(alive & same, (e * e).mean(0), 0.0); cnt_same += alive & same
+            alive &= ~(d.astype(bool) | odone[k])
+        orc.close()
+        rmse = np.sqrt(sq / np.maximum(cnt, 1))
+        until = np.sqrt(sq_same[cnt_same > 0] / cnt_same[cnt_same > 0])
+        _FLOOR[key] = dict(what="oracle fp32 build vs oracle fp64 build, same window and actions (CPU)",
+                           median_rad=float(np.median(rmse)), p99_rad=float(np.percentile(rmse, 99)), max_rad=float(rmse.max()),
+                           share_same_event_sequence=float(same.mean()),
+                           p99_rad_same_events=float(np.percentile(rmse[same], 99)) if same.any() else None,
+                           p99_rad_until_first_divergence=float(np.percentile(until, 99)) if until.size else None)
+    return _FLOOR[key]
+
+
+def window(name, env, steps=200, seed=23, threads=None, trace=True):
+    """Run the window on `env` (freshly created with `seed`; its episode counters must be 0) -> record dict.
+
+    Two passes over the same reset state and actions:
+      1. the PRODUCT kernels (no event trace set: the instantiations bench.py times and users run) -- every error figure of the
+         record (median / p99 / max, the matched-subset figures, the divergence curve) is computed from THIS pass's joint angles;
+      2. (trace=True) the `_trace` instantiations (rex_set_event_trace: separate code objects, -DREX_TU_TRACE=1) for the event
+         split alone -- which envs took every discrete decision as the oracle did -- and, after every step, the whole state block
+         is compared bit for bit with pass 1 (`trace_pass_bit_identical`): the debug kernels are tied to the product kernels
+         over the very window they annotate."""
     import torch
-    from helpers import product_state_to_numeric
     acts, oq, opos, odone, _, (otrace, _pre) = oracle_trajectory(name, env, steps, seed, threads)
     n, nm = env.num_envs, env.num_motors
+    # ---- pass 1: product kernels
+    env.set_event_trace(False)
     env.reset()
-    ktrace = env.set_event_trace(True)
+    dev_acts = torch.as_tensor(acts, device=env.device)
+    states, dones = [], []
+    for k in range(steps):
+        _, _, d, _ = env.step(dev_acts[k])
+        states.append(env.state.clone()); dones.append(d.clone())
+    pq = np.stack([s[orclib.S_Q:orclib.S_Q + nm].cpu().numpy().astype(np.float64) for s in states])      # [steps, nm, n] (float words)
+    ppos = np.stack([s[0:3].cpu().numpy().astype(np.float64) for s in states])
+    pdone = np.stack([d.cpu().numpy().astype(bool) for d in dones])
+    # ---- pass 2: the trace instantiations, from the same reset state (episode counters back to 0: they key the Philox draws)
+    ktr = None
+    identical_steps = None
+    if trace:
+        env.state.zero_()
+        env.reset()
+        ktrace = env.set_event_trace(True)
+        ktr = np.zeros((steps, 3, n), np.uint32)
+        identical_steps = 0
+        for k in range(steps):
+            _, _, d, _ = env.step(dev_acts[k])
+            identical_steps += int(torch.equal(env.state, states[k]) and torch.equal(d, dones[k]))
+            ktr[k] = ktrace.cpu().numpy().view(np.uint32)
+        env.set_event_trace(False)
+    del states, dones
     same_events = np.ones(n, bool)      # the env's event sequence has been the oracle's so far (chained hash equal)
     same_sweeps = np.ones(n, bool)      # ... and so have its solver sweep counts
     same_leg_events = np.ones(n, bool)  # the event sequence without the arm's bounds (mark arm)
@@ -99,31 +166,29 @@ def window(name, env, steps=200, seed=23, threads=None):
     pos_err = np.zeros(n)
     curve = {}
     for k in range(steps):
-        _, _, d, _ = env.step(torch.as_tensor(acts[k], device=env.device))
-        ps = product_state_to_numeric(env.state)
-        kt = ktrace.cpu().numpy().view(np.uint32)
-        ev_eq, sw_eq = kt[0] == otrace[k, 0], kt[1] == otrace[k, 1]
-        same_leg_events &= (kt[2] == otrace[k, 2]) | ~alive
-        first_div = np.where(alive & same_events & ~ev_eq, k, first_div)
-        same_events &= ev_eq | ~alive; same_sweeps &= sw_eq | ~alive
-        e = ps[orclib.S_Q:orclib.S_Q + nm] - oq[k]
+        if trace:
+            kt = ktr[k]
+            ev_eq, sw_eq = kt[0] == otrace[k, 0], kt[1] == otrace[k, 1]
+            same_leg_events &= (kt[2] == otrace[k, 2]) | ~alive
+            first_div = np.where(alive & same_events & ~ev_eq, k, first_div)
+            same_events &= ev_eq | ~alive; same_sweeps &= sw_eq | ~alive
+        e = pq[k] - oq[k]
         sq += np.where(alive, (e * e).mean(0), 0.0); cnt += alive
         sq_same += np.where(alive & same_events, (e * e).mean(0), 0.0); cnt_same += alive & same_events
         sq_legs += np.where(alive, (e[:12] * e[:12]).mean(0), 0.0)
-        pos_err = np.where(alive, np.abs(ps[0:3] - opos[k]).max(0), pos_err)
+        pos_err = np.where(alive, np.abs(ppos[k] - opos[k]).max(0), pos_err)
         if k + 1 in (1, 5, 10, 25, 50, 100, 200) and alive.any():
             a = np.abs(e).max(0)[alive]
             curve[k + 1] = dict(median=float(np.median(a)), p99=float(np.percentile(a, 99)), max=float(a.max()), envs=int(alive.sum()))
-        alive &= ~(d.cpu().numpy().astype(bool) | odone[k])      # an episode that ended (fall, goal) leaves the comparison
+        alive &= ~(pdone[k] | odone[k])      # an episode that ended (fall, goal) leaves the comparison
     rmse = np.sqrt(sq / np.maximum(cnt, 1))
     legs = np.sqrt(sq_legs / np.maximum(cnt, 1))
-    env.set_event_trace(False)
 
     def stats(x):
         return dict(envs=int(x.size), median_rad=float(np.median(x)), p99_rad=float(np.percentile(x, 99)), max_rad=float(x.max())) if x.size else dict(envs=0)
     hist_edges = [0, 1, 2, 5, 10, 25, 50, 100, 200, 10 ** 9]
     div = first_div[first_div >= 0]
-    events = dict(
+    events = None if not trace else dict(
         what="per env and substep: toe points within the breaking distance, the heightfield facet under each of them (end centre "
              "and contact point), joint and arm bounds reached -- chained hash, HIP path vs fp64 oracle, compared after every "
              "control step while both episodes run (rex_set_event_trace / orc_set_event_trace)",
@@ -138,7 +203,13 @@ def window(name, env, steps=200, seed=23, threads=None):
         leg_joints_rmse_same_events=stats(legs[same_events]),
         first_divergence_step_histogram={f"[{a}, {b})" if b < 10 ** 9 else f">= {a}": int(((div >= a) & (div < b)).sum())
                                          for a, b in zip(hist_edges[:-1], hist_edges[1:])})
-    return dict(events=events, workload=name, envs=n, window_steps=steps, seed=seed, median_rad=float(np.median(rmse)),
+    return dict(events=events, workload=name, envs=n, window_steps=steps, seed=seed,
+                kernels="product kernels (rex_step_kernel<..., TRACE = false>, no event trace set): every error figure of this record; "
+                        "the event split comes from a second pass with the _trace instantiations" if trace else
+                        "product kernels (rex_step_kernel<..., TRACE = false>, no event trace set)",
+                trace_pass_bit_identical=None if not trace else bool(identical_steps == steps),
+                trace_pass_identical_steps=identical_steps,
+                median_rad=float(np.median(rmse)),
                 p99_rad=float(np.percentile(rmse, 99)), max_rad=float(rmse.max()),
                 leg_joints_median_rad=float(np.median(legs)), leg_joints_p99_rad=float(np.percentile(legs, 99)),
                 base_pos_err_p99_m=float(np.percentile(pos_err, 99)), base_pos_err_max_m=float(pos_err.max()),

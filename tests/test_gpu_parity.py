@@ -1117,7 +1117,9 @@ def test_every_kernel_variant_against_the_oracle_at_baseline_sizes(torch, name, 
         window -- 99th percentile <= 1e-3 rad (BASELINE.json's bar) and median / p99 / max within twice the measured
         values.  Contact dynamics amplify fp32 round-off (a toe that touches down one substep apart is a transient of
         ~1e-2 rad), so the max is looser than the median; the divergence curve goes to gpurun_out/ for
-        profiles/r04_parity.json (tools/parity_report.py), with the event-trace split of the window."""
+        profiles/r05_parity.json (tools/parity_report.py), with the event-trace split of the window.
+    Round 5: the window's error figures come from the PRODUCT kernels (tests/parity_window.py: pass 1 without the event
+    trace); the `_trace` instantiations run a second pass for the event split and must reproduce pass 1 bit for bit."""
     import json
     import os
     import parity_window as pw
@@ -1169,16 +1171,24 @@ def test_every_kernel_variant_against_the_oracle_at_baseline_sizes(torch, name, 
     # --- 200-step window from reset (episode counters back to 0: the oracle's rollout is every env's FIRST episode, and the
     #     episode number keys the Philox draws of target / direction)
     env.state.zero_()
-    rec = pw.window(name, env, steps=steps, seed=seed)
+    rec = pw.window(name, env, steps=steps, seed=seed)      # error figures: the PRODUCT kernels; event split: a second, traced pass
     rec["envs_per_wave"] = epw
     rec["single_steps_from_common_states"] = single
+    floor = rec["float32_floor"] = pw.float32_floor(name, env, steps, seed)     # the oracle's fp32 build against its fp64 build, this window
     os.makedirs(os.path.join(os.path.dirname(__file__), "..", "gpurun_out"), exist_ok=True)
-    with open(os.path.join(os.path.dirname(__file__), "..", "gpurun_out", "r04_parity.jsonl"), "a") as f:
+    with open(os.path.join(os.path.dirname(__file__), "..", "gpurun_out", "r05_parity.jsonl"), "a") as f:
         f.write(json.dumps(rec) + "\n")
     print(json.dumps(rec))
+    # the traced pass reproduced the product pass bit for bit after every one of the 200 steps: the event split below annotates
+    # the product kernels' own trajectory
+    assert rec["trace_pass_bit_identical"], (name, epw, rec["trace_pass_identical_steps"])
     med, p99, mx = _PARITY_BOUNDS[name]
     assert rec["median_rad"] <= 1e-3 and (name not in _MEETS_THE_BAR_AT_P99 or rec["p99_rad"] <= 1e-3), rec      # BASELINE.json's bar
     assert rec["median_rad"] <= med and rec["p99_rad"] <= p99 and rec["max_rad"] <= mx, rec
+    # the stated fp32 tolerance where 1e-3 rad at the 99th percentile is below what float32 itself gives on the workload (heightfield,
+    # mark arm): the whole-batch p99 within the FLOAT32 FLOOR of this very window + 20 % -- measured in the same run, not a constant
+    assert rec["p99_rad"] <= max(1e-3, 1.2 * floor["p99_rad"]), (name, epw, rec["p99_rad"], floor)
+    assert rec["median_rad"] <= max(1e-5, 1.2 * floor["median_rad"]), (name, epw, rec["median_rad"], floor)
     # the envs whose whole 200-step event sequence was the oracle's: BASELINE.json's bar at the 99th percentile, every workload
     ev = rec["events"]
     share = _SAME_EVENTS_SHARE[name]
@@ -1507,3 +1517,56 @@ def test_self_collision_rows_of_the_rolled_pose(torch, n, epw, monkeypatch):
     print("deepest leg-box / base-box overlap [mm]: with rows %.3f, without %.3f" % (1e3 * with_rows, 1e3 * without))
     assert without < -2e-3 and with_rows > -3e-4
     env.close(); free.close()
+
+
+# ------------------------------------------------------------------ the debug (_trace) kernels are the product kernels
+_MIX_KW = dict(mass_scale_range=(0.8, 1.2), friction_range=(0.25, 0.625))
+_TIE_CASES = [
+    # id, envs per wave the host can select for the group, envs (the BASELINE shard size of the group's workload), env keywords
+    ("base-walk_ik", (4, 8, 16, 64), 4096, dict(task="walk", signal_type="ik")),
+    ("base-gallop_ol", (4, 8, 16, 64), 8192, dict(task="gallop", signal_type="ol")),
+    ("base-turn_ik_heightfield", (4, 8, 16, 64), 4096, dict(task="turn", signal_type="ik", terrain_type="random")),
+    ("arm-walk_ik", (4, 8, 16), 4096, dict(task="walk", signal_type="ik", mark="arm")),
+    ("mixed_base", (4, 8, 16), 4096, dict(task="mixed", signal_type="ik", **_MIX_KW)),
+    ("mixed_arm", (4, 8, 16), 2048, dict(task="mixed", signal_type="ik", mark="arm", **_MIX_KW)),
+    ("body-poses", (4, 8), 4096, dict(task="poses", signal_type="ik")),
+    ("body-poses_rolled", (4, 8), 4096, dict(task="poses", signal_type="ik", base_roll=-0.74)),      # the link-link rows act
+    ("arm_body-poses_rolled", (4,), 2048, dict(task="poses", signal_type="ik", mark="arm", base_roll=-0.74)),
+]
+
+
+@pytest.mark.parametrize("case,epw", [(c[0], e) for c in _TIE_CASES for e in c[1]])
+def test_trace_kernels_are_bit_identical_to_the_product_kernels(torch, case, epw, monkeypatch):
+    """rex_set_event_trace switches rex_step to the `_trace` instantiations -- separate code objects, compiled from the same
+    step units with -DREX_TU_TRACE=1 (rex_gym_amd/build.py) -- and the event split of every long parity window is taken from
+    them.  This ties the two together: for every variant group (base / arm / mixed_base / mixed_arm / body) x every envs-per-wave
+    the host can select, at the BASELINE shard size of the group's workload, 70 steps from reset with in-launch auto-resets
+    (episode cap 25: every env goes through two resets inside a launch, besides the falls), one env with the trace and one
+    without, same seed and actions: state block, observation, reward, done and info['action'] are compared BIT FOR BIT after
+    every step.  (tests/parity_window.py repeats the comparison over each 200-step oracle window.)"""
+    from rex_gym_amd import RexBatchEnv
+    _, _, n, kw = next(c for c in _TIE_CASES if c[0] == case)
+    monkeypatch.setenv("REX_ENVS_PER_WAVE", str(epw))
+    mk = lambda: RexBatchEnv(n, seed=17, auto_reset=True, max_episode_steps=25, **kw)
+    prod, dbg = mk(), mk()
+    assert prod._L.rex_envs_per_wave(prod._h) == epw and dbg._L.rex_envs_per_wave(dbg._h) == epw
+    o0, o1 = prod.reset(), dbg.reset()
+    tr = dbg.set_event_trace(True)
+    assert torch.equal(o0, o1) and torch.equal(prod.state, dbg.state)
+    lo = torch.as_tensor(np.minimum(prod.action_space.low, prod.action_space.high), device="cuda", dtype=torch.float32)
+    hi = torch.as_tensor(np.maximum(prod.action_space.low, prod.action_space.high), device="cuda", dtype=torch.float32)
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    ended = 0
+    for k in range(70):
+        a = torch.rand((n, prod.action_dim), device="cuda", generator=g) * (hi - lo) + lo
+        po, pr, pd, pi = prod.step(a)
+        do, dr, dd, di = dbg.step(a)
+        for name, x, y in (("state", prod.state, dbg.state), ("obs", po, do), ("reward", pr, dr), ("done", pd, dd), ("action", pi["action"], di["action"])):
+            if not torch.equal(x, y):
+                bad = (x != y)
+                pytest.fail(f"{case} epw {epw}: step {k}: the _trace kernel's {name} differs from the product kernel's in {int(bad.sum())} words "
+                            f"(first at {tuple(int(v) for v in torch.nonzero(bad)[0])}): a miscompile of one of the two -- diff their ISA")
+        ended += int(pd.sum())
+    assert ended >= 2 * n                       # the comparison ran through in-launch resets in every env
+    assert int((tr[0] != 0).sum()) == n         # ... and the debug env really ran the trace instantiation
+    prod.close(); dbg.close()

@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
-"""profiles/r04_parity.json: joint-angle RMSE of the HIP path against the fp64 oracle over the 200-step window of every
-BASELINE config (records written by tests/test_gpu_parity.py::test_every_kernel_variant_... into gpurun_out/r04_parity.jsonl
+"""profiles/r05_parity.json: joint-angle RMSE of the HIP path against the fp64 oracle over the 200-step window of every
+BASELINE config (records written by tests/test_gpu_parity.py::test_every_kernel_variant_... into gpurun_out/r05_parity.jsonl
 on the GPU box), next to the FLOAT32 FLOOR of each workload: the same window, the fp32 build of the oracle against its own
 fp64 build (CPU, --floor) -- what float32 arithmetic costs on that workload whatever the implementation.  Round 4: both
 comparisons are split by the EVENT TRACE (rex_set_event_trace / orc_set_event_trace): the envs whose discrete decisions --
 toe points in reach, heightfield facets, joint / arm bounds reached, controller flags, substep by substep -- were those of the
 fp64 oracle over the whole window, and the others.
 
-    python tools/parity_report.py --floor            # CPU: compute the floors (minutes), merge, write profiles/r04_parity.json
+    python tools/parity_report.py --floor            # CPU: compute the floors (minutes), merge, write profiles/r05_parity.json
 """
 import argparse
 import json
@@ -76,10 +76,11 @@ def floor(name, steps=200, seed=23, threads=8):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--floor", action="store_true")
-    ap.add_argument("--records", default=os.path.join(ROOT, "gpurun_out", "r04_parity.jsonl"))
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r04_parity.json"))
+    ap.add_argument("--records", default=os.path.join(ROOT, "gpurun_out", "r05_parity.jsonl"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r05_parity.json"))
     a = ap.parse_args()
-    out = {"_comment": "per-env joint-angle RMSE (rad) over the first 200 control steps from reset, HIP path vs the fp64 oracle "
+    out = {"_comment": "per-env joint-angle RMSE (rad) over the first 200 control steps from reset, HIP path -- the PRODUCT kernels, no event trace set; the event split is a second "
+                       "pass with the _trace instantiations, bit-identical to the first after every step (trace_pass_bit_identical) -- vs the fp64 oracle "
                        "(oracle/rex_oracle.c: a restatement -- PyBullet is not installable), every kernel variant, MI355X; "
                        "float32_floor = the oracle's own fp32 build vs its fp64 build over the same window (CPU). BASELINE.json's bar: 1e-3 rad. "
                        "events = the same numbers split by the event trace (include/rexsim.h rex_set_event_trace): envs whose toe points in "
@@ -97,7 +98,7 @@ def main():
             w = out["workloads"].setdefault(r["workload"], {"envs": r["envs"], "window_steps": r["window_steps"], "hip_vs_fp64_oracle": {}})
             w["hip_vs_fp64_oracle"][f"{r['envs_per_wave']}_envs_per_wave"] = {k: r.get(k) for k in (
                 "median_rad", "p99_rad", "max_rad", "leg_joints_median_rad", "leg_joints_p99_rad", "base_pos_err_p99_m", "base_pos_err_max_m", "envs_compared_to_the_end", "mean_steps_compared",
-                "abs_error_by_step", "events", "single_steps_from_common_states")}
+                "abs_error_by_step", "events", "single_steps_from_common_states", "kernels", "trace_pass_bit_identical", "trace_pass_identical_steps", "float32_floor")}
     if a.floor:
         for name in WORKLOADS:
             w = out["workloads"].setdefault(name, {"envs": WORKLOADS[name][0], "window_steps": 200, "hip_vs_fp64_oracle": {}})

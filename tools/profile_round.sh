@@ -15,7 +15,7 @@ timeout 60 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU
 cd $GRAFT_REPO_ROOT
 # (launches 1550 .. 1949 of the step kernel = bench.py's 400 timed launches behind its 1 500-step pre-roll and the 50 warm-up steps:
 #  the window bench.py's own device-side kernel_ms covers -- the two figures of one run, side by side)
-python tools/rocprof_stats.py $(find gpurun_out/${TAG}_prof -name "*_results.db" | head -1) --window 1550:1950 | head -4
+python tools/rocprof_stats.py $(find gpurun_out/${TAG}_prof -name "*_results.db" | head -1) --window 1550:1950 --csv gpurun_out/${TAG}_kernel_stats.csv | head -4
 python - <<PY
 import json
 for l in open("gpurun_out/${TAG}_bench_under_rocprof.json"):

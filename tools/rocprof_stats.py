@@ -14,6 +14,7 @@ def main():
     ap.add_argument("db")
     ap.add_argument("--skip", type=int, default=0)
     ap.add_argument("--window", default=None, help="a:b -- steady-state columns over dispatches a..b-1 of every kernel instead of --skip")
+    ap.add_argument("--csv", default=None, help="also write the table as CSV to this path (the per-kernel statistics kept under profiles/)")
     a = ap.parse_args()
     cur = sqlite3.connect(a.db).cursor()
     names = dict(cur.execute("select id, kernel_name from rocpd_info_kernel_symbol"))
@@ -23,6 +24,7 @@ def main():
         per.setdefault(kid, []).append((e - s, gx, wx))
     print("| kernel | calls | avg us (all) | steady calls | avg us | min us | max us | grid | wg | VGPR | AGPR | SGPR | LDS B | scratch B |")
     print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
+    csv_rows = []
     for kid, rows in sorted(per.items(), key=lambda kv: -sum(r[0] for r in kv[1])):
         d = [r[0] / 1e3 for r in rows]
         if a.window:
@@ -33,6 +35,15 @@ def main():
         v, ag, sg, lds, scr = regs[kid]
         print(f"| `{names[kid][:90]}` | {len(d)} | {sum(d) / len(d):.1f} | {len(st)} | {sum(st) / len(st):.1f} | {min(st):.1f} | {max(st):.1f} | "
               f"{rows[-1][1]} | {rows[-1][2]} | {v} | {ag} | {sg} | {lds} | {scr} |")
+        csv_rows.append([names[kid][:90], len(d), f"{sum(d) / len(d):.1f}", len(st), f"{sum(st) / len(st):.1f}", f"{min(st):.1f}", f"{max(st):.1f}",
+                         rows[-1][1], rows[-1][2], v, ag, sg, lds, scr])
+    if a.csv:
+        import csv
+        with open(a.csv, "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow([f"# rocprofv3 --kernel-trace --stats, per kernel; 'steady' columns = dispatches {a.window or str(a.skip) + ':'} of each kernel; tools/rocprof_stats.py"])
+            w.writerow(["kernel", "calls", "avg us (all)", "steady calls", "avg us", "min us", "max us", "grid", "wg", "VGPR", "AGPR", "SGPR", "LDS B", "scratch B"])
+            w.writerows(csv_rows)
 
 
 if __name__ == "__main__":
