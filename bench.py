@@ -142,6 +142,120 @@ def joint_rmse_vs_oracle(workload, kwargs, n=256, steps=200, seed=11):
     return rec
 
 
+class Rollout:
+    """An env shard stepped the way the timed region steps it: every step writes observation / reward / done straight into slice t
+    of a rollout segment [T, n, ...] (RexBatchEnv.step(out=...), no copies); every T steps the finished segment is all-gathered to
+    all ranks (the learner hand-off, sharding.gather_rollout) while the next segment fills the other buffer -- the collective runs
+    on RCCL's stream, the steps keep the compute stream busy --; the actions of every step are drawn afresh on the device, one
+    draw (one kernel) per segment on the launch stream, a segment ahead of its use."""
+
+    def __init__(self, env, n, T, dev, gen):
+        import torch
+        self.env, self.n, self.T, self.dev, self.gen = env, n, T, dev, gen
+        lo = self.lo = torch.as_tensor(env.action_space.low, device=dev).minimum(torch.as_tensor(env.action_space.high, device=dev)).float()
+        hi = self.hi = torch.as_tensor(env.action_space.low, device=dev).maximum(torch.as_tensor(env.action_space.high, device=dev)).float()
+        self.span = (hi - lo).contiguous()
+        self.one_box = bool((lo == lo[0]).all() and (hi == hi[0]).all())   # every dimension of the env's Box has the same bounds (all five envs)
+        self.lo0, self.hi0 = float(lo[0]), float(hi[0])
+        # (the action pool is drawn inside the env's Box and lives in HBM before the timed region: BatchEnv's per-step Box test -- a
+        #  host synchronisation per step -- has nothing to find and is switched off by the caller: check_actions=False)
+        self.pool = self.draw_actions(torch.empty((T, n, env.action_dim), device=dev))
+        assert bool(((self.pool >= lo) & (self.pool <= hi)).all())     # by construction; checked once on a drawn segment
+        self.seg = [dict(obs=torch.zeros((T, n, env.obs_dim), device=dev), reward=torch.zeros((T, n), device=dev),
+                         done=torch.zeros((T, n), dtype=torch.uint8, device=dev), action=self.draw_actions(torch.empty_like(self.pool)))
+                    for _ in range(2)]
+        self.seg_bytes = sum(v.numel() * v.element_size() for v in self.seg[0].values())
+        # (slices and their device pointers are taken once, outside the timed loops: nothing but the launch is left per step)
+        self.acts = [self.pool[t] for t in range(T)]
+        self.sacts = [[s["action"][t] for t in range(T)] for s in self.seg]
+        self.outs = [[env.bind_out(s["obs"][t], s["reward"][t], s["done"][t]) for t in range(T)] for s in self.seg]
+        self.clock = 0     # steps taken through run() so far: the segments continue across the warm-up / timed / untimed calls
+
+    def draw_actions(self, buf):
+        """a rollout segment of fresh actions, uniform over the env's Box, drawn on the launch stream: one kernel"""
+        import torch
+        if self.one_box:
+            return buf.uniform_(self.lo0, self.hi0, generator=self.gen)
+        torch.rand(buf.shape, device=self.dev, generator=self.gen, out=buf)
+        return buf.mul_(self.span).add_(self.lo)
+
+    def preroll(self, stagger=True, steps=PREROLL_STEPS):
+        """untimed, outside --warmup: right after a synchronous reset every env is in the same episode phase and the solver
+        converges quickly; the number reported is the steady state a training run sees"""
+        import torch
+        env, n, T = self.env, self.n, self.T
+        env.reset()
+        for k in range(steps):
+            env.step(self.pool[k % T])
+            if k % 50 == 0 and k < steps - 200 and stagger:
+                # stagger the episodes: half the envs (those that walk backwards) never fall, and started together they would
+                # all run into the 2 000-step cap in the same step, stand up together, fall together ... -- a load that swings
+                # by 30 % with a 2 000-step period.  Resetting a random 1 / 32 of the batch every 50 pre-roll steps spreads the
+                # episode ages, as a training run that has been going for a while has them.
+                idx = torch.randperm(n, device=self.dev, generator=self.gen)[: max(1, n // 32)].to(torch.int32)
+                env.reset(idx)
+
+    def run(self, steps, gather):
+        from rex_gym_amd.sharding import gather_rollout
+        T, seg, sacts, outs = self.T, self.seg, self.sacts, self.outs
+        pending = [None, None]
+        step = self.env.step
+        for k in range(self.clock, self.clock + steps):
+            b, t = (k // T) & 1, k % T
+            if t == 0 and pending[b] is not None:
+                pending[b].wait(); pending[b] = None         # this buffer's previous segment has left before it is overwritten
+            step(sacts[b][t], outs[b][t])
+            if t == T - 1:
+                if gather:
+                    pending[b] = gather_rollout(seg[b], async_op=True, slot=b)
+                # fresh actions for every step (SURVEY.md 8d): the OTHER buffer's next segment is drawn now, behind this
+                # segment's last launch (its previous segment was handed over one segment ago)
+                if pending[b ^ 1] is not None:
+                    pending[b ^ 1].wait(); pending[b ^ 1] = None
+                self.draw_actions(seg[b ^ 1]["action"])
+        self.clock += steps
+        for p in pending:
+            if p is not None:
+                p.wait()
+
+
+def north_star_workload(args, dev, local_rank, rank, world, dist, barrier, T):
+    """BASELINE.json north_star: "65 536 parallel Rex walk-IK envs at 8 x MI355X" = 8 192 per GPU.  The `value` of the line stays the
+    weak-scaling one of configs[1] (4 096 per GPU, so that N = 1 agrees with the single-GPU record); a multi-GPU run reports this
+    block next to it: walk-IK, 65 536 / 8 x n_gpus envs in total, the same pre-roll and segment hand-off, with and without the
+    all-gather.  Returns the dict rank 0 prints (every rank takes part)."""
+    import torch
+    from rex_gym_amd import RexBatchEnv
+    per_gpu = 65536 // 8
+    env = RexBatchEnv(per_gpu, device=local_rank, seed=0, env_index_base=rank * per_gpu, auto_reset=True, max_episode_steps=2000,
+                      check_actions=False, task="walk", signal_type="ik")
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(4321 + rank)
+    ro = Rollout(env, per_gpu, T, dev, gen)
+    ro.preroll()
+    res = {}
+    for name, gather in (("with_gather", True), ("without_gather", False)):
+        ro.run(args.warmup, gather)
+        barrier()
+        t0 = time.perf_counter()
+        ro.run(args.steps, gather)
+        torch.cuda.synchronize(dev)
+        e = time.perf_counter() - t0
+        barrier()
+        t = torch.tensor([e], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        res[name] = float(t.item())
+    finite = bool(torch.isfinite(ro.seg[0]["obs"]).all().item())
+    env.close()
+    total = per_gpu * world
+    return {"workload": f"walk-IK, flat plane, base mark, {per_gpu} envs per GPU = 65 536 / 8 x {world} GPUs = {total} envs in total (north_star: "
+                        f"65 536 at 8 GPUs), same pre-roll, {T}-step segments, fresh actions every step",
+            "envs_total": total, "envs_per_gpu": per_gpu, "scaling": "weak (8 192 per GPU)",
+            "value": total * args.steps / res["with_gather"], "unit": "env-steps/s", "ms_per_step": res["with_gather"] / args.steps * 1e3,
+            "value_without_gather": total * args.steps / res["without_gather"],
+            "ms_per_step_without_gather": res["without_gather"] / args.steps * 1e3, "steps": args.steps, "finite": finite}
+
+
 # BASELINE.json configs, numbered as SURVEY.md 8(d) numbers them (config 1 is the 1-env CPU plumbing case): what --config N runs.
 # total = envs of the WHOLE job (strong scaling: divided over the GPUs); None = 4 096 per GPU (weak scaling, configs[1])
 CONFIGS = {
@@ -232,35 +346,7 @@ def main():
                       **env_kw)
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
-    lo = torch.as_tensor(env.action_space.low, device=dev).minimum(torch.as_tensor(env.action_space.high, device=dev)).float()
-    hi = torch.as_tensor(env.action_space.low, device=dev).maximum(torch.as_tensor(env.action_space.high, device=dev)).float()
     T = max(1, args.gather_every)
-
-    span = (hi - lo).contiguous()
-    one_box = bool((lo == lo[0]).all() and (hi == hi[0]).all())      # every dimension of the env's Box has the same bounds (all five envs)
-    lo0, hi0 = float(lo[0]), float(hi[0])
-
-    def draw_actions(buf):
-        """a rollout segment of fresh actions, uniform over the env's Box, drawn on the launch stream: one kernel"""
-        if one_box:
-            return buf.uniform_(lo0, hi0, generator=gen)
-        torch.rand(buf.shape, device=dev, generator=gen, out=buf)
-        return buf.mul_(span).add_(lo)
-
-    pool = draw_actions(torch.empty((T, n, env.action_dim), device=dev))
-    assert bool(((pool >= lo) & (pool <= hi)).all())     # by construction; checked once on a drawn segment
-    env.reset()
-    # pre-roll (untimed, outside --warmup): right after a synchronous reset every env is in the same episode phase and
-    # the solver converges quickly; the number reported is the steady state a training run sees
-    for k in range(PREROLL_STEPS):
-        env.step(pool[k % T])
-        if k % 50 == 0 and k < PREROLL_STEPS - 200 and not args.mixed and not args.no_stagger:
-            # stagger the episodes: half the envs (those that walk backwards) never fall, and started together they would
-            # all run into the 2 000-step cap in the same step, stand up together, fall together ... -- a load that swings
-            # by 30 % with a 2 000-step period.  Resetting a random 1 / 32 of the batch every 50 pre-roll steps spreads the
-            # episode ages, as a training run that has been going for a while has them.
-            idx = torch.randperm(n, device=dev, generator=gen)[: max(1, n // 32)].to(torch.int32)
-            env.reset(idx)
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -268,41 +354,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    # The step writes observation / reward / done straight into slice t of a rollout segment [T, n, ...] (no copies); every
-    # T steps the finished segment is all-gathered to all ranks (the learner hand-off, sharding.gather_rollout) while the
-    # next segment fills the other buffer: the collective runs on RCCL's stream, the steps keep the compute stream busy.
-    seg = [dict(obs=torch.zeros((T, n, env.obs_dim), device=dev), reward=torch.zeros((T, n), device=dev),
-                done=torch.zeros((T, n), dtype=torch.uint8, device=dev), action=draw_actions(torch.empty_like(pool))) for _ in range(2)]
-    seg_bytes = sum(v.numel() * v.element_size() for v in seg[0].values())
+    ro = Rollout(env, n, T, dev, gen)
+    ro.preroll(stagger=not args.mixed and not args.no_stagger)
+    pool, acts, seg, seg_bytes, run, lo, hi = ro.pool, ro.acts, ro.seg, ro.seg_bytes, ro.run, ro.lo, ro.hi
     do_gather = not args.no_gather
-
-    # (slices and their device pointers are taken once, outside the timed loops: nothing but the launch is left per step)
-    acts = [pool[t] for t in range(T)]
-    sacts = [[s["action"][t] for t in range(T)] for s in seg]
-    outs = [[env.bind_out(s["obs"][t], s["reward"][t], s["done"][t]) for t in range(T)] for s in seg]
-
-    clock = [0]     # steps taken through run() so far: the segments continue across the warm-up / timed / untimed calls
-
-    def run(steps, gather):
-        pending = [None, None]
-        step = env.step
-        for k in range(clock[0], clock[0] + steps):
-            b, t = (k // T) & 1, k % T
-            if t == 0 and pending[b] is not None:
-                pending[b].wait(); pending[b] = None         # this buffer's previous segment has left before it is overwritten
-            step(sacts[b][t], outs[b][t])
-            if t == T - 1:
-                if gather:
-                    pending[b] = gather_rollout(seg[b], async_op=True, slot=b)
-                # fresh actions for every step: the OTHER buffer's next segment is drawn now, behind this
-                # segment's last launch (its previous segment was handed over one segment ago)
-                if pending[b ^ 1] is not None:
-                    pending[b ^ 1].wait(); pending[b ^ 1] = None
-                draw_actions(seg[b ^ 1]["action"])
-        clock[0] += steps
-        for p in pending:
-            if p is not None:
-                p.wait()
 
     run(args.warmup, do_gather)
     if not args.no_device_timing:
@@ -343,6 +398,17 @@ def main():
                        "bytes_per_env_step": seg_bytes / (T * n), "gather_ms_blocking": g_ms,
                        "value_without_gather": n * world * args.steps / e_plain, "ms_per_step_without_gather": e_plain / args.steps * 1e3,
                        "backend": args.backend, "overlap": "segment k is gathered on the collective stream while segment k+1 is stepped"}
+
+    # north_star's own multi-GPU workload next to the weak-scaling line (default workload, N > 1 only)
+    north_star = None
+    if dist is not None and do_gather and args.config is None and args.envs_per_gpu is None and not args.mixed \
+            and (args.task, args.signal, args.terrain, args.mark) == ("walk", "ik", "plane", "base"):
+        north_star = north_star_workload(args, dev, local_rank, rank, world, dist, barrier, T)
+
+    # does this sim regroup its envs every step?  (two sorting launches behind each step kernel, outside kernel_ms: include/rexsim.h)
+    probe = torch.empty(n, dtype=torch.int32, device=dev)
+    regroups = env._L.rex_get_sweeps(env._h, probe.data_ptr(), env._stream_ptr()) == 0
+    del probe
 
     # Launch duration of the dominant kernel over the TIMED launches: device-side timestamps (rex_set_timing(3)): first-wave
     # start to last-wave end of each launch -- the kernel alone, comparable with rocprofv3's kernel trace (profiles/).
@@ -436,6 +502,7 @@ def main():
                          "kernel": "rex_step_kernel", "kernel_ms": kernel_ms, "kernel_ms_min": kms[0],
                          "kernel_ms_over": f"{len(kms)} of the {args.steps} timed launches" if not args.no_device_timing else f"{len(kms)} launches after the timed region",
                          "launch_ms": launch_ms,
+                         "regroup_launches_ms": (launch_ms - kernel_ms) if regroups else None,   # the per-step sort of a regrouped batch: in launch_ms and ms_per_step, not in kernel_ms
                          "algorithmic_bytes_per_env_step": algo_bytes,
                          "layout_bytes_per_env_step": layout_bytes(state_words, act_dim, obs_dim),
                          "note": "the fused step is bound by the VALU issue rate of one wave per SIMD through the sequential "
@@ -449,6 +516,8 @@ def main():
         }
         if gather_info:
             out["rollout_gather"] = gather_info
+        if north_star:
+            out["north_star_workload"] = north_star
         if walking:
             out["walking_gait_workload"] = walking
         if not args.no_cpu_baseline and world == 1:

@@ -283,7 +283,11 @@ REX_API int rex_step(RexSim* sim, const float* d_action, float* d_obs, float* d_
  * min(max_count, recorded, 256 -- 4096 in mode 3) durations, oldest first -- the return value is their number (< 0: error).
  * rex_set_timing(3): the next 4096 launches are timed on the DEVICE: every workgroup of a launch folds its first / last wall-clock
  * tick (constant 100 MHz counter) into a (min, max) pair, so a duration is first-wave-start to last-wave-end of the kernel
- * alone -- what rocprofv3's kernel trace reports -- with no event or dispatch hand-over in it. */
+ * alone -- what rocprofv3's kernel trace reports -- with no event or dispatch hand-over in it.
+ * In every mode the timed span is the STEP KERNEL's: a sim that regroups its envs every step (single task: from 262 144 envs or
+ * REX_REGROUP=1; mixed tasks: beyond one workgroup per SIMD) issues two small sorting launches behind each step kernel on the same
+ * stream, and those are NOT inside the span -- compare with the wall clock per step (bench.py reports both: `ms_per_step` next to
+ * `roofline.kernel_ms`, and `roofline.regroup_launches_ms` = their difference when the sim regroups). */
 REX_API int rex_set_timing(RexSim* sim, int enable);
 REX_API int rex_last_step_ms(RexSim* sim, float* ms);
 REX_API int rex_step_times_ms(RexSim* sim, float* ms, int max_count);

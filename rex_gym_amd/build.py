@@ -28,7 +28,12 @@ SOURCES = ["rexsim.hip"] + sorted(GROUPS)
 # (rex_set_event_trace, a debug aid of the parity tests) compiled in -- the product kernels carry none of it
 TRACE_SOURCES = sorted(f for f in GROUPS if f.startswith("rex_step_"))
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h"))   # every header the sources can include
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden"]
+# -ffp-contract=on: a * b + c inside one expression is one fma and nothing else is fused -- the arithmetic of a kernel is fixed by its
+# source and does not depend on what else is compiled into it (hipcc's default lets the backend fuse across statements by heuristics:
+# the _trace instantiations then differ from the product kernels in the last bit).  csrc/rex_kernels.h repeats it as a pragma; the
+# flag also covers the HIP headers' inline functions.  tools/kres.sh, kstat.sh and check_dpp_masks.py compile with COMPILE_FLAGS too.
+COMPILE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on"]
+HIPCC_FLAGS = COMPILE_FLAGS + ["-fPIC", "-fvisibility=hidden"]
 
 
 def _hipcc():

@@ -17,6 +17,16 @@
 #include <math.h>
 #include <stdlib.h>
 
+// Floating-point contraction is fixed BY THE SOURCE, for every translation unit of the library and every tool that compiles one
+// (tools/kres.sh, kstat.sh, check_dpp_masks.py): `a * b + c` inside one expression is one fma, nothing else is fused.  hipcc's
+// default (fast-honor-pragmas) lets the backend fuse whatever multiply-add pairs it finds after inlining, and which ones it finds
+// depends on the code around them: the `_trace` instantiations of the step kernels (-DREX_TU_TRACE=1: the same source plus a few
+// integer taps) came out with other fma / mul+add mixes than the product kernels and parted from them in the last bit after one
+// step (round 5, tests/test_gpu_parity.py::test_trace_kernels_are_bit_identical_to_the_product_kernels).  With the contraction
+// in the source the two are bit-identical, the kernels are 1-4 % faster (fewer packed-fp32 pairs, 30-90 fewer registers in the
+// mark-arm kernels) -- and a kernel's arithmetic no longer depends on what else was compiled into it.
+#pragma clang fp contract(on)
+
 #include "rex_device.h"
 #include "rex_arm_device.h"
 #include "rex_controller.h"
@@ -83,6 +93,7 @@ struct MotorSide {
   uint32_t overheat2[(N + 1) / 2];
   __device__ __forceinline__ uint32_t heat(int jl) const { return (jl & 1) ? overheat2[jl >> 1] >> 16 : overheat2[jl >> 1] & 0xFFFFu; }
   __device__ __forceinline__ void set_heat(int jl, uint32_t v) {
+    v &= 0xFFFFu;   // (callers hand in <= 65 535 -- the state packs two u16 per word and the increment saturates --; the mask folds away)
     overheat2[jl >> 1] = (jl & 1) ? (overheat2[jl >> 1] & 0xFFFFu) | (v << 16) : (overheat2[jl >> 1] & 0xFFFF0000u) | v;
   }
   __device__ __forceinline__ void clear_heat() {

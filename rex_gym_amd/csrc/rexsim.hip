@@ -477,14 +477,18 @@ int rex_create(const RexConfig* cfg, int device, float* d_state, void* stream, R
   if (cfg->task == REX_TASK_MIXED) {
     std::vector<int32_t> slots, tasks;
     int busy = task_slot_map(d, s->epw, slots, tasks);
-    // up to 1 024 workgroups the launch is one wave per SIMD; the padding of the map must not push it into a second round
+    // up to one workgroup per SIMD (MI355X: 256 CUs x 4 = 1 024) the launch is one wave per SIMD; the padding of the map must not
+    // push it into a second round
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+    const int one_round = 4 * (cus > 0 ? cus : 256);
     const bool pinned = getenv("REX_ENVS_PER_WAVE") != nullptr;
-    while (!pinned && s->epw < 16 && busy > 1024) { s->epw *= 2; busy = task_slot_map(d, s->epw, slots, tasks); }
-    // More workgroups than the machine holds at once (1 024: one wave per SIMD): the batch is regrouped by sweep counts every
+    while (!pinned && s->epw < 16 && busy > one_round) { s->epw *= 2; busy = task_slot_map(d, s->epw, slots, tasks); }
+    // More workgroups than the machine holds at once (one wave per SIMD): the batch is regrouped by sweep counts every
     // step (REX_REGROUP=0 / 1 overrides) -- regions of whole waves per task, sorted inside.  Measured at 16 384 mark-arm envs,
     // 16 envs per wave: the padding of the chunked map is a second round of full-length waves; sorted, the late waves are the short ones.
     const char* ov = getenv("REX_REGROUP");
-    const bool regroup = ov ? atoi(ov) != 0 : busy > 1024;
+    const bool regroup = ov ? atoi(ov) != 0 : busy > one_round;
     std::vector<int32_t> cls;
     if (regroup) task_region_map(d, s->epw, slots, tasks, cls, s->mix_regions.base);
     s->mixed_blocks = (int)tasks.size();
@@ -495,9 +499,11 @@ int rex_create(const RexConfig* cfg, int device, float* d_state, void* stream, R
       if (e2 == hipSuccess) e2 = hipMalloc(&s->d_class, sizeof(int32_t) * cls.size());
       if (e2 == hipSuccess) e2 = hipMemcpy(s->d_class, cls.data(), sizeof(int32_t) * cls.size(), hipMemcpyHostToDevice);
       if (e2 == hipSuccess) e2 = hipMalloc(&s->d_sweeps, sizeof(int32_t) * (size_t)cfg->num_envs);
-      if (e2 == hipSuccess) e2 = hipMemset(s->d_sweeps, 0, sizeof(int32_t) * (size_t)cfg->num_envs);
+      if (e2 == hipSuccess) e2 = hipMemsetAsync(s->d_sweeps, 0, sizeof(int32_t) * (size_t)cfg->num_envs, (hipStream_t)stream);   // (on the caller's stream, like the
+      //  single-task path: ordered ahead of the first rex_regroup_mixed_count_kernel also when that stream is non-blocking; the
+      //  hipStreamSynchronize at the end of rex_create covers them.  The hipMemcpy calls below block until the data is on the device.)
       if (e2 == hipSuccess) e2 = hipMalloc(&s->d_regroup, sizeof(int32_t) * ((size_t)chunks * 64 + 1));
-      if (e2 == hipSuccess) e2 = hipMemset(s->d_regroup, 0, sizeof(int32_t) * ((size_t)chunks * 64 + 1));
+      if (e2 == hipSuccess) e2 = hipMemsetAsync(s->d_regroup, 0, sizeof(int32_t) * ((size_t)chunks * 64 + 1), (hipStream_t)stream);
       d.sweeps = s->d_sweeps;
     }
     if (e2 == hipSuccess) e2 = hipMalloc(&s->d_block_task, sizeof(int32_t) * tasks.size());

@@ -21,8 +21,12 @@ os.makedirs(OUT, exist_ok=True)
 groups = sys.argv[1:] or ["step_base", "step_arm", "step_mixed_base", "step_mixed_arm", "step_body", "settle_base", "settle_arm"]
 
 
+sys.path.insert(0, ROOT)
+from rex_gym_amd.build import COMPILE_FLAGS      # the library's own compile flags (floating-point contraction among them)  # noqa: E402
+
+
 def compile_group(g):
-    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-save-temps", "-I", CSRC, "-c",
+    subprocess.run(["hipcc"] + COMPILE_FLAGS + ["-save-temps", "-I", CSRC, "-c",
                     os.path.join(CSRC, f"rex_{g}.hip"), "-o", os.devnull], cwd=OUT, check=True, stderr=subprocess.DEVNULL)
     return g
 
