@@ -1027,8 +1027,11 @@ __device__ __forceinline__ void mirror_sync() { __builtin_amdgcn_fence(__ATOMIC_
 // formulations that were measured and dropped: DESIGN.md section 5, profiles/r03_microbench.md.
 #ifdef REX_PROF
 __device__ long long g_prof[10 * 1024];  // per block: cycle counters of the sections of physics_substep (+ [8] whole kernel, [9] launches)
-__device__ long long g_prof2[8 * 1024];  // per block: inside pgs_dv: [0] set-up, [1] sweep loop, [2] hand-back; of the kernel: [3] load + command,
-                                         // [4] substeps, [5] epilogue, [6] the 100 MHz counter over the kernel, [7] start of the last launch
+__device__ long long g_prof2[16 * 1024]; // per block: inside pgs_dv: [0] set-up, [1] sweep loop, [2] hand-back; of the kernel: [3] load + command,
+                                         // [4] substeps, [5] epilogue, [6] the 100 MHz counter over the kernel, [7] start of the last launch;
+                                         // inside the sweeps: [8] link-box rows run, [9] joint-limit rows run, cycles of [10] the limit rows,
+                                         // [11] link-box normals, [12] toe rows, [13] link-box friction rows, [14] sweeps of thread 0's env
+                                         // (what [8]-[13] cover)
 #define REX_STAMP(var) const long long var = clock64()
 #else
 #define REX_STAMP(var)
@@ -1066,47 +1069,76 @@ __device__ __forceinline__ int crow_leg_rt(int r) { return r < REX_NPOINT ? r >>
 template <int NY, int EPW>
 struct DvLane {
   int oy[NY], oz;   // byte offsets (from the LDS base) of this lane's components in row 0
+  int oti;          // (LDS-resident rows: of the row's (tgt, invd) pair)
   template <class SM>
   __device__ __forceinline__ static float ld(const SM& sm, int off) {
     return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(sm.p) + off);
   }
 };
 
-// one Gauss-Seidel step of a link-box contact row, straight from LDS (like the joint-limit rows): row r of the body
-// region; leg < 0: a base-group row (no leg part).  Split into the LDS reads of a lane's slice of the row and the step itself,
-// so that inside a group of rows the slice of the NEXT row is read while the current one is solved (round 4: the three reads
-// right before their use cost a lone wave 170 cycles a row in isolation, one row ahead 91 -- tools/microbench/body_rows.hip,
-// profiles/r04_microbench.md; the arithmetic and its order are unchanged, the results bit-identical).
-template <int NY> struct BodySlice { float jy[NY]; float jz; float4 c2; };
-// The reads of the NEXT row are issued, then this: nothing may be scheduled across it.  Without it the machine scheduler sinks the
-// reads back to their first use, behind the current row's group sum (round 5: the ISA of the round-4 form had every row's three
+// The LDS-resident rows of the sweep -- link-box contact rows, joint-limit rows -- are plain Gauss-Seidel steps on a lane's slice of
+// the row: its component(s) of the base part, its component of the leg part, (invd * target | friction coefficient, invd).  Word
+// order of such a row (physics_substep, row finishing): g0..g5, z0 z1 z2, 0, tgt, invd -- the pair (tgt, invd) is one 8-byte read,
+// word 9 is the zero the lanes without a component of their own read (the toe rows keep theirs in word 11).
+// What such a row costs a lone wave is its INSTRUCTION COUNT, ~5 cycles each, as long as no read is waited for:
+//  * round 4: the three reads right in front of their use 170 cycles a row, one row ahead 91 (tools/microbench/body_rows.hip);
+//  * round 5, measured in the step kernel with per-section counters (tools/prof_sections.py, profiles/r05_sections_poses.txt): the
+//    rows of a held roll pose still cost 160-230 cycles each, because every GROUP of rows (a leg's three limit rows, a slot pair's
+//    rows) began with a read nobody had issued ahead -- one LDS latency per group and sweep; running the rows software-pipelined like
+//    the toe rows (sum of row k + 1 before row k's step, couplings A(k + 1, k) next to the rows) made them SLOWER (two more
+//    instructions a row: the chain was never the cost), and so did running all 48 rows as static zero-padded runs (110 cycles a row,
+//    but 48 rows in every wave that has one).  So: the groups stay conditional, and the first two rows of group g + 1 are read before
+//    group g is solved (RunHead, unconditionally: a read of rows nobody wrote is harmless and cheaper than a branch).
+template <int NY> struct RowSlice { float jy[NY]; float jz; float tgt, invd; };   // tgt: invd * target (normal, limit) or the slot's friction coefficient
+template <int NY> struct RunHead { RowSlice<NY> a, b; };                          // the first two rows of a group, read ahead
+// The reads of a later row are issued, then this: nothing may be scheduled across it.  Without it the machine scheduler sinks the
+// reads back to their first use, behind the current row's group sum (round 5: the ISA of the round-4 form had every row's
 // ds_reads right in front of its own DPP adds again, and the step kernel measured no faster than with the reads at their use).
 __device__ __forceinline__ void prefetch_fence() { __builtin_amdgcn_sched_barrier(0); }
-template <int LPE, int NY, class SM, class LN>
-__device__ __forceinline__ BodySlice<NY> body_load(const SM& sm, const LN& ln, int bodyoff, int r, bool leg_part) {
-  constexpr int kRow = REX_ROW_F4 * SM::kEpw * 16;
-  BodySlice<NY> s;
+// this lane's slice of the row whose chunk 0 sits `rowoff` bytes into LDS; ln: the lane's word offsets (DvLane, zero word 9)
+template <int NY, class SM, class LN>
+__device__ __forceinline__ RowSlice<NY> slice_load(const SM& sm, const LN& ln, int rowoff, bool leg_part) {
+  RowSlice<NY> s;
 #pragma unroll
-  for (int i = 0; i < NY; ++i) s.jy[i] = ln.ld(sm, bodyoff + r * kRow + ln.oy[i]);
-  s.jz = leg_part ? ln.ld(sm, bodyoff + r * kRow + ln.oz) : 0.0f;
-  s.c2 = sm.brow(r, 2);
+  for (int i = 0; i < NY; ++i) s.jy[i] = ln.ld(sm, rowoff + ln.oy[i]);
+  s.jz = leg_part ? ln.ld(sm, rowoff + ln.oz) : 0.0f;
+  const float2 ti = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(sm.p) + rowoff + ln.oti);
+  s.tgt = ti.x; s.invd = ti.y;
   return s;
 }
 template <int LPE, int NY>
-__device__ __forceinline__ void body_solve(const BodySlice<NY>& s, int leg, float* ys, float* zs, float& lam, float lim, bool friction, float& worst,
-                                           float thr) {
-  float part = leg >= 0 ? s.jz * zs[leg] : 0.0f;
+__device__ __forceinline__ float slice_step(const RowSlice<NY>& s, int leg, float* ys, float* zs, float& lam, float lim, bool friction, float& worst,
+                                            float thr) {
+  float part = leg >= 0 ? s.jz * zs[leg >= 0 ? leg : 0] : 0.0f;
 #pragma unroll
   for (int i = 0; i < NY; ++i) part = fmaf(s.jy[i], ys[i], part);
   const float vel = group_sum<LPE>(part);
-  float nl = fmaf(-s.c2.z, vel, friction ? lam : lam + s.c2.y);   // (.y of a friction row is its coefficient, not a target)
+  float nl = fmaf(-s.invd, vel, friction ? lam : lam + s.tgt);
   nl = friction ? __builtin_amdgcn_fmed3f(nl, -lim, lim) : fmaxf(nl, 0.0f);
   const float dl = nl - lam;
   lam = nl;
-  worst = fmaxf(worst, fmaf(-thr, s.c2.z, fabsf(dl)));
+  worst = fmaxf(worst, fmaf(-thr, s.invd, fabsf(dl)));
 #pragma unroll
   for (int i = 0; i < NY; ++i) ys[i] = fmaf(s.jy[i], dl, ys[i]);
-  if (leg >= 0) zs[leg] = fmaf(s.jz, dl, zs[leg]);
+  if (leg >= 0) zs[leg >= 0 ? leg : 0] = fmaf(s.jz, dl, zs[leg >= 0 ? leg : 0]);
+  return dl;
+}
+// rows 0 .. N-1 of a group, straight-line; rows 0 and 1 were read ahead (`head`), row k + 2 is read while row k is solved.
+// FRICTION: rows 2 j, 2 j + 1 are the friction pair of the point whose normal impulse is lamn[j]; the pair's coefficient sits in .tgt
+// of its first row.  leg < 0: base-group rows (no leg part).
+template <int LPE, int NY, int N, bool FRICTION, class LOAD>
+__device__ __forceinline__ void solve_run(const RunHead<NY>& head, const LOAD& load, int leg, float* ys, float* zs, float* lam, const float* lamn,
+                                          float& worst, float thr) {
+  RowSlice<NY> s0 = head.a, s1 = head.b;
+  float coef = 0.0f;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    RowSlice<NY> s2 = s1;
+    if (k + 2 < N) { s2 = load(k + 2); prefetch_fence(); }
+    if (FRICTION && (k & 1) == 0) coef = s0.tgt;
+    slice_step<LPE, NY>(s0, leg, ys, zs, lam[k], FRICTION ? coef * lamn[k >> 1] : 0.0f, FRICTION, worst, thr);
+    s0 = s1; s1 = s2;
+  }
 }
 
 // `cpl_free`: called once the couplings have been read into registers -- their six LDS chunks are idle until the next
@@ -1119,7 +1151,8 @@ __device__ __forceinline__ void pgs_dv(const SM& sm, ARMP& armp, PgsX& x, int p,
   constexpr int kRow = REX_ROW_F4 * EPW * 16;   // bytes from a row to the next
   constexpr bool kPairedSweeps = REX_PAIRED_SWEEPS(EPW, ARMP::NM > 12, SM::kBody, LANECAP);
   REX_STAMP(t_dv0);
-  DvLane<NY, EPW> ln;
+  DvLane<NY, EPW> ln;   // toe rows: the lanes without a component read the zero in word 11
+  DvLane<NY, EPW> lr;   // LDS-resident rows (joint limits, link boxes): zero word 9, (tgt, invd) in words 10-11
   int okt;                  // byte offset of the lane's target word in row 0
   int opair = 0, ozc = 0;   // pair layout: of the lane's (y_p, y_(p+4)) word and of its leg component in a contact row
   constexpr bool kPairLayout = REX_PAIR_LAYOUT(EPW, ARMP::NM > 12);
@@ -1135,10 +1168,13 @@ __device__ __forceinline__ void pgs_dv(const SM& sm, ARMP& armp, PgsX& x, int p,
       const int k = p + i * LPE;
       const int f = k < 6 ? k : 11;
       ln.oy[i] = ((f >> 2) * EPW + sm.slot) * 16 + (f & 3) * 4;
+      lr.oy[i] = k < 6 ? ln.oy[i] : (2 * EPW + sm.slot) * 16 + 4;
       ys[i] = sm.parkf(REX_PARK_XY, k < 6 ? k : 6);
     }
     const int f = p < 3 ? 6 + p : 11;
     ln.oz = ((f >> 2) * EPW + sm.slot) * 16 + (f & 3) * 4;
+    lr.oz = p < 3 ? ln.oz : (2 * EPW + sm.slot) * 16 + 4;
+    ln.oti = lr.oti = (2 * EPW + sm.slot) * 16 + 8;
     okt = (2 * EPW + sm.slot) * 16 + (p == 0 ? 1 : 3) * 4;
     if constexpr (kPairLayout) {   // contact rows: (g0 g4 g1 g5) (g2 0 g3 0) (z0 z1 z2 -target); word 5 is a zero
       opair = ((p >> 1) * EPW + sm.slot) * 16 + (p & 1) * 8;
@@ -1201,82 +1237,99 @@ __device__ __forceinline__ void pgs_dv(const SM& sm, ARMP& armp, PgsX& x, int p,
   REX_STAMP(t_dv1);
   const bool any_lim = lim[0] || lim[1] || lim[2] || lim[3];
   bool running = true;
-  auto lim_load = [&](int r) __attribute__((always_inline)) {   // this lane's slice of joint-limit row r (rows REX_NCROW.. of the toe region)
-    BodySlice<NY> sl;
-#pragma unroll
-    for (int i = 0; i < NY; ++i) sl.jy[i] = ln.ld(sm, r * kRow + ln.oy[i]);
-    sl.jz = ln.ld(sm, r * kRow + ln.oz);
-    sl.c2 = sm.row(r, 2);
-    return sl;
-  };
+  auto lim_load = [&](int r) __attribute__((always_inline)) { return slice_load<NY>(sm, lr, r * kRow, true); };   // joint-limit row r (rows REX_NCROW.. of the toe region)
+  auto body_load = [&](int r, bool leg_part) __attribute__((always_inline)) { return slice_load<NY>(sm, lr, bodyoff + r * kRow, leg_part); };
+  (void)body_load;
   auto sweep = [&](const auto& li, auto& lo, int it) __attribute__((always_inline)) {
     ++nsweeps;
     if (running) {
       ++lane_sweeps;
       float worst = 0.0f;
+      REX_STAMP(t_s0);
       // joint-limit rows (non-contact rows come first in Bullet's sweep): plain Gauss-Seidel steps.  One test for all four
       // legs first: a sweep without a bound in reach (nearly all of them) then takes one branch instead of four
-#pragma unroll
-      for (int l = 0; l < REX_NLEG; ++l) {
-        if (__builtin_expect(!any_lim, 1)) break;  // wave-uniform
-        if (!lim[l]) continue;                     // wave-uniform
-        // (the three rows of a leg: the slice of row k + 1 is read from LDS while row k is solved, as the link-box rows do)
-        BodySlice<NY> cur = lim_load(REX_NCROW + 3 * l);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          const int r = REX_NCROW + 3 * l + k;
-          BodySlice<NY> nxt = cur;
-          if (k + 1 < 3) { nxt = lim_load(r + 1); prefetch_fence(); }
-          const float4 c2 = cur.c2;
-          float part = cur.jz * zs[l];
-#pragma unroll
-          for (int i = 0; i < NY; ++i) part = fmaf(cur.jy[i], ys[i], part);
-          const float vel = group_sum<LPE>(part);
-          float dl;
-          if constexpr (kLimLamByLane) {
-            // the impulse of limit row 3 l + k lives in lane (3 l + k) % 4 of the group only (three registers instead of
-            // twelve): every lane evaluates the step on the register of that index, the owner's result goes round (one DPP
-            // broadcast inside the quad), the owner keeps the new impulse.  Two more instructions on a row that is rarely run.
-            const int own = (3 * l + k) & 3, idx = (3 * l + k) >> 2;   // (constants once the loops are unrolled)
-            const float nlo = fmaxf(fmaf(-c2.z, vel, laml[idx] + c2.y), 0.0f);
-            dl = quad_bcast(nlo - laml[idx], own);
-            laml[idx] = p == own ? nlo : laml[idx];
-          } else {
-            const float nl = fmaxf(fmaf(-c2.z, vel, lam[r] + c2.y), 0.0f);   // (in place, also when the contact rows alternate)
-            dl = nl - lam[r];
-            lam[r] = nl;
-          }
-          worst = fmaxf(worst, fmaf(-thr, c2.z, fabsf(dl)));
-#pragma unroll
-          for (int i = 0; i < NY; ++i) ys[i] = fmaf(cur.jy[i], dl, ys[i]);
-          zs[l] = fmaf(cur.jz, dl, zs[l]);
-          cur = nxt;
-        }
-      }
-      armp.template dv_sweep<LPE, NY>(ys, worst, thr);
       if constexpr (SM::kBody) {
-        // link-box normals (among the normals they come before the toe points: the toe rows stay one pipelined block)
-        // one branch per GROUP (wave-uniform), its rows in one block: the row loads of a group issue together
-        if (bgroups & 1u) {
-          BodySlice<NY> cur = body_load<LPE, NY>(sm, ln, bodyoff, 0, false);
+        // the link-box kernels (a held pose keeps joints on their bounds sweep after sweep): the first two rows of leg l + 1 are read
+        // before leg l's rows are solved
+        if (__builtin_expect(any_lim, 0)) {
+          RunHead<NY> h[2];
+          h[0].a = lim_load(REX_NCROW); h[0].b = lim_load(REX_NCROW + 1);
 #pragma unroll
-          for (int sl = 0; sl < 4; ++sl) {
-            BodySlice<NY> nxt = cur;
-            if (sl + 1 < 4) { nxt = body_load<LPE, NY>(sm, ln, bodyoff, sl + 1, false); prefetch_fence(); }      // read while row sl is solved
-            body_solve<LPE, NY>(cur, -1, ys, zs, lamb[sl], 0.0f, false, worst, thr);
+          for (int l = 0; l < REX_NLEG; ++l) {
+            if (l + 1 < REX_NLEG) { h[(l + 1) & 1].a = lim_load(REX_NCROW + 3 * l + 3); h[(l + 1) & 1].b = lim_load(REX_NCROW + 3 * l + 4); }
+            prefetch_fence();
+            if (!lim[l]) continue;                   // wave-uniform
+            solve_run<LPE, NY, 3, false>(h[l & 1], [&](int k) __attribute__((always_inline)) { return lim_load(REX_NCROW + 3 * l + k); }, l, ys, zs,
+                                         lam + REX_NCROW + 3 * l, lam, worst, thr);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int l = 0; l < REX_NLEG; ++l) {
+          if (__builtin_expect(!any_lim, 1)) break;  // wave-uniform
+          if (!lim[l]) continue;                     // wave-uniform
+          // (the three rows of a leg: the slice of row k + 1 is read from LDS while row k is solved)
+          RowSlice<NY> cur = lim_load(REX_NCROW + 3 * l);
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const int r = REX_NCROW + 3 * l + k;
+            RowSlice<NY> nxt = cur;
+            if (k + 1 < 3) { nxt = lim_load(r + 1); prefetch_fence(); }
+            if constexpr (kLimLamByLane) {
+              // the impulse of limit row 3 l + k lives in lane (3 l + k) % 4 of the group only (three registers instead of
+              // twelve): every lane evaluates the step on the register of that index, the owner's result goes round (one DPP
+              // broadcast inside the quad), the owner keeps the new impulse.  Two more instructions on a row that is rarely run.
+              const int own = (3 * l + k) & 3, idx = (3 * l + k) >> 2;   // (constants once the loops are unrolled)
+              float part = cur.jz * zs[l];
+#pragma unroll
+              for (int i = 0; i < NY; ++i) part = fmaf(cur.jy[i], ys[i], part);
+              const float vel = group_sum<LPE>(part);
+              const float nlo = fmaxf(fmaf(-cur.invd, vel, laml[idx] + cur.tgt), 0.0f);
+              const float dl = quad_bcast(nlo - laml[idx], own);
+              laml[idx] = p == own ? nlo : laml[idx];
+              worst = fmaxf(worst, fmaf(-thr, cur.invd, fabsf(dl)));
+#pragma unroll
+              for (int i = 0; i < NY; ++i) ys[i] = fmaf(cur.jy[i], dl, ys[i]);
+              zs[l] = fmaf(cur.jz, dl, zs[l]);
+            } else {
+              slice_step<LPE, NY>(cur, l, ys, zs, lam[r], 0.0f, false, worst, thr);   // (in place, also when the contact rows alternate)
+            }
             cur = nxt;
           }
         }
+      }
+      armp.template dv_sweep<LPE, NY>(ys, worst, thr);
+      REX_STAMP(t_s1);
+      if constexpr (SM::kBody) {
+        // link-box normals (among the normals they come before the toe points: the toe rows stay one pipelined block): one branch for
+        // the lot, one per GROUP (wave-uniform) -- base group (slots 0-3), then leg L's slots 4 + 2 L, 5 + 2 L -- and the first two rows of
+        // the next group read before a group is solved
+        if (bgroups != 0) {
+          RunHead<NY> h[2];
+          h[0].a = body_load(0, false); h[0].b = body_load(1, false);
+          h[1].a = body_load(4, true); h[1].b = body_load(5, true);
+          prefetch_fence();
+          if (bgroups & 1u)
+            solve_run<LPE, NY, 4, false>(h[0], [&](int k) __attribute__((always_inline)) { return body_load(k, false); }, -1, ys, zs, lamb, lamb, worst, thr);
 #pragma unroll
-        for (int l = 0; l < REX_NLEG; ++l) {
-          if (!((bgroups >> (1 + l)) & 1u)) continue;       // (a second slot is never filled before the first)
-          const bool two = ((bgroups >> (5 + l)) & 1u) != 0;
-          const BodySlice<NY> a = body_load<LPE, NY>(sm, ln, bodyoff, 4 + 2 * l, true);
-          BodySlice<NY> b = a;
-          if (two) { b = body_load<LPE, NY>(sm, ln, bodyoff, 5 + 2 * l, true); prefetch_fence(); }
-          body_solve<LPE, NY>(a, l, ys, zs, lamb[4 + 2 * l], 0.0f, false, worst, thr);
-          if (two) body_solve<LPE, NY>(b, l, ys, zs, lamb[5 + 2 * l], 0.0f, false, worst, thr);
+          for (int l = 0; l < REX_NLEG; ++l) {
+            if (l + 1 < REX_NLEG) { h[l & 1].a = body_load(6 + 2 * l, true); h[l & 1].b = body_load(7 + 2 * l, true); }
+            prefetch_fence();
+            if (!((bgroups >> (1 + l)) & 1u)) continue;       // (a second slot is never filled before the first)
+            // (one branch for the second slot, each side straight-line)
+            if ((bgroups >> (5 + l)) & 1u)
+              solve_run<LPE, NY, 2, false>(h[(l + 1) & 1], [&](int k) __attribute__((always_inline)) { return body_load(4 + 2 * l + k, true); }, l, ys, zs,
+                                           lamb + 4 + 2 * l, lamb, worst, thr);
+            else
+              solve_run<LPE, NY, 1, false>(h[(l + 1) & 1], [&](int k) __attribute__((always_inline)) { return body_load(4 + 2 * l + k, true); }, l, ys, zs,
+                                           lamb + 4 + 2 * l, lamb, worst, thr);
+          }
         }
+      }
+      REX_STAMP(t_s2);
+      RunHead<NY> hf;   // link-box friction: the first two rows of the base group, read behind the toe rows
+      if constexpr (SM::kBody) {
+        if (bgroups != 0) { hf.a = body_load(REX_NBSLOT, false); hf.b = body_load(REX_NBSLOT + 1, false); prefetch_fence(); }
       }
       if (any_contact) {
         // contact rows, pipelined; this lane's slice of the rows sits in registers (Jy, Jz, Kc, Ki)
@@ -1312,43 +1365,48 @@ __device__ __forceinline__ void pgs_dv(const SM& sm, ARMP& armp, PgsX& x, int p,
           zs[L] = fmaf(Jz[r], dl, zs[L]);
         }
       }
+      REX_STAMP(t_s3);
       if constexpr (SM::kBody) {
         // link-box friction pairs: after the toe friction rows; the coefficient of a slot sits in its first friction row
-        // (ground: the env's foot friction; link against link: kSelfMu)
-        // (the friction rows of a group are contiguous: rows 12 + 2 slot and 13 + 2 slot; the coefficient of a slot is word .y of its
-        //  FIRST friction row; each row's slice is read while the row before it is solved)
-        if (bgroups & 1u) {
-          BodySlice<NY> cur = body_load<LPE, NY>(sm, ln, bodyoff, REX_NBSLOT, false);
-          float coef = 0.0f;
+        // (ground: the env's foot friction; link against link: kSelfMu); the friction rows of a group are contiguous: rows
+        // 12 + 2 slot and 13 + 2 slot
+        if (bgroups != 0) {
+          RunHead<NY> h[2];
+          h[0] = hf;
+          h[1].a = body_load(REX_NBSLOT + 8, true); h[1].b = body_load(REX_NBSLOT + 9, true);
+          prefetch_fence();
+          if (bgroups & 1u)
+            solve_run<LPE, NY, 8, true>(h[0], [&](int k) __attribute__((always_inline)) { return body_load(REX_NBSLOT + k, false); }, -1, ys, zs,
+                                        lamb + REX_NBSLOT, lamb, worst, thr);
 #pragma unroll
-          for (int k = 0; k < 8; ++k) {
-            const int sl = k >> 1;
-            BodySlice<NY> nxt = cur;
-            if (k + 1 < 8) { nxt = body_load<LPE, NY>(sm, ln, bodyoff, REX_NBSLOT + k + 1, false); prefetch_fence(); }
-            if ((k & 1) == 0) coef = cur.c2.y;
-            body_solve<LPE, NY>(cur, -1, ys, zs, lamb[REX_NBSLOT + k], coef * lamb[sl], true, worst, thr);
-            cur = nxt;
-          }
-        }
-#pragma unroll
-        for (int l = 0; l < REX_NLEG; ++l) {
-          if (!((bgroups >> (1 + l)) & 1u)) continue;
-          const bool two = ((bgroups >> (5 + l)) & 1u) != 0;
-          const int r0 = REX_NBSLOT + 2 * (4 + 2 * l);                                   // first friction row of the leg's first slot
-          BodySlice<NY> cur = body_load<LPE, NY>(sm, ln, bodyoff, r0, true);
-          float coef = 0.0f;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            if (j >= 2 && !two) break;                                                    // wave-uniform
-            const int sl = 4 + 2 * l + (j >> 1);
-            BodySlice<NY> nxt = cur;
-            if (j + 1 < 2 || (j + 1 < 4 && two)) { nxt = body_load<LPE, NY>(sm, ln, bodyoff, r0 + j + 1, true); prefetch_fence(); }
-            if ((j & 1) == 0) coef = cur.c2.y;
-            body_solve<LPE, NY>(cur, l, ys, zs, lamb[r0 + j], coef * lamb[sl], true, worst, thr);
-            cur = nxt;
+          for (int l = 0; l < REX_NLEG; ++l) {
+            const int r0 = REX_NBSLOT + 2 * (4 + 2 * l);                                   // first friction row of the leg's first slot
+            if (l + 1 < REX_NLEG) { h[l & 1].a = body_load(r0 + 4, true); h[l & 1].b = body_load(r0 + 5, true); }
+            prefetch_fence();
+            if (!((bgroups >> (1 + l)) & 1u)) continue;
+            if ((bgroups >> (5 + l)) & 1u)
+              solve_run<LPE, NY, 4, true>(h[(l + 1) & 1], [&](int k) __attribute__((always_inline)) { return body_load(r0 + k, true); }, l, ys, zs, lamb + r0,
+                                          lamb + 4 + 2 * l, worst, thr);
+            else
+              solve_run<LPE, NY, 2, true>(h[(l + 1) & 1], [&](int k) __attribute__((always_inline)) { return body_load(r0 + k, true); }, l, ys, zs, lamb + r0,
+                                          lamb + 4 + 2 * l, worst, thr);
           }
         }
       }
+#ifdef REX_PROF
+      if (threadIdx.x == 0 && blockIdx.x < 1024) {
+        long long* p2 = g_prof2 + 16 * blockIdx.x;
+        int nb = 0, nl = 0;
+        if constexpr (SM::kBody) {
+          nb = (bgroups & 1u) ? 12 : 0;
+          for (int l = 0; l < REX_NLEG; ++l) nb += ((bgroups >> (1 + l)) & 1u) ? (((bgroups >> (5 + l)) & 1u) ? 6 : 3) : 0;
+        }
+        if (any_lim) for (int l = 0; l < REX_NLEG; ++l) nl += lim[l] ? 3 : 0;
+        p2[8] += nb; p2[9] += nl;
+        const long long t_s4 = clock64();
+        p2[10] += t_s1 - t_s0; p2[11] += t_s2 - t_s1; p2[12] += t_s3 - t_s2; p2[13] += t_s4 - t_s3; p2[14] += 1;
+      }
+#endif
       // (the per-lane cap is compiled in for mixed-task batches only: even as a scalar condition it lengthens the loop's
       // back edge enough to cost 2.3 % of a step)
       running = LANECAP ? (worst > 0.0f && it + 1 < lane_iterations) : worst > 0.0f;
@@ -1385,7 +1443,7 @@ __device__ __forceinline__ void pgs_dv(const SM& sm, ARMP& armp, PgsX& x, int p,
   armp.dv_gather();
 #ifdef REX_PROF
   if (threadIdx.x == 0 && blockIdx.x < 1024) {
-    long long* p2 = g_prof2 + 8 * blockIdx.x;
+    long long* p2 = g_prof2 + 16 * blockIdx.x;
     p2[0] += t_dv1 - t_dv0; p2[1] += t_dv2 - t_dv1; p2[2] += clock64() - t_dv2;
   }
 #endif
@@ -1655,7 +1713,9 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
     // the one-env-per-lane layout), the plain -target (0 when the row is out of reach) for the pipelined contact rows of a
     // lane group (pgs_dv: the group sum is then vel - target); .w = 0 there: the word of the lanes that own no component
     c2.y = contact_dv && !REX_TARGET_BY_DIVISION(SM::kEpw, ARMP::NM > 12) ? (c2.z != 0.0f ? -c2.y : 0.0f) : c2.y * invd;
-    sm.row(r, 2) = make_float4(c2.x, c2.y, invd, kSplitLegs ? 0.0f : diag);
+    // (lane groups, joint-limit rows: read from LDS row by row in the sweep -- (tgt, invd) as one aligned pair, the zero in word 9)
+    if (kSplitLegs && !contact_dv) sm.row(r, 2) = make_float4(c2.x, 0.0f, c2.y, invd);
+    else sm.row(r, 2) = make_float4(c2.x, c2.y, invd, kSplitLegs ? 0.0f : diag);
   };
   if constexpr (kSplitLegs) {
     // lane p finishes the contact rows [kBlock p, kBlock (p + 1)): consecutive rows meet in one lane, and the couplings of
@@ -1743,7 +1803,7 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
         const float invd = c2.z != 0.0f ? __builtin_amdgcn_rcpf(diag) : 0.0f;
         sm.brow(r, 0) = make_float4(gw[0], gw[1], gw[2], gw[3]);
         sm.brow(r, 1) = make_float4(gw[4], gw[5], c1.z, c1.w);
-        sm.brow(r, 2) = make_float4(c2.x, r < REX_NBSLOT ? c2.y * invd : c2.y, invd, 0.0f);   // friction rows keep their coefficient in .y
+        sm.brow(r, 2) = make_float4(c2.x, 0.0f, r < REX_NBSLOT ? c2.y * invd : c2.y, invd);   // (z2, 0, tgt, invd); friction rows keep their coefficient as tgt
       }
     }
   }

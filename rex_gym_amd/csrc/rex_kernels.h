@@ -1089,7 +1089,7 @@ __global__ __launch_bounds__(REX_WAVE) REX_STEP_KERNEL_ATTR void rex_step_kernel
   epilogue(live, owner);
 #ifdef REX_PROF
   if (threadIdx.x == 0 && blockIdx.x < 1024) {
-    long long* p2 = g_prof2 + 8 * blockIdx.x;
+    long long* p2 = g_prof2 + 16 * blockIdx.x;
     p2[3] += t_command - t_kernel; p2[4] += t_substeps - t_command; p2[5] += clock64() - t_substeps;
   }
 #endif
@@ -1097,8 +1097,8 @@ __global__ __launch_bounds__(REX_WAVE) REX_STEP_KERNEL_ATTR void rex_step_kernel
 #ifdef REX_PROF
   if (threadIdx.x == 0 && blockIdx.x < 1024) {
     g_prof[10 * blockIdx.x + 8] += clock64() - t_kernel; g_prof[10 * blockIdx.x + 9] += 1;
-    g_prof2[8 * blockIdx.x + 6] += (long long)wall_clock64() - t_wall;   // the 100 MHz counter over the same span: calibrates clock64()
-    g_prof2[8 * blockIdx.x + 7] = t_wall;                                // when this block of the LAST launch started
+    g_prof2[16 * blockIdx.x + 6] += (long long)wall_clock64() - t_wall;   // the 100 MHz counter over the same span: calibrates clock64()
+    g_prof2[16 * blockIdx.x + 7] = t_wall;                                // when this block of the LAST launch started
   }
 #endif
 }

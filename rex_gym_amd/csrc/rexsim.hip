@@ -785,8 +785,8 @@ REX_API int rex_debug_prof(long long* out, int reset) {
   return REX_OK;
 }
 REX_API int rex_debug_prof2(long long* out, int reset) {   /* the sections of the sweep routine (pgs_dv) */
-  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(rex::g_prof2), sizeof(long long) * 8 * 1024) != hipSuccess) return REX_EHIP;
-  if (reset) { static long long z[8 * 1024]; if (hipMemcpyToSymbol(HIP_SYMBOL(rex::g_prof2), z, sizeof(z)) != hipSuccess) return REX_EHIP; }
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(rex::g_prof2), sizeof(long long) * 16 * 1024) != hipSuccess) return REX_EHIP;
+  if (reset) { static long long z[16 * 1024]; if (hipMemcpyToSymbol(HIP_SYMBOL(rex::g_prof2), z, sizeof(z)) != hipSuccess) return REX_EHIP; }
   return REX_OK;
 }
 #endif

@@ -15,7 +15,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-so = os.path.join(ROOT, "scratch", "librexsim_prof.so")
+so = os.environ.get("REX_PROF_LIB") or os.path.join(ROOT, "scratch", "librexsim_prof.so")   # REX_PROF_LIB: a prebuilt -DREX_PROF library (A/B)
 os.makedirs(os.path.dirname(so), exist_ok=True)
 import rex_gym_amd.build as b
 if not os.path.exists(so) or "--rebuild" in sys.argv:
@@ -53,7 +53,7 @@ def window(steps, label):
     torch.cuda.synchronize()
     out = np.zeros((1024, 10), np.int64)
     L.rex_debug_prof(out.ctypes.data, 0)
-    out2 = np.zeros((1024, 8), np.int64)
+    out2 = np.zeros((1024, 16), np.int64)
     L.rex_debug_prof2(out2.ctypes.data, 0)
     out2 = out2[out[:, 4] > 0].astype(float)
     out = out[out[:, 4] > 0].astype(float)
@@ -84,6 +84,20 @@ def window(steps, label):
         su, lp, hb = (np.mean(out2[:, k] / sub) for k in range(3))
         print("  pgs = row couplings %.0f + sweep set-up %.0f + sweep loop %.0f (%.0f per sweep) + hand-back %.0f" %
               (np.mean(pgs / sub) - su - lp - hb, su, lp, out2[:, 1].sum() / sw.sum(), hb))
+    # the workgroup that ends the launch: its own sections, and what its sweeps are made of (thread 0's sweeps: an env that has
+    # converged no longer counts its wave's rows)
+    w = int(np.argmax(tot / sub))
+    print("  SLOWEST workgroup, cycles/substep: total %.0f = legs %.0f + base chol %.0f + finish rows %.0f + pgs %.0f + back-subst/integrate %.0f; "
+          "%.1f sweeps/substep" % (tot[w] / sub[w], legs[w] / sub[w], chol[w] / sub[w], fin[w] / sub[w], pgs[w] / sub[w], rest[w] / sub[w], sw[w] / sub[w]))
+    if out2[w, 10:14].sum() > 0:
+        nsw = max(out2[w, 14], 1.0)
+        c = out2[w, 10:14] / nsw
+        print("    per sweep: %.1f link-box rows + %.1f joint-limit rows + 24 toe rows; cycles: limit rows %.0f, link-box normals %.0f, toe rows %.0f, "
+              "link-box friction %.0f (sum %.0f of %.0f per sweep)" % (out2[w, 8] / nsw, out2[w, 9] / nsw, c[0], c[1], c[2], c[3], c.sum(), out2[w, 1] / nsw))
+        nsa = max(out2[:, 14].sum(), 1.0)
+        ca = out2[:, 10:14].sum(0) / nsa
+        print("    all workgroups, per sweep: %.1f link-box rows + %.1f joint-limit rows; cycles: limit rows %.0f, link-box normals %.0f, toe rows %.0f, "
+              "link-box friction %.0f" % (out2[:, 8].sum() / nsa, out2[:, 9].sum() / nsa, ca[0], ca[1], ca[2], ca[3]))
 
 
 window(20, "first 20 steps after reset")
