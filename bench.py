@@ -195,16 +195,26 @@ class Rollout:
                 idx = torch.randperm(n, device=self.dev, generator=self.gen)[: max(1, n // 32)].to(torch.int32)
                 env.reset(idx)
 
-    def run(self, steps, gather):
+    def run(self, steps, gather, segment_launch=False):
+        """segment_launch: the steps of a segment in ONE launch (RexBatchEnv.step_segment / rex_step_segment: the actions of a segment
+        are drawn a segment ahead anyway) instead of one launch per step; the same steps, the same results, bit for bit."""
         from rex_gym_amd.sharding import gather_rollout
         T, seg, sacts, outs = self.T, self.seg, self.sacts, self.outs
         pending = [None, None]
         step = self.env.step
-        for k in range(self.clock, self.clock + steps):
+        k, end = self.clock, self.clock + steps
+        while k < end:
             b, t = (k // T) & 1, k % T
             if t == 0 and pending[b] is not None:
                 pending[b].wait(); pending[b] = None         # this buffer's previous segment has left before it is overwritten
-            step(sacts[b][t], outs[b][t])
+            if segment_launch:
+                m = min(T - t, end - k)
+                sb = seg[b]
+                self.env.step_segment(sb["action"][t:t + m], out=(sb["obs"][t:t + m], sb["reward"][t:t + m], sb["done"][t:t + m]))
+                k += m; t += m - 1
+            else:
+                step(sacts[b][t], outs[b][t])
+                k += 1
             if t == T - 1:
                 if gather:
                     pending[b] = gather_rollout(seg[b], async_op=True, slot=b)
@@ -280,6 +290,8 @@ def main():
                     "reward, done of the shard) is all-gathered to all ranks -- the learner hand-off, the design's one collective")
     ap.add_argument("--no-gather", action="store_true", help="time the independent shards only (no learner hand-off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--segment-launch", action="store_true", help="the timed region launches once per rollout segment (rex_step_segment) instead of once per step")
+    ap.add_argument("--no-segment-launch", action="store_true", help="skip the secondary segment-launch measurement")
     ap.add_argument("--no-walking-workload", action="store_true", help="skip the secondary gait-clock-1.5 measurement (profiling runs)")
     ap.add_argument("--no-stagger", action="store_true", help="developer A/B runs only: pre-roll without the staggered resets")
     ap.add_argument("--no-device-timing", action="store_true", help="developer A/B runs only: no device-side kernel timestamps in the timed region")
@@ -359,12 +371,12 @@ def main():
     pool, acts, seg, seg_bytes, run, lo, hi = ro.pool, ro.acts, ro.seg, ro.seg_bytes, ro.run, ro.lo, ro.hi
     do_gather = not args.no_gather
 
-    run(args.warmup, do_gather)
+    run(args.warmup, do_gather, args.segment_launch)
     if not args.no_device_timing:
         env.set_timing(3)      # device-side (first wave start, last wave end) ticks of the next launches: no event, no sync in the loop
     barrier()
     t0 = time.perf_counter()
-    run(args.steps, do_gather)
+    run(args.steps, do_gather, args.segment_launch)
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     barrier()
@@ -404,6 +416,46 @@ def main():
     if dist is not None and do_gather and args.config is None and args.envs_per_gpu is None and not args.mixed \
             and (args.task, args.signal, args.terrain, args.mark) == ("walk", "ik", "plane", "base"):
         north_star = north_star_workload(args, dev, local_rank, rank, world, dist, barrier, T)
+
+    # The same K steps with the steps of a segment in ONE launch (rex_step_segment): the timed region above launches once per step, the
+    # Gym surface a policy in the loop needs; a rollout whose actions are known a segment ahead -- this benchmark's random-action
+    # rollouts draw them a segment ahead -- does not have to.  Same steps, same results bit for bit; what changes is that a wave goes on
+    # to its envs' next step without waiting for the slowest wave of every step.
+    segment_launch = None
+    if not args.no_segment_launch and not args.segment_launch:
+        run(2 * T, do_gather, True)
+        barrier()
+        t3 = time.perf_counter()
+        run(args.steps, do_gather, True)
+        torch.cuda.synchronize(dev)
+        e_seg = time.perf_counter() - t3
+        barrier()
+        if dist is not None:
+            tt = torch.tensor([e_seg], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            e_seg = float(tt.item())
+        # ... and with segments four times as long (their own buffers; the same env goes on): the longer the segment, the closer a
+        # wave's sum of step times is to the mean
+        ro4 = Rollout(env, n, 4 * T, dev, gen)
+        ro4.run(8 * T, do_gather, True)
+        barrier()
+        t4 = time.perf_counter()
+        ro4.run(args.steps, do_gather, True)
+        torch.cuda.synchronize(dev)
+        e_seg4 = time.perf_counter() - t4
+        barrier()
+        if dist is not None:
+            tt = torch.tensor([e_seg4], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            e_seg4 = float(tt.item())
+        del ro4
+        segment_launch = {"steps_per_launch": T, "value": n * world * args.steps / e_seg, "unit": "env-steps/s", "ms_per_step": e_seg / args.steps * 1e3,
+                          "vs_one_launch_per_step": elapsed / e_seg,
+                          "longer_segments": {"steps_per_launch": 4 * T, "value": n * world * args.steps / e_seg4, "ms_per_step": e_seg4 / args.steps * 1e3,
+                                              "vs_one_launch_per_step": elapsed / e_seg4},
+                          "what": "the timed region again, the T steps of a rollout segment in one launch (RexBatchEnv.step_segment -> rex_step_segment; "
+                                  "actions drawn a segment ahead, as in the timed region); results bit-identical to the per-step launches "
+                                  "(tests/test_gpu_parity.py::test_segment_launch_is_bit_identical_to_single_steps)"}
 
     # does this sim regroup its envs every step?  (two sorting launches behind each step kernel, outside kernel_ms: include/rexsim.h)
     probe = torch.empty(n, dtype=torch.int32, device=dev)
@@ -516,6 +568,10 @@ def main():
         }
         if gather_info:
             out["rollout_gather"] = gather_info
+        if segment_launch:
+            out["segment_launch"] = segment_launch
+        out["config"]["launches"] = (f"one launch per {T}-step rollout segment (rex_step_segment)" if args.segment_launch else
+                                     "one launch per env.step() (rex_step)")
         if north_star:
             out["north_star_workload"] = north_star
         if walking:

@@ -276,6 +276,21 @@ REX_API int rex_reset(RexSim* sim, const int32_t* d_indices, int n, float* d_obs
 REX_API int rex_step(RexSim* sim, const float* d_action, float* d_obs, float* d_reward,
              uint8_t* d_done, float* d_motor_cmd, void* stream);
 
+/* A rollout SEGMENT in one launch: num_steps consecutive env.step() calls for every env, for a caller that already holds the actions
+ * of the whole segment (open-loop rollouts: random-action throughput runs, replayed action tapes, a policy that acts on a stale
+ * observation by design).  Step t reads d_action[t] and writes d_obs[t], d_reward[t], d_done[t], d_motor_cmd[t]; the blocks are
+ *   d_action [T, N, action_dim]   d_obs [T, N, obs_dim]   d_reward [T, N]   d_done [T, N] uint8   d_motor_cmd [T, N, num_motors] (nullable)
+ * and the results are BIT-IDENTICAL to T calls of rex_step on the slices (tests/test_gpu_parity.py::
+ * test_segment_launch_is_bit_identical_to_single_steps): the same step code runs T times, an env's state staying in registers in
+ * between.  What it buys: a launch ends with its slowest wave; stepping one by one pays the slowest wave of EVERY step (a freshly
+ * reset or fallen robot that runs into the solver's sweep cap), a segment pays the largest SUM over a wave's steps.  It replaces
+ * nothing of the reference's surface (env.step() stays one rex_step): the reference has no counterpart -- its envs step one
+ * action at a time (rex_gym_env.py:369).  Envs that finish an episode inside the segment are reset in the launch when the sim was
+ * created with auto_reset, exactly as rex_step does; sims that regroup their envs between steps regroup between segments.
+ * num_steps * N * max(action_dim, obs_dim, num_motors) must stay below 2^31. */
+REX_API int rex_step_segment(RexSim* sim, int num_steps, const float* d_action, float* d_obs, float* d_reward,
+             uint8_t* d_done, float* d_motor_cmd, void* stream);
+
 /* HIP event timing of rex_step launches on their own stream (ms).  rex_set_timing(1): one event pair, read with
  * rex_last_step_ms (synchronises on the launch).  rex_set_timing(2): a ring of event pairs around the last 256 launches,
  * recorded without any host synchronisation between launches (the stream stays full, so a duration is that of the kernel

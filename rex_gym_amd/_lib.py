@@ -59,6 +59,8 @@ _SIGS = {
     "rex_reset": ([ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p], ctypes.c_int),
     "rex_step": ([ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                   ctypes.c_void_p, ctypes.c_void_p], ctypes.c_int),
+    "rex_step_segment": ([ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                          ctypes.c_void_p, ctypes.c_void_p], ctypes.c_int),
     "rex_set_timing": ([ctypes.c_void_p, ctypes.c_int], ctypes.c_int),
     "rex_last_step_ms": ([ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)], ctypes.c_int),
     "rex_ik_solve": ([ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,

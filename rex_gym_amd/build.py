@@ -2,7 +2,7 @@
 
 The library is compiled variant group by variant group -- one translation unit per group of rex_step_kernel /
 rex_settle_kernel instantiations (csrc/rex_step_*.hip, rex_settle_*.hip) next to the C ABI (csrc/rexsim.hip) -- in
-parallel, then linked: 31 s on 8 cores (13 jobs: the step units are compiled twice, see TRACE_SOURCES) where the single translation
+parallel, then linked: ~45 s on 8 cores (18 jobs: the step units are compiled three times, see TRACE_SOURCES / SEG_SOURCES) where the single translation
 unit took over 2 minutes.
 
 Developer knobs (never needed for the product build):
@@ -27,6 +27,10 @@ SOURCES = ["rexsim.hip"] + sorted(GROUPS)
 # the step translation units are compiled a second time with -DREX_TU_TRACE=1: the kernel instantiations with the event trace
 # (rex_set_event_trace, a debug aid of the parity tests) compiled in -- the product kernels carry none of it
 TRACE_SOURCES = sorted(f for f in GROUPS if f.startswith("rex_step_"))
+# ... and a third time with -DREX_TU_SEG=1: the instantiations behind rex_step_segment (a loop over the steps of a rollout segment around
+# the step; kept apart because the loop costs registers -- what the body forms from loop invariants is hoisted -- and rex_step's own
+# kernels stay exactly what they were)
+SEG_SOURCES = TRACE_SOURCES
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h"))   # every header the sources can include
 # -ffp-contract=on: a * b + c inside one expression is one fma and nothing else is fused -- the arithmetic of a kernel is fixed by its
 # source and does not depend on what else is compiled into it (hipcc's default lets the backend fuse across statements by heuristics:
@@ -61,7 +65,7 @@ _STUB = """// stub of a variant group left out of a developer build (REX_BUILD_O
 
 
 def _stub_source(tu, trace=False):
-    name = tu[:-4] + ("_trace" if trace else "")
+    name = tu[:-4] + (trace if isinstance(trace, str) else ("_trace" if trace else ""))
     if name.startswith("rex_step_"):
         sig = "void rex_launch_%s(RexSim*, int, hipStream_t, const float*, float*, float*, uint8_t*, float*)" % name[4:]
     else:
@@ -88,21 +92,26 @@ def build(force=False, verbose=False, lib_path=None, defines=(), unity=False, on
                         "#define REX_LAUNCH_STEP(EPW, ARM, MIXED, BODY) hipLaunchKernelGGL((rex::rex_step_kernel<EPW, ARM, MIXED, BODY, true>), "
                         "dim3(blocks), dim3(REX_WAVE), 0, st, s->dev, s->d_state, s->d_snap, a, o, r, d, m)\n")
                 f.write("".join('#include "%s"\n' % os.path.join(CSRC, s) for s in TRACE_SOURCES))
+                f.write("#undef REX_STEP_LAUNCHER\n#undef REX_LAUNCH_STEP\n"
+                        "#define REX_STEP_LAUNCHER(group) rex_launch_step_##group##_seg\n"
+                        "#define REX_LAUNCH_STEP(EPW, ARM, MIXED, BODY) hipLaunchKernelGGL((rex::rex_step_kernel<EPW, ARM, MIXED, BODY, false, true>), "
+                        "dim3(blocks), dim3(REX_WAVE), 0, st, s->dev, s->d_state, s->d_snap, a, o, r, d, m)\n")
+                f.write("".join('#include "%s"\n' % os.path.join(CSRC, s) for s in SEG_SOURCES))
             cmd = [hipcc] + flags + ["-shared", uni, "-o", lib_path]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
             return lib_path
         jobs_list = []
-        for s, trace in [(s, False) for s in SOURCES] + [(s, True) for s in TRACE_SOURCES]:
+        for s, trace in [(s, "") for s in SOURCES] + [(s, "_trace") for s in TRACE_SOURCES] + [(s, "_seg") for s in SEG_SOURCES]:
             src = os.path.join(CSRC, s)
-            tag = "_trace" if trace else ""
+            tag = trace
             if keep is not None and s in GROUPS and GROUPS[s] not in keep:
                 src = os.path.join(tmp, "stub_" + s[:-4] + tag + ".hip")
                 with open(src, "w") as f:
                     f.write(_stub_source(s, trace))
             obj = os.path.join(tmp, s[:-4] + tag + ".o")
-            jobs_list.append(([hipcc] + flags + (["-DREX_TU_TRACE=1"] if trace else []) + ["-c", src, "-o", obj], obj))
+            jobs_list.append(([hipcc] + flags + ({"_trace": ["-DREX_TU_TRACE=1"], "_seg": ["-DREX_TU_SEG=1"]}.get(trace, [])) + ["-c", src, "-o", obj], obj))
 
         def run(job):
             if verbose:

@@ -229,6 +229,7 @@ enum { kNzGoal = 0, kNzRewardRpy = 1, kNzFallenRpy = 2, kNzObsRpy = 3, kNzObsRat
 
 struct DevCfg {
   int32_t n, env_index_base, task, signal, action_repeat, iterations;
+  int32_t nsteps;            // env.step() calls per launch (rex_step: 1; rex_step_segment: the segment's length)
   float dt, kp, kd, res_thr;
   // the reference's clocks are Python floats: time step and gait clock factor as the caller wrote them, in double
   // (host: as_written), for the controller's discrete decisions (rexsim.h, "Clocks")
@@ -854,11 +855,16 @@ __device__ __forceinline__ void gather_legs(const SM& sm, int leg0, EnvState& e,
 #ifndef REX_FAST_EPW
 #define REX_FAST_EPW 4
 #endif
-template <int EPW, bool ARM, bool MIXED, bool BODY, bool TRACE = false>
+template <int EPW, bool ARM, bool MIXED, bool BODY, bool TRACE = false, bool SEG = false>
 __global__ __launch_bounds__(REX_WAVE) REX_STEP_KERNEL_ATTR void rex_step_kernel(DevCfg c, float* __restrict__ state, const float* __restrict__ snap,
-                                                            const float* __restrict__ action, float* __restrict__ obs_out,
-                                                            float* __restrict__ reward_out, uint8_t* __restrict__ done_out,
-                                                            float* __restrict__ cmd_out) {
+                                                            const float* __restrict__ action0, float* __restrict__ obs_out0,
+                                                            float* __restrict__ reward_out0, uint8_t* __restrict__ done_out0,
+                                                            float* __restrict__ cmd_out0) {
+  // SEG (the instantiations behind rex_step_segment; every step translation unit is compiled once more with -DREX_TU_SEG=1): one launch =
+  // c.nsteps consecutive env.step() calls of the shard, a rollout segment whose actions the caller already holds -- action0 /
+  // obs_out0 / ... are then [nsteps][n][...] blocks.  Without SEG the loop below runs once and folds away: rex_step's kernels.  An env's state stays in its wave's
+  // registers from step to step; a wave goes on to ITS envs' next step as soon as it has finished this one, so the launch ends with
+  // the largest SUM of a wave's step times instead of paying the slowest wave of every step.
   // EPW envs share this wave (host picks it, rex_step): a small batch is spread over MORE, emptier waves because
   // idle SIMDs are free and a wave leaves the PGS sweep loop only when its slowest env has converged (and skips
   // only the legs no env of the wave has in contact), so fewer envs per wave means fewer sweeps and rows per
@@ -922,9 +928,23 @@ __global__ __launch_bounds__(REX_WAVE) REX_STEP_KERNEL_ATTR void rex_step_kernel
 
   EnvState e;
   load_env<NM, NL>(state, c.n, i, e, leg0);
+  const int i_env = i, leg0_env = leg0;
+#pragma clang loop unroll(disable)
+  for (int seg_step = 0; seg_step < (SEG ? c.nsteps : 1); ++seg_step) {
+  // SEG: an opaque copy of the env index per step: otherwise every address the body forms from it (state words, history ring, output
+  // rows: ~100 registers' worth) is loop-invariant, hoisted in front of the loop and carried through the solver sweeps
+  int i = i_env, leg0 = leg0_env;
+  if constexpr (SEG) asm volatile("" : "+v"(i), "+v"(leg0));   // (and of the lane's leg: the per-leg constants of the controller and of the leg pass)
+  // this step's slices of the caller's blocks (32-bit element offsets: rex_step_segment checks nsteps * n * width < 2^31)
+  const float* __restrict__ action = action0 + (unsigned)(seg_step * c.n * c.action_dim);
+  float* __restrict__ obs_out = obs_out0 + (unsigned)(seg_step * c.n * c.obs_dim);
+  float* __restrict__ reward_out = reward_out0 + (unsigned)(seg_step * c.n);
+  uint8_t* __restrict__ done_out = done_out0 + (unsigned)(seg_step * c.n);
+  float* __restrict__ cmd_out = cmd_out0 ? cmd_out0 + (unsigned)(seg_step * c.n * NM) : nullptr;
+  REX_STAMP(t_step);
   e.sweeps = 0;
   MS ms;
-  take_overheat(e, leg0, ms);
+  take_overheat(e, leg0, ms);      // (a later step of a segment: e.overheat holds all counters again -- gather_legs)
   const uint32_t motor_en0 = e.motor_en;
   float act[8];
 #pragma unroll
@@ -1090,9 +1110,11 @@ __global__ __launch_bounds__(REX_WAVE) REX_STEP_KERNEL_ATTR void rex_step_kernel
 #ifdef REX_PROF
   if (threadIdx.x == 0 && blockIdx.x < 1024) {
     long long* p2 = g_prof2 + 16 * blockIdx.x;
-    p2[3] += t_command - t_kernel; p2[4] += t_substeps - t_command; p2[5] += clock64() - t_substeps;
+    p2[3] += t_command - t_step; p2[4] += t_substeps - t_command; p2[5] += clock64() - t_substeps;
   }
 #endif
+  if constexpr (SEG) mirror_sync();   // the next step's LDS writes and history reads come behind this step's LDS reads and history stores
+  }
   if (c.clock && threadIdx.x == 0) atomicMax(&c.clock[2 * (blockIdx.x & (REX_CLOCK_WAYS - 1)) + 1], (unsigned long long)wall_clock64());
 #ifdef REX_PROF
   if (threadIdx.x == 0 && blockIdx.x < 1024) {
@@ -1259,6 +1281,11 @@ void rex_launch_step_arm_trace(RexSim* s, int blocks, hipStream_t st, const floa
 void rex_launch_step_mixed_base_trace(RexSim* s, int blocks, hipStream_t st, const float* a, float* o, float* r, uint8_t* d, float* m);
 void rex_launch_step_mixed_arm_trace(RexSim* s, int blocks, hipStream_t st, const float* a, float* o, float* r, uint8_t* d, float* m);
 void rex_launch_step_body_trace(RexSim* s, int blocks, hipStream_t st, const float* a, float* o, float* r, uint8_t* d, float* m);
+void rex_launch_step_base_seg(RexSim* s, int blocks, hipStream_t st, const float* a, float* o, float* r, uint8_t* d, float* m);
+void rex_launch_step_arm_seg(RexSim* s, int blocks, hipStream_t st, const float* a, float* o, float* r, uint8_t* d, float* m);
+void rex_launch_step_mixed_base_seg(RexSim* s, int blocks, hipStream_t st, const float* a, float* o, float* r, uint8_t* d, float* m);
+void rex_launch_step_mixed_arm_seg(RexSim* s, int blocks, hipStream_t st, const float* a, float* o, float* r, uint8_t* d, float* m);
+void rex_launch_step_body_seg(RexSim* s, int blocks, hipStream_t st, const float* a, float* o, float* r, uint8_t* d, float* m);
 void rex_launch_settle_base(RexSim* s, int nrec, hipStream_t st, float* snap);   // <false, *>
 void rex_launch_settle_arm(RexSim* s, int nrec, hipStream_t st, float* snap);    // <true, *>
 
@@ -1267,13 +1294,18 @@ void rex_launch_settle_arm(RexSim* s, int nrec, hipStream_t st, float* snap);   
 #ifndef REX_TU_TRACE
 #define REX_TU_TRACE 0
 #endif
+#ifndef REX_TU_SEG
+#define REX_TU_SEG 0      /* -DREX_TU_SEG=1: the segment instantiations (rex_step_segment; launcher names end in _seg) */
+#endif
 #if REX_TU_TRACE
 #define REX_STEP_LAUNCHER(group) rex_launch_step_##group##_trace
+#elif REX_TU_SEG
+#define REX_STEP_LAUNCHER(group) rex_launch_step_##group##_seg
 #else
 #define REX_STEP_LAUNCHER(group) rex_launch_step_##group
 #endif
 #define REX_LAUNCH_STEP(EPW, ARM, MIXED, BODY)                                                                                  \
-  hipLaunchKernelGGL((rex::rex_step_kernel<EPW, ARM, MIXED, BODY, REX_TU_TRACE != 0>), dim3(blocks), dim3(REX_WAVE), 0, st, s->dev, s->d_state, s->d_snap, \
+  hipLaunchKernelGGL((rex::rex_step_kernel<EPW, ARM, MIXED, BODY, REX_TU_TRACE != 0, REX_TU_SEG != 0>), dim3(blocks), dim3(REX_WAVE), 0, st, s->dev, s->d_state, s->d_snap, \
                      a, o, r, d, m)
 #define REX_LAUNCH_BY_EPW(ARM, MIXED, BODY)                                           \
   do {                                                                                \

@@ -4,6 +4,7 @@
 // The step and settle kernels are instantiated in rex_step_*.hip / rex_settle.hip (rex_kernels.h); this file holds the
 // C ABI, the reset kernel and the small kernels (regrouping, controller-only entry points).
 #include "rex_kernels.h"
+#include <algorithm>
 #include <vector>
 
 namespace rex {
@@ -396,6 +397,7 @@ int rex_create(const RexConfig* cfg, int device, float* d_state, void* stream, R
   s->have_timing = 0;
   rex::DevCfg& d = s->dev;
   d.n = cfg->num_envs; d.env_index_base = cfg->env_index_base; d.task = cfg->task; d.signal = cfg->signal;
+  d.nsteps = 1;
   d.action_repeat = cfg->action_repeat; d.iterations = cfg->solver_iterations; d.dt = cfg->sim_time_step;
   d.kp = cfg->motor_kp; d.kd = cfg->motor_kd; d.res_thr = sqrtf(fmaxf(cfg->solver_residual_threshold, 0.0f)); d.backwards = cfg->backwards; d.target_position = cfg->target_position;
   d.seed_lo = (uint32_t)cfg->seed; d.seed_hi = (uint32_t)(cfg->seed >> 32);
@@ -627,9 +629,25 @@ int rex_reset(RexSim* s, const int32_t* d_indices, int n, float* d_obs, void* st
   return REX_OK;
 }
 
+static int step_launch(RexSim* s, int num_steps, const float* d_action, float* d_obs, float* d_reward, uint8_t* d_done, float* d_motor_cmd, void* stream);
+
 int rex_step(RexSim* s, const float* d_action, float* d_obs, float* d_reward, uint8_t* d_done, float* d_motor_cmd, void* stream) {
   if (!s || !d_action || !d_obs || !d_reward || !d_done) return fail(REX_EINVAL, "rex_step: null pointer%s", "");
+  return step_launch(s, 1, d_action, d_obs, d_reward, d_done, d_motor_cmd, stream);
+}
+
+int rex_step_segment(RexSim* s, int num_steps, const float* d_action, float* d_obs, float* d_reward, uint8_t* d_done, float* d_motor_cmd, void* stream) {
+  if (!s || !d_action || !d_obs || !d_reward || !d_done) return fail(REX_EINVAL, "rex_step_segment: null pointer%s", "");
+  if (num_steps < 1) return fail(REX_EINVAL, "rex_step_segment: num_steps must be at least 1%s", "");
+  const long long width = std::max(std::max(rex_action_dim(&s->cfg), rex_obs_dim(&s->cfg)), rex_num_motors(&s->cfg));
+  if ((long long)num_steps * s->cfg.num_envs * width >= (1ll << 31))
+    return fail(REX_EINVAL, "rex_step_segment: a segment this long exceeds the 32-bit element offsets of its blocks (num_steps * num_envs * row width < 2^31)%s", "");
+  return step_launch(s, num_steps, d_action, d_obs, d_reward, d_done, d_motor_cmd, stream);
+}
+
+static int step_launch(RexSim* s, int num_steps, const float* d_action, float* d_obs, float* d_reward, uint8_t* d_done, float* d_motor_cmd, void* stream) {
   HIPCHK(hipSetDevice(s->device));
+  s->dev.nsteps = num_steps;
   hipStream_t st = (hipStream_t)stream;
   const int blocks = s->d_slot_env ? s->mixed_blocks : (s->cfg.num_envs + s->epw - 1) / s->epw;
   hipEvent_t e0 = s->ev0, e1 = s->ev1;
@@ -794,11 +812,27 @@ REX_API int rex_debug_prof2(long long* out, int reset) {   /* the sections of th
 
 static void launch_step(RexSim* s, int blocks, hipStream_t st, const float* a, float* o, float* r, uint8_t* d, float* m) {
   const bool arm = s->cfg.mark == REX_MARK_ARM;
+  if (s->dev.trace && s->dev.nsteps > 1) {   // a segment under the event trace (debug runs): step by step through the _trace kernels
+    const int T = s->dev.nsteps, n = s->cfg.num_envs;
+    const int ad = rex_action_dim(&s->cfg), od = rex_obs_dim(&s->cfg), nm = rex_num_motors(&s->cfg);
+    s->dev.nsteps = 1;
+    for (int t = 0; t < T; ++t)
+      launch_step(s, blocks, st, a + (size_t)t * n * ad, o + (size_t)t * n * od, r + (size_t)t * n, d + (size_t)t * n, m ? m + (size_t)t * n * nm : nullptr);
+    s->dev.nsteps = T;
+    return;
+  }
   if (s->dev.trace) {   // rex_set_event_trace: the instantiations with the event trace compiled in (debug runs)
     if (s->cfg.task == REX_TASK_MIXED) { if (arm) rex_launch_step_mixed_arm_trace(s, blocks, st, a, o, r, d, m); else rex_launch_step_mixed_base_trace(s, blocks, st, a, o, r, d, m); }
     else if (s->cfg.body_contacts) rex_launch_step_body_trace(s, blocks, st, a, o, r, d, m);
     else if (arm) rex_launch_step_arm_trace(s, blocks, st, a, o, r, d, m);
     else rex_launch_step_base_trace(s, blocks, st, a, o, r, d, m);
+    return;
+  }
+  if (s->dev.nsteps > 1) {   // rex_step_segment: the instantiations with the loop over the segment's steps
+    if (s->cfg.task == REX_TASK_MIXED) { if (arm) rex_launch_step_mixed_arm_seg(s, blocks, st, a, o, r, d, m); else rex_launch_step_mixed_base_seg(s, blocks, st, a, o, r, d, m); }
+    else if (s->cfg.body_contacts) rex_launch_step_body_seg(s, blocks, st, a, o, r, d, m);
+    else if (arm) rex_launch_step_arm_seg(s, blocks, st, a, o, r, d, m);
+    else rex_launch_step_base_seg(s, blocks, st, a, o, r, d, m);
     return;
   }
   if (s->cfg.task == REX_TASK_MIXED) {   // lane groups only (rex_create caps the envs per wave at 16)

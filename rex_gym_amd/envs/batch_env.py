@@ -403,6 +403,56 @@ class RexBatchEnv:
         _lib.check(self._L.rex_step(self._h, a.data_ptr(), out.p_obs, out.p_reward, out.p_done, self._p_cmd, self._stream_ptr()), "rex_step")
         return out.obs, out.reward, out.done_bool, self._info
 
+    def step_segment(self, actions, out=None, motor_cmd=None):
+        """A rollout segment in ONE launch (rex_step_segment): actions [T, N, action_dim] that the caller already holds -- an
+        open-loop rollout: random-action throughput runs, a replayed action tape -- gives (obs [T, N, O], reward [T, N],
+        done [T, N] bool), bit-identical to T calls of step() on the slices.  A wave goes on to its envs' next step as soon as it
+        has finished this one, so the launch ends with the largest sum of a wave's step times instead of paying the slowest wave of
+        every step.  The reference has no counterpart (its envs take one action at a time); step() is unchanged.
+
+        out=(obs, reward, done): contiguous device tensors of those shapes (done uint8 or bool) the launch writes into.
+        motor_cmd: optional [T, N, num_motors] float32 tensor for info['action'] of every step.  Per-step randomizers
+        (randomize_step) and the per-step Box test do not fit a segment: envs that use them raise."""
+        torch = self._torch
+        if self._needs_reset:
+            raise RuntimeError("Must reset environment.")
+        if any(hasattr(r, "randomize_step") for r in self._env_randomizers):
+            raise ValueError("step_segment: a randomizer with randomize_step() acts between steps; use step()")
+        with self._on_stream():
+            a = torch.as_tensor(actions, dtype=torch.float32, device=self.device)
+            if a.dim() != 3 or a.shape[1:] != (self.num_envs, self.action_dim) or a.shape[0] < 1:
+                raise ValueError(f"actions must have shape (T, {self.num_envs}, {self.action_dim}), got {tuple(a.shape)}")
+            a = a.contiguous()
+            T = int(a.shape[0])
+            if self.check_actions:     # the Box test of BatchEnv.step on the whole segment up front: one host synchronisation
+                bad = ~torch.isfinite(a)
+                if not self.config.range_normalize:
+                    lo = torch.as_tensor(np.minimum(self.action_space.low, self.action_space.high).astype(np.float32), device=self.device)
+                    hi = torch.as_tensor(np.maximum(self.action_space.low, self.action_space.high).astype(np.float32), device=self.device)
+                    bad |= (a < lo) | (a > hi)
+                if bool(bad.any()):
+                    t, i = (int(v) for v in torch.nonzero(bad.any(dim=2))[0])
+                    raise ValueError(f"Invalid action at step {t}, index {i}: {a[t, i].tolist()}")
+            if out is None:
+                out = (torch.empty((T, self.num_envs, self.obs_dim), dtype=torch.float32, device=self.device),
+                       torch.empty((T, self.num_envs), dtype=torch.float32, device=self.device),
+                       torch.empty((T, self.num_envs), dtype=torch.uint8, device=self.device))
+            obs, reward, done = out
+            for t_, shape, dt in ((obs, (T, self.num_envs, self.obs_dim), (torch.float32,)), (reward, (T, self.num_envs), (torch.float32,)),
+                                  (done, (T, self.num_envs), (torch.uint8, torch.bool))):
+                if tuple(t_.shape) != shape or t_.dtype not in dt or not t_.is_contiguous() or t_.device != self.device:
+                    raise ValueError(f"out tensors must be contiguous on {self.device}: obs {(T, self.num_envs, self.obs_dim)} float32, "
+                                     f"reward {(T, self.num_envs)} float32, done {(T, self.num_envs)} uint8 / bool")
+            p_cmd = None
+            if motor_cmd is not None:
+                nm = self._info["action"].shape[1]
+                if tuple(motor_cmd.shape) != (T, self.num_envs, nm) or motor_cmd.dtype != torch.float32 or not motor_cmd.is_contiguous():
+                    raise ValueError(f"motor_cmd must be a contiguous float32 tensor of shape {(T, self.num_envs, nm)}")
+                p_cmd = motor_cmd.data_ptr()
+        _lib.check(self._L.rex_step_segment(self._h, T, a.data_ptr(), obs.data_ptr(), reward.data_ptr(), done.data_ptr(), p_cmd, self._stream_ptr()),
+                   "rex_step_segment")
+        return obs, reward, (done if done.dtype == torch.bool else done.view(torch.bool)), {"action": motor_cmd}
+
     def bind_out(self, obs, reward, done):
         """Validate a set of output tensors once (`step(..., out=...)`): returns a StepOut that a loop can pass again and again."""
         torch = self._torch

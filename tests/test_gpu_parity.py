@@ -1536,6 +1536,82 @@ _TIE_CASES = [
 ]
 
 
+_SEG_EXTRA_CASES = [
+    # the observation-history ring (latency model): a later step of a segment reads what an earlier one stored, from other lanes
+    ("base-walk_ik_latency", (4, 16), 4096, dict(task="walk", signal_type="ik", control_latency=0.02, pd_latency=0.003)),
+    ("base-turn_ik_latency_noise", (4,), 2048, dict(task="turn", signal_type="ik", control_latency=0.02, observation_noise_stdev=(0.01, 0.01, 0.01, 0.01, 0.01))),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,epw", [(c[0], e) for c in _TIE_CASES + _SEG_EXTRA_CASES for e in c[1]])
+def test_segment_launch_is_bit_identical_to_single_steps(torch, case, epw, monkeypatch):
+    """rex_step_segment (RexBatchEnv.step_segment) runs T consecutive env.step() calls in one launch -- the `_seg` instantiations of
+    the step kernel, the step body inside a loop, an env's state in registers from step to step.  For every variant group x envs
+    per wave, at the BASELINE shard size of the group's workload: 3 segments of 23 steps from reset, with in-launch auto-resets
+    (episode cap 25), against the same 69 actions through step(): observation, reward, done and info['action'] of EVERY step and
+    the state block after every segment BIT FOR BIT.  Also: a segment of one step, and the event trace set (step by step through
+    the _trace kernels) give the same."""
+    from rex_gym_amd import RexBatchEnv
+    _, _, n, kw = next(c for c in _TIE_CASES + _SEG_EXTRA_CASES if c[0] == case)
+    monkeypatch.setenv("REX_ENVS_PER_WAVE", str(epw))
+    mk = lambda: RexBatchEnv(n, seed=17, auto_reset=True, max_episode_steps=25, check_actions=False, **kw)
+    one, seg = mk(), mk()
+    assert seg._L.rex_envs_per_wave(seg._h) == epw
+    assert torch.equal(one.reset(), seg.reset()) and torch.equal(one.state, seg.state)
+    lo = torch.as_tensor(np.minimum(one.action_space.low, one.action_space.high), device="cuda", dtype=torch.float32)
+    hi = torch.as_tensor(np.maximum(one.action_space.low, one.action_space.high), device="cuda", dtype=torch.float32)
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    T, nm = 23, one._info["action"].shape[1]
+    ended = 0
+    for s in range(3):
+        a = torch.rand((T, n, one.action_dim), device="cuda", generator=g) * (hi - lo) + lo
+        cmd = torch.zeros((T, n, nm), device="cuda")
+        so, sr, sd, si = seg.step_segment(a, motor_cmd=cmd)
+        assert so.shape == (T, n, one.obs_dim) and sr.shape == (T, n) and sd.shape == (T, n) and sd.dtype == torch.bool and si["action"] is cmd
+        for t in range(T):
+            oo, orw, od, oi = one.step(a[t])
+            for name, x, y in (("obs", oo, so[t]), ("reward", orw, sr[t]), ("done", od, sd[t]), ("action", oi["action"], cmd[t])):
+                if not torch.equal(x, y):
+                    bad = (x != y)
+                    pytest.fail(f"{case} epw {epw}: segment {s} step {t}: {name} of the segment launch differs from the single steps' in "
+                                f"{int(bad.sum())} words (first at {tuple(int(v) for v in torch.nonzero(bad)[0])})")
+            ended += int(od.sum())
+        assert torch.equal(one.state, seg.state), (case, epw, s)
+    assert ended >= 2 * n                       # the comparison ran through in-launch resets in every env
+    # a segment of one step; a segment under the event trace
+    a = torch.rand((1, n, one.action_dim), device="cuda", generator=g) * (hi - lo) + lo
+    so, sr, sd, _ = seg.step_segment(a)
+    oo, orw, od, _ = one.step(a[0])
+    assert torch.equal(so[0], oo) and torch.equal(sr[0], orw) and torch.equal(sd[0], od) and torch.equal(one.state, seg.state)
+    seg.set_event_trace(True)
+    a = torch.rand((5, n, one.action_dim), device="cuda", generator=g) * (hi - lo) + lo
+    so, sr, sd, _ = seg.step_segment(a)
+    for t in range(5):
+        oo, orw, od, _ = one.step(a[t])
+        assert torch.equal(so[t], oo) and torch.equal(sr[t], orw) and torch.equal(sd[t], od), (case, epw, "trace", t)
+    assert torch.equal(one.state, seg.state)
+    one.close(); seg.close()
+
+
+def test_segment_launch_argument_checks(torch):
+    from rex_gym_amd import RexBatchEnv
+    env = RexBatchEnv(8, task="walk", signal_type="ik", seed=1)
+    with pytest.raises(RuntimeError):
+        env.step_segment(torch.zeros((2, 8, env.action_dim), device="cuda"))      # before reset
+    env.reset()
+    with pytest.raises(ValueError):
+        env.step_segment(torch.zeros((8, env.action_dim), device="cuda"))         # not a segment
+    with pytest.raises(ValueError):
+        env.step_segment(torch.full((2, 8, env.action_dim), 9.0, device="cuda"))  # outside the Box (check_actions is on)
+    with pytest.raises(ValueError):
+        env.step_segment(torch.zeros((2, 8, env.action_dim), device="cuda"), out=(torch.zeros((2, 8, env.obs_dim), device="cuda"),
+                                                                                   torch.zeros((2, 8), device="cuda"), torch.zeros((3, 8), dtype=torch.uint8, device="cuda")))
+    o, r, d, info = env.step_segment(torch.zeros((4, 8, env.action_dim), device="cuda"))
+    assert o.shape == (4, 8, env.obs_dim) and bool(torch.isfinite(o).all()) and info["action"] is None
+    env.close()
+
+
 @pytest.mark.parametrize("case,epw", [(c[0], e) for c in _TIE_CASES for e in c[1]])
 def test_trace_kernels_are_bit_identical_to_the_product_kernels(torch, case, epw, monkeypatch):
     """rex_set_event_trace switches rex_step to the `_trace` instantiations -- separate code objects, compiled from the same
