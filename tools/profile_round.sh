@@ -7,7 +7,7 @@ cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 cd /tmp
-B="--no-cpu-baseline --no-walking-workload --no-gather"
+B="--no-cpu-baseline --no-walking-workload --no-gather --no-segment-launch"
 timeout 100 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_prof -- python $GRAFT_REPO_ROOT/bench.py --steps 400 --warmup 50 $B "$@" > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_bench_under_rocprof.json 2>/dev/null
 timeout 60 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_FETCH_SIZE -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 50 $B "$@" > /dev/null 2>&1
 timeout 60 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_WRITE_SIZE -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 50 $B "$@" > /dev/null 2>&1
