@@ -61,6 +61,9 @@ for f in sorted(glob.glob(os.path.join(G, f"{tag}_profile_*.txt"))):
     same = [json.loads(l) for l in txt.splitlines() if l.startswith('{"bench_kernel_ms_same_launches"')]
     if not stats or not js:
         continue
+    if json.loads(js[-1]).get("FETCH_SIZE") is None or json.loads(js[-1]).get("WRITE_SIZE") is None or json.loads(js[-1]).get("SQ_ACTIVE_INST_VALU") is None:
+        print(f"{name}: a counter pass is missing (timed out?) -- entry left as it was", file=sys.stderr)
+        continue
     d = json.loads(js[-1]); g = lambda k: d.get(k, {}).get("avg_steady")
     st = [c.strip() for c in stats[0].split("|")]
     mb = (g("FETCH_SIZE") + g("WRITE_SIZE")) * 1024 / 1e6   # both counters are in KiB and exact for this access pattern (profiles/r04_hbm_counter_calibration.md)

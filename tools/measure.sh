@@ -3,7 +3,7 @@
 # summary in gpurun_out/ before the next starts (rocprofv3 databases are deleted on the box: gpurun copies back <= 64 MiB, and round 4's
 # closing call lost everything to that cap and to one 40-minute limit).
 #   usage: tools/measure.sh TAG step [step ...]        -> gpurun_out/TAG_*; progress in gpurun_out/TAG_progress.txt
-#   steps: lib=<path to a build of the library, or "default"> | mb:<tools/microbench/NAME> | tie | parity | gputests | bench | bench_driver | bench_2rank | bench_configs | ab:<lib1>,<lib2>[:<bench flags>] | prof:<workload> | sections:<task>
+#   steps: lib=<path to a build of the library, or "default"> | mb:<tools/microbench/NAME> | tie | parity | gputests | bench | bench_driver | bench_2rank | bench_2rank_ns (the default workload on 2 ranks: prints north_star_workload) | bench_configs | ab:<lib1>,<lib2>[:<bench flags>] | prof:<workload> | sections:<task>
 #   prof workloads: walk4096 walk262144 arm4096 mixedarm2048 gallop8192 turnhf4096 poses4096
 TAG=$1; shift
 cd $GRAFT_REPO_ROOT
@@ -22,6 +22,7 @@ for step in "$@"; do
     bench)        timeout 300 bash -c "python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err" ;;
     bench_driver) timeout 180 bash -c "python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_driver_cmd.json 2>> gpurun_out/${TAG}_bench.err" ;;
     bench_2rank)  timeout 300 bash -c "python bench.py --gpus 2 --steps 200 --warmup 50 --config 3 --backend gloo --no-cpu-baseline > gpurun_out/${TAG}_bench_2rank_gloo_1gpu.json 2>> gpurun_out/${TAG}_bench.err" ;;
+    bench_2rank_ns) timeout 300 bash -c "python bench.py --gpus 2 --steps 50 --warmup 10 --backend gloo --no-cpu-baseline > gpurun_out/${TAG}_bench_2rank_north_star_gloo_1gpu.json 2>> gpurun_out/${TAG}_bench.err" ;;
     bench_configs) timeout 600 bash -c "bash tools/bench_configs.sh ${TAG} 600 > gpurun_out/${TAG}_bench_configs.txt 2>&1" ;;
     ab:*)         IFS=: read -r _ libs flags <<< "$step"
                   OUT=gpurun_out/${TAG}_ab.txt; echo "== bench.py --steps 600 --warmup 100 $flags" >> $OUT
@@ -30,7 +31,7 @@ for step in "$@"; do
                       python -c "import json,sys; d=json.loads(sys.stdin.read()); print('  %-28s %8.2f M env-steps/s  %.4f ms/step  kernel %.4f ms (min %.4f)' % ('$lib'.split('/')[-1], d['value']/1e6, d['ms_per_step'], d['roofline']['kernel_ms'], d['roofline']['kernel_ms_min']))" >> $OUT
                   done ;;
     prof:*)       w=${step#prof:}
-                  timeout 420 bash tools/profile_round.sh ${TAG}_$w ${WL[$w]} > gpurun_out/${TAG}_profile_$w.txt 2>&1
+                  timeout 700 bash tools/profile_round.sh ${TAG}_$w ${WL[$w]} > gpurun_out/${TAG}_profile_$w.txt 2>&1
                   rm -rf gpurun_out/${TAG}_${w}_prof gpurun_out/${TAG}_${w}_pmc_* ;;
     sections:*)   t=${step#sections:}
                   timeout 400 python tools/prof_sections.py --task=$t > gpurun_out/${TAG}_sections_$t.txt 2>&1 ;;
