@@ -481,6 +481,10 @@ def main():
         kms = sorted(env.step_times_ms(m))
         env.set_timing(False)
     kernel_ms = sum(kms) / len(kms)
+    if args.segment_launch and not args.no_device_timing:
+        # the timed launches covered the K steps, up to T steps each: per STEP, as everywhere else in the line
+        kernel_ms = sum(kms) / args.steps
+        kms = [k / T for k in kms]
 
     # HBM bytes per launch and the VALU issue fraction as measured with rocprofv3 PMC passes of this same command (cannot be
     # collected from inside the process); null when no measurement of this workload is committed

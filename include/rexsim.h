@@ -338,7 +338,8 @@ REX_API int rex_envs_per_wave(const RexSim* sim);
  * Returns the number of workgroups (pass NULL buffers to size them), or a negative error. */
 REX_API int rex_mixed_slot_map(const RexConfig* cfg, int envs_per_wave, int32_t* slots, int32_t* tasks, int max_blocks);
 
-/* Solver sweeps every env ran in the last rex_step (summed over its substeps), int32 [num_envs] copied to the caller's
+/* Solver sweeps every env ran in the last rex_step (summed over its substeps; after rex_step_segment: the mean per step over the
+ * segment), int32 [num_envs] copied to the caller's
  * device buffer -- the key a batch created under REX_REGROUP=1 is regrouped into waves by (opt-in). */
 REX_API int rex_get_sweeps(RexSim* sim, int32_t* d_out, void* stream);
 

@@ -929,6 +929,7 @@ __global__ __launch_bounds__(REX_WAVE) REX_STEP_KERNEL_ATTR void rex_step_kernel
   EnvState e;
   load_env<NM, NL>(state, c.n, i, e, leg0);
   const int i_env = i, leg0_env = leg0;
+  int seg_sweeps = 0;     // SEG: the env's solver sweeps summed over the steps of the segment so far
 #pragma clang loop unroll(disable)
   for (int seg_step = 0; seg_step < (SEG ? c.nsteps : 1); ++seg_step) {
   // SEG: an opaque copy of the env index per step: otherwise every address the body forms from it (state words, history ring, output
@@ -1088,7 +1089,11 @@ __global__ __launch_bounds__(REX_WAVE) REX_STEP_KERNEL_ATTR void rex_step_kernel
     for (int k = 0; k < 4; ++k) obs_out[(size_t)is * c.obs_dim + k] = c.range_normalize ? normalize_obs1(c, k, obs[k]) : obs[k];
     reward_out[is] = reward;
     done_out[is] = done ? 1 : 0;
-    if (c.sweeps) c.sweeps[is] = e.sweeps;
+    if (c.sweeps) {
+      // (a segment: the mean over its steps so far -- what the host sorts the envs by between launches; the last step's store stands)
+      if constexpr (SEG) { seg_sweeps += e.sweeps; c.sweeps[is] = (seg_sweeps + (seg_step >> 1)) / (seg_step + 1); }
+      else c.sweeps[is] = e.sweeps;
+    }
   }
   // the words of the lane's motors: info['action'] and -- where the row carries motor angles (gallop; a mixed batch with
   // gallop in it: the other tasks leave them 0) -- its part of the observation row

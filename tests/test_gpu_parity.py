@@ -764,6 +764,28 @@ def test_bench_two_ranks_gather_rollout_segments(torch):
     assert g["gather_ms_blocking"] > 0 and g["value_without_gather"] > 0
 
 
+def test_bench_two_ranks_report_the_north_star_workload_and_segment_launches(torch):
+    """`python bench.py --gpus 2` on the default workload (gloo on the one-GPU box): `value` stays the weak-scaling line of configs[1]
+    (4 096 envs per rank), and the line carries north_star's own multi-GPU workload -- walk-IK at 65 536 / 8 envs per rank, with and
+    without the learner hand-off -- and the same steps launched once per rollout segment (rex_step_segment) next to it."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "50", "--warmup", "10", "--backend", "gloo",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["config"]["envs_total"] == 2 * 4096 and d["scaling"] == "weak" and d["finite"]
+    assert d["config"]["baseline_config"] == 2 and d["config"]["launches"].startswith("one launch per env.step()")
+    ns = d["north_star_workload"]
+    assert ns["envs_per_gpu"] == 65536 // 8 and ns["envs_total"] == 2 * 8192 and ns["finite"]
+    assert ns["value"] > 0 and ns["value_without_gather"] >= 0.9 * ns["value"]
+    sg = d["segment_launch"]
+    assert sg["steps_per_launch"] == 25 and sg["value"] > 0 and sg["longer_segments"]["steps_per_launch"] == 100
+
+
 @pytest.mark.parametrize("task,signal,mark,terrain", [
     ("walk", "ik", "base", "random"), ("gallop", "ik", "base", "random"), ("poses", "ik", "base", "plane"),
     ("standup", "ol", "base", "plane"), ("turn", "ol", "arm", "random"), ("gallop", "ol", "arm", "plane"),
