@@ -1400,14 +1400,14 @@ def test_regrouped_batch_is_bit_identical(torch, monkeypatch, n):
     assert torch.equal(outs["0"][1], outs["1"][1])
 
 
-@pytest.mark.parametrize("n,epw", [(700, 4), (5000, 16)])    # one chunk of the count / scatter pair and five, ragged
-def test_regrouped_mixed_batch_is_bit_identical(torch, monkeypatch, n, epw):
+@pytest.mark.parametrize("n,epw,mark", [(700, 4, "arm"), (5000, 16, "arm"), (3000, 8, "base"), (5000, 8, "arm")])    # one chunk of the count / scatter pair and several, ragged; both marks
+def test_regrouped_mixed_batch_is_bit_identical(torch, monkeypatch, n, epw, mark):
     """A REX_TASK_MIXED batch under REX_REGROUP=1: every task owns a static region of whole waves of the slot map and is
     sorted inside it by the solver sweeps of the previous step (rex_regroup_mixed_*); against the chunked static map
     (REX_REGROUP=0) the waves change every step, an env's results must not -- through falls, in-launch resets and the
     per-reset mass / friction draws."""
     from rex_gym_amd import RexMixedBatchEnv
-    kw = dict(mark="arm", seed=6, auto_reset=True, max_episode_steps=30, mass_scale_range=(0.8, 1.2), friction_range=(0.25, 0.625))
+    kw = dict(mark=mark, seed=6, auto_reset=True, max_episode_steps=30, mass_scale_range=(0.8, 1.2), friction_range=(0.25, 0.625))
     outs = {}
     for flag in ("0", "1"):
         monkeypatch.setenv("REX_REGROUP", flag)
