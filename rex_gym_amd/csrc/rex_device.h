@@ -1032,6 +1032,7 @@ __device__ long long g_prof2[16 * 1024]; // per block: inside pgs_dv: [0] set-up
                                          // inside the sweeps: [8] link-box rows run, [9] joint-limit rows run, cycles of [10] the limit rows,
                                          // [11] link-box normals, [12] toe rows, [13] link-box friction rows, [14] sweeps of thread 0's env
                                          // (what [8]-[13] cover)
+__device__ unsigned g_legmask[65536];   // per env: bits 0-7 the toe points in reach in the last substep, bits 8-15 their OR since the last read-out
 #define REX_STAMP(var) const long long var = clock64()
 #else
 #define REX_STAMP(var)
@@ -1814,6 +1815,10 @@ __device__ __forceinline__ void physics_substep(PhysState& s, float* tau, float 
   float lam[REX_NROW];
 #pragma unroll
   for (int r = 0; r < REX_NROW; ++r) lam[r] = 0.0f;
+#ifdef REX_PROF
+  // (census: the env's own toe points in reach this substep, one bit per point, and the wave's union per leg -- tools/leg_census.py)
+  if (live && env < 65536) { const unsigned g = g_legmask[env]; g_legmask[env] = (active & 0xFFu) | ((((g >> 8) | active) & 0xFFu) << 8); }
+#endif
   const bool any0 = __builtin_amdgcn_ballot_w64((active & 0x03u) != 0) != 0;
   const bool any1 = __builtin_amdgcn_ballot_w64((active & 0x0Cu) != 0) != 0;
   const bool any2 = __builtin_amdgcn_ballot_w64((active & 0x30u) != 0) != 0;

@@ -802,6 +802,12 @@ REX_API int rex_debug_prof(long long* out, int reset) {
   if (reset) { static long long z[10 * 1024]; if (hipMemcpyToSymbol(HIP_SYMBOL(rex::g_prof), z, sizeof(z)) != hipSuccess) return REX_EHIP; }
   return REX_OK;
 }
+REX_API int rex_debug_legmask(unsigned* out, int n) {   /* per env: toe points in reach (last substep; OR since the last call) */
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(rex::g_legmask), sizeof(unsigned) * (size_t)(n < 65536 ? n : 65536)) != hipSuccess) return REX_EHIP;
+  static unsigned z[65536];
+  if (hipMemcpyToSymbol(HIP_SYMBOL(rex::g_legmask), z, sizeof(z)) != hipSuccess) return REX_EHIP;
+  return REX_OK;
+}
 REX_API int rex_debug_prof2(long long* out, int reset) {   /* the sections of the sweep routine (pgs_dv) */
   if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(rex::g_prof2), sizeof(long long) * 16 * 1024) != hipSuccess) return REX_EHIP;
   if (reset) { static long long z[16 * 1024]; if (hipMemcpyToSymbol(HIP_SYMBOL(rex::g_prof2), z, sizeof(z)) != hipSuccess) return REX_EHIP; }
