@@ -1243,9 +1243,11 @@ __device__ __forceinline__ void pgs_dv(const SM& sm, ARMP& armp, PgsX& x, int p,
   (void)body_load;
   auto sweep = [&](const auto& li, auto& lo, int it) __attribute__((always_inline)) {
     ++nsweeps;
+    // (`worst` lives outside the lane mask: a lane that has stopped keeps 0, and `running` is then one compare under the full EXEC --
+    //  the wave's exit test reads that very mask instead of rebuilding a full-wave vote from a partial one)
+    float worst = 0.0f;
     if (running) {
       ++lane_sweeps;
-      float worst = 0.0f;
       REX_STAMP(t_s0);
       // joint-limit rows (non-contact rows come first in Bullet's sweep): plain Gauss-Seidel steps.  One test for all four
       // legs first: a sweep without a bound in reach (nearly all of them) then takes one branch instead of four
@@ -1408,10 +1410,9 @@ __device__ __forceinline__ void pgs_dv(const SM& sm, ARMP& armp, PgsX& x, int p,
         p2[10] += t_s1 - t_s0; p2[11] += t_s2 - t_s1; p2[12] += t_s3 - t_s2; p2[13] += t_s4 - t_s3; p2[14] += 1;
       }
 #endif
-      // (the per-lane cap is compiled in for mixed-task batches only: even as a scalar condition it lengthens the loop's
-      // back edge enough to cost 2.3 % of a step)
-      running = LANECAP ? (worst > 0.0f && it + 1 < lane_iterations) : worst > 0.0f;
     }             // (a lane that has stopped never sweeps again: what it leaves in `lo` is never read)
+    // (the per-lane cap is compiled in for mixed-task batches only)
+    running = LANECAP ? (worst > 0.0f && it + 1 < lane_iterations) : worst > 0.0f;
   };
   if constexpr (kPairedSweeps) {
     float lamB[REX_NCROW];
