@@ -78,6 +78,14 @@ def test_bad_arguments_return_error_codes(L):
     assert lib.rex_ik_solve(0, None, None, None, None, None) < 0
 
 
+def test_segment_entry_point_rejects_bad_arguments_without_a_gpu(L):
+    """rex_step / rex_step_segment check their pointers before anything touches a device: null arguments come back as REX_EINVAL
+    with a message on any host (the segment's other checks -- num_steps >= 1, 32-bit block offsets -- need a sim, i.e. a GPU)."""
+    lib = L.lib()
+    assert lib.rex_step(None, None, None, None, None, None, None) < 0 and b"rex_step" in lib.rex_last_error()
+    assert lib.rex_step_segment(None, 3, None, None, None, None, None, None) < 0 and b"rex_step_segment" in lib.rex_last_error()
+
+
 def test_spaces_match_reference_bounds():
     from rex_gym_amd.envs.batch_env import _spaces
     a, o = _spaces("walk", "ik", 0.001)
