@@ -423,10 +423,12 @@ def main():
     # to its envs' next step without waiting for the slowest wave of every step.
     segment_launch = None
     if not args.no_segment_launch and not args.segment_launch:
-        run(2 * T, do_gather, True)
+        # (its own step counts: at least 8 launches of each segment length, however short the timed region above was)
+        steps_seg, steps_seg4 = max(args.steps, 8 * T), max(args.steps, 32 * T)
+        run(2 * T - ro.clock % T, do_gather, True)          # (up to a segment boundary: the timed launches below are whole segments)
         barrier()
         t3 = time.perf_counter()
-        run(args.steps, do_gather, True)
+        run(steps_seg, do_gather, True)
         torch.cuda.synchronize(dev)
         e_seg = time.perf_counter() - t3
         barrier()
@@ -440,7 +442,7 @@ def main():
         ro4.run(8 * T, do_gather, True)
         barrier()
         t4 = time.perf_counter()
-        ro4.run(args.steps, do_gather, True)
+        ro4.run(steps_seg4, do_gather, True)
         torch.cuda.synchronize(dev)
         e_seg4 = time.perf_counter() - t4
         barrier()
@@ -449,11 +451,12 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             e_seg4 = float(tt.item())
         del ro4
-        segment_launch = {"steps_per_launch": T, "value": n * world * args.steps / e_seg, "unit": "env-steps/s", "ms_per_step": e_seg / args.steps * 1e3,
-                          "vs_one_launch_per_step": elapsed / e_seg,
-                          "longer_segments": {"steps_per_launch": 4 * T, "value": n * world * args.steps / e_seg4, "ms_per_step": e_seg4 / args.steps * 1e3,
-                                              "vs_one_launch_per_step": elapsed / e_seg4},
-                          "what": "the timed region again, the T steps of a rollout segment in one launch (RexBatchEnv.step_segment -> rex_step_segment; "
+        ms_step = elapsed / args.steps * 1e3
+        segment_launch = {"steps_per_launch": T, "steps": steps_seg, "value": n * world * steps_seg / e_seg, "unit": "env-steps/s", "ms_per_step": e_seg / steps_seg * 1e3,
+                          "vs_one_launch_per_step": ms_step / (e_seg / steps_seg * 1e3),
+                          "longer_segments": {"steps_per_launch": 4 * T, "steps": steps_seg4, "value": n * world * steps_seg4 / e_seg4,
+                                              "ms_per_step": e_seg4 / steps_seg4 * 1e3, "vs_one_launch_per_step": ms_step / (e_seg4 / steps_seg4 * 1e3)},
+                          "what": "the workload of the timed region again (its own step count: `steps`), the T steps of a rollout segment in one launch (RexBatchEnv.step_segment -> rex_step_segment; "
                                   "actions drawn a segment ahead, as in the timed region); results bit-identical to the per-step launches "
                                   "(tests/test_gpu_parity.py::test_segment_launch_is_bit_identical_to_single_steps)"}
 
