@@ -266,6 +266,102 @@ def north_star_workload(args, dev, local_rank, rank, world, dist, barrier, T):
             "ms_per_step_without_gather": res["without_gather"] / args.steps * 1e3, "steps": args.steps, "finite": finite}
 
 
+def closed_loop_workload(n, dev, local_rank, rank, env_kw, steps, T=25):
+    """The rollout the reference's PPO agents actually run: a POLICY IN THE LOOP -- `action = algo.perform(prevob)` then
+    `batch_env.simulate(action)` for every step (agents/tools/simulate.py:57-76, agents/ppo/algorithm.py:105-134) -- on the workload of the
+    timed region (same envs, auto-reset, episode cap 2000), behind the wrapper stack the agents act through (RangeNormalize + ClipAction
+    folded into the launch).  Policy: the reference's shape (agents/scripts/networks.py:66-110, configs.py:29-34: observ filter -> 200 relu ->
+    100 relu -> tanh mean, free logstd -1, Gaussian sample), random initial weights.  Four ways to run it, same envs, same policy:
+      torch_policy_per_step   perform() as PyTorch ops (filter, three matmuls, sample) + one rex_step launch per step
+      fused_per_step          the actor inside the step launch (rex_step_policy): one launch per step
+      fused_segment_T / 4T    rex_step_segment_policy: one launch per T-step (4T-step) rollout segment
+    Every variant writes obs / action / mean / reward / done of every step into rollout-segment blocks, as the learner's memory needs them."""
+    import torch
+    from rex_gym_amd import RexBatchEnv
+    from rex_gym_amd.agents.fused_actor import FusedActor
+    from rex_gym_amd.agents.ppo import ForwardGaussianPolicy, PPOConfig, StreamingNormalize
+    env = RexBatchEnv(n, device=local_rank, seed=0, env_index_base=rank * n, auto_reset=True, max_episode_steps=2000, check_actions=False,
+                      range_normalize=True, **env_kw)
+    O, A = env.obs_dim, env.action_dim
+    with torch.random.fork_rng(devices=[]):
+        torch.manual_seed(0)
+        net = ForwardGaussianPolicy(O, A, PPOConfig()).to(dev)
+    flt = StreamingNormalize((O,), center=True, scale=True, clip=5, device=dev)
+    obs0 = env.reset()
+    flt.update(obs0)
+    actor = FusedActor(env, net, flt, sample=True, seed=1)
+    gen = torch.Generator(device=dev); gen.manual_seed(77 + rank)
+    T4 = 4 * T
+    obs = torch.zeros((T4 + 1, n, O), device=dev); act = torch.zeros((T4, n, A), device=dev); mean = torch.zeros((T4, n, A), device=dev)
+    rew = torch.zeros((T4, n), device=dev); done = torch.zeros((T4, n), dtype=torch.uint8, device=dev)
+    obs[0].copy_(obs0)
+
+    def segment(length):
+        env.step_segment_policy(length, obs[0], out=(obs[1:length + 1], rew[:length], done[:length]), action=act[:length], mean=mean[:length])
+        obs[0].copy_(obs[length])
+
+    # untimed pre-roll, closed loop: 1 500 steps with staggered resets (as the open-loop pre-roll), the filter following the rollout
+    for k in range(PREROLL_STEPS // 50):
+        segment(50)
+        if k % 4 == 0:
+            flt.update(obs[1:51].reshape(-1, O)); actor.sync()
+        if k < PREROLL_STEPS // 50 - 4:
+            idx = torch.randperm(n, device=dev, generator=gen)[: max(1, n // 32)].to(torch.int32)
+            obs[0][idx.long()] = env.reset(idx)
+    res = {}
+
+    def timed(name, fn, count, launches):
+        fn(max(2, count // 8))
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        fn(count)
+        torch.cuda.synchronize(dev)
+        e = time.perf_counter() - t0
+        res[name] = {"value": n * count / e, "ms_per_step": e / count * 1e3, "steps": count, "launches_per_step": launches}
+
+    # (a) perform() in PyTorch + rex_step: what a learner written against env.step() gets (no host synchronisation in the loop)
+    sgen = torch.Generator(device=dev); sgen.manual_seed(5)
+    outs = [env.bind_out(obs[t + 1], rew[t], done[t]) for t in range(T)]
+
+    def torch_loop(count):
+        with torch.no_grad():
+            for k in range(count):
+                t = k % T
+                if t == 0 and k:
+                    obs[0].copy_(obs[T])
+                m_ = torch.tanh(net.mean(net.policy(flt.transform(obs[t]))))     # (the actor only: the value network is not evaluated during a rollout)
+                mean[t].copy_(m_)
+                torch.addcmul(m_, torch.exp(net.logstd), torch.randn(m_.shape, device=dev, generator=sgen), out=act[t])
+                env.step(act[t], outs[t])
+        obs[0].copy_(obs[(count - 1) % T + 1])
+    timed("torch_policy_per_step", torch_loop, steps, None)   # (launches per step: the rocprofv3 kernel trace of this command, profiles/)
+
+    # (b) the actor inside the launch, one launch per step
+    def fused_loop(count):
+        for k in range(count):
+            t = k % T
+            if t == 0 and k:
+                obs[0].copy_(obs[T])
+            env.step_policy(obs[t], out=(obs[t + 1], rew[t], done[t]), action=act[t], mean=mean[t])
+        obs[0].copy_(obs[(count - 1) % T + 1])
+    timed("fused_per_step", fused_loop, steps, 1.0)
+
+    # (c) one launch per rollout segment
+    def seg_loop(length):
+        def run(count):
+            for _ in range(count // length):
+                segment(length)
+        return run
+    timed(f"fused_segment_{T}", seg_loop(T), max(steps, 8 * T) // T * T, 1.0 / T)
+    timed(f"fused_segment_{T4}", seg_loop(T4), max(steps, 8 * T4) // T4 * T4, 1.0 / T4)
+    finite = bool(torch.isfinite(obs).all().item())
+    falls = float(done[:T].float().mean().item())
+    env.close()
+    return {"what": "closed-loop rollout (policy in the loop: the reference's 4-200-100-A Gaussian MLP actor behind its observ filter, random "
+                    "initial weights, Gaussian sample every step; RangeNormalize + ClipAction folded) on the workload of the timed region",
+            "unit": "env-steps/s", "finite": finite, "done_rate_per_step": falls, **res}
+
+
 # BASELINE.json configs, numbered as SURVEY.md 8(d) numbers them (config 1 is the 1-env CPU plumbing case): what --config N runs.
 # total = envs of the WHOLE job (strong scaling: divided over the GPUs); None = 4 096 per GPU (weak scaling, configs[1])
 CONFIGS = {
@@ -293,6 +389,7 @@ def main():
     ap.add_argument("--segment-launch", action="store_true", help="the timed region launches once per rollout segment (rex_step_segment) instead of once per step")
     ap.add_argument("--no-segment-launch", action="store_true", help="skip the secondary segment-launch measurement")
     ap.add_argument("--no-walking-workload", action="store_true", help="skip the secondary gait-clock-1.5 measurement (profiling runs)")
+    ap.add_argument("--no-closed-loop", action="store_true", help="skip the secondary closed-loop (policy in the loop) measurement")
     ap.add_argument("--no-stagger", action="store_true", help="developer A/B runs only: pre-roll without the staggered resets")
     ap.add_argument("--no-device-timing", action="store_true", help="developer A/B runs only: no device-side kernel timestamps in the timed region")
     # the default line is BASELINE.json configs[1]; the other supported workloads can be timed with these
@@ -527,6 +624,14 @@ def main():
         walking = {"gait_clock_scale": 1.5, "value": n * args.steps / e2, "unit": "env-steps/s", "ms_per_step": e2 / args.steps * 1e3}
         env2.close()
 
+    # the rollout a PPO learner runs: the policy in the loop (single-task workloads; the toes-only kernels carry the fused actor)
+    closed_loop = None
+    if world == 1 and not args.mixed and not args.no_closed_loop and not body_contacts:
+        try:
+            closed_loop = closed_loop_workload(n, dev, local_rank, rank, env_kw, max(args.steps, 200), T)
+        except Exception as e:   # reporting only; never fail the headline for it
+            closed_loop = {"failed": f"{type(e).__name__}: {e}"}
+
     task_name = "mixed" if args.mixed else args.task
     ranks_seen = dist.get_world_size() if dist is not None else 1
     try:
@@ -583,6 +688,8 @@ def main():
             out["north_star_workload"] = north_star
         if walking:
             out["walking_gait_workload"] = walking
+        if closed_loop:
+            out["closed_loop"] = closed_loop
         if not args.no_cpu_baseline and world == 1:
             if not args.mixed:
                 try:   # SURVEY.md 8(d) baseline (ii): the CPU restatement on all granted threads and on one

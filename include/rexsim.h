@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define REX_ABI_VERSION 5
+#define REX_ABI_VERSION 6
 #define REX_API __attribute__((visibility("default")))
 
 /* tasks (reference env classes) */
@@ -290,6 +290,52 @@ REX_API int rex_step(RexSim* sim, const float* d_action, float* d_obs, float* d_
  * num_steps * N * max(action_dim, obs_dim, num_motors) must stay below 2^31. */
 REX_API int rex_step_segment(RexSim* sim, int num_steps, const float* d_action, float* d_obs, float* d_reward,
              uint8_t* d_done, float* d_motor_cmd, void* stream);
+
+/* ---- ABI 6: the actor inside the launch -- closed-loop rollouts, one launch per step or per segment ----
+ * The reference's rollout is `action = algo.perform(prevob)` -> `batch_env.simulate(action)` every step (agents/tools/simulate.py:
+ * 57-76, agents/ppo/algorithm.py:105-134): a policy in the loop, so the actions of step t + 1 do not exist before step t has returned
+ * its observation and rex_step_segment cannot serve it.  rex_step_policy / rex_step_segment_policy evaluate the actor of the
+ * reference's agents INSIDE the step kernel: the observ filter (agents/ppo/normalize.py:47-66: centre, scale, clip -- with the
+ * statistics the caller hands in, frozen for the launch), the network every shipped config uses (agents/scripts/networks.py:66-110
+ * ForwardGaussianPolicy: two ReLU layers, tanh mean layer, a free logstd vector; configs.py:29-34) and the Gaussian sample of
+ * `network.policy.sample` (Philox keyed by seed, global env index, episode, step: a rollout is a pure function of the seeds and the
+ * weights, whatever the sharding or the segment length).
+ * All arrays are caller-owned DEVICE buffers that must stay valid while the policy is set; the caller may rewrite their CONTENTS
+ * between launches (a learner updating its weights in place).  Weight matrices are input-major: d_w1[k * hidden1 + j] = the weight
+ * from input k to unit j (the transpose of a torch.nn.Linear weight; the layout of a TF1 `fully_connected/weights` variable).
+ * Needs range_normalize = 1 in the sim's config -- the reference's agents always act through RangeNormalize + ClipAction
+ * (playground/trainer.py:48-52): the sampled action is clipped to [-1, 1] and mapped to the env's Box inside the launch, a fused
+ * path has no Box test to fail -- a single-task sim (not REX_TASK_MIXED), toes-only contact rows (body_contacts = 0), no event trace. */
+typedef struct RexPolicy {
+  int32_t obs_dim, action_dim;        /* must equal rex_obs_dim / rex_action_dim of the sim's config */
+  int32_t hidden1, hidden2;           /* units of the two ReLU layers (configs.py:31: 200, 100); obs_dim + 12 + hidden1 + hidden2 floats
+                                         per env must fit the kernel's contact-row region of LDS (448 for mark base up to 8 192 envs) */
+  const float* d_w1; const float* d_b1;   /* [obs_dim][hidden1], [hidden1] */
+  const float* d_w2; const float* d_b2;   /* [hidden1][hidden2], [hidden2] */
+  const float* d_w3; const float* d_b3;   /* [hidden2][action_dim], [action_dim]: the mean layer, tanh on top */
+  const float* d_logstd;                  /* [action_dim] */
+  const float* d_obs_mean;                /* [obs_dim], nullable (with d_obs_scale): no observ filter */
+  const float* d_obs_scale;               /* [obs_dim]: 1 / (std + 1e-8) of the filter (normalize.py:60-62) */
+  float   obs_clip;                       /* 5 (algorithm.py:48-52) */
+  int32_t sample;                         /* 1: action = mean + exp(logstd) * N(0, 1) (training); 0: action = mean (evaluation) */
+  uint64_t seed;                          /* Philox key of the samples */
+} RexPolicy;
+/* Install (copy) the policy description; NULL removes it.  Validates the dimensions against the sim. */
+REX_API int rex_set_policy(RexSim* sim, const RexPolicy* policy);
+
+/* One closed-loop env.step() for every env: action = perform(d_obs_in), then the step.
+ *   d_obs_in [N, obs_dim]     in  -- the observation the envs returned last (rex_reset, or the previous step's d_obs)
+ *   d_action [N, action_dim]  out -- the action the policy took, as the agent's memory stores it (BEFORE ClipAction / RangeNormalize)
+ *   d_mean   [N, action_dim]  out, nullable -- the policy's mean (algorithm.py:126-133 stores action, mean and logstd)
+ *   d_obs, d_reward, d_done, d_motor_cmd  out -- as rex_step (d_obs may NOT alias d_obs_in) */
+REX_API int rex_step_policy(RexSim* sim, const float* d_obs_in, float* d_action, float* d_mean, float* d_obs, float* d_reward,
+             uint8_t* d_done, float* d_motor_cmd, void* stream);
+/* A closed-loop rollout SEGMENT in one launch: step t acts on d_obs[t - 1] (d_obs_in for t = 0) and writes d_action[t], d_mean[t],
+ * d_obs[t], d_reward[t], d_done[t], d_motor_cmd[t] -- blocks [T, N, ...] as in rex_step_segment.  BIT-IDENTICAL to T calls of
+ * rex_step_policy chained through their observations (tests/test_gpu_policy.py), with what a segment launch buys (rex_step_segment).
+ * A caller that keeps one block obs[T + 1, N, obs_dim] passes d_obs_in = obs[0], d_obs = obs[1]: prevob of step t is obs[t]. */
+REX_API int rex_step_segment_policy(RexSim* sim, int num_steps, const float* d_obs_in, float* d_action, float* d_mean, float* d_obs,
+             float* d_reward, uint8_t* d_done, float* d_motor_cmd, void* stream);
 
 /* HIP event timing of rex_step launches on their own stream (ms).  rex_set_timing(1): one event pair, read with
  * rex_last_step_ms (synchronises on the launch).  rex_set_timing(2): a ring of event pairs around the last 256 launches,

@@ -31,6 +31,9 @@ TRACE_SOURCES = sorted(f for f in GROUPS if f.startswith("rex_step_"))
 # the step; kept apart because the loop costs registers -- what the body forms from loop invariants is hoisted -- and rex_step's own
 # kernels stay exactly what they were)
 SEG_SOURCES = TRACE_SOURCES
+# ... and the single-task toes-only units a fourth time with -DREX_TU_POL=1: the segment kernels with the reference's Gaussian MLP actor
+# evaluated in front of every step (rex_step_policy / rex_step_segment_policy, csrc/rex_policy.h)
+POL_SOURCES = ["rex_step_arm.hip", "rex_step_base.hip"]
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h"))   # every header the sources can include
 # -ffp-contract=on: a * b + c inside one expression is one fma and nothing else is fused -- the arithmetic of a kernel is fixed by its
 # source and does not depend on what else is compiled into it (hipcc's default lets the backend fuse across statements by heuristics:
@@ -47,13 +50,31 @@ def _hipcc():
     raise RuntimeError("hipcc not found: the rexsim HIP extension cannot be built")
 
 
+def _flags_stamp():
+    # the compile flags fix the kernels' arithmetic (-ffp-contract=on): a flags-only edit of this file must rebuild too
+    import hashlib
+    return hashlib.sha256(" ".join(HIPCC_FLAGS + POL_SOURCES).encode()).hexdigest()[:16]
+
+
 def needs_build(lib_path=None):
     lib_path = lib_path or LIB_PATH
     if not os.path.exists(lib_path):
         return True
+    try:
+        with open(lib_path + ".flags") as f:
+            if f.read().strip() != _flags_stamp():
+                return True
+    except OSError:
+        return True
     t = os.path.getmtime(lib_path)
     deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(PKG_DIR, "..", "include", "rexsim.h")]
     return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _stamp(lib_path, defines, only):
+    if not defines and not only:          # (developer builds with extra defines / left-out groups are never "up to date")
+        with open(lib_path + ".flags", "w") as f:
+            f.write(_flags_stamp() + "\n")
 
 
 _STUB = """// stub of a variant group left out of a developer build (REX_BUILD_ONLY)
@@ -90,20 +111,26 @@ def build(force=False, verbose=False, lib_path=None, defines=(), unity=False, on
                 f.write("#undef REX_TU_TRACE\n#undef REX_STEP_LAUNCHER\n#undef REX_LAUNCH_STEP\n#define REX_TU_TRACE 1\n"
                         "#define REX_STEP_LAUNCHER(group) rex_launch_step_##group##_trace\n"
                         "#define REX_LAUNCH_STEP(EPW, ARM, MIXED, BODY) hipLaunchKernelGGL((rex::rex_step_kernel<EPW, ARM, MIXED, BODY, true>), "
-                        "dim3(blocks), dim3(REX_WAVE), 0, st, s->dev, s->d_state, s->d_snap, a, o, r, d, m)\n")
+                        "dim3(blocks), dim3(REX_WAVE), 0, st, s->dev, s->d_state, s->d_snap, a, o, r, d, m, rex::NoPol{})\n")
                 f.write("".join('#include "%s"\n' % os.path.join(CSRC, s) for s in TRACE_SOURCES))
                 f.write("#undef REX_STEP_LAUNCHER\n#undef REX_LAUNCH_STEP\n"
                         "#define REX_STEP_LAUNCHER(group) rex_launch_step_##group##_seg\n"
                         "#define REX_LAUNCH_STEP(EPW, ARM, MIXED, BODY) hipLaunchKernelGGL((rex::rex_step_kernel<EPW, ARM, MIXED, BODY, false, true>), "
-                        "dim3(blocks), dim3(REX_WAVE), 0, st, s->dev, s->d_state, s->d_snap, a, o, r, d, m)\n")
+                        "dim3(blocks), dim3(REX_WAVE), 0, st, s->dev, s->d_state, s->d_snap, a, o, r, d, m, rex::NoPol{})\n")
                 f.write("".join('#include "%s"\n' % os.path.join(CSRC, s) for s in SEG_SOURCES))
+                f.write("#undef REX_STEP_LAUNCHER\n#undef REX_LAUNCH_STEP\n#undef REX_TU_POL\n#define REX_TU_POL 1\n"
+                        "#define REX_STEP_LAUNCHER(group) rex_launch_step_##group##_pol\n"
+                        "#define REX_LAUNCH_STEP(EPW, ARM, MIXED, BODY) hipLaunchKernelGGL((rex::rex_step_kernel<EPW, ARM, MIXED, BODY, false, true, true>), "
+                        "dim3(blocks), dim3(REX_WAVE), 0, st, s->dev, s->d_state, s->d_snap, a, o, r, d, m, s->pol)\n")
+                f.write("".join('#include "%s"\n' % os.path.join(CSRC, s) for s in POL_SOURCES))
             cmd = [hipcc] + flags + ["-shared", uni, "-o", lib_path]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
+            _stamp(lib_path, defines, only)
             return lib_path
         jobs_list = []
-        for s, trace in [(s, "") for s in SOURCES] + [(s, "_trace") for s in TRACE_SOURCES] + [(s, "_seg") for s in SEG_SOURCES]:
+        for s, trace in [(s, "") for s in SOURCES] + [(s, "_trace") for s in TRACE_SOURCES] + [(s, "_seg") for s in SEG_SOURCES] + [(s, "_pol") for s in POL_SOURCES]:
             src = os.path.join(CSRC, s)
             tag = trace
             if keep is not None and s in GROUPS and GROUPS[s] not in keep:
@@ -111,7 +138,7 @@ def build(force=False, verbose=False, lib_path=None, defines=(), unity=False, on
                 with open(src, "w") as f:
                     f.write(_stub_source(s, trace))
             obj = os.path.join(tmp, s[:-4] + tag + ".o")
-            jobs_list.append(([hipcc] + flags + ({"_trace": ["-DREX_TU_TRACE=1"], "_seg": ["-DREX_TU_SEG=1"]}.get(trace, [])) + ["-c", src, "-o", obj], obj))
+            jobs_list.append(([hipcc] + flags + ({"_trace": ["-DREX_TU_TRACE=1"], "_seg": ["-DREX_TU_SEG=1"], "_pol": ["-DREX_TU_POL=1"]}.get(trace, [])) + ["-c", src, "-o", obj], obj))
 
         def run(job):
             if verbose:
@@ -125,6 +152,7 @@ def build(force=False, verbose=False, lib_path=None, defines=(), unity=False, on
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+        _stamp(lib_path, defines, only)
     return lib_path
 
 

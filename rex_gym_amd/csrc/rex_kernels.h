@@ -325,6 +325,10 @@ __device__ __forceinline__ int mix_slot(const DevCfg& c, int task) {
   return sl;
 }
 
+}  // namespace rex
+#include "rex_policy.h"
+namespace rex {
+
 // INIT_POSES['rest_position'] (rex_constants.py:41-46): the foot target 6 rad lies beyond the URDF bound 2.59
 __device__ __forceinline__ float pose_rest(int j) {
   const int k = j % 3;
@@ -855,11 +859,15 @@ __device__ __forceinline__ void gather_legs(const SM& sm, int leg0, EnvState& e,
 #ifndef REX_FAST_EPW
 #define REX_FAST_EPW 4
 #endif
-template <int EPW, bool ARM, bool MIXED, bool BODY, bool TRACE = false, bool SEG = false>
+template <int EPW, bool ARM, bool MIXED, bool BODY, bool TRACE = false, bool SEG = false, bool POLICY = false>
 __global__ __launch_bounds__(REX_WAVE) REX_STEP_KERNEL_ATTR void rex_step_kernel(DevCfg c, float* __restrict__ state, const float* __restrict__ snap,
                                                             const float* __restrict__ action0, float* __restrict__ obs_out0,
                                                             float* __restrict__ reward_out0, uint8_t* __restrict__ done_out0,
-                                                            float* __restrict__ cmd_out0) {
+                                                            float* __restrict__ cmd_out0, typename PolArg<POLICY>::type pol) {
+  // POLICY (the instantiations behind rex_step_policy / rex_step_segment_policy; the base and arm step units are compiled once more with
+  // -DREX_TU_POL=1): a SEG kernel whose actions are not read from action0 but computed, step by step, by the reference's Gaussian MLP
+  // actor on the observation the env returned last (rex_policy.h) -- a closed-loop rollout segment in one launch.
+  static_assert(!POLICY || (SEG && !MIXED && !BODY && !TRACE && EPW <= 16), "the fused actor: segment kernels of the single-task lane-group variants");
   // SEG (the instantiations behind rex_step_segment; every step translation unit is compiled once more with -DREX_TU_SEG=1): one launch =
   // c.nsteps consecutive env.step() calls of the shard, a rollout segment whose actions the caller already holds -- action0 /
   // obs_out0 / ... are then [nsteps][n][...] blocks.  Without SEG the loop below runs once and folds away: rex_step's kernels.  An env's state stays in its wave's
@@ -948,9 +956,16 @@ __global__ __launch_bounds__(REX_WAVE) REX_STEP_KERNEL_ATTR void rex_step_kernel
   take_overheat(e, leg0, ms);      // (a later step of a segment: e.overheat holds all counters again -- gather_legs)
   const uint32_t motor_en0 = e.motor_en;
   float act[8];
+  if constexpr (POLICY) {
+    // algo.perform(prevob) (agents/ppo/algorithm.py:105-134): the observation of the previous step -- slice seg_step - 1 of the
+    // segment's observation block, stored by this wave in front of the fence that ended that step; the caller's obs_in for the first
+    const float* obs_prev = seg_step == 0 ? pol.obs_in : obs_out0 + (unsigned)((seg_step - 1) * c.n * c.obs_dim);
+    policy_act<EPW, LPE, ARM>(c, pol, reinterpret_cast<float*>(lds), lane, slot, pl, leg0, i, ingrid, e.episode, e.steps, obs_prev,
+                              (unsigned)(seg_step * c.n * c.action_dim), act);
+  }
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    float a = k < c.action_dim ? action[(size_t)i * c.action_dim + k] : 0.0f;
+    float a = POLICY ? act[k] : (k < c.action_dim ? action[(size_t)i * c.action_dim + k] : 0.0f);
     if (c.range_normalize) {                       // ClipAction + RangeNormalize (wrappers.py:229-234,261-265)
       a = fminf(fmaxf(a, -1.0f), 1.0f);
       a = (a + 1.0f) / 2.0f * (c_.act_hi - c_.act_lo) + c_.act_lo;
@@ -1273,6 +1288,9 @@ struct RexSim {
   int mixed_blocks;
   int32_t* d_class;      // a regrouped mixed batch: task slot of every env (rexsim.hip, rex_regroup_mixed_*), and its regions
   rex::MixRegions mix_regions;
+  rex::PolDev pol;       // rex_set_policy: the actor of rex_step_policy / rex_step_segment_policy (pointers: caller-owned device buffers)
+  int have_policy;
+  bool use_policy;        // this launch runs the fused-actor kernels (set by step_launch)
 };
 
 // launchers, one per variant group (each in its own translation unit)
@@ -1291,6 +1309,8 @@ void rex_launch_step_arm_seg(RexSim* s, int blocks, hipStream_t st, const float*
 void rex_launch_step_mixed_base_seg(RexSim* s, int blocks, hipStream_t st, const float* a, float* o, float* r, uint8_t* d, float* m);
 void rex_launch_step_mixed_arm_seg(RexSim* s, int blocks, hipStream_t st, const float* a, float* o, float* r, uint8_t* d, float* m);
 void rex_launch_step_body_seg(RexSim* s, int blocks, hipStream_t st, const float* a, float* o, float* r, uint8_t* d, float* m);
+void rex_launch_step_base_pol(RexSim* s, int blocks, hipStream_t st, const float* a, float* o, float* r, uint8_t* d, float* m);
+void rex_launch_step_arm_pol(RexSim* s, int blocks, hipStream_t st, const float* a, float* o, float* r, uint8_t* d, float* m);
 void rex_launch_settle_base(RexSim* s, int nrec, hipStream_t st, float* snap);   // <false, *>
 void rex_launch_settle_arm(RexSim* s, int nrec, hipStream_t st, float* snap);    // <true, *>
 
@@ -1302,16 +1322,26 @@ void rex_launch_settle_arm(RexSim* s, int nrec, hipStream_t st, float* snap);   
 #ifndef REX_TU_SEG
 #define REX_TU_SEG 0      /* -DREX_TU_SEG=1: the segment instantiations (rex_step_segment; launcher names end in _seg) */
 #endif
+#ifndef REX_TU_POL
+#define REX_TU_POL 0      /* -DREX_TU_POL=1: the fused-actor instantiations (rex_step_policy / rex_step_segment_policy; launcher names end in _pol) */
+#endif
 #if REX_TU_TRACE
 #define REX_STEP_LAUNCHER(group) rex_launch_step_##group##_trace
 #elif REX_TU_SEG
 #define REX_STEP_LAUNCHER(group) rex_launch_step_##group##_seg
+#elif REX_TU_POL
+#define REX_STEP_LAUNCHER(group) rex_launch_step_##group##_pol
 #else
 #define REX_STEP_LAUNCHER(group) rex_launch_step_##group
 #endif
+#if REX_TU_POL
+#define REX_POL_ARG s->pol
+#else
+#define REX_POL_ARG rex::NoPol{}
+#endif
 #define REX_LAUNCH_STEP(EPW, ARM, MIXED, BODY)                                                                                  \
-  hipLaunchKernelGGL((rex::rex_step_kernel<EPW, ARM, MIXED, BODY, REX_TU_TRACE != 0, REX_TU_SEG != 0>), dim3(blocks), dim3(REX_WAVE), 0, st, s->dev, s->d_state, s->d_snap, \
-                     a, o, r, d, m)
+  hipLaunchKernelGGL((rex::rex_step_kernel<EPW, ARM, MIXED, BODY, REX_TU_TRACE != 0, (REX_TU_SEG != 0 || REX_TU_POL != 0), REX_TU_POL != 0>), dim3(blocks), dim3(REX_WAVE), 0, st, s->dev, s->d_state, s->d_snap, \
+                     a, o, r, d, m, REX_POL_ARG)
 #define REX_LAUNCH_BY_EPW(ARM, MIXED, BODY)                                           \
   do {                                                                                \
     if (s->epw == 4) REX_LAUNCH_STEP(4, ARM, MIXED, BODY);                            \

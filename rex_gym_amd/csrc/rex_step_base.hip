@@ -2,6 +2,9 @@
 #include "rex_kernels.h"
 
 void REX_STEP_LAUNCHER(base)(RexSim* s, int blocks, hipStream_t st, const float* a, float* o, float* r, uint8_t* d, float* m) {
+#if !REX_TU_POL   /* (the fused actor spreads its neurons over the lanes of an env group: lane-group kernels only) */
   if (s->epw == 64) REX_LAUNCH_STEP(64, false, false, false);
-  else REX_LAUNCH_BY_EPW(false, false, false);
+  else
+#endif
+  REX_LAUNCH_BY_EPW(false, false, false);
 }

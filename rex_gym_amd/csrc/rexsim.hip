@@ -5,6 +5,7 @@
 // C ABI, the reset kernel and the small kernels (regrouping, controller-only entry points).
 #include "rex_kernels.h"
 #include <algorithm>
+#include <cstdarg>
 #include <vector>
 
 namespace rex {
@@ -165,6 +166,14 @@ __global__ void rex_gait_kernel(int n, int mode, double* __restrict__ planner, c
 static thread_local char g_err[512] = "";
 static int fail(int code, const char* fmt, const char* detail) {
   snprintf(g_err, sizeof(g_err), fmt, detail ? detail : "");
+  return code;
+}
+static int failf(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+static int failf(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
   return code;
 }
 #define HIPCHK(expr)                                                                  \
@@ -395,6 +404,7 @@ int rex_create(const RexConfig* cfg, int device, float* d_state, void* stream, R
   s->d_state = d_state;
   s->timing = 0;
   s->have_timing = 0;
+  s->have_policy = 0; s->use_policy = false;
   rex::DevCfg& d = s->dev;
   d.n = cfg->num_envs; d.env_index_base = cfg->env_index_base; d.task = cfg->task; d.signal = cfg->signal;
   d.nsteps = 1;
@@ -645,8 +655,63 @@ int rex_step_segment(RexSim* s, int num_steps, const float* d_action, float* d_o
   return step_launch(s, num_steps, d_action, d_obs, d_reward, d_done, d_motor_cmd, stream);
 }
 
+// ---- the actor inside the launch (rex_policy.h) ----
+static int rows_floats_per_env(const RexSim* s) {   // the contact-row region of the step kernel's LDS, per env of a wave: the actor's scratch
+  const bool arm = s->cfg.mark == REX_MARK_ARM;
+  const int legf4 = REX_LEG_F4_OF(s->epw, arm, false);
+  return 4 * (arm ? REX_LDS_F4_PER_ENV_ARM_OF(s->epw) : REX_ROWS_F4_OF(legf4));
+}
+
+int rex_set_policy(RexSim* s, const RexPolicy* p) {
+  if (!s) return fail(REX_EINVAL, "rex_set_policy: null sim%s", "");
+  if (!p) { s->have_policy = 0; return REX_OK; }
+  if (s->cfg.task == REX_TASK_MIXED || s->cfg.body_contacts || s->epw > 16)
+    return fail(REX_EINVAL, "rex_set_policy: the fused actor runs in the single-task lane-group kernels (not REX_TASK_MIXED, body_contacts = 0, REX_ENVS_PER_WAVE <= 16)%s", "");
+  if (!s->cfg.range_normalize)
+    return fail(REX_EINVAL, "rex_set_policy: the sim must fold the reference's wrapper stack (RexConfig.range_normalize = 1): the agents act through "
+                            "RangeNormalize + ClipAction (playground/trainer.py:48-52)%s", "");
+  if (p->obs_dim != rex_obs_dim(&s->cfg) || p->action_dim != rex_action_dim(&s->cfg))
+    return failf(REX_EINVAL, "rex_set_policy: obs_dim / action_dim %d / %d do not match the sim's %d / %d", p->obs_dim, p->action_dim, rex_obs_dim(&s->cfg), rex_action_dim(&s->cfg));
+  if (p->hidden1 < 1 || p->hidden2 < 1 || rex::policy_scratch_floats(p->obs_dim, p->hidden1, p->hidden2) > rows_floats_per_env(s))
+    return failf(REX_EINVAL, "rex_set_policy: hidden layers of %d and %d units need %d floats of LDS per env, this kernel variant has %d", p->hidden1, p->hidden2,
+                rex::policy_scratch_floats(p->obs_dim, p->hidden1 > 0 ? p->hidden1 : 0, p->hidden2 > 0 ? p->hidden2 : 0), rows_floats_per_env(s));
+  if (!p->d_w1 || !p->d_b1 || !p->d_w2 || !p->d_b2 || !p->d_w3 || !p->d_b3 || !p->d_logstd || (!p->d_obs_mean) != (!p->d_obs_scale))
+    return fail(REX_EINVAL, "rex_set_policy: null weight pointer (d_obs_mean and d_obs_scale go together)%s", "");
+  if (!(p->obs_clip > 0.0f) && p->d_obs_mean) return fail(REX_EINVAL, "rex_set_policy: obs_clip must be positive%s", "");
+  rex::PolDev& d = s->pol;
+  d.w1 = p->d_w1; d.b1 = p->d_b1; d.w2 = p->d_w2; d.b2 = p->d_b2; d.w3 = p->d_w3; d.b3 = p->d_b3; d.logstd = p->d_logstd;
+  d.obs_mean = p->d_obs_mean; d.obs_scale = p->d_obs_scale; d.obs_in = nullptr; d.action_out = nullptr; d.mean_out = nullptr;
+  d.h1 = p->hidden1; d.h2 = p->hidden2; d.obs_clip = p->obs_clip; d.sample = p->sample ? 1 : 0;
+  d.seed_lo = (uint32_t)p->seed; d.seed_hi = (uint32_t)(p->seed >> 32);
+  s->have_policy = 1;
+  return REX_OK;
+}
+
+static int policy_launch(RexSim* s, const char* who, int num_steps, const float* d_obs_in, float* d_action, float* d_mean, float* d_obs, float* d_reward,
+                         uint8_t* d_done, float* d_motor_cmd, void* stream) {
+  if (!s || !d_obs_in || !d_action || !d_obs || !d_reward || !d_done) return fail(REX_EINVAL, "%s: null pointer", who);
+  if (!s->have_policy) return fail(REX_EINVAL, "%s: no policy set (rex_set_policy)", who);
+  if (s->dev.trace) return fail(REX_EINVAL, "%s: not available while an event trace is set (rex_set_event_trace)", who);
+  if (num_steps < 1) return fail(REX_EINVAL, "%s: num_steps must be at least 1", who);
+  if (d_obs_in == d_obs) return fail(REX_EINVAL, "%s: d_obs must not alias d_obs_in", who);
+  const long long width = std::max(std::max(rex_action_dim(&s->cfg), rex_obs_dim(&s->cfg)), rex_num_motors(&s->cfg));
+  if ((long long)num_steps * s->cfg.num_envs * width >= (1ll << 31))
+    return fail(REX_EINVAL, "%s: a segment this long exceeds the 32-bit element offsets of its blocks (num_steps * num_envs * row width < 2^31)", who);
+  s->pol.obs_in = d_obs_in; s->pol.action_out = d_action; s->pol.mean_out = d_mean;
+  return step_launch(s, -num_steps, nullptr, d_obs, d_reward, d_done, d_motor_cmd, stream);   // (negative: the fused-actor kernels)
+}
+int rex_step_policy(RexSim* s, const float* d_obs_in, float* d_action, float* d_mean, float* d_obs, float* d_reward, uint8_t* d_done, float* d_motor_cmd, void* stream) {
+  return policy_launch(s, "rex_step_policy", 1, d_obs_in, d_action, d_mean, d_obs, d_reward, d_done, d_motor_cmd, stream);
+}
+int rex_step_segment_policy(RexSim* s, int num_steps, const float* d_obs_in, float* d_action, float* d_mean, float* d_obs, float* d_reward, uint8_t* d_done,
+                            float* d_motor_cmd, void* stream) {
+  return policy_launch(s, "rex_step_segment_policy", num_steps, d_obs_in, d_action, d_mean, d_obs, d_reward, d_done, d_motor_cmd, stream);
+}
+
 static int step_launch(RexSim* s, int num_steps, const float* d_action, float* d_obs, float* d_reward, uint8_t* d_done, float* d_motor_cmd, void* stream) {
   HIPCHK(hipSetDevice(s->device));
+  s->use_policy = num_steps < 0;
+  if (num_steps < 0) num_steps = -num_steps;
   s->dev.nsteps = num_steps;
   hipStream_t st = (hipStream_t)stream;
   const int blocks = s->d_slot_env ? s->mixed_blocks : (s->cfg.num_envs + s->epw - 1) / s->epw;
@@ -832,6 +897,10 @@ static void launch_step(RexSim* s, int blocks, hipStream_t st, const float* a, f
     else if (s->cfg.body_contacts) rex_launch_step_body_trace(s, blocks, st, a, o, r, d, m);
     else if (arm) rex_launch_step_arm_trace(s, blocks, st, a, o, r, d, m);
     else rex_launch_step_base_trace(s, blocks, st, a, o, r, d, m);
+    return;
+  }
+  if (s->use_policy) {       // rex_step_policy / rex_step_segment_policy: the segment kernels with the actor in front of every step
+    if (arm) rex_launch_step_arm_pol(s, blocks, st, a, o, r, d, m); else rex_launch_step_base_pol(s, blocks, st, a, o, r, d, m);
     return;
   }
   if (s->dev.nsteps > 1) {   // rex_step_segment: the instantiations with the loop over the segment's steps

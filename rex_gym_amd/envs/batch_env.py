@@ -388,10 +388,8 @@ class RexBatchEnv:
                 # above); throughput loops that have validated their actions beforehand pass check_actions=False.
                 bad = ~torch.isfinite(a)
                 if not self.config.range_normalize:
-                    if self._act_lo is None:
-                        self._act_lo = torch.as_tensor(np.minimum(self.action_space.low, self.action_space.high).astype(np.float32), device=self.device)
-                        self._act_hi = torch.as_tensor(np.maximum(self.action_space.low, self.action_space.high).astype(np.float32), device=self.device)
-                    bad |= (a < self._act_lo) | (a > self._act_hi)
+                    lo, hi = self._action_bounds()
+                    bad |= (a < lo) | (a > hi)
                 rows = bad.any(dim=1)
                 if bool(rows.any()):
                     i = int(torch.nonzero(rows)[0])
@@ -403,6 +401,13 @@ class RexBatchEnv:
         _lib.check(self._L.rex_step(self._h, a.data_ptr(), out.p_obs, out.p_reward, out.p_done, self._p_cmd, self._stream_ptr()), "rex_step")
         return out.obs, out.reward, out.done_bool, self._info
 
+    def _action_bounds(self):
+        if self._act_lo is None:
+            torch = self._torch
+            self._act_lo = torch.as_tensor(np.minimum(self.action_space.low, self.action_space.high).astype(np.float32), device=self.device)
+            self._act_hi = torch.as_tensor(np.maximum(self.action_space.low, self.action_space.high).astype(np.float32), device=self.device)
+        return self._act_lo, self._act_hi
+
     def step_segment(self, actions, out=None, motor_cmd=None):
         """A rollout segment in ONE launch (rex_step_segment): actions [T, N, action_dim] that the caller already holds -- an
         open-loop rollout: random-action throughput runs, a replayed action tape -- gives (obs [T, N, O], reward [T, N],
@@ -411,7 +416,8 @@ class RexBatchEnv:
         every step.  The reference has no counterpart (its envs take one action at a time); step() is unchanged.
 
         out=(obs, reward, done): contiguous device tensors of those shapes (done uint8 or bool) the launch writes into.
-        motor_cmd: optional [T, N, num_motors] float32 tensor for info['action'] of every step.  Per-step randomizers
+        motor_cmd: optional [T, N, num_motors] float32 tensor for info['action'] of every step (without it info['action'] is None:
+        a segment does not record the motor commands unless asked to).  Per-step randomizers
         (randomize_step) and the per-step Box test do not fit a segment: envs that use them raise."""
         torch = self._torch
         if self._needs_reset:
@@ -427,8 +433,7 @@ class RexBatchEnv:
             if self.check_actions:     # the Box test of BatchEnv.step on the whole segment up front: one host synchronisation
                 bad = ~torch.isfinite(a)
                 if not self.config.range_normalize:
-                    lo = torch.as_tensor(np.minimum(self.action_space.low, self.action_space.high).astype(np.float32), device=self.device)
-                    hi = torch.as_tensor(np.maximum(self.action_space.low, self.action_space.high).astype(np.float32), device=self.device)
+                    lo, hi = self._action_bounds()
                     bad |= (a < lo) | (a > hi)
                 if bool(bad.any()):
                     t, i = (int(v) for v in torch.nonzero(bad.any(dim=2))[0])
@@ -446,12 +451,102 @@ class RexBatchEnv:
             p_cmd = None
             if motor_cmd is not None:
                 nm = self._info["action"].shape[1]
-                if tuple(motor_cmd.shape) != (T, self.num_envs, nm) or motor_cmd.dtype != torch.float32 or not motor_cmd.is_contiguous():
-                    raise ValueError(f"motor_cmd must be a contiguous float32 tensor of shape {(T, self.num_envs, nm)}")
+                if tuple(motor_cmd.shape) != (T, self.num_envs, nm) or motor_cmd.dtype != torch.float32 or not motor_cmd.is_contiguous() \
+                        or motor_cmd.device != self.device:
+                    raise ValueError(f"motor_cmd must be a contiguous float32 tensor of shape {(T, self.num_envs, nm)} on {self.device}")
                 p_cmd = motor_cmd.data_ptr()
         _lib.check(self._L.rex_step_segment(self._h, T, a.data_ptr(), obs.data_ptr(), reward.data_ptr(), done.data_ptr(), p_cmd, self._stream_ptr()),
                    "rex_step_segment")
         return obs, reward, (done if done.dtype == torch.bool else done.view(torch.bool)), {"action": motor_cmd}
+
+    # ---- the actor inside the launch (rex_set_policy / rex_step_policy / rex_step_segment_policy) ----
+    def set_policy(self, w1, b1, w2, b2, w3, b3, logstd, obs_mean=None, obs_scale=None, obs_clip=5.0, sample=True, seed=0):
+        """Install the actor the closed-loop launches evaluate (include/rexsim.h `RexPolicy`): the reference's ForwardGaussianPolicy
+        (agents/scripts/networks.py:66-110) behind its observ filter (agents/ppo/normalize.py:47-66).  Contiguous float32 device
+        tensors, INPUT-major weights: w1 [obs_dim, h1], w2 [h1, h2], w3 [h2, action_dim] (the transpose of torch.nn.Linear.weight),
+        biases and logstd as vectors, obs_mean / obs_scale [obs_dim] or both None.  The env keeps the tensors (not copies): a learner
+        that updates them IN PLACE changes what the next launch computes; set_policy(None) removes the policy.
+        The env must have been created with range_normalize=True (the agents act through RangeNormalize + ClipAction)."""
+        torch = self._torch
+        if w1 is None:
+            _lib.check(self._L.rex_set_policy(self._h, None), "rex_set_policy")
+            self._policy = None
+            return
+        ts = dict(w1=w1, b1=b1, w2=w2, b2=b2, w3=w3, b3=b3, logstd=logstd)
+        if (obs_mean is None) != (obs_scale is None):
+            raise ValueError("obs_mean and obs_scale go together")
+        if obs_mean is not None:
+            ts.update(obs_mean=obs_mean, obs_scale=obs_scale)
+        for name, t in ts.items():
+            if not isinstance(t, torch.Tensor) or t.dtype != torch.float32 or t.device != self.device or not t.is_contiguous():
+                raise ValueError(f"set_policy: {name} must be a contiguous float32 tensor on {self.device}")
+        h1, h2 = int(w1.shape[1]) if w1.dim() == 2 else -1, int(w2.shape[1]) if w2.dim() == 2 else -1
+        want = dict(w1=(self.obs_dim, h1), b1=(h1,), w2=(h1, h2), b2=(h2,), w3=(h2, self.action_dim), b3=(self.action_dim,),
+                    logstd=(self.action_dim,), obs_mean=(self.obs_dim,), obs_scale=(self.obs_dim,))
+        for name, t in ts.items():
+            if tuple(t.shape) != want[name]:
+                raise ValueError(f"set_policy: {name} has shape {tuple(t.shape)}, expected {want[name]}")
+        pol = _lib.RexPolicy()
+        pol.obs_dim, pol.action_dim, pol.hidden1, pol.hidden2 = self.obs_dim, self.action_dim, h1, h2
+        for name in ("w1", "b1", "w2", "b2", "w3", "b3", "logstd", "obs_mean", "obs_scale"):
+            setattr(pol, "d_" + name, ts[name].data_ptr() if name in ts else None)
+        pol.obs_clip, pol.sample, pol.seed = float(obs_clip), int(bool(sample)), int(seed) & (2 ** 64 - 1)
+        _lib.check(self._L.rex_set_policy(self._h, ctypes.byref(pol)), "rex_set_policy")
+        self._policy = ts   # (keeps the tensors alive)
+
+    def _policy_blocks(self, T, obs_in, out, action, mean, motor_cmd):
+        torch = self._torch
+        if self._needs_reset:
+            raise RuntimeError("Must reset environment.")
+        if getattr(self, "_policy", None) is None:
+            raise RuntimeError("no policy set: call set_policy(...) first")
+        if any(hasattr(r, "randomize_step") for r in self._env_randomizers):
+            raise ValueError("a randomizer with randomize_step() acts between steps on the host; use step()")
+        n, lead = self.num_envs, ((T,) if T is not None else ())
+        def block(t, shape, dts, name):
+            if t is None:
+                return torch.empty(lead + shape, dtype=dts[0], device=self.device)
+            if tuple(t.shape) != lead + shape or t.dtype not in dts or not t.is_contiguous() or t.device != self.device:
+                raise ValueError(f"{name} must be a contiguous {dts[0]} tensor of shape {lead + shape} on {self.device}")
+            return t
+        if not isinstance(obs_in, torch.Tensor) or tuple(obs_in.shape) != (n, self.obs_dim) or obs_in.dtype != torch.float32 \
+                or not obs_in.is_contiguous() or obs_in.device != self.device:
+            raise ValueError(f"obs_in must be a contiguous float32 tensor of shape {(n, self.obs_dim)} on {self.device}")
+        o, r, d = out if out is not None else (None, None, None)
+        o = block(o, (n, self.obs_dim), (torch.float32,), "out obs")
+        r = block(r, (n,), (torch.float32,), "out reward")
+        d = block(d, (n,), (torch.uint8, torch.bool), "out done")
+        action = block(action, (n, self.action_dim), (torch.float32,), "action")
+        mean = block(mean, (n, self.action_dim), (torch.float32,), "mean")
+        if motor_cmd is not None:
+            motor_cmd = block(motor_cmd, (n, self.num_motors), (torch.float32,), "motor_cmd")
+        return obs_in, o, r, d, action, mean, motor_cmd
+
+    def step_policy(self, obs_in, out=None, action=None, mean=None, motor_cmd=None):
+        """One CLOSED-LOOP env.step() of every env in one launch (rex_step_policy): action = policy(obs_in) -- obs_in [N, obs_dim]
+        is what the envs returned last (reset() or the previous step) --, then the step.  Returns (obs, reward, done, info) as
+        step(); info['policy_action'] [N, A] is the action the policy took as the agent's memory stores it (before ClipAction /
+        RangeNormalize), info['policy_mean'] its mean, info['action'] the motor commands (the tensor passed as motor_cmd, else None)."""
+        torch = self._torch
+        obs_in, o, r, d, action, mean, motor_cmd = self._policy_blocks(None, obs_in, out, action, mean, motor_cmd)
+        _lib.check(self._L.rex_step_policy(self._h, obs_in.data_ptr(), action.data_ptr(), mean.data_ptr(), o.data_ptr(), r.data_ptr(), d.data_ptr(),
+                                           motor_cmd.data_ptr() if motor_cmd is not None else None, self._stream_ptr()), "rex_step_policy")
+        return o, r, (d if d.dtype == torch.bool else d.view(torch.bool)), {"action": motor_cmd, "policy_action": action, "policy_mean": mean}
+
+    def step_segment_policy(self, num_steps, obs_in, out=None, action=None, mean=None, motor_cmd=None):
+        """A closed-loop rollout SEGMENT in one launch (rex_step_segment_policy): T = num_steps consecutive step_policy() calls, step t
+        acting on the observation of step t - 1 (obs_in for t = 0), bit-identical to them.  Blocks [T, N, ...]: returns (obs, reward,
+        done, info) with info['policy_action'] / ['policy_mean'] [T, N, A].  A caller that keeps obs[T + 1, N, O] passes
+        obs_in=obs[0], out=(obs[1:], reward, done): the policy's input of step t is obs[t]."""
+        torch = self._torch
+        T = int(num_steps)
+        if T < 1:
+            raise ValueError("num_steps must be at least 1")
+        obs_in, o, r, d, action, mean, motor_cmd = self._policy_blocks(T, obs_in, out, action, mean, motor_cmd)
+        _lib.check(self._L.rex_step_segment_policy(self._h, T, obs_in.data_ptr(), action.data_ptr(), mean.data_ptr(), o.data_ptr(), r.data_ptr(),
+                                                   d.data_ptr(), motor_cmd.data_ptr() if motor_cmd is not None else None, self._stream_ptr()),
+                   "rex_step_segment_policy")
+        return o, r, (d if d.dtype == torch.bool else d.view(torch.bool)), {"action": motor_cmd, "policy_action": action, "policy_mean": mean}
 
     def bind_out(self, obs, reward, done):
         """Validate a set of output tensors once (`step(..., out=...)`): returns a StepOut that a loop can pass again and again."""

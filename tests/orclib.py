@@ -55,7 +55,7 @@ SIGNALS = {"ik": 0, "ol": 1}
 def default_config(task="walk", signal="ik", num_envs=1, **kw):
     """Reference defaults."""
     repeat = 6 if task in ("gallop", "poses") else 5
-    c = RexConfig(abi_version=5, num_envs=num_envs, env_index_base=0, task=TASKS[task], signal=SIGNALS[signal],
+    c = RexConfig(abi_version=6, num_envs=num_envs, env_index_base=0, task=TASKS[task], signal=SIGNALS[signal],
                   action_repeat=repeat, solver_iterations=300 // repeat, sim_time_step=0.001,
                   motor_kp=1.0, motor_kd=0.02, backwards=-1, target_position=0.0, seed=0, auto_reset=0,
                   max_episode_steps=0, distance_weight=1.0, energy_weight=0.005 if task == "gallop" else 0.0005, drift_weight=2.0,

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol(L):
     lib = L.lib()
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.rex_abi_version() == L.ABI_VERSION == 5
+    assert lib.rex_abi_version() == L.ABI_VERSION == 6
 
 
 def test_default_config_matches_reference_constants(L):
