@@ -300,16 +300,19 @@ REX_API int rex_step_segment(RexSim* sim, int num_steps, const float* d_action, 
  * ForwardGaussianPolicy: two ReLU layers, tanh mean layer, a free logstd vector; configs.py:29-34) and the Gaussian sample of
  * `network.policy.sample` (Philox keyed by seed, global env index, episode, step: a rollout is a pure function of the seeds and the
  * weights, whatever the sharding or the segment length).
- * All arrays are caller-owned DEVICE buffers that must stay valid while the policy is set; the caller may rewrite their CONTENTS
- * between launches (a learner updating its weights in place).  Weight matrices are input-major: d_w1[k * hidden1 + j] = the weight
- * from input k to unit j (the transpose of a torch.nn.Linear weight; the layout of a TF1 `fully_connected/weights` variable).
+ * The arrays are caller-owned DEVICE buffers; rex_set_policy SNAPSHOTS them (a packing kernel on `stream`, into a library-owned
+ * buffer laid out for the kernels: rex_gym_amd/csrc/rex_policy.h), so they only have to stay valid until the stream has passed that
+ * point, and a learner that has updated its weights or its filter statistics calls rex_set_policy again.  Weight matrices are
+ * input-major: d_w1[k * hidden1 + j] = the weight from input k to unit j (the transpose of a torch.nn.Linear weight; the layout
+ * of a TF1 `fully_connected/weights` variable).
  * Needs range_normalize = 1 in the sim's config -- the reference's agents always act through RangeNormalize + ClipAction
  * (playground/trainer.py:48-52): the sampled action is clipped to [-1, 1] and mapped to the env's Box inside the launch, a fused
  * path has no Box test to fail -- a single-task sim (not REX_TASK_MIXED), toes-only contact rows (body_contacts = 0), no event trace. */
 typedef struct RexPolicy {
   int32_t obs_dim, action_dim;        /* must equal rex_obs_dim / rex_action_dim of the sim's config */
   int32_t hidden1, hidden2;           /* units of the two ReLU layers (configs.py:31: 200, 100); obs_dim + 12 + hidden1 + hidden2 floats
-                                         per env must fit the kernel's contact-row region of LDS (448 for mark base up to 8 192 envs) */
+                                         (each term rounded up to a multiple of 4) per env must fit the kernel's contact-row region of
+                                         LDS (448 for mark base up to 8 192 envs) */
   const float* d_w1; const float* d_b1;   /* [obs_dim][hidden1], [hidden1] */
   const float* d_w2; const float* d_b2;   /* [hidden1][hidden2], [hidden2] */
   const float* d_w3; const float* d_b3;   /* [hidden2][action_dim], [action_dim]: the mean layer, tanh on top */
@@ -320,8 +323,8 @@ typedef struct RexPolicy {
   int32_t sample;                         /* 1: action = mean + exp(logstd) * N(0, 1) (training); 0: action = mean (evaluation) */
   uint64_t seed;                          /* Philox key of the samples */
 } RexPolicy;
-/* Install (copy) the policy description; NULL removes it.  Validates the dimensions against the sim. */
-REX_API int rex_set_policy(RexSim* sim, const RexPolicy* policy);
+/* Install the policy (validates the dimensions against the sim, packs the arrays on `stream`); NULL removes it. */
+REX_API int rex_set_policy(RexSim* sim, const RexPolicy* policy, void* stream);
 
 /* One closed-loop env.step() for every env: action = perform(d_obs_in), then the step.
  *   d_obs_in [N, obs_dim]     in  -- the observation the envs returned last (rex_reset, or the previous step's d_obs)

@@ -72,7 +72,7 @@ _SIGS = {
                   ctypes.c_void_p, ctypes.c_void_p], ctypes.c_int),
     "rex_step_segment": ([ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                           ctypes.c_void_p, ctypes.c_void_p], ctypes.c_int),
-    "rex_set_policy": ([ctypes.c_void_p, ctypes.POINTER(RexPolicy)], ctypes.c_int),
+    "rex_set_policy": ([ctypes.c_void_p, ctypes.POINTER(RexPolicy), ctypes.c_void_p], ctypes.c_int),
     "rex_step_policy": ([ctypes.c_void_p] + [ctypes.c_void_p] * 8, ctypes.c_int),
     "rex_step_segment_policy": ([ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 8, ctypes.c_int),
     "rex_set_timing": ([ctypes.c_void_p, ctypes.c_int], ctypes.c_int),

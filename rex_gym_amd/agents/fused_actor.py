@@ -4,10 +4,11 @@ The reference's rollout loop is `action = algo.perform(prevob)` -> `batch_env.si
 (rex_gym/agents/tools/simulate.py:57-76, agents/ppo/algorithm.py:105-134).  `FusedActor` packs what perform() evaluates
 -- the observ filter's statistics (agents/ppo/normalize.py:47-66) and the ForwardGaussianPolicy weights
 (agents/scripts/networks.py:66-110) -- into the device buffers `RexBatchEnv.set_policy` hands to the library, in the
-kernel's layout (input-major weight matrices), so that `env.step_policy` / `env.step_segment_policy` run perform() inside
-the step launch (csrc/rex_policy.h).  `sync()` refreshes the buffers IN PLACE from the torch module and the filter: the
-learner calls it after every update (and whenever it wants the filter statistics of the rollout refreshed); between two
-sync() calls the actor is frozen, as the reference's is between two training phases.
+ABI's layout (input-major weight matrices), so that `env.step_policy` / `env.step_segment_policy` run perform() inside
+the step launch (csrc/rex_policy.h).  `sync()` refreshes the buffers from the torch module and the filter and hands them to
+the library again (which snapshots them: `rex_set_policy`): the learner calls it after every update (and whenever it wants the
+filter statistics of the rollout refreshed); between two sync() calls the actor is frozen, as the reference's is between two
+training phases.
 """
 import torch
 
@@ -30,9 +31,8 @@ class FusedActor:
         self.w1, self.b1, self.w2, self.b2, self.w3, self.b3, self.logstd = f(O, h1), f(h1), f(h1, h2), f(h2), f(h2, A), f(A), f(A)
         self.obs_mean, self.obs_scale = (f(O), f(O)) if observ_filter is not None else (None, None)
         self.obs_clip = float(observ_filter.clip) if observ_filter is not None and observ_filter.clip else 5.0
+        self.sample, self.seed = bool(sample), int(seed)
         self.sync()
-        env.set_policy(self.w1, self.b1, self.w2, self.b2, self.w3, self.b3, self.logstd, self.obs_mean, self.obs_scale,
-                       obs_clip=self.obs_clip, sample=sample, seed=seed)
 
     @torch.no_grad()
     def sync(self):
@@ -48,6 +48,9 @@ class FusedActor:
                 self.obs_scale.copy_(1.0 / (flt.std() + 1e-8))      # normalize.py:60-62
             else:
                 self.obs_scale.fill_(1.0)
+        # the library snapshots (packs) the arrays on the env's stream
+        self.env.set_policy(self.w1, self.b1, self.w2, self.b2, self.w3, self.b3, self.logstd, self.obs_mean, self.obs_scale,
+                            obs_clip=self.obs_clip, sample=self.sample, seed=self.seed)
 
     @torch.no_grad()
     def forward_reference(self, observ):

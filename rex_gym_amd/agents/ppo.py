@@ -490,6 +490,89 @@ def train(env, agent, steps, training=True, sync_poll=8):
     return float(torch.cat(scores).mean()), float(torch.cat(lengths).float().mean())
 
 
+def train_segments(env, agent, steps, segment=25, training=True, actor=None, seed=0):
+    """The same loop with the ACTOR INSIDE THE LAUNCH and no per-step host synchronisation: what simulate() does step by step
+    (agents/tools/simulate.py:57-131: reset finished envs, perform, simulate, experience, end_episode) done a rollout SEGMENT at a
+    time.  `env.step_segment_policy` (rex_step_segment_policy) runs `segment` closed-loop steps in one launch -- the policy of
+    `agent.net` behind `agent.observ_filter`, sampled in the kernel; finished envs are reset inside the launch (the env must have
+    been created with auto_reset=True, range_normalize=True and max_episode_steps=agent.cfg.max_length: LimitDuration folded) -- and
+    hands back the segment's blocks obs [T + 1, N, O], action / mean [T, N, A], reward, done [T, N].  The episode bookkeeping then
+    runs on those blocks on the device: the filters are updated with the segment's observations and rewards (one batched Welford
+    step instead of T), every transition is scattered to its place in its env's running episode, finished episodes go to the
+    agent's memory (end_episode -> the update when it is full), in the order (episode ordinal within the segment, env index).
+    Host synchronisations: one per segment (how many episodes ended) plus one per ordinal with finished episodes -- not three per
+    step.  The actor's weights and filter statistics are refreshed (FusedActor.sync) before every segment, so a segment is rolled
+    out with the policy and the filter as they stood at its start (the reference's perform() sees the filter of the step before).
+
+    steps: control steps of every env (rounded up to whole segments).  Returns the mean score and length of the episodes that ended.
+    `actor`: a FusedActor to reuse between calls (else one is made and left installed in the env)."""
+    from .fused_actor import FusedActor
+    dev, cfg, n = agent.device, agent.cfg, agent.n
+    T = int(segment)
+    if not env.config.auto_reset or not env.config.range_normalize or env.config.max_episode_steps != cfg.max_length:
+        raise ValueError("train_segments: create the env with auto_reset=True, range_normalize=True, max_episode_steps=agent.cfg.max_length")
+    if agent.state is not None:
+        raise NotImplementedError("the recurrent policy runs through train(): its GRU state is not carried by the fused actor")
+    if actor is None:
+        actor = FusedActor(env, agent.net, agent.observ_filter, sample=training, seed=seed)
+    O, A, Tmax = env.obs_dim, env.action_dim, cfg.max_length
+    obs = torch.zeros((T + 1, n, O), device=dev)
+    action, mean = torch.zeros((T, n, A), device=dev), torch.zeros((T, n, A), device=dev)
+    reward, done = torch.zeros((T, n), device=dev), torch.zeros((T, n), dtype=torch.uint8, device=dev)
+    obs[0].copy_(env.reset())
+    agent.begin_episode(torch.arange(n, device=dev))
+    score0 = torch.zeros(n, device=dev)
+    tt = torch.arange(T, device=dev)[:, None]
+    rows = torch.arange(n, device=dev)
+    scores, lengths = [], []
+    for _ in range((int(steps) + T - 1) // T):
+        actor.sync()
+        logstd = agent.net.logstd.detach().clone()
+        env.step_segment_policy(T, obs[0], out=(obs[1:], reward, done), action=action, mean=mean)
+        d = done.bool()
+        if training:
+            agent.observ_filter.update(obs[:T].reshape(T * n, O))
+            agent.reward_filter.update(reward.reshape(T * n))
+        # every transition's episode ordinal within the segment and its position inside its episode
+        cnt = d.long().cumsum(0)
+        ordinal = cnt - d.long()
+        last_done = torch.where(d, tt, torch.full_like(cnt, -1)).cummax(0).values          # latest done step <= t
+        prev_done = torch.cat([torch.full((1, n), -1, device=dev, dtype=torch.long), last_done[:-1]], 0)   # latest done step < t
+        len0 = agent.episode_length.clone()
+        pos = torch.where(ordinal == 0, len0[None, :] + tt, tt - prev_done - 1)
+        csum = reward.cumsum(0)
+        before = torch.where(prev_done >= 0, csum.gather(0, prev_done.clamp(min=0)), -score0[None, :].expand(T, n))
+        ep_score = csum - before                                                             # of the episode (t, n) belongs to, up to t
+        total = cnt[-1]
+        rounds = int(total.max())                                                            # (the segment's one unconditional sync)
+        for r in range(rounds + 1):
+            m = ordinal == r
+            if training:
+                t_idx, n_idx = m.nonzero(as_tuple=True)
+                p_idx = pos[t_idx, n_idx].clamp(max=Tmax - 1)
+                for buf, val in zip(agent.episodes, (obs[:T], action, mean, None, reward)):
+                    buf[n_idx, p_idx] = val[t_idx, n_idx] if val is not None else logstd.expand(t_idx.numel(), A)
+            if r < rounds:
+                ends = m & d                                                                 # at most one per env
+                fin = (total > r).nonzero()[:, 0]
+                ep_len = torch.where(ends, pos + 1, torch.zeros_like(pos)).sum(0)
+                scores.append(torch.where(ends, ep_score, torch.zeros_like(ep_score)).sum(0)[fin])
+                lengths.append(ep_len[fin])
+                if training:
+                    agent.episode_length[fin] = ep_len[fin]
+                    agent.end_episode(fin)
+                agent.begin_episode(fin)
+        if training:
+            agent.train_if_all_full()               # no-op for a single-rank learner
+        # what the running episodes hold after the segment
+        agent.episode_length.copy_(torch.where(total == 0, len0 + T, T - 1 - last_done[-1]))
+        score0 = torch.where(total == 0, score0 + csum[-1], csum[-1] - csum.gather(0, last_done[-1:].clamp(min=0))[0])
+        obs[0].copy_(obs[T])
+    if not scores:
+        return float("nan"), float("nan")
+    return float(torch.cat(scores).mean()), float(torch.cat(lengths).float().mean())
+
+
 if __name__ == "__main__":   # python -m rex_gym_amd.agents.ppo --task walk --envs 1024 --iterations 20
     import argparse
     from ..envs.batch_env import RexBatchEnv
@@ -499,12 +582,25 @@ if __name__ == "__main__":   # python -m rex_gym_amd.agents.ppo --task walk --en
     ap.add_argument("--max-length", type=int, default=500); ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--gait-clock-scale", type=float, default=1.0,
                     help="wall-clock seconds per simulated second seen by GaitPlanner.loop (gait_planner.py:108-110)")
+    ap.add_argument("--loop", default="segments", choices=["segments", "steps"],
+                    help="segments: the actor inside the launch, one launch per --segment steps (train_segments); steps: perform() in PyTorch, "
+                         "one launch and three host synchronisations per step (train, the reference's loop shape)")
+    ap.add_argument("--segment", type=int, default=25)
     a = ap.parse_args()
+    import time
     # the reference trains through RangeNormalize + ClipAction (playground/trainer.py:48-52): actions in [-1, 1]
     env = RexBatchEnv(a.envs, task=a.task, signal_type=a.signal, seed=a.seed, max_episode_steps=a.max_length, range_normalize=True,
-                      gait_clock_scale=a.gait_clock_scale)
+                      gait_clock_scale=a.gait_clock_scale, auto_reset=a.loop == "segments", check_actions=False)
     agent = PPOAgent(a.envs, env.obs_dim, env.action_dim, PPOConfig(update_every=a.envs, max_length=a.max_length), seed=a.seed)
+    actor = None
+    if a.loop == "segments":
+        from .fused_actor import FusedActor
+        actor = FusedActor(env, agent.net, agent.observ_filter, sample=True, seed=a.seed)
+    t0 = time.perf_counter()
     for it in range(a.iterations):
-        score, length = train(env, agent, a.max_length)
+        if a.loop == "segments":
+            score, length = train_segments(env, agent, a.max_length, segment=a.segment, actor=actor)
+        else:
+            score, length = train(env, agent, a.max_length)
         print(f"iteration {it}: mean score {score:.3f}, mean length {length:.1f}, updates {agent.updates}, "
-              f"penalty {agent.penalty:.3g}", flush=True)
+              f"penalty {agent.penalty:.3g}, {time.perf_counter() - t0:.1f} s", flush=True)

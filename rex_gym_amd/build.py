@@ -120,8 +120,7 @@ def build(force=False, verbose=False, lib_path=None, defines=(), unity=False, on
                 f.write("".join('#include "%s"\n' % os.path.join(CSRC, s) for s in SEG_SOURCES))
                 f.write("#undef REX_STEP_LAUNCHER\n#undef REX_LAUNCH_STEP\n#undef REX_TU_POL\n#define REX_TU_POL 1\n"
                         "#define REX_STEP_LAUNCHER(group) rex_launch_step_##group##_pol\n"
-                        "#define REX_LAUNCH_STEP(EPW, ARM, MIXED, BODY) hipLaunchKernelGGL((rex::rex_step_kernel<EPW, ARM, MIXED, BODY, false, true, true>), "
-                        "dim3(blocks), dim3(REX_WAVE), 0, st, s->dev, s->d_state, s->d_snap, a, o, r, d, m, s->pol)\n")
+                        "#define REX_LAUNCH_STEP(EPW, ARM, MIXED, BODY) rex_launch_policy_kernel<EPW, ARM>(s, blocks, st, a, o, r, d, m)\n")
                 f.write("".join('#include "%s"\n' % os.path.join(CSRC, s) for s in POL_SOURCES))
             cmd = [hipcc] + flags + ["-shared", uni, "-o", lib_path]
             if verbose:

@@ -859,14 +859,18 @@ __device__ __forceinline__ void gather_legs(const SM& sm, int leg0, EnvState& e,
 #ifndef REX_FAST_EPW
 #define REX_FAST_EPW 4
 #endif
+#define REX_POLICY_WAVES 4   /* waves per workgroup of the fused-actor kernels: they share one copy of the actor's weights in LDS */
 template <int EPW, bool ARM, bool MIXED, bool BODY, bool TRACE = false, bool SEG = false, bool POLICY = false>
-__global__ __launch_bounds__(REX_WAVE) REX_STEP_KERNEL_ATTR void rex_step_kernel(DevCfg c, float* __restrict__ state, const float* __restrict__ snap,
+__global__ __launch_bounds__(POLICY ? REX_WAVE * REX_POLICY_WAVES : REX_WAVE) REX_STEP_KERNEL_ATTR void rex_step_kernel(DevCfg c, float* __restrict__ state, const float* __restrict__ snap,
                                                             const float* __restrict__ action0, float* __restrict__ obs_out0,
                                                             float* __restrict__ reward_out0, uint8_t* __restrict__ done_out0,
                                                             float* __restrict__ cmd_out0, typename PolArg<POLICY>::type pol) {
   // POLICY (the instantiations behind rex_step_policy / rex_step_segment_policy; the base and arm step units are compiled once more with
   // -DREX_TU_POL=1): a SEG kernel whose actions are not read from action0 but computed, step by step, by the reference's Gaussian MLP
-  // actor on the observation the env returned last (rex_policy.h) -- a closed-loop rollout segment in one launch.
+  // actor on the observation the env returned last (rex_policy.h) -- a closed-loop rollout segment in one launch.  Their workgroup is
+  // FOUR waves (one per SIMD of a CU, each with its own envs and its own LDS rows exactly as a one-wave workgroup has them) that share
+  // one copy of the actor's weights in dynamic LDS, loaded once per launch, where it fits next to the rows (pol.in_lds; else the weights
+  // are streamed from L2 every step).
   static_assert(!POLICY || (SEG && !MIXED && !BODY && !TRACE && EPW <= 16), "the fused actor: segment kernels of the single-task lane-group variants");
   // SEG (the instantiations behind rex_step_segment; every step translation unit is compiled once more with -DREX_TU_SEG=1): one launch =
   // c.nsteps consecutive env.step() calls of the shard, a rollout segment whose actions the caller already holds -- action0 /
@@ -887,13 +891,26 @@ __global__ __launch_bounds__(REX_WAVE) REX_STEP_KERNEL_ATTR void rex_step_kernel
   constexpr int kLegF4 = REX_LEG_F4_OF(EPW, ARM, BODY);
   constexpr int kRowsF4 = ARM ? REX_LDS_F4_PER_ENV_ARM_OF(EPW) : REX_ROWS_F4_OF(kLegF4);
   static_assert(!BODY || EPW <= 16, "link-box contact rows: lane-group kernels only");
-  __shared__ float4 lds[(kRowsF4 + (EPW <= 16 ? REX_PARK_F4_OF(EPW, ARM) : 0) + (BODY ? REX_BODY_F4 : 0)) * EPW];
+  constexpr int kWaveF4 = (kRowsF4 + (EPW <= 16 ? REX_PARK_F4_OF(EPW, ARM) : 0) + (BODY ? REX_BODY_F4 : 0)) * EPW;
+  __shared__ float4 lds_wg[kWaveF4 * (POLICY ? REX_POLICY_WAVES : 1)];
+  float4* const lds = lds_wg + (POLICY ? (int)(threadIdx.x >> 6) * kWaveF4 : 0);     // this wave's rows
   REX_STAMP(t_kernel);
 #ifdef REX_PROF
   const long long t_wall = (long long)wall_clock64();
 #endif
-  if (c.clock && threadIdx.x == 0) atomicMin(&c.clock[2 * (blockIdx.x & (REX_CLOCK_WAYS - 1))], (unsigned long long)wall_clock64());
-  const int lane = threadIdx.x;
+  const int lane = POLICY ? (int)(threadIdx.x & (REX_WAVE - 1)) : (int)threadIdx.x;
+  const int wg_block = POLICY ? (int)blockIdx.x * REX_POLICY_WAVES + (int)(threadIdx.x >> 6) : (int)blockIdx.x;   // the one-wave block this wave stands for
+  if (c.clock && lane == 0) atomicMin(&c.clock[2 * (wg_block & (REX_CLOCK_WAYS - 1))], (unsigned long long)wall_clock64());
+  const float* pol_wl = nullptr;          // POLICY: the actor's weights in LDS (null: streamed)
+  if constexpr (POLICY) {
+    extern __shared__ float4 rex_dyn_lds[];
+    if (pol.in_lds) {
+      policy_weights_to_lds(pol, policy_offsets(c.obs_dim, c.action_dim, pol.h1, pol.h2).total, reinterpret_cast<float*>(rex_dyn_lds), (int)threadIdx.x,
+                            REX_WAVE * REX_POLICY_WAVES);
+      pol_wl = reinterpret_cast<const float*>(rex_dyn_lds);
+    }
+    __syncthreads();
+  }
   constexpr int LPE = EPW < 64 ? lanes_per_env(EPW) : 1;     // EPW <= 16: lane = LPE * slot + p (rex_device.h, group layout)
   constexpr int NL = EPW < 64 ? 1 : 4;                       // legs whose controller / motors a lane carries
   using MS = MotorSide<NL, ARM>;
@@ -903,7 +920,7 @@ __global__ __launch_bounds__(REX_WAVE) REX_STEP_KERNEL_ATTR void rex_step_kernel
   // Block b runs on XCD b % 8 (observed placement; speed only).  A 64-byte sector of a state word holds 16 envs = 16 / EPW
   // blocks' worth: hand the blocks of one sector to the same XCD, so that one L2 fetches (and writes back) the sector
   // instead of 16 / EPW of them.  A bijection on the full groups of 8 x (16 / EPW) blocks; the tail keeps its order.
-  int blk = (int)blockIdx.x;
+  int blk = wg_block;
   int gi, i;
   bool ingrid;
   DevCfg cmix;                          // MIXED only
@@ -918,7 +935,7 @@ __global__ __launch_bounds__(REX_WAVE) REX_STEP_KERNEL_ATTR void rex_step_kernel
     mixed_config_of_task(c, c.block_task[blk], cmix);        // wave-uniform: the task's constants stay in SGPRs
     cmix.max_repeat = cmix.action_repeat; cmix.max_iterations = cmix.iterations;
   } else {
-    if constexpr (EPW < 16) {
+    if constexpr (EPW < 16 && !POLICY) {   // (a four-wave workgroup covers whole sectors by itself)
       constexpr int G = 16 / EPW;
       const int full = ((int)gridDim.x / (8 * G)) * (8 * G);
       if (blk < full) { const int xcd = blk & 7, q = blk >> 3; blk = ((q / G) * 8 + xcd) * G + (q % G); }
@@ -960,8 +977,10 @@ __global__ __launch_bounds__(REX_WAVE) REX_STEP_KERNEL_ATTR void rex_step_kernel
     // algo.perform(prevob) (agents/ppo/algorithm.py:105-134): the observation of the previous step -- slice seg_step - 1 of the
     // segment's observation block, stored by this wave in front of the fence that ended that step; the caller's obs_in for the first
     const float* obs_prev = seg_step == 0 ? pol.obs_in : obs_out0 + (unsigned)((seg_step - 1) * c.n * c.obs_dim);
-    policy_act<EPW, LPE, ARM>(c, pol, reinterpret_cast<float*>(lds), lane, slot, pl, leg0, i, ingrid, e.episode, e.steps, obs_prev,
-                              (unsigned)(seg_step * c.n * c.action_dim), act);
+    if (pol_wl) policy_act<EPW, LPE, ARM, true>(c, pol, pol_wl, reinterpret_cast<float*>(lds), lane, slot, pl, leg0, i, ingrid, e.episode, e.steps, obs_prev,
+                                                (unsigned)(seg_step * c.n * c.action_dim), act);
+    else policy_act<EPW, LPE, ARM, false>(c, pol, nullptr, reinterpret_cast<float*>(lds), lane, slot, pl, leg0, i, ingrid, e.episode, e.steps, obs_prev,
+                                          (unsigned)(seg_step * c.n * c.action_dim), act);
   }
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
@@ -1135,7 +1154,7 @@ __global__ __launch_bounds__(REX_WAVE) REX_STEP_KERNEL_ATTR void rex_step_kernel
 #endif
   if constexpr (SEG) mirror_sync();   // the next step's LDS writes and history reads come behind this step's LDS reads and history stores
   }
-  if (c.clock && threadIdx.x == 0) atomicMax(&c.clock[2 * (blockIdx.x & (REX_CLOCK_WAYS - 1)) + 1], (unsigned long long)wall_clock64());
+  if (c.clock && lane == 0) atomicMax(&c.clock[2 * (wg_block & (REX_CLOCK_WAYS - 1)) + 1], (unsigned long long)wall_clock64());
 #ifdef REX_PROF
   if (threadIdx.x == 0 && blockIdx.x < 1024) {
     g_prof[10 * blockIdx.x + 8] += clock64() - t_kernel; g_prof[10 * blockIdx.x + 9] += 1;
@@ -1288,9 +1307,12 @@ struct RexSim {
   int mixed_blocks;
   int32_t* d_class;      // a regrouped mixed batch: task slot of every env (rexsim.hip, rex_regroup_mixed_*), and its regions
   rex::MixRegions mix_regions;
-  rex::PolDev pol;       // rex_set_policy: the actor of rex_step_policy / rex_step_segment_policy (pointers: caller-owned device buffers)
+  rex::PolDev pol;       // rex_set_policy: the actor of rex_step_policy / rex_step_segment_policy
+  float* d_polbuf;       // the packed actor (library-owned; rex_policy.h policy_offsets) and its capacity in floats
+  int polbuf_floats;
   int have_policy;
   bool use_policy;        // this launch runs the fused-actor kernels (set by step_launch)
+  int pol_lds_bytes;      // dynamic LDS of the fused-actor kernels: the weights' copy (0: they do not fit next to four waves' rows and are streamed)
 };
 
 // launchers, one per variant group (each in its own translation unit)
@@ -1334,14 +1356,25 @@ void rex_launch_settle_arm(RexSim* s, int nrec, hipStream_t st, float* snap);   
 #else
 #define REX_STEP_LAUNCHER(group) rex_launch_step_##group
 #endif
+// the fused-actor kernels: four one-wave blocks to a workgroup; the actor's weights in dynamic LDS where they fit (RexSim::pol_lds_bytes, rex_set_policy)
+template <int EPW, bool ARM>
+static void rex_launch_policy_kernel(RexSim* s, int blocks, hipStream_t st, const float* a, float* o, float* r, uint8_t* d, float* m) {
+  auto kern = rex::rex_step_kernel<EPW, ARM, false, false, false, true, true>;
+  static int attr_bytes = -1;      // (per instantiation: the largest dynamic LDS size requested so far)
+  if (s->pol_lds_bytes > attr_bytes) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, s->pol_lds_bytes);
+    attr_bytes = s->pol_lds_bytes;
+  }
+  hipLaunchKernelGGL(kern, dim3((blocks + REX_POLICY_WAVES - 1) / REX_POLICY_WAVES), dim3(REX_WAVE * REX_POLICY_WAVES), (size_t)s->pol_lds_bytes, st,
+                     s->dev, s->d_state, s->d_snap, a, o, r, d, m, s->pol);
+}
 #if REX_TU_POL
-#define REX_POL_ARG s->pol
+#define REX_LAUNCH_STEP(EPW, ARM, MIXED, BODY) rex_launch_policy_kernel<EPW, ARM>(s, blocks, st, a, o, r, d, m)
 #else
-#define REX_POL_ARG rex::NoPol{}
-#endif
 #define REX_LAUNCH_STEP(EPW, ARM, MIXED, BODY)                                                                                  \
-  hipLaunchKernelGGL((rex::rex_step_kernel<EPW, ARM, MIXED, BODY, REX_TU_TRACE != 0, (REX_TU_SEG != 0 || REX_TU_POL != 0), REX_TU_POL != 0>), dim3(blocks), dim3(REX_WAVE), 0, st, s->dev, s->d_state, s->d_snap, \
-                     a, o, r, d, m, REX_POL_ARG)
+  hipLaunchKernelGGL((rex::rex_step_kernel<EPW, ARM, MIXED, BODY, REX_TU_TRACE != 0, REX_TU_SEG != 0, false>), dim3(blocks), dim3(REX_WAVE), 0, st, s->dev, s->d_state, s->d_snap, \
+                     a, o, r, d, m, rex::NoPol{})
+#endif
 #define REX_LAUNCH_BY_EPW(ARM, MIXED, BODY)                                           \
   do {                                                                                \
     if (s->epw == 4) REX_LAUNCH_STEP(4, ARM, MIXED, BODY);                            \

@@ -10,6 +10,26 @@
 
 namespace rex {
 
+// rex_set_policy: the caller's plain arrays (input-major weight matrices) -> the packed actor.  One thread per destination float.
+struct PolSrc { const float *w1, *b1, *w2, *b2, *w3, *b3, *logstd, *mean, *scale; };
+__global__ void rex_pack_policy_kernel(PolSrc s, int O, int A, int H1, int H2, float* __restrict__ dst) {
+  const PolOff o = policy_offsets(O, A, H1, H2);
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < o.total; t += gridDim.x * blockDim.x) {
+    float v = 0.0f;
+    if (t < o.b1) { const int r = t & 3, j = (t >> 2) % H1, k = 4 * ((t >> 2) / H1) + r; if (k < O) v = s.w1[k * H1 + j]; }
+    else if (t < o.w2) { if (t - o.b1 < H1) v = s.b1[t - o.b1]; }
+    else if (t < o.b2) { const int u = t - o.w2, r = u & 3, j = (u >> 2) % H2, k = 4 * ((u >> 2) / H2) + r; if (k < H1) v = s.w2[k * H2 + j]; }
+    else if (t < o.w3) { if (t - o.b2 < H2) v = s.b2[t - o.b2]; }
+    else if (t < o.b3) { if (t - o.w3 < H2 * A) v = s.w3[t - o.w3]; }
+    else if (t < o.logstd) { if (t - o.b3 < A) v = s.b3[t - o.b3]; }
+    else if (t < o.mean) { if (t - o.logstd < A) v = s.logstd[t - o.logstd]; }
+    else if (t < o.scale) { if (t - o.mean < O && s.mean) v = s.mean[t - o.mean]; }
+    else if (t < o.scale + O) { v = s.scale ? s.scale[t - o.scale] : 1.0f; }
+    dst[t] = v;
+  }
+}
+
+
 // Regrouping of a large batch (one workgroup): counting sort of the env indices by the solver sweeps of the last step,
 // most sweeps first (the long waves start first), 64 bins.  perm[k] = env of wave slot k.  The order inside a bin does
 // not matter: an env's result does not depend on its wave-mates.
@@ -614,6 +634,7 @@ int rex_destroy(RexSim* s) {
   if (s->d_slot_env) (void)hipFree(s->d_slot_env);
   if (s->d_block_task) (void)hipFree(s->d_block_task);
   if (s->d_class) (void)hipFree(s->d_class);
+  if (s->d_polbuf) (void)hipFree(s->d_polbuf);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
   for (int k = 0; k < REX_TIMING_RING; ++k) if (s->ring0[k]) { (void)hipEventDestroy(s->ring0[k]); (void)hipEventDestroy(s->ring1[k]); }
@@ -662,7 +683,7 @@ static int rows_floats_per_env(const RexSim* s) {   // the contact-row region of
   return 4 * (arm ? REX_LDS_F4_PER_ENV_ARM_OF(s->epw) : REX_ROWS_F4_OF(legf4));
 }
 
-int rex_set_policy(RexSim* s, const RexPolicy* p) {
+int rex_set_policy(RexSim* s, const RexPolicy* p, void* stream) {
   if (!s) return fail(REX_EINVAL, "rex_set_policy: null sim%s", "");
   if (!p) { s->have_policy = 0; return REX_OK; }
   if (s->cfg.task == REX_TASK_MIXED || s->cfg.body_contacts || s->epw > 16)
@@ -672,17 +693,38 @@ int rex_set_policy(RexSim* s, const RexPolicy* p) {
                             "RangeNormalize + ClipAction (playground/trainer.py:48-52)%s", "");
   if (p->obs_dim != rex_obs_dim(&s->cfg) || p->action_dim != rex_action_dim(&s->cfg))
     return failf(REX_EINVAL, "rex_set_policy: obs_dim / action_dim %d / %d do not match the sim's %d / %d", p->obs_dim, p->action_dim, rex_obs_dim(&s->cfg), rex_action_dim(&s->cfg));
-  if (p->hidden1 < 1 || p->hidden2 < 1 || rex::policy_scratch_floats(p->obs_dim, p->hidden1, p->hidden2) > rows_floats_per_env(s))
+  if (p->hidden1 < 1 || p->hidden2 < 1 || p->hidden1 > 4096 || p->hidden2 > 4096 || rex::policy_scratch_floats(p->obs_dim, p->hidden1, p->hidden2) > rows_floats_per_env(s))
     return failf(REX_EINVAL, "rex_set_policy: hidden layers of %d and %d units need %d floats of LDS per env, this kernel variant has %d", p->hidden1, p->hidden2,
-                rex::policy_scratch_floats(p->obs_dim, p->hidden1 > 0 ? p->hidden1 : 0, p->hidden2 > 0 ? p->hidden2 : 0), rows_floats_per_env(s));
+                 rex::policy_scratch_floats(p->obs_dim, p->hidden1 > 0 ? p->hidden1 : 0, p->hidden2 > 0 ? p->hidden2 : 0), rows_floats_per_env(s));
   if (!p->d_w1 || !p->d_b1 || !p->d_w2 || !p->d_b2 || !p->d_w3 || !p->d_b3 || !p->d_logstd || (!p->d_obs_mean) != (!p->d_obs_scale))
     return fail(REX_EINVAL, "rex_set_policy: null weight pointer (d_obs_mean and d_obs_scale go together)%s", "");
   if (!(p->obs_clip > 0.0f) && p->d_obs_mean) return fail(REX_EINVAL, "rex_set_policy: obs_clip must be positive%s", "");
+  HIPCHK(hipSetDevice(s->device));
+  const rex::PolOff off = rex::policy_offsets(p->obs_dim, p->action_dim, p->hidden1, p->hidden2);
+  if (off.total > s->polbuf_floats) {            // (a launch that is still reading the old buffer: the free below waits for the device)
+    if (s->d_polbuf) { HIPCHK(hipDeviceSynchronize()); (void)hipFree(s->d_polbuf); s->d_polbuf = nullptr; s->polbuf_floats = 0; }
+    if (hipMalloc(&s->d_polbuf, sizeof(float) * (size_t)off.total) != hipSuccess) return fail(REX_ENOMEM, "rex_set_policy: hipMalloc%s", "");
+    s->polbuf_floats = off.total;
+  }
+  // pack (stream-ordered: behind the launches that read the previous contents, ahead of those that follow): input-major matrices ->
+  // [k / 4][unit][4], every block 16-byte aligned, zero padding (rex_policy.h)
+  rex::PolSrc src{p->d_w1, p->d_b1, p->d_w2, p->d_b2, p->d_w3, p->d_b3, p->d_logstd, p->d_obs_mean, p->d_obs_scale};
+  hipLaunchKernelGGL(rex::rex_pack_policy_kernel, dim3((off.total + 255) / 256), dim3(256), 0, (hipStream_t)stream, src, p->obs_dim, p->action_dim, p->hidden1,
+                     p->hidden2, s->d_polbuf);
+  HIPCHK(hipGetLastError());
   rex::PolDev& d = s->pol;
-  d.w1 = p->d_w1; d.b1 = p->d_b1; d.w2 = p->d_w2; d.b2 = p->d_b2; d.w3 = p->d_w3; d.b3 = p->d_b3; d.logstd = p->d_logstd;
-  d.obs_mean = p->d_obs_mean; d.obs_scale = p->d_obs_scale; d.obs_in = nullptr; d.action_out = nullptr; d.mean_out = nullptr;
-  d.h1 = p->hidden1; d.h2 = p->hidden2; d.obs_clip = p->obs_clip; d.sample = p->sample ? 1 : 0;
+  d.pk = s->d_polbuf; d.obs_in = nullptr; d.action_out = nullptr; d.mean_out = nullptr;
+  d.h1 = p->hidden1; d.h2 = p->hidden2; d.obs_clip = p->d_obs_mean ? p->obs_clip : 0.0f; d.sample = p->sample ? 1 : 0;
   d.seed_lo = (uint32_t)p->seed; d.seed_hi = (uint32_t)(p->seed >> 32);
+  {   // one copy of the packed actor per four-wave workgroup, in dynamic LDS, if it fits next to the waves' rows (MI355X: 160 KB per CU)
+    const bool arm = s->cfg.mark == REX_MARK_ARM;
+    const int wave_bytes = (rows_floats_per_env(s) / 4 + REX_PARK_F4_OF(s->epw, arm)) * s->epw * 16;
+    const int want = off.total * 4;
+    const char* ov = getenv("REX_POLICY_LDS");      // developer A/B runs: 0 streams the weights from L2 everywhere
+    const bool fits = REX_POLICY_WAVES * wave_bytes + want <= 160 * 1024 && !(ov && atoi(ov) == 0);
+    s->pol_lds_bytes = fits ? want : 0;
+    d.in_lds = fits ? 1 : 0;
+  }
   s->have_policy = 1;
   return REX_OK;
 }

@@ -200,3 +200,107 @@ def test_recurrent_policy_is_the_reference_gru_and_learns():
     assert agent.updates >= 20 and last > first + 0.5, (first, last)
     with pytest.raises(ValueError):
         PPOAgent(2, 1, 1, PPOConfig(network="lstm"), device="cpu")
+
+
+# ---------------------------------------------------------------- train_segments: the actor inside the launch, bookkeeping per segment
+class _SegmentPointEnv:
+    """The closed-loop surface of RexBatchEnv (set_policy / step_segment_policy, in-launch auto-reset, folded episode cap) on the toy
+    task, on the CPU: the actor is evaluated here from the arrays FusedActor hands over, exactly as csrc/rex_policy.h defines it.
+    Every transition is logged per env so that a test can rebuild the episodes independently."""
+    def __init__(self, n, seed=0, fall=0.0, max_episode_steps=12):
+        from types import SimpleNamespace
+        self.n, self.g = n, torch.Generator().manual_seed(seed)
+        self.device, self.obs_dim, self.action_dim = torch.device("cpu"), 1, 1
+        self.config = SimpleNamespace(auto_reset=1, range_normalize=1, max_episode_steps=max_episode_steps)
+        self.fall, self.x, self.steps = fall, torch.zeros(n, 1), torch.zeros(n, dtype=torch.long)
+        self.log = [[] for _ in range(n)]
+        self.pol = None
+
+    def reset(self):
+        self.x = torch.rand((self.n, 1), generator=self.g) * 4 - 2
+        self.steps.zero_()
+        return self.x.clone()
+
+    def set_policy(self, w1, b1, w2, b2, w3, b3, logstd, obs_mean=None, obs_scale=None, obs_clip=5.0, sample=True, seed=0):
+        self.pol = [t.clone() if t is not None else None for t in (w1, b1, w2, b2, w3, b3, logstd, obs_mean, obs_scale)] + [obs_clip, sample]
+
+    def step_segment_policy(self, T, obs_in, out, action, mean):
+        w1, b1, w2, b2, w3, b3, logstd, om, osc, clip, sample = self.pol
+        obs, reward, done = out
+        prev = obs_in
+        for t in range(T):
+            x = ((prev - om) * osc).clamp(-clip, clip) if om is not None else prev
+            m = torch.tanh(torch.relu(torch.relu(x @ w1 + b1) @ w2 + b2) @ w3 + b3)
+            a = m + torch.exp(logstd) * torch.randn(m.shape, generator=self.g) if sample else m
+            self.x = self.x + 0.5 * a.clamp(-1, 1)
+            self.steps += 1
+            r = -self.x[:, 0].abs()
+            d = (torch.rand(self.n, generator=self.g) < self.fall) | (self.steps >= self.config.max_episode_steps)
+            for i in range(self.n):
+                self.log[i].append((prev[i].clone(), a[i].clone(), m[i].clone(), float(r[i]), bool(d[i])))
+            idx = d.nonzero()[:, 0]
+            if idx.numel():                                         # in-launch auto-reset: the returned observation opens the new episode
+                self.x[idx] = torch.rand((idx.numel(), 1), generator=self.g) * 4 - 2
+                self.steps[idx] = 0
+            action[t], mean[t], obs[t], reward[t], done[t] = a, m, self.x, r, d.to(done.dtype)
+            prev = self.x.clone()
+        return obs, reward, done.bool(), {}
+
+
+@pytest.mark.parametrize("fall,T", [(0.0, 5), (0.15, 7), (0.6, 25)])     # no falls; some; several episodes of an env inside one segment
+def test_train_segments_rebuilds_every_episode_from_the_segment_blocks(fall, T):
+    """The device-side bookkeeping of train_segments (episode ordinal and position of every transition of a [T, N] block, scatter into the
+    running episodes, hand-over of the finished ones) against episodes rebuilt step by step from the env's own log: every episode
+    handed to end_episode is, transition for transition, the next unfinished episode of its env; the running episodes and scores
+    after the call are the tails."""
+    n, Tmax = 9, 6
+    cfg = PPOConfig(policy_layers=(8, 8), value_layers=(8,), update_every=100000, max_length=Tmax)
+    env, agent = _SegmentPointEnv(n, seed=4, fall=fall, max_episode_steps=Tmax), PPOAgent(n, 1, 1, cfg, device="cpu", seed=2)
+    handed = [[] for _ in range(n)]
+    orig = agent.end_episode
+
+    def spy(indices):
+        for i in indices.tolist():
+            L = int(agent.episode_length[i])
+            handed[i].append([(agent.episodes[0][i, t].clone(), agent.episodes[1][i, t].clone(), agent.episodes[2][i, t].clone(),
+                               float(agent.episodes[4][i, t])) for t in range(L)])
+        return orig(indices)
+    agent.end_episode = spy
+    score, length = ppo.train_segments(env, agent, 4 * T + 3, segment=T)
+    steps = ((4 * T + 3 + T - 1) // T) * T
+    total_eps, total_len, total_score = 0, 0, 0.0
+    for i in range(n):
+        assert len(env.log[i]) == steps
+        want, cur = [], []
+        for tr in env.log[i]:
+            cur.append(tr)
+            if tr[4]:
+                want.append(cur); cur = []
+        assert len(handed[i]) == len(want), (i, len(handed[i]), len(want))
+        for got, exp in zip(handed[i], want):
+            assert len(got) == len(exp)
+            for (go, ga, gm, gr), (eo, ea, em, er, _) in zip(got, exp):
+                assert torch.equal(go, eo) and torch.equal(ga, ea) and torch.equal(gm, em) and abs(gr - er) < 1e-6
+            total_eps += 1; total_len += len(exp); total_score += sum(e[3] for e in exp)
+        assert int(agent.episode_length[i]) == len(cur)             # the running episode: the tail
+        for t, (eo, ea, em, er, _) in enumerate(cur):
+            assert torch.equal(agent.episodes[0][i, t], eo) and torch.equal(agent.episodes[1][i, t], ea) and abs(float(agent.episodes[4][i, t]) - er) < 1e-6
+    assert total_eps > 0 and abs(length - total_len / total_eps) < 1e-4 and abs(score - total_score / total_eps) < 1e-3
+    assert int(agent.observ_filter.count) == steps * n and int(agent.reward_filter.count) == steps * n
+    if fall == 0.6:
+        assert max(len(h) for h in handed) >= 2 * (steps // T)       # (the multi-episode-per-segment path ran)
+
+
+def test_train_segments_learns_the_toy_task():
+    torch.manual_seed(0)
+    n = 64
+    cfg = PPOConfig(policy_layers=(32, 16), value_layers=(32,), update_every=n, update_epochs_policy=15, update_epochs_value=15,
+                    policy_lr=3e-3, value_lr=3e-3, max_length=12, discount=0.9, init_mean_factor=0.1)
+    env, agent = _SegmentPointEnv(n, max_episode_steps=12), PPOAgent(n, 1, 1, cfg, device="cpu", seed=3)
+    first, _ = ppo.train_segments(env, agent, 12 * 3, segment=6)
+    for _ in range(12):
+        last, length = ppo.train_segments(env, agent, 12 * 3, segment=6)
+    assert agent.updates >= 30 and length == 12
+    assert last > first + 1.0, (first, last)
+    with pytest.raises(ValueError):                                 # the env must fold auto-reset, the wrappers and the episode cap
+        ppo.train_segments(_SegmentPointEnv(n, max_episode_steps=7), agent, 12)

@@ -786,6 +786,30 @@ def test_bench_two_ranks_report_the_north_star_workload_and_segment_launches(tor
     assert sg["steps_per_launch"] == 25 and sg["value"] > 0 and sg["longer_segments"]["steps_per_launch"] == 100
 
 
+@pytest.mark.parametrize("case", ["walk_ik", "mixed_arm", "walk_ik_policy"])
+def test_hip_shards_on_two_ranks_reproduce_the_single_process_batch(torch, case, tmp_path):
+    """"seeds = base_seed (+) global_env_index so results are invariant to G" -- on the HIP path, across REAL ranks: two
+    processes (torch.distributed.run, gloo, sharing the one GPU) each step RexBatchEnv(n / 2, env_index_base = rank n / 2) through a
+    50-step segment with in-launch resets (episode cap 17) and all-gather it (sharding.gather_rollout); the gathered observation /
+    reward / done / action blocks, the reset observations and the final state blocks equal a single-process RexBatchEnv(n) run BIT
+    FOR BIT.  walk-IK, the mixed-task mark-arm batch with per-reset mass / friction draws (BASELINE configs[4]), and a closed-loop
+    segment (the fused actor: its Gaussian samples are keyed by the global env index too).  tests/hip_shard_worker.py."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out_path = str(tmp_path / "res.json")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(root, "tests", "hip_shard_worker.py"), case, out_path],
+                         capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    res = json.load(open(out_path))
+    assert res["ranks"] == 2 and res["resets_in_segment"] >= 2 * 2048
+    assert all(res[k] for k in ("obs0", "obs", "reward", "done", "action", "state")), res
+
+
 @pytest.mark.parametrize("task,signal,mark,terrain", [
     ("walk", "ik", "base", "random"), ("gallop", "ik", "base", "random"), ("poses", "ik", "base", "plane"),
     ("standup", "ol", "base", "plane"), ("turn", "ol", "arm", "random"), ("gallop", "ol", "arm", "plane"),

@@ -15,6 +15,9 @@ run --mixed --mark arm --envs-per-gpu 2048
 run --mixed --mark arm --envs-per-gpu 16384
 run --task standup --signal ol
 run --task poses
+run --envs-per-gpu 8192                                      # north_star's shard: 65 536 / 8
+run --task gallop --signal ol --envs-per-gpu 65536           # the WHOLE of configs[2] on one GPU (strong-scaling expectation)
+run --task turn --terrain random --envs-per-gpu 32768        # the whole of configs[3]
 run --envs-per-gpu 16384
 run --envs-per-gpu 65536
 run --envs-per-gpu 262144

@@ -4,14 +4,17 @@
 # closing call lost everything to that cap and to one 40-minute limit).
 #   usage: tools/measure.sh TAG step [step ...]        -> gpurun_out/TAG_*; progress in gpurun_out/TAG_progress.txt
 #   steps: lib=<path to a build of the library, or "default"> | mb:<tools/microbench/NAME> | tie | parity | gputests | bench | bench_driver | bench_2rank | bench_2rank_ns (the default workload on 2 ranks: prints north_star_workload) | bench_configs | ab:<lib1>,<lib2>[:<bench flags>] | prof:<workload> | sections:<task>
-#   prof workloads: walk4096 walk262144 arm4096 mixedarm2048 gallop8192 turnhf4096 poses4096
+#   prof workloads: walk4096 walk8192 (north_star's shard) walk262144 arm4096 mixedarm2048 mixedarm16384 gallop8192 gallop65536 turnhf4096 turnhf32768 poses4096
+#   other steps: policy_cost (tools/policy_cost.py: the fused actor against the open-loop kernels on the same trajectory) | ppo_standup (train_segments, round 1's standup run) | bench_walk8192
 TAG=$1; shift
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 P=gpurun_out/${TAG}_progress.txt
 stamp() { echo "$(date +%s) $*" >> $P; }
 declare -A WL=( [walk4096]="" [walk262144]="--envs-per-gpu 262144" [arm4096]="--mark arm" [mixedarm2048]="--mixed --mark arm --envs-per-gpu 2048"
-                [gallop8192]="--task gallop --signal ol --envs-per-gpu 8192" [turnhf4096]="--task turn --terrain random" [poses4096]="--task poses" )
+                [gallop8192]="--task gallop --signal ol --envs-per-gpu 8192" [turnhf4096]="--task turn --terrain random" [poses4096]="--task poses"
+                [walk8192]="--envs-per-gpu 8192" [gallop65536]="--task gallop --signal ol --envs-per-gpu 65536" [turnhf32768]="--task turn --terrain random --envs-per-gpu 32768"
+                [mixedarm16384]="--mixed --mark arm --envs-per-gpu 16384" )
 for step in "$@"; do
   stamp "start $step"
   case $step in
@@ -33,6 +36,13 @@ for step in "$@"; do
     prof:*)       w=${step#prof:}
                   timeout 700 bash tools/profile_round.sh ${TAG}_$w ${WL[$w]} > gpurun_out/${TAG}_profile_$w.txt 2>&1
                   rm -rf gpurun_out/${TAG}_${w}_prof gpurun_out/${TAG}_${w}_pmc_* ;;
+    policy_cost)  : > gpurun_out/${TAG}_policy_cost.jsonl
+                  for args in "--envs 4096" "--envs 8192" "--envs 16384" "--envs 4096 --mark arm" "--envs 8192 --task gallop --signal ol"; do
+                    timeout 200 python tools/policy_cost.py $args >> gpurun_out/${TAG}_policy_cost.jsonl 2>> gpurun_out/${TAG}_bench.err
+                  done ;;
+    ppo_standup)  timeout 600 python -m rex_gym_amd.agents.ppo --task standup --signal ol --envs 512 --iterations 12 --max-length 400 > gpurun_out/${TAG}_ppo_standup.txt 2>&1
+                  timeout 600 python -m rex_gym_amd.agents.ppo --task standup --signal ol --envs 512 --iterations 12 --max-length 400 --loop steps > gpurun_out/${TAG}_ppo_standup_per_step_loop.txt 2>&1 ;;
+    bench_walk8192) timeout 400 bash -c "python bench.py --envs-per-gpu 8192 --no-cpu-baseline > gpurun_out/${TAG}_bench_walk8192.json 2>> gpurun_out/${TAG}_bench.err" ;;
     sections:*)   t=${step#sections:}
                   timeout 400 python tools/prof_sections.py --task=$t > gpurun_out/${TAG}_sections_$t.txt 2>&1 ;;
     lib=*)        export REX_LIB_PATH=$PWD/${step#lib=}; [ "${step#lib=}" = default ] && unset REX_LIB_PATH ;;      # the steps after it load this build of the library
