@@ -155,5 +155,22 @@ def build(force=False, verbose=False, lib_path=None, defines=(), unity=False, on
     return lib_path
 
 
+DIAG_LIB_PATH = os.path.join(PKG_DIR, "librexsim_hip_diag.so")
+DIAG_INSIDE = "0.3"      # rad; oracle/Makefile DIAG_INSIDE is the same number
+
+
+def build_diag(force=False, verbose=False):
+    """The DIAGNOSTIC twin of the library for one parity test (tests/test_gpu_parity.py::test_mark_arm_window_with_quiet_arm_rows): the mark-arm
+    variant groups compiled with -DREX_DIAG_ARM_REST_INSIDE=0.3 (csrc/rex_arm_model_gen.h: the arm's rest targets 0.3 rad inside their
+    bounds instead of 0.1 rad beyond them).  Never loaded by the product: rex_gym_amd._lib loads LIB_PATH; the test points REX_LIB_PATH
+    at this file in a subprocess."""
+    if not force and os.path.exists(DIAG_LIB_PATH) and \
+            all(os.path.getmtime(os.path.join(CSRC, f)) <= os.path.getmtime(DIAG_LIB_PATH) for f in SOURCES + HEADERS):
+        return DIAG_LIB_PATH
+    return build(force=True, verbose=verbose, lib_path=DIAG_LIB_PATH, defines=[f"-DREX_DIAG_ARM_REST_INSIDE={DIAG_INSIDE}"], only="arm,mixed_arm")
+
+
 if __name__ == "__main__":
     print(build(force=True, verbose=True))
+    if "--diag" in __import__("sys").argv:
+        print(build_diag(force=True, verbose=True))

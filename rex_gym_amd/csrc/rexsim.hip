@@ -515,7 +515,11 @@ int rex_create(const RexConfig* cfg, int device, float* d_state, void* stream, R
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
     const int one_round = 4 * (cus > 0 ? cus : 256);
     const bool pinned = getenv("REX_ENVS_PER_WAVE") != nullptr;
-    while (!pinned && s->epw < 16 && busy > one_round) { s->epw *= 2; busy = task_slot_map(d, s->epw, slots, tasks); }
+    // (the envs per wave decide the arithmetic -- the variants agree to rounding, not bit for bit --, so they are a function of the CONFIG alone:
+    //  one round of the machine this library is written for, MI355X's 1 024 SIMDs, whatever partition or device it runs on; the device's own
+    //  CU count only enters the regrouping decision below, which leaves results unchanged)
+    const int one_round_mi355x = 1024;
+    while (!pinned && s->epw < 16 && busy > one_round_mi355x) { s->epw *= 2; busy = task_slot_map(d, s->epw, slots, tasks); }
     // More workgroups than the machine holds at once (one wave per SIMD): the batch is regrouped by sweep counts every
     // step (REX_REGROUP=0 / 1 overrides) -- regions of whole waves per task, sorted inside.  Measured at 16 384 mark-arm envs,
     // 16 envs per wave: the padding of the chunked map is a second round of full-length waves; sorted, the late waves are the short ones.

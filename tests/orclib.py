@@ -83,7 +83,9 @@ class Oracle:
         _build()
         self.dtype = np.dtype(dtype)
         self.mark = mark
-        suffix = ("arm_" if mark == "arm" else "") + ("f64" if self.dtype == np.float64 else "f32")
+        # REX_ORACLE_DIAG=1 (set by the diagnostic parity test around its subprocess): the twin build whose arm rests inside its bounds
+        diag = "diag_" if mark == "arm" and os.environ.get("REX_ORACLE_DIAG") == "1" else ""
+        suffix = ("arm_" if mark == "arm" else "") + diag + ("f64" if self.dtype == np.float64 else "f32")
         self.lib = ctypes.CDLL(os.path.join(ORACLE_DIR, "_build", f"librex_oracle_{suffix}.so"))
         self.num_motors = self.lib.orc_num_motors()
         self.state_words = self.lib.orc_state_words()

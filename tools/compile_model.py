@@ -294,7 +294,15 @@ def emit_arm(base_bodies):
     w("/* all arm axes are +-z of the joint frame: sign per joint (used by the HIP arm chain) */")
     w("REX_CONST double REXA_AXIS_SIGN[REXA_NJ] = {" + ", ".join(fmt(b["joint"]["axis"][2]) for b in arm) + "};")
     w("/* ARM_POSES['rest'] (rex_gym/model/rex_constants.py:3-8): the command the envs append for the arm motors */")
+    w("#ifndef REX_DIAG_ARM_REST_INSIDE")
     w("REX_CONST double REXA_REST[REXA_NJ] = {-1.6, -1.6, 0.0, 0.0, 1.6, 0.0};")
+    w("#else")
+    w("/* DIAGNOSTIC builds only (test artefacts: the diagnostic twins of the library and of the checker -- never the product): the reference's rest pose")
+    w("   commands m1, m2, m5 0.1 rad BEYOND their +-1.5 rad bounds, so their limit rows switch with the last bit of the joint angle and")
+    w("   no two float paths keep the same event sequence; with the three targets REX_DIAG_ARM_REST_INSIDE rad INSIDE the bounds the arm's rows")
+    w("   stay quiet and the 200-step parity window of the mark-arm workload measures arithmetic, not row flicker (tests/test_gpu_parity.py) */")
+    w("REX_CONST double REXA_REST[REXA_NJ] = {-1.5 + (REX_DIAG_ARM_REST_INSIDE), -1.5 + (REX_DIAG_ARM_REST_INSIDE), 0.0, 0.0, 1.5 - (REX_DIAG_ARM_REST_INSIDE), 0.0};")
+    w("#endif")
     w("#endif /* REX_ARM_MODEL_GEN_H */")
     with open(DEFAULT_ARM_OUT, "w") as f:
         f.write("\n".join(out) + "\n")

@@ -43,6 +43,10 @@ for step in "$@"; do
     ppo_standup)  timeout 600 python -m rex_gym_amd.agents.ppo --task standup --signal ol --envs 512 --iterations 12 --max-length 400 > gpurun_out/${TAG}_ppo_standup.txt 2>&1
                   timeout 600 python -m rex_gym_amd.agents.ppo --task standup --signal ol --envs 512 --iterations 12 --max-length 400 --loop steps > gpurun_out/${TAG}_ppo_standup_per_step_loop.txt 2>&1 ;;
     bench_walk8192) timeout 400 bash -c "python bench.py --envs-per-gpu 8192 --no-cpu-baseline > gpurun_out/${TAG}_bench_walk8192.json 2>> gpurun_out/${TAG}_bench.err" ;;
+    prof_policy:*) IFS=: read -r _ pn pt <<< "$step"; pn=${pn:-4096}; pt=${pt:-25}; export TMPDIR=/tmp
+                  ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_polprof -- python $GRAFT_REPO_ROOT/tools/closed_loop_run.py --envs $pn --segment $pt --launches 40 > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_prof_policy_${pn}_T${pt}.txt 2>/dev/null )
+                  python tools/rocprof_stats.py $(find gpurun_out/${TAG}_polprof -name "*_results.db" | head -1) --window 30:70 --csv gpurun_out/${TAG}_kernel_stats_policy_${pn}_T${pt}.csv | head -5 >> gpurun_out/${TAG}_prof_policy_${pn}_T${pt}.txt
+                  rm -rf gpurun_out/${TAG}_polprof ;;
     sections:*)   t=${step#sections:}
                   timeout 400 python tools/prof_sections.py --task=$t > gpurun_out/${TAG}_sections_$t.txt 2>&1 ;;
     lib=*)        export REX_LIB_PATH=$PWD/${step#lib=}; [ "${step#lib=}" = default ] && unset REX_LIB_PATH ;;      # the steps after it load this build of the library
