@@ -1252,6 +1252,8 @@ def test_every_kernel_variant_against_the_oracle_at_baseline_sizes(torch, name, 
     rec["envs_per_wave"] = epw
     rec["single_steps_from_common_states"] = single
     floor = rec["float32_floor"] = pw.float32_floor(name, env, steps, seed)     # the oracle's fp32 build against its fp64 build, this window
+    # the ABSOLUTE verdict of north_star's bar, recorded next to the floor-relative one and never relaxed by it
+    rec["meets_1e-3_rad_absolute"] = dict(median=bool(rec["median_rad"] <= 1e-3), p99=bool(rec["p99_rad"] <= 1e-3), max=bool(rec["max_rad"] <= 1e-3))
     os.makedirs(os.path.join(os.path.dirname(__file__), "..", "gpurun_out"), exist_ok=True)
     with open(os.path.join(os.path.dirname(__file__), "..", "gpurun_out", "r05_parity.jsonl"), "a") as f:
         f.write(json.dumps(rec) + "\n")
@@ -1261,6 +1263,7 @@ def test_every_kernel_variant_against_the_oracle_at_baseline_sizes(torch, name, 
     assert rec["trace_pass_bit_identical"], (name, epw, rec["trace_pass_identical_steps"])
     med, p99, mx = _PARITY_BOUNDS[name]
     assert rec["median_rad"] <= 1e-3 and (name not in _MEETS_THE_BAR_AT_P99 or rec["p99_rad"] <= 1e-3), rec      # BASELINE.json's bar
+    assert rec["meets_1e-3_rad_absolute"]["p99"] == (name in _MEETS_THE_BAR_AT_P99), (name, rec["p99_rad"])      # (which workloads meet it is itself pinned)
     assert rec["median_rad"] <= med and rec["p99_rad"] <= p99 and rec["max_rad"] <= mx, rec
     # the stated fp32 tolerance where 1e-3 rad at the 99th percentile is below what float32 itself gives on the workload (heightfield,
     # mark arm): the whole-batch p99 within the FLOAT32 FLOOR of this very window + 20 % -- measured in the same run, not a constant
@@ -1335,12 +1338,19 @@ def test_caller_supplied_heightfield_terrain(torch):
     orc.set_heightfield(fields, mids, cell, origin[:2])
     # (the robots are still rocking on the bumps when the 600 settle substeps end -- pitch rate -1.3 rad/s --, so the two float32
     #  paths have parted by up to 8e-3 in the rate words by then: measured 8.2e-3 since the contraction fix of round 5, 2e-3 before)
-    np.testing.assert_allclose(env.reset().cpu().numpy(), orc.reset(), atol=1.5e-2)
+    hip_reset, o32_reset = env.reset().cpu().numpy(), orc.reset()
+    np.testing.assert_allclose(hip_reset, o32_reset, atol=1.5e-2)
     # the float32 floor of this scenario, measured here: the oracle's fp32 build against its fp64 build through the same reset and steps
     # (reset observation 0.13 apart, joint angles after the 25 steps 5.6e-3 at the median: tumbling robots amplify the last bit)
     orc64 = orclib.OracleEnv(cfg, np.float64)
     orc64.set_heightfield(fields, mids, cell, origin[:2])
-    orc64.reset()
+    o64_reset = orc64.reset()
+    # ... and the gate that does not move with the kernels' contraction mode: the HIP path against the FP64 oracle, held to the float32
+    # floor of the same reset (the fp32 oracle -- built with contraction off -- against the fp64 one): per observation word, the median
+    # over the envs of the HIP error within 1.2 x the floor's median, the worst env within 1.2 x the floor's worst
+    e_hip, e_floor = np.abs(hip_reset - o64_reset), np.abs(o32_reset - o64_reset)
+    assert np.all(np.median(e_hip, 0) <= 1.2 * np.median(e_floor, 0) + 1e-4), (np.median(e_hip, 0), np.median(e_floor, 0))
+    assert e_hip.max() <= 1.2 * e_floor.max() + 1e-3, (e_hip.max(), e_floor.max())
     ps, os_ = product_state_to_numeric(env.state), orc.get_state()
     # shape centred on (min + max) / 2 = 0.03 and placed at z = 0.5: the surface spans 0.47 .. 0.53, the base stands ~0.2 above it
     assert np.all(ps[2] > 0.62) and np.all(ps[2] < 0.76)

@@ -21,12 +21,12 @@ for step in "$@"; do
     tie)          timeout 600 python -m pytest tests/test_gpu_parity.py -q -m gpu -k "trace_kernels_are_bit_identical" > gpurun_out/${TAG}_tie_tests_$(basename ${REX_LIB_PATH:-default} .so).txt 2>&1 ;;
     parity)       rm -f gpurun_out/r05_parity.jsonl
                   timeout 900 python -m pytest tests/test_gpu_parity.py -q -m gpu -k "every_kernel_variant or walk_ik_trajectory_rmse" > gpurun_out/${TAG}_parity_tests.txt 2>&1 ;;
-    gputests)     timeout 1200 python -m pytest tests -q -m gpu > gpurun_out/${TAG}_gpu_tests.txt 2>&1 ;;
+    gputests)     timeout 1500 python -m pytest tests -q -m gpu > gpurun_out/${TAG}_gpu_tests.txt 2>&1 ;;
     bench)        timeout 300 bash -c "python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err" ;;
     bench_driver) timeout 180 bash -c "python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_driver_cmd.json 2>> gpurun_out/${TAG}_bench.err" ;;
     bench_2rank)  timeout 300 bash -c "python bench.py --gpus 2 --steps 200 --warmup 50 --config 3 --backend gloo --no-cpu-baseline > gpurun_out/${TAG}_bench_2rank_gloo_1gpu.json 2>> gpurun_out/${TAG}_bench.err" ;;
     bench_2rank_ns) timeout 300 bash -c "python bench.py --gpus 2 --steps 50 --warmup 10 --backend gloo --no-cpu-baseline > gpurun_out/${TAG}_bench_2rank_north_star_gloo_1gpu.json 2>> gpurun_out/${TAG}_bench.err" ;;
-    bench_configs) timeout 600 bash -c "bash tools/bench_configs.sh ${TAG} 600 > gpurun_out/${TAG}_bench_configs.txt 2>&1" ;;
+    bench_configs) timeout 2400 bash -c "bash tools/bench_configs.sh ${TAG} 600 > gpurun_out/${TAG}_bench_configs.txt 2>&1" ;;
     ab:*)         IFS=: read -r _ libs flags <<< "$step"
                   OUT=gpurun_out/${TAG}_ab.txt; echo "== bench.py --steps 600 --warmup 100 $flags" >> $OUT
                   for lib in ${libs//,/ }; do
@@ -51,7 +51,8 @@ for step in "$@"; do
                   timeout 400 python tools/prof_sections.py --task=$t > gpurun_out/${TAG}_sections_$t.txt 2>&1 ;;
     lib=*)        export REX_LIB_PATH=$PWD/${step#lib=}; [ "${step#lib=}" = default ] && unset REX_LIB_PATH ;;      # the steps after it load this build of the library
     mb:*)         m=${step#mb:}; export TMPDIR=/tmp
-                  timeout 300 bash -c "hipcc --offload-arch=gfx950 -O3 -o /tmp/$m tools/microbench/$m.hip && /tmp/$m" > gpurun_out/${TAG}_mb_$m.txt 2>&1 ;;
+                  MBFLAGS=""; [ "$m" = policy_mb ] && MBFLAGS="-std=c++17 -ffp-contract=on -I rex_gym_amd/csrc"     # (includes the kernels' headers)
+                  timeout 300 bash -c "hipcc --offload-arch=gfx950 -O3 $MBFLAGS -o /tmp/$m tools/microbench/$m.hip 2>/dev/null && /tmp/$m" > gpurun_out/${TAG}_mb_$m.txt 2>&1 ;;
     *)            echo "unknown step $step" >> $P ;;
   esac
   stamp "rc=$? $step"
