@@ -286,7 +286,7 @@ def north_star_workload(args, dev, local_rank, rank, world, dist, barrier, T):
             "ms_per_step_without_gather": res["without_gather"] / args.steps * 1e3, "steps": args.steps, "finite": finite}
 
 
-def closed_loop_workload(n, dev, local_rank, rank, env_kw, steps, T=25):
+def closed_loop_workload(n, dev, local_rank, rank, env_kw, steps, T=25, world=1, dist=None, backend="nccl"):
     """The rollout the reference's PPO agents actually run: a POLICY IN THE LOOP -- `action = algo.perform(prevob)` then
     `batch_env.simulate(action)` for every step (agents/tools/simulate.py:57-76, agents/ppo/algorithm.py:105-134) -- on the workload of the
     timed region (same envs, auto-reset, episode cap 2000), behind the wrapper stack the agents act through (RangeNormalize + ClipAction
@@ -333,11 +333,17 @@ def closed_loop_workload(n, dev, local_rank, rank, env_kw, steps, T=25):
     def timed(name, fn, count, launches):
         fn(max(2, count // 8))
         torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
         t0 = time.perf_counter()
         fn(count)
         torch.cuda.synchronize(dev)
         e = time.perf_counter() - t0
-        res[name] = {"value": n * count / e, "ms_per_step": e / count * 1e3, "steps": count, "launches_per_step": launches}
+        if dist is not None:       # every rank rolls out its own shard (no exchange on this path): the job's rate is set by the slowest rank
+            t = torch.tensor([e], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            e = float(t.item())
+        res[name] = {"value": n * world * count / e, "ms_per_step": e / count * 1e3, "steps": count, "launches_per_step": launches}
 
     # (a) perform() in PyTorch + rex_step: what a learner written against env.step() gets (no host synchronisation in the loop)
     sgen = torch.Generator(device=dev); sgen.manual_seed(5)
@@ -379,7 +385,7 @@ def closed_loop_workload(n, dev, local_rank, rank, env_kw, steps, T=25):
     env.close()
     return {"what": "closed-loop rollout (policy in the loop: the reference's 4-200-100-A Gaussian MLP actor behind its observ filter, random "
                     "initial weights, Gaussian sample every step; RangeNormalize + ClipAction folded) on the workload of the timed region",
-            "unit": "env-steps/s", "finite": finite, "done_rate_per_step": falls, **res}
+            "unit": "env-steps/s", "envs_total": n * world, "finite": finite, "done_rate_per_step": falls, **res}
 
 
 # BASELINE.json configs, numbered as SURVEY.md 8(d) numbers them (config 1 is the 1-env CPU plumbing case): what --config N runs.
@@ -651,11 +657,14 @@ def main():
 
     # the rollout a PPO learner runs: the policy in the loop (single-task workloads; the toes-only kernels carry the fused actor)
     closed_loop = None
-    if world == 1 and not args.mixed and not args.no_closed_loop and not body_contacts:
-        try:
-            closed_loop = closed_loop_workload(n, dev, local_rank, rank, env_kw, max(args.steps, 200), T)
-        except Exception as e:   # reporting only; never fail the headline for it
-            closed_loop = {"failed": f"{type(e).__name__}: {e}"}
+    if not args.mixed and not args.no_closed_loop and not body_contacts:
+        if dist is None:
+            try:
+                closed_loop = closed_loop_workload(n, dev, local_rank, rank, env_kw, max(args.steps, 200), T)
+            except Exception as e:   # reporting only; never fail the headline for it
+                closed_loop = {"failed": f"{type(e).__name__}: {e}"}
+        else:                        # (multi-rank: the block's barriers and reductions are collective -- an exception on one rank must surface)
+            closed_loop = closed_loop_workload(n, dev, local_rank, rank, env_kw, max(args.steps, 200), T, world, dist, args.backend)
 
     task_name = "mixed" if args.mixed else args.task
     ranks_seen = dist.get_world_size() if dist is not None else 1

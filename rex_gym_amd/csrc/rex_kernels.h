@@ -859,9 +859,13 @@ __device__ __forceinline__ void gather_legs(const SM& sm, int leg0, EnvState& e,
 #ifndef REX_FAST_EPW
 #define REX_FAST_EPW 4
 #endif
-#define REX_POLICY_WAVES 4   /* waves per workgroup of the fused-actor kernels: they share one copy of the actor's weights in LDS */
+// waves per workgroup of the fused-actor kernels: four (one per SIMD of a CU) that share one copy of the actor's weights in LDS -- at 4 and 8
+// envs per wave; at 16 the copy does not fit next to four waves' rows anyway (base 4 x 38 KB, arm 4 x 40 KB of 160), the weights are streamed,
+// and one-wave workgroups keep a multi-round launch (> 16 384 envs) from waiting for the slowest of four waves before a CU takes new work
+// (65 536 walk-IK envs, fused actor per step: 68.9 M env-steps/s with four-wave workgroups)
+#define REX_POLICY_WAVES(EPW) ((EPW) <= 8 ? 4 : 1)
 template <int EPW, bool ARM, bool MIXED, bool BODY, bool TRACE = false, bool SEG = false, bool POLICY = false>
-__global__ __launch_bounds__(POLICY ? REX_WAVE * REX_POLICY_WAVES : REX_WAVE) REX_STEP_KERNEL_ATTR void rex_step_kernel(DevCfg c, float* __restrict__ state, const float* __restrict__ snap,
+__global__ __launch_bounds__(POLICY ? REX_WAVE * REX_POLICY_WAVES(EPW) : REX_WAVE) REX_STEP_KERNEL_ATTR void rex_step_kernel(DevCfg c, float* __restrict__ state, const float* __restrict__ snap,
                                                             const float* __restrict__ action0, float* __restrict__ obs_out0,
                                                             float* __restrict__ reward_out0, uint8_t* __restrict__ done_out0,
                                                             float* __restrict__ cmd_out0, typename PolArg<POLICY>::type pol) {
@@ -892,21 +896,22 @@ __global__ __launch_bounds__(POLICY ? REX_WAVE * REX_POLICY_WAVES : REX_WAVE) RE
   constexpr int kRowsF4 = ARM ? REX_LDS_F4_PER_ENV_ARM_OF(EPW) : REX_ROWS_F4_OF(kLegF4);
   static_assert(!BODY || EPW <= 16, "link-box contact rows: lane-group kernels only");
   constexpr int kWaveF4 = (kRowsF4 + (EPW <= 16 ? REX_PARK_F4_OF(EPW, ARM) : 0) + (BODY ? REX_BODY_F4 : 0)) * EPW;
-  __shared__ float4 lds_wg[kWaveF4 * (POLICY ? REX_POLICY_WAVES : 1)];
-  float4* const lds = lds_wg + (POLICY ? (int)(threadIdx.x >> 6) * kWaveF4 : 0);     // this wave's rows
+  constexpr int kWaves = POLICY ? REX_POLICY_WAVES(EPW) : 1;     // waves of this workgroup (each works as a one-wave workgroup does)
+  __shared__ float4 lds_wg[kWaveF4 * kWaves];
+  float4* const lds = lds_wg + (kWaves > 1 ? (int)(threadIdx.x >> 6) * kWaveF4 : 0);     // this wave's rows
   REX_STAMP(t_kernel);
 #ifdef REX_PROF
   const long long t_wall = (long long)wall_clock64();
 #endif
-  const int lane = POLICY ? (int)(threadIdx.x & (REX_WAVE - 1)) : (int)threadIdx.x;
-  const int wg_block = POLICY ? (int)blockIdx.x * REX_POLICY_WAVES + (int)(threadIdx.x >> 6) : (int)blockIdx.x;   // the one-wave block this wave stands for
+  const int lane = kWaves > 1 ? (int)(threadIdx.x & (REX_WAVE - 1)) : (int)threadIdx.x;
+  const int wg_block = kWaves > 1 ? (int)blockIdx.x * kWaves + (int)(threadIdx.x >> 6) : (int)blockIdx.x;   // the one-wave block this wave stands for
   if (c.clock && lane == 0) atomicMin(&c.clock[2 * (wg_block & (REX_CLOCK_WAYS - 1))], (unsigned long long)wall_clock64());
   const float* pol_wl = nullptr;          // POLICY: the actor's weights in LDS (null: streamed)
   if constexpr (POLICY) {
     extern __shared__ float4 rex_dyn_lds[];
     if (pol.in_lds) {
       policy_weights_to_lds(pol, policy_offsets(c.obs_dim, c.action_dim, pol.h1, pol.h2).total, reinterpret_cast<float*>(rex_dyn_lds), (int)threadIdx.x,
-                            REX_WAVE * REX_POLICY_WAVES);
+                            REX_WAVE * kWaves);
       pol_wl = reinterpret_cast<const float*>(rex_dyn_lds);
     }
     __syncthreads();
@@ -1365,7 +1370,8 @@ static void rex_launch_policy_kernel(RexSim* s, int blocks, hipStream_t st, cons
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, s->pol_lds_bytes);
     attr_bytes = s->pol_lds_bytes;
   }
-  hipLaunchKernelGGL(kern, dim3((blocks + REX_POLICY_WAVES - 1) / REX_POLICY_WAVES), dim3(REX_WAVE * REX_POLICY_WAVES), (size_t)s->pol_lds_bytes, st,
+  constexpr int W = REX_POLICY_WAVES(EPW);
+  hipLaunchKernelGGL(kern, dim3((blocks + W - 1) / W), dim3(REX_WAVE * W), (size_t)s->pol_lds_bytes, st,
                      s->dev, s->d_state, s->d_snap, a, o, r, d, m, s->pol);
 }
 #if REX_TU_POL

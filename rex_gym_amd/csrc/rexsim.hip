@@ -725,7 +725,7 @@ int rex_set_policy(RexSim* s, const RexPolicy* p, void* stream) {
     const int wave_bytes = (rows_floats_per_env(s) / 4 + REX_PARK_F4_OF(s->epw, arm)) * s->epw * 16;
     const int want = off.total * 4;
     const char* ov = getenv("REX_POLICY_LDS");      // developer A/B runs: 0 streams the weights from L2 everywhere
-    const bool fits = REX_POLICY_WAVES * wave_bytes + want <= 160 * 1024 && !(ov && atoi(ov) == 0);
+    const bool fits = REX_POLICY_WAVES(s->epw) > 1 && REX_POLICY_WAVES(s->epw) * wave_bytes + want <= 160 * 1024 && !(ov && atoi(ov) == 0);
     s->pol_lds_bytes = fits ? want : 0;
     d.in_lds = fits ? 1 : 0;
   }

@@ -739,6 +739,17 @@ def test_bench_prints_one_json_line_with_the_contract_fields(torch):
     assert 0.05 < r["kernel_ms"] < 5.0 and r["kernel_ms_min"] <= r["kernel_ms"]
     assert r["kernel_ms_over"].startswith("60 of the 60 timed launches")         # the kernel time is that of the timed launches
     assert abs(r["kernel_ms"] - d["ms_per_step"]) / d["ms_per_step"] < 0.2
+    # the secondary measurements: full blocks at the top level, compact flat copies inside `config` / `roofline` (what a record keeper
+    # that reduces unknown top-level keys to their names still carries)
+    cl, cfg = d["closed_loop"], d["config"]
+    assert cl["finite"] and cl["torch_policy_per_step"]["value"] > 0 and cl["fused_segment_100"]["launches_per_step"] == 0.01
+    assert cl["fused_segment_25"]["value"] > cl["torch_policy_per_step"]["value"]           # a segment per launch beats a launch + ~20 PyTorch ops per step
+    for k in ("open_loop_segment_25_env_steps_per_s", "open_loop_segment_100_env_steps_per_s", "walking_gait_clock_1.5_env_steps_per_s",
+              "closed_loop_torch_policy_per_step_env_steps_per_s", "closed_loop_fused_per_step_env_steps_per_s",
+              "closed_loop_fused_segment_25_env_steps_per_s", "closed_loop_fused_segment_100_env_steps_per_s"):
+        assert isinstance(cfg[k], float) and cfg[k] > 0, k
+    assert r["joint_rmse_p99_rad"] <= 1e-3 and r["joint_rmse_within_1e-3_rad"] is True and 0.9 <= r["joint_rmse_share_envs_with_the_oracles_events"] <= 1.0
+    assert len(r["csrc_sha16"]) == 16 and "traffic_library_commit" in r and "traffic_is_of_this_library" in r
 
 
 def test_bench_two_ranks_gather_rollout_segments(torch):
@@ -784,6 +795,10 @@ def test_bench_two_ranks_report_the_north_star_workload_and_segment_launches(tor
     assert ns["value"] > 0 and ns["value_without_gather"] >= 0.9 * ns["value"]
     sg = d["segment_launch"]
     assert sg["steps_per_launch"] == 25 and sg["value"] > 0 and sg["longer_segments"]["steps_per_launch"] == 100
+    # ... and the closed-loop rollout (policy in the loop) over both ranks' shards, its compact copies in `config`
+    cl = d["closed_loop"]
+    assert cl["envs_total"] == 2 * 4096 and cl["finite"] and all(cl[k]["value"] > 0 for k in ("torch_policy_per_step", "fused_per_step", "fused_segment_25", "fused_segment_100"))
+    assert d["config"]["closed_loop_fused_segment_100_env_steps_per_s"] == cl["fused_segment_100"]["value"]
 
 
 def test_mark_arm_window_with_quiet_arm_rows(torch, tmp_path):

@@ -34,7 +34,8 @@ for step in "$@"; do
                       python -c "import json,sys; d=json.loads(sys.stdin.read()); print('  %-28s %8.2f M env-steps/s  %.4f ms/step  kernel %.4f ms (min %.4f)' % ('$lib'.split('/')[-1], d['value']/1e6, d['ms_per_step'], d['roofline']['kernel_ms'], d['roofline']['kernel_ms_min']))" >> $OUT
                   done ;;
     prof:*)       w=${step#prof:}
-                  timeout 700 bash tools/profile_round.sh ${TAG}_$w ${WL[$w]} > gpurun_out/${TAG}_profile_$w.txt 2>&1
+                  PT=150; [ "$w" = walk262144 ] && PT=420       # (the 262 144-env bench run is 1 950 launches of 1.8 ms + its pre-roll under the profiler)
+                  REX_PROFILE_TIMEOUT=$PT timeout $((4 * PT + 100)) bash tools/profile_round.sh ${TAG}_$w ${WL[$w]} > gpurun_out/${TAG}_profile_$w.txt 2>&1
                   rm -rf gpurun_out/${TAG}_${w}_prof gpurun_out/${TAG}_${w}_pmc_* ;;
     policy_cost)  : > gpurun_out/${TAG}_policy_cost.jsonl
                   for args in "--envs 4096" "--envs 8192" "--envs 16384" "--envs 4096 --mark arm" "--envs 8192 --task gallop --signal ol"; do

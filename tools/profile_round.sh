@@ -7,11 +7,12 @@ cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 cd /tmp
-B="--no-cpu-baseline --no-walking-workload --no-gather --no-segment-launch"
-timeout 150 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_prof -- python $GRAFT_REPO_ROOT/bench.py --steps 400 --warmup 50 $B "$@" > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_bench_under_rocprof.json 2>/dev/null
-timeout 150 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_FETCH_SIZE -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 50 $B "$@" > /dev/null 2>&1
-timeout 150 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_WRITE_SIZE -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 50 $B "$@" > /dev/null 2>&1
-timeout 150 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --kernel-trace -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_SQ -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 50 $B "$@" > /dev/null 2>&1
+B="--no-cpu-baseline --no-walking-workload --no-gather --no-segment-launch --no-closed-loop"   # the per-step rex_step launches alone
+TO=${REX_PROFILE_TIMEOUT:-150}
+timeout $TO rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_prof -- python $GRAFT_REPO_ROOT/bench.py --steps 400 --warmup 50 $B "$@" > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_bench_under_rocprof.json 2>/dev/null
+timeout $TO rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_FETCH_SIZE -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 50 $B "$@" > /dev/null 2>&1
+timeout $TO rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_WRITE_SIZE -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 50 $B "$@" > /dev/null 2>&1
+timeout $TO rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --kernel-trace -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_SQ -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 50 $B "$@" > /dev/null 2>&1
 cd $GRAFT_REPO_ROOT
 # (launches 1550 .. 1949 of the step kernel = bench.py's 400 timed launches behind its 1 500-step pre-roll and the 50 warm-up steps:
 #  the window bench.py's own device-side kernel_ms covers -- the two figures of one run, side by side)
