@@ -117,8 +117,8 @@ def cpu_baseline(task="walk", signal="ik", mark="base", n=ENVS_PER_GPU, cores=No
                       f"over envs on {threads} thread(s) of the {usable_cores()} CPUs this container is granted "
                       f"({dt:.1f} s); CPU restatement, not PyBullet (pybullet is not installable here).  SURVEY 8(d) baseline (iii), the "
                       "reference's own pure-Python controller (GaitPlanner.loop + Kinematics.solve + 5 x MotorModel.convert_to_torque), "
-                      "needs /root/reference and cannot run on the GPU box: 1 134 control steps/s on one core of the build container "
-                      "(DESIGN.md section 6, round-1 record)"}
+                      "needs /root/reference and cannot run on the GPU box: 990 control steps/s on one core of the build container "
+                      "(profiles/r06_reference_python_controller.json, tools/time_reference_controller.py; round 1: 1 134)"}
 
 
 def orclib_mark(mark):

@@ -86,6 +86,20 @@ def test_segment_entry_point_rejects_bad_arguments_without_a_gpu(L):
     assert lib.rex_step_segment(None, 3, None, None, None, None, None, None) < 0 and b"rex_step_segment" in lib.rex_last_error()
 
 
+def test_policy_entry_points_reject_bad_arguments_without_a_gpu(L):
+    """rex_set_policy / rex_step_policy / rex_step_segment_policy (ABI 6: the actor inside the launch) check their handles and pointers
+    before anything touches a device; the RexPolicy mirror has the header's layout (4 ints, 9 pointers, float, int, uint64)."""
+    lib = L.lib()
+    assert lib.rex_set_policy(None, None, None) < 0 and b"rex_set_policy" in lib.rex_last_error()
+    assert lib.rex_step_policy(None, None, None, None, None, None, None, None, None) < 0 and b"rex_step_policy" in lib.rex_last_error()
+    assert lib.rex_step_segment_policy(None, 5, None, None, None, None, None, None, None, None) < 0 and b"rex_step_segment_policy" in lib.rex_last_error()
+    assert ctypes.sizeof(L.RexPolicy) == 4 * 4 + 9 * 8 + 4 + 4 + 8 and L.RexPolicy.seed.offset == 96 and L.RexPolicy.d_w1.offset == 16
+    hdr = open(os.path.join(ROOT, "include", "rexsim.h")).read()
+    body = hdr[hdr.index("typedef struct RexPolicy {"):hdr.index("} RexPolicy;")]
+    names = re.findall(r"\b(obs_dim|action_dim|hidden1|hidden2|d_w1|d_b1|d_w2|d_b2|d_w3|d_b3|d_logstd|d_obs_mean|d_obs_scale|obs_clip|sample|seed)\b\s*[;,]", body)
+    assert names == [f[0] for f in L.RexPolicy._fields_], names
+
+
 def test_spaces_match_reference_bounds():
     from rex_gym_amd.envs.batch_env import _spaces
     a, o = _spaces("walk", "ik", 0.001)

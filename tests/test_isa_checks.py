@@ -74,3 +74,27 @@ def test_contact_row_block_of_the_base_kernels_keeps_its_shape(compiled, epw):
         assert mix.get("v_accvgpr_read_b32", 0) == 0, mix    # the row slices live in VGPRs
         assert mix.get("v_mov_b32_e32", 0) <= 6, mix         # no impulse copies at the end of a sweep
         assert mix.get("v_add_f32_dpp", 0) == (72 if epw <= 8 else 48), mix   # 3 (8 lanes per env) or 2 (4 lanes) steps per group sum
+
+
+def test_fused_actor_kernels_run_their_layers_on_the_matrix_cores_with_the_reads_a_chunk_ahead():
+    """The `_pol` instantiations (rex_step_policy / rex_step_segment_policy, csrc/rex_policy.h), compiled here for the base group:
+    every kernel carries the actor twice (weights in LDS / streamed) x two ReLU layers of 4x4x1 16-block MFMAs; the weights and
+    activations arrive as b128 reads; the DPP sums of the mean layer -- like every cross-lane instruction of the step -- do not sit
+    among EXEC writes of the row finishing (the tool's first check) and the kernels do not spill to scratch."""
+    env = dict(os.environ)
+    env["PATH"] = env.get("PATH", "") + ":/opt/rocm/bin"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_dpp_masks.py"), "--pol", "step_base"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    s = open(os.path.join(ROOT, "scratch", "isa_pol", "rex_step_base-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
+    kernels = list(re.finditer(r"^(_ZN3rex15rex_step_kernel\S*):", s, re.M))
+    assert len(kernels) == 3                                           # 4 / 8 / 16 envs per wave
+    for m, epw in zip(kernels, (4, 8, 16)):
+        assert f"ILi{epw}E" in m.group(1) and m.group(1).count("Lb1E") == 2      # <EPW, base, ..., SEG, POLICY>
+        body = s[m.start():s.index(".Lfunc_end", m.start())]
+        mfma = len(re.findall(r"v_mfma_f32_4x4x1_16b_f32", body))
+        # per layer call: KC quads x 2 chunks consumed per loop trip x 8 MFMAs per quad and env group; 2 layers x (LDS, streamed)
+        assert mfma >= 2 * 2 * 8 * (epw // 4), (epw, mfma)
+        assert len(re.findall(r"ds_read_b128", body)) >= 16 and len(re.findall(r"global_load_dwordx4", body)) >= 8, epw
+        meta = re.search(r"\.name:\s*%s\n(?:.*\n){0,40}?\s*\.private_segment_fixed_size:\s*(\d+)" % re.escape(m.group(1)), s)
+        if meta:
+            assert int(meta.group(1)) == 0, (epw, meta.group(1))

@@ -18,7 +18,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "rex_gym_amd", "csrc")
 OUT = os.path.join(ROOT, "scratch", "isa")
 os.makedirs(OUT, exist_ok=True)
-groups = sys.argv[1:] or ["step_base", "step_arm", "step_mixed_base", "step_mixed_arm", "step_body", "settle_base", "settle_arm"]
+# --pol: the fused-actor instantiations (-DREX_TU_POL=1) of the groups instead of the product kernels, into scratch/isa_pol
+POL = "--pol" in sys.argv
+groups = [a for a in sys.argv[1:] if a != "--pol"] or (["step_base", "step_arm"] if POL else
+                                                       ["step_base", "step_arm", "step_mixed_base", "step_mixed_arm", "step_body", "settle_base", "settle_arm"])
+if POL:
+    OUT = os.path.join(ROOT, "scratch", "isa_pol")
+    os.makedirs(OUT, exist_ok=True)
 
 
 sys.path.insert(0, ROOT)
@@ -26,7 +32,7 @@ from rex_gym_amd.build import COMPILE_FLAGS      # the library's own compile fla
 
 
 def compile_group(g):
-    subprocess.run(["hipcc"] + COMPILE_FLAGS + ["-save-temps", "-I", CSRC, "-c",
+    subprocess.run(["hipcc"] + COMPILE_FLAGS + (["-DREX_TU_POL=1"] if POL else []) + ["-save-temps", "-I", CSRC, "-c",
                     os.path.join(CSRC, f"rex_{g}.hip"), "-o", os.devnull], cwd=OUT, check=True, stderr=subprocess.DEVNULL)
     return g
 
