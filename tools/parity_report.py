@@ -98,7 +98,10 @@ def main():
             w = out["workloads"].setdefault(r["workload"], {"envs": r["envs"], "window_steps": r["window_steps"], "hip_vs_fp64_oracle": {}})
             w["hip_vs_fp64_oracle"][f"{r['envs_per_wave']}_envs_per_wave"] = {k: r.get(k) for k in (
                 "median_rad", "p99_rad", "max_rad", "leg_joints_median_rad", "leg_joints_p99_rad", "base_pos_err_p99_m", "base_pos_err_max_m", "envs_compared_to_the_end", "mean_steps_compared",
-                "abs_error_by_step", "events", "single_steps_from_common_states", "kernels", "trace_pass_bit_identical", "trace_pass_identical_steps", "float32_floor")}
+                "abs_error_by_step", "events", "single_steps_from_common_states", "kernels", "trace_pass_bit_identical", "trace_pass_identical_steps", "float32_floor",
+                "meets_1e-3_rad_absolute")}
+            if r.get("float32_floor") and "float32_floor" not in w:
+                w["float32_floor"] = r["float32_floor"]        # (the floor of the window, measured in the same test run)
     if a.floor:
         for name in WORKLOADS:
             w = out["workloads"].setdefault(name, {"envs": WORKLOADS[name][0], "window_steps": 200, "hip_vs_fp64_oracle": {}})
