@@ -191,6 +191,11 @@ typedef struct RexConfig {
   /* RexGymEnv(forward_reward_cap=...) (envs/rex_gym_env.py:81,217,525): `forward_reward = min(forward_reward, cap)` in the
      base reward.  +inf (the reference default, what rex_default_config sets): no cap.  NaN is rejected. */
   float   forward_reward_cap;
+  /* ---- ABI 6 ---- */
+  /* RexReactiveEnv(use_angle_in_observation=False) (envs/gym/gallop_env.py:56,93,344-356,374-377): 1 = the gallop observation is the four
+     base words alone (roll, pitch and their rates), without the motor angles; rex_obs_dim() is then 4 for gallop.  0: the reference
+     default, 4 + num_motors. */
+  int32_t gallop_no_angles;
 } RexConfig;
 
 typedef struct RexSim RexSim;

@@ -1266,6 +1266,7 @@ static Ground env_ground(const Orc* o, int idx, int episode) {
 }
 
 ORC_API int orc_obs_dim(const RexConfig* c) {
+  if (c->gallop_no_angles) return 4;                       /* use_angle_in_observation=False, gallop_env.py:344-356 */
   if (c->task == REX_TASK_MIXED) return ((c->task_mix >> REX_TASK_GALLOP) & 1) ? 4 + NJ : 4;
   return c->task == REX_TASK_GALLOP ? 4 + NJ : 4;
 }
@@ -1414,7 +1415,7 @@ static void env_observation(const RexConfig* c, const Env* e, real* obs) {
   if (c->noise_stdev[3] > 0) { gauss4(c, e->nz_gidx, e->nz_episode, e->nz_step, NZ_OBS_RPY, z); rpy[0] += cfgf(c->noise_stdev[3]) * z[0]; rpy[1] += cfgf(c->noise_stdev[3]) * z[1]; }
   if (c->noise_stdev[4] > 0) { gauss4(c, e->nz_gidx, e->nz_episode, e->nz_step, NZ_OBS_RATE, z); wx += cfgf(c->noise_stdev[4]) * z[0]; wy += cfgf(c->noise_stdev[4]) * z[1]; }
   obs[0] = rpy[0]; obs[1] = rpy[1]; obs[2] = wx; obs[3] = wy;
-  if (c->task == REX_TASK_GALLOP) {
+  if (c->task == REX_TASK_GALLOP && !c->gallop_no_angles) {   /* `if self._use_angle_in_observation:` gallop_env.py:353 */
     real nz[20] = {0};
     if (c->noise_stdev[0] > 0) for (int b = 0; b < (NJ + 3) / 4; ++b) gauss4(c, e->nz_gidx, e->nz_episode, e->nz_step, NZ_ANGLE + b, nz + 4 * b);
     for (int j = 0; j < NJ; ++j) { /* GetMotorAngles: noise, then MapToMinusPiToPi (rex.py:26-41,457-468) */

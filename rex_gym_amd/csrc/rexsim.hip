@@ -237,6 +237,7 @@ int rex_default_config(int task, int signal, int num_envs, RexConfig* cfg) {
   cfg->body_contacts = task == REX_TASK_POSES;
   cfg->solver_residual_threshold = 1e-7f;                        /* PyBullet default solverResidualThreshold */
   cfg->forward_reward_cap = INFINITY;                            /* rex_gym_env.py:81 */
+  cfg->gallop_no_angles = 0;                                     /* gallop_env.py:56 use_angle_in_observation=True */
   if (task == REX_TASK_MIXED) {   /* BASELINE.json configs[4]: walk, gallop and turn; per-task repeat / sweeps / weights apply per env */
     cfg->task_mix = (1 << REX_TASK_WALK) | (1 << REX_TASK_GALLOP) | (1 << REX_TASK_TURN);
     cfg->action_repeat = 6; cfg->solver_iterations = 60;         /* the largest of the mix (loop bounds only) */
@@ -274,6 +275,7 @@ int rex_state_words(const RexConfig* c) {
 }
 int rex_obs_dim(const RexConfig* c) {
   if (!c) return REX_EINVAL;
+  if (c->gallop_no_angles) return 4;                                             /* use_angle_in_observation=False, gallop_env.py:344-356 */
   if (c->task == REX_TASK_MIXED) return ((c->task_mix >> REX_TASK_GALLOP) & 1) ? 4 + rex_num_motors(c) : 4;
   return c->task == REX_TASK_GALLOP ? 4 + rex_num_motors(c) : 4;                 /* gallop_env.py:349-356 */
 }

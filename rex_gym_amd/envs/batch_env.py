@@ -81,7 +81,7 @@ class RexBatchEnv:
                  distance_weight=None, energy_weight=None, drift_weight=None, shake_weight=None,
                  tasks=None, mass_scale_range=None, friction_range=None, observation_noise_stdev=None,
                  heightfield=None, heightfield_cell=None, heightfield_origin=(0.0, 0.0, 0.0), init_height=None,
-                 body_contacts=None, on_rack=False, env_randomizer=None, forward_reward_cap=None, **ignored):
+                 body_contacts=None, on_rack=False, env_randomizer=None, forward_reward_cap=None, use_angle_in_observation=True, **ignored):
         import torch
         # Reference constructor keywords that only touch the GUI, logging or debugging are accepted and ignored; anything
         # else that would change what the env computes is an error here, not a silent no-op.
@@ -160,6 +160,10 @@ class RexBatchEnv:
                         ("drift_weight", drift_weight), ("shake_weight", shake_weight)):   # rex_gym_env.py:56-59
             if v is not None:
                 setattr(cfg, name, float(v))
+        if not use_angle_in_observation:       # RexReactiveEnv(use_angle_in_observation=False): the four base words alone (gallop_env.py:344-356)
+            if task != "gallop":
+                raise ValueError("use_angle_in_observation is a keyword of the gallop env (RexReactiveEnv)")
+            cfg.gallop_no_angles = 1
         if forward_reward_cap is not None:     # `min(forward_reward, cap)` in the base reward, rex_gym_env.py:81,525
             cfg.forward_reward_cap = float(forward_reward_cap)
         if task == "mixed" and energy_weight is not None:
@@ -196,7 +200,7 @@ class RexBatchEnv:
             tight = min(float(np.abs(sp[0].high).min()) for sp in per.values())     # inside every task's Box
             self.action_space, self.observation_space = Box(-np.full(wide_a.shape, tight), np.full(wide_a.shape, tight)), wide_o
         else:
-            self.action_space, self.observation_space = _spaces(task, signal_type, cfg.sim_time_step, self.num_motors)
+            self.action_space, self.observation_space = _spaces(task, signal_type, cfg.sim_time_step, self.num_motors if use_angle_in_observation else 0)
         if range_normalize:   # RangeNormalize / ClipAction expose [-1, 1] boxes (wrappers.py:205-219)
             self.inner_action_space, self.inner_observation_space = self.action_space, self.observation_space
             self.action_space = Box(-np.ones(self.action_space.shape), np.ones(self.action_space.shape))

@@ -44,7 +44,7 @@ class RexConfig(ctypes.Structure):
         ("gait_clock_scale", ctypes.c_float), ("body_contacts", ctypes.c_int32), ("noise_stdev", ctypes.c_float * 5),
         ("task_mix", ctypes.c_int32), ("mass_scale_lo", ctypes.c_float), ("mass_scale_hi", ctypes.c_float),
         ("friction_lo", ctypes.c_float), ("friction_hi", ctypes.c_float), ("init_height", ctypes.c_float), ("on_rack", ctypes.c_int32),
-        ("forward_reward_cap", ctypes.c_float),
+        ("forward_reward_cap", ctypes.c_float), ("gallop_no_angles", ctypes.c_int32),
     ]
 
 

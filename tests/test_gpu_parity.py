@@ -522,7 +522,8 @@ def test_every_reference_env_class_has_its_single_env_counterpart(torch):
     from rex_gym_amd.envs import gym as g
     cases = [(g.RexWalkEnv, {}, 2, 4), (g.RexWalkEnv, {"signal_type": "ol"}, 8, 4), (g.RexReactiveEnv, {}, 2, 16),
              (g.RexReactiveEnv, {"signal_type": "ol"}, 4, 16), (g.RexTurnEnv, {}, 2, 4), (g.RexPosesEnv, {"base_y": 0.05}, 1, 4),
-             (g.RexStandupEnv, {}, 1, 4), (g.RexWalkEnv, {"mark": "arm"}, 2, 4), (g.RexTurnEnv, {"terrain_type": "random"}, 2, 4)]
+             (g.RexStandupEnv, {}, 1, 4), (g.RexWalkEnv, {"mark": "arm"}, 2, 4), (g.RexTurnEnv, {"terrain_type": "random"}, 2, 4),
+             (g.RexReactiveEnv, {"signal_type": "ol", "use_angle_in_observation": False}, 4, 4)]    # gallop_env.py:56,344-356
     for cls, kw, adim, odim in cases:
         env = cls(render=False, **kw)
         assert env.action_space.shape == (adim,) and env.observation_space.shape == (odim,), (cls.__name__, kw)
@@ -533,6 +534,37 @@ def test_every_reference_env_class_has_its_single_env_counterpart(torch):
         assert o.shape == (odim,) and isinstance(r, float) and isinstance(d, bool)
         assert info["action"].shape == ((18,) if kw.get("mark") == "arm" else (12,))
         env.close()
+
+
+def test_gallop_observation_without_motor_angles(torch):
+    """RexReactiveEnv(use_angle_in_observation=False) (envs/gym/gallop_env.py:56,93,344-356,374-377): the observation is roll, pitch
+    and their rates alone.  Same seed and actions as the default env: the four words are the default observation's first four bit
+    for bit, the physics is untouched, the Box has four bounds; the oracle built the same way agrees; with the wrappers folded the
+    fused actor takes a 4-wide input."""
+    from rex_gym_amd import RexBatchEnv
+    n = 300
+    full = RexBatchEnv(n, task="gallop", signal_type="ol", seed=6, auto_reset=True, max_episode_steps=30, check_actions=False)
+    bare = RexBatchEnv(n, task="gallop", signal_type="ol", seed=6, auto_reset=True, max_episode_steps=30, check_actions=False, use_angle_in_observation=False)
+    assert full.obs_dim == 16 and bare.obs_dim == 4 and bare.observation_space.shape == (4,) and bare.action_space.shape == (4,)
+    cfg = orclib.RexConfig.from_buffer_copy(bytes(bare.config))
+    orc = orclib.OracleEnv(cfg, np.float32)
+    assert orc.obs_dim == 4
+    o_full, o_bare = full.reset(), bare.reset()
+    assert torch.equal(o_full[:, :4], o_bare)
+    np.testing.assert_allclose(o_bare.cpu().numpy(), orc.reset(), atol=2e-3)
+    g = torch.Generator(device="cuda"); g.manual_seed(1)
+    for k in range(45):
+        a = torch.rand((n, 4), device="cuda", generator=g) * 0.6 - 0.3
+        of, rf, df, _ = full.step(a)
+        ob, rb, db, _ = bare.step(a)
+        assert ob.shape == (n, 4) and torch.equal(of[:, :4], ob) and torch.equal(rf, rb) and torch.equal(df, db), k
+        if k < 5:
+            oo, orr, od, _ = orc.step(a.cpu().numpy())
+            np.testing.assert_allclose(ob.cpu().numpy(), oo, atol=5e-3); np.testing.assert_array_equal(db.cpu().numpy(), od)
+    assert torch.equal(full.state, bare.state)
+    full.close(); bare.close()
+    with pytest.raises(ValueError):
+        RexBatchEnv(4, task="walk", use_angle_in_observation=False)
 
 
 def test_step_before_reset_raises(torch):

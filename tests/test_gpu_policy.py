@@ -169,6 +169,26 @@ def test_policy_rollouts_do_not_depend_on_the_sharding_or_the_envs_per_wave(torc
     assert torch.equal(whole[4][:, : n // 2], lo[4]) and torch.equal(whole[4][:, n // 2:], hi[4])
 
 
+def test_streamed_and_lds_resident_weights_give_the_same_bits(torch, monkeypatch):
+    """Where the packed actor fits next to four waves' rows it is loaded into LDS once per launch, else streamed from L2 every step
+    (csrc/rex_policy.h); the arithmetic is the same MFMA chains either way.  REX_POLICY_LDS=0 (read at rex_set_policy) forces the
+    streamed path: a 40-step closed-loop segment through in-launch resets returns the same bits as the default, at 4 and 8 envs per wave,
+    walk-IK and gallop-OL (16 observation words)."""
+    from rex_gym_amd import RexBatchEnv
+    for task, signal, epw in (("walk", "ik", 4), ("walk", "ik", 8), ("gallop", "ol", 4)):
+        outs = []
+        for lds in ("1", "0"):
+            monkeypatch.setenv("REX_ENVS_PER_WAVE", str(epw)); monkeypatch.setenv("REX_POLICY_LDS", lds)
+            env = RexBatchEnv(700, task=task, signal_type=signal, seed=4, auto_reset=True, max_episode_steps=15, check_actions=False, range_normalize=True)
+            _actor(torch, env, seed=8, big=True)
+            o, r, d, info = env.step_segment_policy(40, env.reset())
+            outs.append((o.clone(), r.clone(), d.clone(), info["policy_action"].clone(), info["policy_mean"].clone(), env.state.clone()))
+            env.close()
+        for a, b in zip(*outs):
+            assert torch.equal(a, b), (task, signal, epw)
+        assert int(outs[0][2].sum()) >= 2 * 700
+
+
 def test_policy_argument_checks(torch):
     from rex_gym_amd import RexBatchEnv, _lib
     plain = RexBatchEnv(8, task="walk", signal_type="ik", seed=1)                    # no range_normalize: the agents' wrapper stack is not folded
