@@ -129,7 +129,7 @@ def joint_rmse_vs_oracle(workload, kwargs, n=256, steps=200, seed=11):
     """Half of BASELINE.json's metric ("joint RMSE vs PyBullet"): PyBullet cannot run here, so this is the HIP path
     against the fp64 oracle -- `n` envs of the bench workload from reset, the same random actions, `steps` control steps
     (1 s of robot time); per env the RMSE over time and joints of (q_hip - q_oracle), median / p99 / max over the envs
-    (tests/parity_window.py; the full-size windows of every BASELINE config are in profiles/r05_parity.json).
+    (tests/parity_window.py; the full-size windows of every BASELINE config are in profiles/r06_parity.json).
     The error figures are those of the PRODUCT kernels (the instantiations timed above: no event trace set); a second pass with
     the debug `_trace` instantiations splits the envs by their discrete events and must reproduce the first bit for bit
     (`trace_pass_bit_identical`).  `fp32_tolerance` is the stated tolerance of north_star: next to the whole-batch p99 the

@@ -7,7 +7,7 @@ max over the envs.  The workloads are BASELINE.json's configs[1..4] at their per
 workload (gait clock 1.5: the robot does not fall, so the whole window counts).
 
 TEST INFRASTRUCTURE: imported by tests/test_gpu_parity.py, by bench.py's reported `joint_rmse_vs_oracle` and by
-tools/parity_report.py (profiles/r05_parity.json); never by the product.
+tools/parity_report.py (profiles/r06_parity.json); never by the product.
 """
 import numpy as np
 
@@ -16,6 +16,7 @@ import orclib
 WORKLOADS = {
     # name: (envs, RexBatchEnv keywords)
     "walk_ik_4096": (4096, dict(task="walk", signal_type="ik")),                                   # configs[1]
+    "walk_ik_8192": (8192, dict(task="walk", signal_type="ik")),                                   # north_star's shard: 65 536 / 8
     "gallop_ol_8192": (8192, dict(task="gallop", signal_type="ol")),                               # configs[2] shard
     "turn_ik_heightfield_4096": (4096, dict(task="turn", signal_type="ik", terrain_type="random")),  # configs[3] shard
     "mixed_arm_2048": (2048, dict(task="mixed", signal_type="ik", mark="arm", mass_scale_range=(0.8, 1.2),

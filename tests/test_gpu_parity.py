@@ -1202,6 +1202,7 @@ def test_rollout_gather_runs_on_rccl(torch):
 _PARITY_BOUNDS = {
     # measured (4 / 8 / 16 / 64 envs per wave):      median            p99               max
     "walk_ik_4096": (6e-6, 5e-4, 4e-3),                # 1.5-2.9e-6      1.4-2.4e-4        1.2-1.8e-3
+    "walk_ik_8192": (6e-6, 5e-4, 6e-3),                # north_star's shard (65 536 / 8): the walk-IK window at twice the envs
     "gallop_ol_8192": (3e-6, 6e-5, 4e-3),              # 1.3e-6          2.3-2.5e-5        3.9-5.7e-4 (round 5: 2.1e-3 at 4 / 8 / 16, ONE env of
     #                                                     8 192 after an event flip; 6.7e-4 at 64; the oracle's own fp32 build 6.1e-4)
     # the heightfield is the float32 floor, not the kernels: the fp32 build of the ORACLE against its own fp64 build reads
@@ -1215,21 +1216,21 @@ _PARITY_BOUNDS = {
     "mixed_arm_2048": (6e-4, 8e-3, 8e-2),
     "walk_ik_gait_clock_1.5_4096": (8e-6, 1.6e-4, 3.2e-3),  # 2.5-3.7e-6  3.8-7.7e-5       1.2-1.6e-3
 }
-_MEETS_THE_BAR_AT_P99 = {"walk_ik_4096", "gallop_ol_8192", "walk_ik_gait_clock_1.5_4096"}
+_MEETS_THE_BAR_AT_P99 = {"walk_ik_4096", "walk_ik_8192", "gallop_ol_8192", "walk_ik_gait_clock_1.5_4096"}
 # Share of the envs whose event sequence over the 200-step window (toe points in reach, heightfield facets, joint / arm bounds
 # reached, substep by substep: rex_set_event_trace) equals the fp64 oracle's -- lower bounds at ~0.8 x measured.  On that subset
 # the joint RMSE meets BASELINE.json's 1e-3 rad at the 99th percentile in EVERY workload (heightfield: p99 7.8e-5, max 7.8e-4):
 # what misses the bar in the table above is envs in which float32 took a discrete decision the other way, not drift.  Mark arm
 # keeps no env: its three arm joints sit ON their bounds and the limit rows switch with the last bit in every env within ~25
 # steps (its single steps from common states are split the same way above: same events -> 2e-4 rad).
-_SINGLE_STEP_SAME_EVENTS_RAD = {"walk_ik_4096": 2e-4, "gallop_ol_8192": 2e-4, "turn_ik_heightfield_4096": 1, "mixed_arm_2048": 1,
+_SINGLE_STEP_SAME_EVENTS_RAD = {"walk_ik_4096": 2e-4, "walk_ik_8192": 2e-4, "gallop_ol_8192": 2e-4, "turn_ik_heightfield_4096": 1, "mixed_arm_2048": 1,
                                 "walk_ik_gait_clock_1.5_4096": 2e-4}
-_SAME_EVENTS_SHARE = {"walk_ik_4096": 0.95, "gallop_ol_8192": 0.97, "turn_ik_heightfield_4096": 0.33, "mixed_arm_2048": 0.0,
+_SAME_EVENTS_SHARE = {"walk_ik_4096": 0.95, "walk_ik_8192": 0.95, "gallop_ol_8192": 0.97, "turn_ik_heightfield_4096": 0.33, "mixed_arm_2048": 0.0,
                       "walk_ik_gait_clock_1.5_4096": 0.9}
 
 
 @pytest.mark.parametrize("epw", [4, 8, 16, 64])
-@pytest.mark.parametrize("name", ["walk_ik_4096", "gallop_ol_8192", "turn_ik_heightfield_4096", "mixed_arm_2048", "walk_ik_gait_clock_1.5_4096"])
+@pytest.mark.parametrize("name", ["walk_ik_4096", "gallop_ol_8192", "turn_ik_heightfield_4096", "mixed_arm_2048", "walk_ik_gait_clock_1.5_4096", "walk_ik_8192"])
 def test_every_kernel_variant_against_the_oracle_at_baseline_sizes(torch, name, epw, monkeypatch):
     """BASELINE.json configs[1..4] at their per-GPU shard sizes (4 096 walk-IK, 8 192 gallop-OL, 4 096 turn-IK on the
     heightfield pool, 2 048 mark-arm envs with per-env mixed tasks and per-reset mass / friction draws) and the walking
@@ -1241,7 +1242,7 @@ def test_every_kernel_variant_against_the_oracle_at_baseline_sizes(torch, name, 
         window -- 99th percentile <= 1e-3 rad (BASELINE.json's bar) and median / p99 / max within twice the measured
         values.  Contact dynamics amplify fp32 round-off (a toe that touches down one substep apart is a transient of
         ~1e-2 rad), so the max is looser than the median; the divergence curve goes to gpurun_out/ for
-        profiles/r05_parity.json (tools/parity_report.py), with the event-trace split of the window.
+        profiles/r06_parity.json (tools/parity_report.py), with the event-trace split of the window.
     Round 5: the window's error figures come from the PRODUCT kernels (tests/parity_window.py: pass 1 without the event
     trace); the `_trace` instantiations run a second pass for the event split and must reproduce pass 1 bit for bit."""
     import json
@@ -1249,6 +1250,8 @@ def test_every_kernel_variant_against_the_oracle_at_baseline_sizes(torch, name, 
     import parity_window as pw
     if epw == 64 and name == "mixed_arm_2048":
         pytest.skip("mark arm / mixed tasks: lane-group kernels only")
+    if name == "walk_ik_8192" and epw not in (8, 16):
+        pytest.skip("north_star's shard: the variant the host selects at 8 192 envs (8 per wave) and the next one")
     monkeypatch.setenv("REX_ENVS_PER_WAVE", str(epw))
     steps, seed = 200, 23
     env = pw.make_env(name, seed=seed)
@@ -1302,7 +1305,7 @@ def test_every_kernel_variant_against_the_oracle_at_baseline_sizes(torch, name, 
     # the ABSOLUTE verdict of north_star's bar, recorded next to the floor-relative one and never relaxed by it
     rec["meets_1e-3_rad_absolute"] = dict(median=bool(rec["median_rad"] <= 1e-3), p99=bool(rec["p99_rad"] <= 1e-3), max=bool(rec["max_rad"] <= 1e-3))
     os.makedirs(os.path.join(os.path.dirname(__file__), "..", "gpurun_out"), exist_ok=True)
-    with open(os.path.join(os.path.dirname(__file__), "..", "gpurun_out", "r05_parity.jsonl"), "a") as f:
+    with open(os.path.join(os.path.dirname(__file__), "..", "gpurun_out", "parity_windows.jsonl"), "a") as f:
         f.write(json.dumps(rec) + "\n")
     print(json.dumps(rec))
     # the traced pass reproduced the product pass bit for bit after every one of the 200 steps: the event split below annotates

@@ -19,7 +19,7 @@ for step in "$@"; do
   stamp "start $step"
   case $step in
     tie)          timeout 600 python -m pytest tests/test_gpu_parity.py -q -m gpu -k "trace_kernels_are_bit_identical" > gpurun_out/${TAG}_tie_tests_$(basename ${REX_LIB_PATH:-default} .so).txt 2>&1 ;;
-    parity)       rm -f gpurun_out/r05_parity.jsonl
+    parity)       rm -f gpurun_out/parity_windows.jsonl
                   timeout 900 python -m pytest tests/test_gpu_parity.py -q -m gpu -k "every_kernel_variant or walk_ik_trajectory_rmse" > gpurun_out/${TAG}_parity_tests.txt 2>&1 ;;
     gputests)     timeout 1500 python -m pytest tests -q -m gpu > gpurun_out/${TAG}_gpu_tests.txt 2>&1 ;;
     bench)        timeout 300 bash -c "python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err" ;;

@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
-"""profiles/r05_parity.json: joint-angle RMSE of the HIP path against the fp64 oracle over the 200-step window of every
-BASELINE config (records written by tests/test_gpu_parity.py::test_every_kernel_variant_... into gpurun_out/r05_parity.jsonl
+"""profiles/r06_parity.json: joint-angle RMSE of the HIP path against the fp64 oracle over the 200-step window of every
+BASELINE config (records written by tests/test_gpu_parity.py::test_every_kernel_variant_... into gpurun_out/parity_windows.jsonl
 on the GPU box), next to the FLOAT32 FLOOR of each workload: the same window, the fp32 build of the oracle against its own
 fp64 build (CPU, --floor) -- what float32 arithmetic costs on that workload whatever the implementation.  Round 4: both
 comparisons are split by the EVENT TRACE (rex_set_event_trace / orc_set_event_trace): the envs whose discrete decisions --
 toe points in reach, heightfield facets, joint / arm bounds reached, controller flags, substep by substep -- were those of the
 fp64 oracle over the whole window, and the others.
 
-    python tools/parity_report.py --floor            # CPU: compute the floors (minutes), merge, write profiles/r05_parity.json
+    python tools/parity_report.py --floor            # CPU: compute the floors (minutes), merge, write profiles/r06_parity.json
 """
 import argparse
 import json
@@ -22,6 +22,7 @@ import orclib                                                    # noqa: E402
 
 WORKLOADS = {   # name: (envs, oracle config keywords, mark, action bound, heightfield?) -- mirrors tests/parity_window.py
     "walk_ik_4096": (4096, dict(task="walk", signal="ik"), "base", 0.4, False),
+    "walk_ik_8192": (8192, dict(task="walk", signal="ik"), "base", 0.4, False),
     "gallop_ol_8192": (8192, dict(task="gallop", signal="ol"), "base", 0.3, False),
     "turn_ik_heightfield_4096": (4096, dict(task="turn", signal="ik"), "base", 0.01, True),
     "mixed_arm_2048": (2048, dict(task="mixed", signal="ik", mark=1, task_mix=0b111, action_repeat=6, solver_iterations=60,
@@ -76,8 +77,8 @@ def floor(name, steps=200, seed=23, threads=8):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--floor", action="store_true")
-    ap.add_argument("--records", default=os.path.join(ROOT, "gpurun_out", "r05_parity.jsonl"))
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r05_parity.json"))
+    ap.add_argument("--records", default=os.path.join(ROOT, "gpurun_out", "parity_windows.jsonl"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r06_parity.json"))
     a = ap.parse_args()
     out = {"_comment": "per-env joint-angle RMSE (rad) over the first 200 control steps from reset, HIP path -- the PRODUCT kernels, no event trace set; the event split is a second "
                        "pass with the _trace instantiations, bit-identical to the first after every step (trace_pass_bit_identical) -- vs the fp64 oracle "
