@@ -126,6 +126,40 @@ def play(env, policy, max_steps=2500):
     return total, length, ~alive
 
 
+@torch.no_grad()
+def play_segments(env, policy, max_steps=2500, segment=100):
+    """play() with the ACTOR INSIDE THE LAUNCH: the checkpoint's network and observation filter go to the library once
+    (FusedActor -> rex_set_policy, evaluation mode: the mean action) and the episodes run `segment` closed-loop steps per launch
+    (RexBatchEnv.step_segment_policy).  `env` must fold the wrapper stack the reference plays its policies through
+    (RexBatchEnv(range_normalize=True, auto_reset=True): `_normalize_observ` / `_denormalize_action` of simple_ppo_agent.py:77-88 are
+    RangeNormalize's formulas, applied inside the launch) -- `policy` is a SimplePPOPolicy built on that env.  One episode per env, as
+    play(): what an env does after its first `done` (it is reset inside the launch) is masked out.  One host synchronisation per segment.
+    Returns per-env (sum of rewards, episode length, whether the env ended by itself before max_steps)."""
+    from .fused_actor import FusedActor
+    if not env.config.range_normalize or not env.config.auto_reset:
+        raise ValueError("play_segments: create the env with range_normalize=True, auto_reset=True")
+    FusedActor(env, policy.network, policy._observ_filter, sample=False)
+    observ = env.reset()
+    n, dev = observ.shape[0], observ.device
+    total = torch.zeros(n, device=dev)
+    length = torch.zeros(n, dtype=torch.int32, device=dev)
+    alive = torch.ones(n, dtype=torch.bool, device=dev)
+    steps = 0
+    while steps < max_steps:
+        T = min(int(segment), max_steps - steps)
+        obs, reward, done, _ = env.step_segment_policy(T, observ)
+        ended_before = torch.cat([torch.zeros((1, n), dtype=torch.bool, device=dev), done[:-1].cumsum(0) > 0], 0)     # [T, n]: a done at an earlier step
+        counted = alive[None, :] & ~ended_before
+        total += (reward * counted).sum(0)
+        length += counted.sum(0).to(length.dtype)
+        alive &= ~done.any(0)
+        observ = obs[-1].clone()
+        steps += T
+        if not bool(alive.any()):
+            break
+    return total, length, ~alive
+
+
 def main(argv=None):
     p = argparse.ArgumentParser(description=__doc__.split("\n")[0])
     p.add_argument("--env", default="walk", choices=["walk", "gallop", "turn", "poses", "standup"])
@@ -134,12 +168,15 @@ def main(argv=None):
     p.add_argument("--num-envs", type=int, default=64)
     p.add_argument("--max-steps", type=int, default=2500)
     p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--fused", action="store_true", help="the actor inside the launch: one launch per --segment steps (play_segments)")
+    p.add_argument("--segment", type=int, default=100)
     args = p.parse_args(argv)
     from ..envs import RexBatchEnv
     # (PolicyPlayer.play steps the bare env, policy_player.py:44-56: BatchEnv's per-step Box test -- a host sync per step here -- is not in that loop)
-    env = RexBatchEnv(args.num_envs, task=args.env, signal_type=args.signal_type, seed=args.seed, check_actions=False)
+    env = RexBatchEnv(args.num_envs, task=args.env, signal_type=args.signal_type, seed=args.seed, check_actions=False,
+                      range_normalize=args.fused, auto_reset=args.fused)
     policy = SimplePPOPolicy(env, args.checkpoint)
-    total, length, ended = play(env, policy, args.max_steps)
+    total, length, ended = play_segments(env, policy, args.max_steps, args.segment) if args.fused else play(env, policy, args.max_steps)
     x = env.state[0].float()
     print(json.dumps(dict(env=args.env, signal=args.signal_type, num_envs=args.num_envs,
                           mean_return=float(total.mean()), mean_length=float(length.float().mean()),

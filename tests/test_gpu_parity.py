@@ -1117,6 +1117,43 @@ def test_policy_player_runs_a_checkpoint_on_the_batch_env(torch, tmp_path):
     env.close()
 
 
+@pytest.mark.parametrize("task,signal,obs_dim,action_dim", [("walk", "ik", 4, 2), ("gallop", "ol", 16, 4)])
+def test_policy_player_with_the_actor_inside_the_launch(torch, tmp_path, task, signal, obs_dim, action_dim):
+    """play_segments: the reference's policy player (playground/policy_player.py:22-56 -> simple_ppo_agent.py:53-88) with the checkpoint's
+    network and observation filter evaluated inside the step launch, 20 closed-loop steps per launch, against play() -- the same
+    checkpoint as PyTorch ops around one launch per step on the bare env.  The two evaluate the same mean action up to float32
+    rounding of the network (different summation orders), so the episodes agree closely, not bit for bit: per-env return within 2e-2
+    and length equal for >= 97 % of the envs over 60 steps; the first action, a function of the reset observation alone, within 1e-5.
+    gallop: the inverted action Box of the reference (gallop_env.py:128-130) goes through both paths alike."""
+    from test_agents_policy_player import policy_tensors, write_bundle
+    from rex_gym_amd import RexBatchEnv
+    from rex_gym_amd.agents.policy_player import SimplePPOPolicy, play, play_segments
+    prefix = str(tmp_path / "model.ckpt-9")
+    write_bundle(prefix, policy_tensors(np.random.RandomState(5), obs_dim=obs_dim, layers=(200, 100), action_dim=action_dim))
+    n = 512
+    bare = RexBatchEnv(n, task=task, signal_type=signal, seed=4, check_actions=False)
+    fold = RexBatchEnv(n, task=task, signal_type=signal, seed=4, check_actions=False, range_normalize=True, auto_reset=True)
+    p_bare, p_fold = SimplePPOPolicy(bare, prefix), SimplePPOPolicy(fold, prefix)
+    # the first action: the policy on the reset observation, through both mappings
+    a_bare = p_bare.get_action(bare.reset())
+    from rex_gym_amd.agents.fused_actor import FusedActor
+    FusedActor(fold, p_fold.network, p_fold._observ_filter, sample=False)
+    _, _, _, info = fold.step_policy(fold.reset())
+    lo = torch.as_tensor(bare.action_space.low, device="cuda", dtype=torch.float32); hi = torch.as_tensor(bare.action_space.high, device="cuda", dtype=torch.float32)
+    a_fold = (info["policy_action"] + 1) / 2 * (hi - lo) + lo
+    assert float((a_bare - a_fold).abs().max()) <= 1e-5 * max(1.0, float(hi.abs().max())) + 1e-6
+    r0, l0, e0 = play(bare, p_bare, max_steps=60)
+    r1, l1, e1 = play_segments(fold, p_fold, max_steps=60, segment=20)
+    assert tuple(r1.shape) == (n,) and bool(torch.isfinite(r1).all())
+    same_len = (l0 == l1)
+    assert float(same_len.float().mean()) >= 0.97, float(same_len.float().mean())
+    assert float(((r0 - r1).abs() <= 2e-2)[same_len].float().mean()) >= 0.97, float((r0 - r1).abs()[same_len].max())
+    assert torch.equal(e0[same_len], e1[same_len])
+    with pytest.raises(ValueError):
+        play_segments(bare, p_bare, max_steps=10)
+    bare.close(); fold.close()
+
+
 def test_make_builds_the_registered_envs_with_their_step_limits(torch):
     import rex_gym_amd
     for env_id, (task, limit) in rex_gym_amd.ENV_IDS.items():
