@@ -1317,6 +1317,7 @@ struct RexSim {
   int polbuf_floats;
   int have_policy;
   bool use_policy;        // this launch runs the fused-actor kernels (set by step_launch)
+  int pol_attr_bytes;     // the dynamic-LDS limit this sim has already set on its fused-actor kernel (hipFuncSetAttribute)
   int pol_lds_bytes;      // dynamic LDS of the fused-actor kernels: the weights' copy (0: they do not fit next to four waves' rows and are streamed)
 };
 
@@ -1365,10 +1366,9 @@ void rex_launch_settle_arm(RexSim* s, int nrec, hipStream_t st, float* snap);   
 template <int EPW, bool ARM>
 static void rex_launch_policy_kernel(RexSim* s, int blocks, hipStream_t st, const float* a, float* o, float* r, uint8_t* d, float* m) {
   auto kern = rex::rex_step_kernel<EPW, ARM, false, false, false, true, true>;
-  static int attr_bytes = -1;      // (per instantiation: the largest dynamic LDS size requested so far)
-  if (s->pol_lds_bytes > attr_bytes) {
+  if (s->pol_lds_bytes > s->pol_attr_bytes) {      // (per sim, i.e. per device: the attribute belongs to the function on the current device)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, s->pol_lds_bytes);
-    attr_bytes = s->pol_lds_bytes;
+    s->pol_attr_bytes = s->pol_lds_bytes;
   }
   constexpr int W = REX_POLICY_WAVES(EPW);
   hipLaunchKernelGGL(kern, dim3((blocks + W - 1) / W), dim3(REX_WAVE * W), (size_t)s->pol_lds_bytes, st,

@@ -53,8 +53,13 @@ def test_segment_launches_take_the_same_steps_as_per_step_launches(T, chunks):
         ro = bench.Rollout(env, n, T, dev, gen)
         rec = []
         for steps in chunks:                               # warm-up, timed region, ... : the segments continue across the calls
+            before = len(env.calls)
             ro.run(steps, False, seg_launch)
             rec.append((ro.clock, [{k: v.clone() for k, v in s.items()} for s in ro.seg]))
+            if seg_launch:      # the env steps behind every launch of THIS call: what bench.py divides each launch's kernel time by
+                assert ro.launch_steps == [c[1] for c in env.calls[before:]] and sum(ro.launch_steps) == steps
+            else:
+                assert ro.launch_steps == []
         outs[seg_launch] = (env.calls, rec, env.clock)
     (c0, r0, k0), (c1, r1, k1) = outs[False], outs[True]
     assert k0 == k1 == sum(chunks)
