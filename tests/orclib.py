@@ -67,12 +67,15 @@ def default_config(task="walk", signal="ik", num_envs=1, **kw):
 
 
 _built = False
+# REX_ORACLE_SANITIZE=1: the AddressSanitizer + UBSan build of the oracle (`make -C oracle sanitize`; run the CPU tests under
+# LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0 -- tools/oracle_sanitize.sh)
+BUILD_DIR = "_build_sanitize" if os.environ.get("REX_ORACLE_SANITIZE") == "1" else "_build"
 
 
 def _build():
     global _built
     if not _built:
-        subprocess.check_call(["make", "-s", "-C", ORACLE_DIR], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-s", "-C", ORACLE_DIR] + (["sanitize"] if BUILD_DIR == "_build_sanitize" else []), stdout=subprocess.DEVNULL)
         _built = True
 
 
@@ -86,7 +89,7 @@ class Oracle:
         # REX_ORACLE_DIAG=1 (set by the diagnostic parity test around its subprocess): the twin build whose arm rests inside its bounds
         diag = "diag_" if mark == "arm" and os.environ.get("REX_ORACLE_DIAG") == "1" else ""
         suffix = ("arm_" if mark == "arm" else "") + diag + ("f64" if self.dtype == np.float64 else "f32")
-        self.lib = ctypes.CDLL(os.path.join(ORACLE_DIR, "_build", f"librex_oracle_{suffix}.so"))
+        self.lib = ctypes.CDLL(os.path.join(ORACLE_DIR, BUILD_DIR, f"librex_oracle_{suffix}.so"))
         self.num_motors = self.lib.orc_num_motors()
         self.state_words = self.lib.orc_state_words()
         assert self.lib.orc_sizeof_real() == self.dtype.itemsize
