@@ -18,7 +18,7 @@ import numpy as np
 import torch
 
 from .ppo import ForwardGaussianPolicy, PPOConfig, StreamingNormalize
-from .tf_checkpoint import Checkpoint, CheckpointError
+from .tf_checkpoint import Checkpoint, CheckpointError, write_checkpoint
 
 SCOPE = "network/rnn"          # simple_ppo_agent.py:47 builds the cell under variable_scope("network/rnn")
 
@@ -78,6 +78,40 @@ def restore_normalizer(ckpt, name, clip, device="cpu"):
     f.mean = torch.as_tensor(mean, dtype=torch.float32, device=device)
     f.var_sum = torch.as_tensor(ckpt.tensor(f"{name}/Variable_2"), dtype=torch.float32, device=device)
     return f
+
+
+def save_policy(prefix, network, observ_filter, global_step=None):
+    """The inverse of restore_network / restore_normalizer: write `network` (a ForwardGaussianPolicy) and its observation filter
+    as a TensorFlow-1 checkpoint `<prefix>.index` / `.data-00000-of-00001` under the variable names of the reference's graph,
+    plus the `checkpoint` state file tf.train.get_checkpoint_state reads (agents/scripts/utility.py:138-142).  These are the
+    variables SimplePPOPolicy's Saver restores (simple_ppo_agent.py:23-27,46-63: `normalize_observ/*` and `network/rnn/*`; its
+    `temporary/*` state is excluded), so a policy trained with rex_gym_amd.agents.ppo plays under the reference's
+    `rex-gym policy` next to the config.yaml of its env.  (Resuming the reference's TRAINING from it needs the optimizer slots
+    and episode memory of that graph as well, which are not state of this learner: not written.)"""
+    import os
+    tensors = {}
+
+    def put(linear, base):
+        tensors[base + "/weights"] = np.ascontiguousarray(linear.weight.detach().cpu().numpy().astype(np.float32).T)   # TF: [in, out]
+        tensors[base + "/biases"] = linear.bias.detach().cpu().numpy().astype(np.float32)
+
+    def branch(layers, last, name):
+        for k, lin in enumerate(layers + [last]):
+            put(lin, f"{SCOPE}/{name}/fully_connected" + (f"_{k}" if k else ""))
+
+    branch([m for m in network.policy if isinstance(m, torch.nn.Linear)], network.mean, "policy")
+    branch([m for m in network.value if isinstance(m, torch.nn.Linear)], network.value_out, "value")
+    tensors[f"{SCOPE}/policy/logstd"] = network.logstd.detach().cpu().numpy().astype(np.float32).reshape(-1)
+    tensors["normalize_observ/Variable"] = np.asarray(int(observ_filter.count), np.int32)            # normalize.py:38-41
+    tensors["normalize_observ/Variable_1"] = observ_filter.mean.detach().cpu().numpy().astype(np.float32)
+    tensors["normalize_observ/Variable_2"] = observ_filter.var_sum.detach().cpu().numpy().astype(np.float32)
+    if global_step is not None:
+        tensors["global_step"] = np.asarray(int(global_step), np.int32)
+    write_checkpoint(prefix, tensors)
+    with open(os.path.join(os.path.dirname(prefix) or ".", "checkpoint"), "w") as f:
+        base = os.path.basename(prefix)
+        f.write(f'model_checkpoint_path: "{base}"\nall_model_checkpoint_paths: "{base}"\n')
+    return prefix
 
 
 class SimplePPOPolicy:

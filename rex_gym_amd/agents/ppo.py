@@ -586,6 +586,8 @@ if __name__ == "__main__":   # python -m rex_gym_amd.agents.ppo --task walk --en
                     help="segments: the actor inside the launch, one launch per --segment steps (train_segments); steps: perform() in PyTorch, "
                          "one launch and three host synchronisations per step (train, the reference's loop shape)")
     ap.add_argument("--segment", type=int, default=25)
+    ap.add_argument("--logdir", default=None, help="write the trained policy there as a TensorFlow-1 checkpoint the reference's policy player "
+                                                   "restores (model.ckpt-<env steps>.index / .data-00000-of-00001 + checkpoint: policy_player.save_policy)")
     a = ap.parse_args()
     import time
     # the reference trains through RangeNormalize + ClipAction (playground/trainer.py:48-52): actions in [-1, 1]
@@ -604,3 +606,9 @@ if __name__ == "__main__":   # python -m rex_gym_amd.agents.ppo --task walk --en
             score, length = train(env, agent, a.max_length)
         print(f"iteration {it}: mean score {score:.3f}, mean length {length:.1f}, updates {agent.updates}, "
               f"penalty {agent.penalty:.3g}, {time.perf_counter() - t0:.1f} s", flush=True)
+    if a.logdir:
+        import os
+        from .policy_player import save_policy
+        os.makedirs(a.logdir, exist_ok=True)
+        steps = a.iterations * a.max_length * a.envs
+        print("saved", save_policy(os.path.join(a.logdir, f"model.ckpt-{steps}"), agent.net, agent.observ_filter, global_step=steps))

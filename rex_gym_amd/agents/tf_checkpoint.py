@@ -258,3 +258,145 @@ class Checkpoint:
         if verify and e["crc"] is not None and masked_crc32c(raw) != e["crc"]:
             raise CheckpointError(f"{name}: tensor checksum mismatch")
         return np.frombuffer(raw, dtype.newbyteorder("<")).astype(dtype).reshape(tuple(e["shape"]))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Writer: the same two files, so that a policy trained here goes back to the reference's tooling (`rex-gym policy`,
+# SimplePPOPolicy's tf.train.Saver.restore: agents/ppo/simple_ppo_agent.py:62-63, agents/scripts/utility.py:79-95).
+# Byte layout as TensorFlow's BundleWriter produces it for the reference's shipped checkpoints (tests/test_agents_policy_player.py
+# rewrites rex_gym/policies/walk/ik/model.ckpt-2000000 and compares both files byte for byte): tensors in key order, back to
+# back, in one data shard; one uncompressed table block of prefix-compressed entries with a restart point every 16 keys
+# (a new block once one reaches BLOCK_SIZE), an empty metaindex block, an index block of (shortest separator, block handle)
+# and the 48-byte footer.
+_DTYPE_CODES = {np.dtype(v): k for k, v in _DTYPES.items()}
+BLOCK_SIZE = 262144          # tensorflow/core/lib/io/table_options.h
+RESTART_INTERVAL = 16
+
+
+def _put_varint(out, v):
+    v = int(v)
+    if v < 0:
+        raise CheckpointError("negative varint")
+    while v >= 0x80:
+        out.append((v & 0x7F) | 0x80)
+        v >>= 7
+    out.append(v)
+
+
+def _entry_proto(dtype_code, shape, offset, size, crc):
+    """BundleEntryProto, fields in number order; zero-valued scalars are not written (proto3), the shape message always is."""
+    m = bytearray()
+    m.append(0x08)
+    _put_varint(m, dtype_code)
+    dims = bytearray()
+    for d in shape:
+        dim = bytearray()
+        if d:
+            dim.append(0x08)
+            _put_varint(dim, d)
+        dims.append(0x12)
+        _put_varint(dims, len(dim))
+        dims += dim
+    m.append(0x12)
+    _put_varint(m, len(dims))
+    m += dims
+    if offset:
+        m.append(0x20)
+        _put_varint(m, offset)
+    if size:
+        m.append(0x28)
+        _put_varint(m, size)
+    m.append(0x35)
+    m += struct.pack("<I", crc)
+    return bytes(m)
+
+
+class _BlockBuilder:
+    def __init__(self, restart_interval=RESTART_INTERVAL):
+        self.buf, self.restarts, self.count, self.last, self.interval = bytearray(), [0], 0, b"", restart_interval
+
+    def add(self, key, value):
+        shared = 0
+        if self.count % self.interval == 0 and self.count:
+            self.restarts.append(len(self.buf))
+        elif self.count:
+            n = min(len(key), len(self.last))
+            while shared < n and key[shared] == self.last[shared]:
+                shared += 1
+        _put_varint(self.buf, shared)
+        _put_varint(self.buf, len(key) - shared)
+        _put_varint(self.buf, len(value))
+        self.buf += key[shared:] + value
+        self.last, self.count = key, self.count + 1
+
+    def size(self):
+        return len(self.buf) + 4 * len(self.restarts) + 4
+
+    def finish(self):
+        return bytes(self.buf) + struct.pack(f"<{len(self.restarts)}I", *self.restarts) + struct.pack("<I", len(self.restarts))
+
+
+def _separator(a, b):
+    """LevelDB's BytewiseComparator::FindShortestSeparator: a short key k with a <= k < b."""
+    n = min(len(a), len(b))
+    d = 0
+    while d < n and a[d] == b[d]:
+        d += 1
+    if d < n and a[d] < 0xFF and a[d] + 1 < b[d]:
+        return a[:d] + bytes([a[d] + 1])
+    return a
+
+
+def _successor(a):
+    """FindShortSuccessor: the key of the last block's index entry."""
+    for i, c in enumerate(a):
+        if c != 0xFF:
+            return a[:i] + bytes([c + 1])
+    return a
+
+
+def write_checkpoint(prefix, tensors, block_size=BLOCK_SIZE):
+    """Write `tensors` (name -> array; float32 / int32 / ... of _DTYPES) as `<prefix>.index` + `<prefix>.data-00000-of-00001`."""
+    names = sorted(tensors, key=lambda s: s.encode())
+    if any(not n for n in names):
+        raise CheckpointError("empty variable name")
+    data = bytearray()
+    entries = [(b"", b"\x08\x01\x1a\x02\x08\x01")]            # BundleHeaderProto: num_shards 1, little endian (0, unwritten), version { producer 1 }
+    for name in names:
+        a = np.asarray(tensors[name])
+        if a.dtype not in _DTYPE_CODES:
+            raise CheckpointError(f"{name}: dtype {a.dtype} has no TensorFlow code here")
+        raw = np.ascontiguousarray(a.astype(a.dtype.newbyteorder("<"))).tobytes()
+        entries.append((name.encode(), _entry_proto(_DTYPE_CODES[a.dtype], a.shape, len(data), len(raw), masked_crc32c(raw))))
+        data += raw
+    out = bytearray()
+
+    def emit(block):
+        handle = bytearray()
+        _put_varint(handle, len(out))
+        _put_varint(handle, len(block))
+        out.extend(block + b"\x00" + struct.pack("<I", masked_crc32c(block + b"\x00")))
+        return bytes(handle)
+
+    index, blk, pending = _BlockBuilder(1), _BlockBuilder(), None      # (index blocks restart at every key: table_builder.cc)
+    for key, value in entries:
+        if pending is not None:
+            index.add(_separator(pending[0], key), pending[1])
+            pending = None
+        blk.add(key, value)
+        if blk.size() >= block_size:
+            pending = (key, emit(blk.finish()))
+            blk = _BlockBuilder()
+    if blk.count:
+        pending = (blk.last, emit(blk.finish()))
+    if pending is not None:
+        index.add(_successor(pending[0]), pending[1])
+    meta = emit(_BlockBuilder().finish())
+    idx = emit(index.finish())
+    footer = meta + idx
+    out += footer + b"\x00" * (40 - len(footer)) + struct.pack("<Q", TABLE_MAGIC)
+    with open(prefix + ".data-00000-of-00001", "wb") as f:
+        f.write(bytes(data))
+    with open(prefix + ".index", "wb") as f:
+        f.write(bytes(out))
+    return prefix

@@ -238,3 +238,58 @@ def test_checkpoints_whose_data_shard_is_missing_fail_loudly():
     if not os.path.exists(ck.prefix + ".data-00000-of-00001"):
         with pytest.raises(CheckpointError, match="shard missing"):
             ck.tensor("network/rnn/policy/logstd")
+
+
+# ---------------------------------------------------------------- the writer (rex_gym_amd.agents.tf_checkpoint.write_checkpoint, save_policy)
+def test_written_checkpoints_read_back(tmp_path):
+    rng = np.random.default_rng(5)
+    tensors = {f"scope/var_{k:03d}/weights": rng.standard_normal((k % 7 + 1, 3)).astype(np.float32) for k in range(90)}
+    tensors.update({"a_scalar": np.asarray(7, np.int32), "z/int64": np.arange(5, dtype=np.int64), "empty": np.zeros((0, 4), np.float32),
+                    "\xffhigh": np.ones(2, np.float32)})
+    for block_size in (tf_checkpoint.BLOCK_SIZE, 300):             # one table block (TensorFlow's case) and many
+        prefix = str(tmp_path / f"m{block_size}")
+        tf_checkpoint.write_checkpoint(prefix, tensors, block_size=block_size)
+        ck = Checkpoint(prefix)
+        assert ck.names() == sorted(tensors)
+        for name, a in tensors.items():
+            b = ck.tensor(name)                                    # (crc32c verified)
+            assert b.dtype == a.dtype and b.shape == a.shape and np.array_equal(a, b)
+    with pytest.raises(CheckpointError, match="dtype"):
+        tf_checkpoint.write_checkpoint(str(tmp_path / "bad"), {"c": np.zeros(2, np.complex64)})
+
+
+def test_save_policy_is_the_inverse_of_the_restore_functions(tmp_path):
+    from rex_gym_amd.agents.ppo import ForwardGaussianPolicy, PPOConfig, StreamingNormalize
+    torch.manual_seed(3)
+    net = ForwardGaussianPolicy(4, 2, PPOConfig())
+    with torch.no_grad():
+        net.logstd.copy_(torch.tensor([-1.5, -0.25]))
+    filt = StreamingNormalize((4,), clip=5.0)
+    filt.update(torch.randn(300, 4) * 3 + 1)
+    prefix = policy_player.save_policy(str(tmp_path / "model.ckpt-1234"), net, filt, global_step=1234)
+    ck = Checkpoint(prefix)
+    assert ck.shape("network/rnn/policy/fully_connected/weights") == (4, 200)          # TensorFlow's [in, out]
+    assert ck.shape("network/rnn/value/fully_connected_2/weights") == (100, 1) and int(ck.tensor("global_step")) == 1234
+    net2, filt2 = policy_player.restore_network(ck), policy_player.restore_normalizer(ck, "normalize_observ", clip=5.0)
+    for a, b in zip(net.state_dict().values(), net2.state_dict().values()):
+        assert torch.equal(a, b)
+    assert filt2.count == filt.count and torch.equal(filt2.mean, filt.mean) and torch.equal(filt2.var_sum, filt.var_sum)
+    x = torch.randn(5, 4)
+    assert torch.equal(net(filt.transform(x))[0], net2(filt2.transform(x))[0])
+    assert (tmp_path / "checkpoint").read_text().splitlines()[0] == 'model_checkpoint_path: "model.ckpt-1234"'
+    env = _fake_env()
+    assert torch.equal(policy_player.SimplePPOPolicy(env, prefix).get_action(torch.zeros(3, 4)),
+                       policy_player.SimplePPOPolicy(env, ck).get_action(torch.zeros(3, 4)))
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REFERENCE, "rex_gym", "policies")), reason="reference tree not present")
+@pytest.mark.parametrize("rel", sorted(SHIPPED))
+def test_rewritten_shipped_checkpoints_are_byte_identical(rel, tmp_path):
+    """TensorFlow's own output is the golden vector of the writer: every shipped checkpoint, read and written again, gives the
+    shipped .index and .data files byte for byte (table block layout, restart points, entry protos, checksums, footer)."""
+    prefix = os.path.join(REFERENCE, "rex_gym", "policies", rel)
+    ck = Checkpoint(prefix)
+    out = tf_checkpoint.write_checkpoint(str(tmp_path / "again"), {n: ck.tensor(n) for n in ck.names()})
+    for ext in (".index", ".data-00000-of-00001"):
+        with open(prefix + ext, "rb") as f, open(out + ext, "rb") as g:
+            assert f.read() == g.read(), ext
