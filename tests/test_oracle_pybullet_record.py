@@ -1,0 +1,56 @@
+"""The oracle's restated `stepSimulation` against RECORDED PYBULLET ROLLOUTS.
+
+tests/golden/pybullet_turn_ol_rollouts.npz is the episode memory of the reference's shipped turn / open-loop checkpoint: 20 episodes,
+8 091 control steps of RexTurnEnv on real PyBullet -- observation, action, reward per step (tests/golden/make_pybullet_golden.py).  It
+is the only PyBullet-produced trajectory data the reference holds, and the only pin on the inside of `stepSimulation` this repo has:
+everything else about a16 is the oracle against its own kernels.  tests/pybullet_replay.py plays the recorded actions and recovers
+what the record does not state (6 substeps per control step, turning direction, start yaw).
+
+What is asserted is what the physics as shipped achieves, with margins -- NOT the 1e-3 rad of north_star: roll / pitch follow the record
+to 2.4e-3 rad RMS over the first 25 control steps (35 % of the signal's RMS), 4.6e-3 over 50; every gait event -- the touch-down after
+the reset's teleport and the leg switches -- lands on the record's control step with the record's angular-velocity peak to 10 %."""
+import numpy as np
+import pytest
+
+import pybullet_replay as pr
+
+
+@pytest.fixture(scope="module")
+def episodes():
+    return pr.load()
+
+
+def test_record_shape(episodes):
+    assert len(episodes) == 20 and sum(e["length"] for e in episodes) == 8091
+    for e in episodes:
+        assert np.all(e["observ"][0] == 0)                               # the training-time reset read the pose back after the teleport
+        assert np.all(np.abs(e["observ"][:, :2]) < 0.2)                   # upright throughout: none of the 20 episodes ends in a fall
+        assert 0.02 < e["reward"].max() <= 0.035                          # 0.035 - |x| - |y|, turn_env.py:362-367
+
+
+@pytest.fixture(scope="module")
+def summary(episodes):
+    return pr.summarize(episodes, pr.replay_oracle, steps=120, windows=(25, 50, 100))
+
+
+def test_gait_events_fall_on_the_records_control_steps(summary):
+    assert summary["rate_profile_correlation"] > 0.85, summary["rate_profile_correlation"]          # measured 0.92
+    for name, ev in summary["event_peaks"].items():
+        assert ev["record"] == ev["replay"], (name, ev)                                              # all six, up to control step 105
+        if int(name.split("-")[0]) < 70:     # the peak heights while the replay still tracks the record: within 9 % (16 % / 30 % at steps 86 / 105)
+            assert abs(ev["replay_rad_s"] / ev["record_rad_s"] - 1) < 0.15, (name, ev)
+
+
+def test_roll_pitch_follow_the_record(summary):
+    w = summary["windows"]
+    assert w[25]["rp_rmse"] < 3.2e-3 and w[25]["rp_rmse"] < 0.5 * w[25]["rp_ref_rms"], w[25]      # measured 2.4e-3 of 6.8e-3
+    assert w[50]["rp_rmse"] < 6.0e-3 and w[50]["rp_rmse"] < 0.7 * w[50]["rp_ref_rms"], w[50]      # measured 4.6e-3 of 8.4e-3
+    assert w[25]["rate_rmse"] < 0.6 * w[25]["rate_ref_rms"], w[25]                                 # world-frame rates after the yaw fit: 0.14 of 0.27
+    assert w[25]["reward_rmse"] < 2.0e-3, w[25]                                                    # |x| + |y| drift: 1.2e-3 m
+    assert summary["direction_fit_ratio_min"] > 1.05                                               # every episode tells its turning direction
+
+
+def test_five_substeps_do_not_reproduce_the_record(episodes):
+    """The recovered time base: with today's constructor default (action_repeat 5) the events drift off the record."""
+    ref, ours, _ = pr.rate_profile(episodes[:8], pr.replay_oracle, action_repeat=5, solver_iterations=60)
+    assert np.corrcoef(ref[1:], ours[1:])[0, 1] < 0.5
