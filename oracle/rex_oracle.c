@@ -23,8 +23,11 @@
  *
  * PARITY STATUS: the controller half and the env-level command logic (goal / brake / hold
  * state machines of the five envs) are pinned against golden vectors generated from the
- * reference's own Python code (tests/golden/).  The physics half is **parity unpinned**: no
- * PyBullet here, no golden trajectories in the reference.
+ * reference's own Python code (tests/golden/).  The physics half has no PyBullet to run against here
+ * (**parity unpinned** in that sense); its one external pin is the record of 20 PyBullet episodes found in the
+ * episode memory of the reference's shipped turn / ol checkpoint (tests/golden/pybullet_turn_ol_rollouts.npz,
+ * tests/test_oracle_pybullet_record.py): gait events on the record's control steps, roll / pitch to 2.4e-3 rad
+ * RMS over 25 steps -- not the 1e-3 rad of north_star.
  *
  * Build: `make -C oracle` -> oracle/_build/librex_oracle_f64.so (REAL=double) and _f32.so (float).
  * The physics deliberately uses a DIFFERENT formulation (body-coordinate spatial ABA, dense 18-dof
