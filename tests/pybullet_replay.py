@@ -179,3 +179,80 @@ class HipReplayer:
         obs, xy, done_at = self.runs[direction]
         end = steps + 1 if done_at[k] < 0 else min(steps, int(done_at[k])) + 1
         return obs[k, :end], xy[k, :end], (int(done_at[k]) if 0 <= done_at[k] <= steps else None)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The second record: RexStandupEnv (signal 'ol') -- tests/golden/pybullet_standup_ol_rollouts.npz, 25 episodes x 400 control steps.
+# No hidden draws (standup_env.py:108-118: the crouch of INIT_POSES['rest_position'], then `stand * ((0.1 + a) / (1 + t) + 1.5)` for
+# 0.1 s, then INIT_POSES['stand']); the reward is the base position folded as standup_env.py:141-155 folds it.
+STANDUP_FIXTURE = os.path.join(HERE, "golden", "pybullet_standup_ol_rollouts.npz")
+
+
+def load_standup():
+    d = np.load(STANDUP_FIXTURE)
+    return [dict(observ=d["observ"][k, :n].astype(np.float64) * OBS_HI, action=d["action"][k, :n].astype(np.float64),
+                 reward=d["reward"][k, :n].astype(np.float64), length=int(n)) for k, n in enumerate(d["length"])]
+
+
+def standup_position_error(reward):
+    """(|x| + |y| + |0.21 - z|, base above 0.21 m) out of the standup reward: r = 1 - e (e < 0.1) or -e below the target height,
+    -1 - that above it (standup_env.py:146-153).  (-1, 0] is read as 'below' -- above the target with e >= 0.1 does not occur in the record.)"""
+    r = np.asarray(reward, np.float64)
+    above = r <= -1.0
+    e = np.where(above, r + 2.0, np.where(r > 0, 1.0 - r, -r))
+    return e, above
+
+
+def replay_standup_oracle(action, steps, dtype=np.float64, probes=None, **cfg_kw):
+    """-> (obs [steps + 1, 4] rad, rad/s; base position [steps + 1, 3]; reward [steps]; the step at which is_fallen ended it, or None)"""
+    import ctypes
+    import orclib
+    kw = dict(num_envs=1, range_normalize=1, max_episode_steps=1000)
+    kw.update(cfg_kw)
+    cfg = orclib.default_config("standup", "ol", **kw)
+    env = orclib.OracleEnv(cfg, dtype)
+    if probes:
+        env.o.lib.orc_set_probe.argtypes = [ctypes.c_char_p, ctypes.c_double]
+        for k, v in probes.items():
+            assert env.o.lib.orc_set_probe(k.encode(), float(v)) == 0, k
+        env.close()
+        env = orclib.OracleEnv(cfg, dtype)
+    try:
+        obs, pos, rew, fell = [env.reset()[0] * OBS_HI], [env.get_state()[:3, 0].copy()], [], None
+        for t in range(steps):
+            o, r, d, _ = env.step(action[t][None])
+            obs.append(o[0] * OBS_HI)
+            pos.append(env.get_state()[:3, 0].copy())
+            rew.append(float(r[0]))
+            if d[0]:
+                fell = t + 1
+                break
+        return np.asarray(obs, np.float64), np.asarray(pos, np.float64), np.asarray(rew, np.float64), fell
+    finally:
+        env.close()
+
+
+def summarize_standup(episodes, replay, steps=400, **kw):
+    rows = []
+    for ep in episodes:
+        obs, pos, rew, fell = replay(ep["action"], min(steps, ep["length"]), **kw)
+        n = len(rew)
+        e_ref, above_ref = standup_position_error(ep["reward"][:n])
+        e, above = standup_position_error(rew)
+        k = min(n, 30)
+        rows.append(dict(
+            fell_at=fell, steps=n, return_replay=float(rew.sum()), return_record=float(ep["reward"][:n].sum()),
+            return_record_400=float(ep["reward"].sum()),
+            crouch_error_replay=float(e[0]), crouch_error_record=float(e_ref[0]),
+            rise_mm_per_step_replay=float((e[2] - e[12]) / 10 * 1e3), rise_mm_per_step_record=float((e_ref[2] - e_ref[12]) / 10 * 1e3),
+            first_above_replay=int(np.argmax(above)) if above.any() else None, first_above_record=int(np.argmax(above_ref)) if above_ref.any() else None,
+            pitch_peak_replay=float(obs[1:k + 1, 1].max()), pitch_peak_record=float(ep["observ"][:k, 1].max()),
+            pitch_rmse_30=float(np.sqrt(((obs[:k, 1] - ep["observ"][:k, 1]) ** 2).mean())),
+            pitch_rmse_all=float(np.sqrt(((obs[:n, 1] - ep["observ"][:n, 1]) ** 2).mean()))))
+    agg = {k: float(np.mean([r[k] for r in rows])) for k in rows[0] if k not in ("fell_at", "first_above_replay", "first_above_record")}
+    agg["episodes"] = len(rows)
+    agg["fell"] = int(sum(r["fell_at"] is not None for r in rows))
+    agg["fell_at_median"] = float(np.median([r["fell_at"] for r in rows if r["fell_at"] is not None])) if agg["fell"] else None
+    agg["first_above_replay_median"] = float(np.median([r["first_above_replay"] for r in rows if r["first_above_replay"] is not None]))
+    agg["first_above_record_median"] = float(np.median([r["first_above_record"] for r in rows if r["first_above_record"] is not None]))
+    return dict(summary=agg, per_episode=rows)

@@ -48,6 +48,30 @@ ROWS = [
 ]
 
 
+STANDUP_ROWS = [
+    ("restatement as shipped (toe friction 0.5)", {}, {}),
+    ("friction mu 0.15", dict(mu=0.15), {}), ("friction mu 0.2", dict(mu=0.2), {}), ("friction mu 0.25", dict(mu=0.25), {}),
+    ("friction mu 0.3", dict(mu=0.3), {}), ("friction mu 0.35", dict(mu=0.35), {}), ("friction mu 0.4", dict(mu=0.4), {}),
+    ("friction mu 1.0", dict(mu=1.0), {}),
+    ("friction cone instead of pyramid", dict(cone=1), {}),
+    ("6 substeps per control step", {}, dict(action_repeat=6, solver_iterations=50)),
+    ("multibody damping 0.4 / 0.4", dict(lin_damping=0.4, ang_damping=0.4), {}),
+    ("link inertias x 2", dict(inertia_scale=2.0), {}),
+    ("leg links + 1e-3 kg m^2", dict(leg_inertia_add=1e-3), {}),
+    ("URDF joint friction honoured (0.5 N m on shoulder / foot joints)", dict(joint_friction=0.5), {}),
+    ("body-vs-ground box contacts on", {}, dict(body_contacts=1)),
+    ("toe collision margin 4 mm", dict(margin=0.004), {}),
+    ("motor gains kp 1.5, kd 0.03", {}, dict(motor_kp=1.5, motor_kd=0.03)),
+    ("solver: 200 sweeps, no residual exit", {}, dict(solver_iterations=200, solver_residual_threshold=0.0)),
+]
+
+
+def work_standup(row):
+    import pybullet_replay as pr
+    name, probes, kw = row
+    return name, pr.summarize_standup(pr.load_standup()[:8], pr.replay_standup_oracle, steps=400, probes=probes or None, **kw)["summary"]
+
+
 def work(row):
     import pybullet_replay as pr
     name, probes, kw = row
@@ -59,6 +83,7 @@ def main():
     out = os.path.join(ROOT, "profiles", "r06_pybullet_record")
     with mp.get_context("spawn").Pool(min(8, os.cpu_count() or 1), maxtasksperchild=1) as pool:      # (the probes are process-wide statics of the oracle)
         results = list(pool.imap(work, ROWS, chunksize=1))
+        standup = list(pool.imap(work_standup, STANDUP_ROWS, chunksize=1))
     lines = ["# The restated `stepSimulation` against the recorded PyBullet rollouts (fp64 oracle; `tools/pybullet_record_report.py`)", "",
              "20 episodes of the reference's RexTurnEnv (signal 'ol') on real PyBullet, out of the episode memory of its shipped checkpoint",
              "(`tests/golden/make_pybullet_golden.py`); the recorded actions replayed, first 25 / 50 / 100 control steps of every episode.",
@@ -74,10 +99,21 @@ def main():
                 f"{w[25]['reward_rmse']:.1e} | {s['rate_profile_correlation']:.2f} | {hit} / {len(ev)} |")
         print(line, flush=True)
         lines.append(line)
+    lines += ["", "## The standup record (25 episodes x 400 control steps of RexStandupEnv, no hidden draws; 8 episodes replayed per row)", "",
+              "On PyBullet every recorded episode stands up and stays up (return +304 ... +345, mean +333).  `fell` = replays that trip `is_fallen`",
+              "(and the median control step), `return` = mean episode return of the replay over the steps it lasted, `crouch` = |x| + |y| + |0.21 - z| after the",
+              "first step (record: 0.184), `rise` = mm per control step over steps 2-12 (record: 6.9), `pitch 30` / `pitch all` = RMS error of the pitch [rad].", "",
+              "| assumption varied | fell | return | crouch | rise | pitch 30 | pitch all |", "|---|---|---|---|---|---|---|"]
+    for name, a in standup:
+        fell = f"{a['fell']} / {a['episodes']}" + (f" (step {a['fell_at_median']:.0f})" if a["fell"] else "")
+        line = (f"| {name} | {fell} | {a['return_replay']:+.0f} | {a['crouch_error_replay']:.3f} | {a['rise_mm_per_step_replay']:.1f} | "
+                f"{a['pitch_rmse_30']:.3f} | {a['pitch_rmse_all']:.3f} |")
+        print(line, flush=True)
+        lines.append(line)
     with open(out + ".md", "w") as f:
         f.write("\n".join(lines) + "\n")
     with open(out + ".json", "w") as f:
-        json.dump({"what": __doc__.split("\n")[0], "shipped": results[0][1], "variants": {n: {"windows": s["windows"], "rate_profile_correlation": s["rate_profile_correlation"], "event_peaks": s["event_peaks"]} for n, s in results[1:]}}, f, indent=1)
+        json.dump({"what": __doc__.split("\n")[0], "standup": dict(standup), "shipped": results[0][1], "variants": {n: {"windows": s["windows"], "rate_profile_correlation": s["rate_profile_correlation"], "event_peaks": s["event_peaks"]} for n, s in results[1:]}}, f, indent=1)
 
 
 if __name__ == "__main__":
