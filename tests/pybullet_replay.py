@@ -256,3 +256,29 @@ def summarize_standup(episodes, replay, steps=400, **kw):
     agg["first_above_replay_median"] = float(np.median([r["first_above_replay"] for r in rows if r["first_above_replay"] is not None]))
     agg["first_above_record_median"] = float(np.median([r["first_above_record"] for r in rows if r["first_above_record"] is not None]))
     return dict(summary=agg, per_episode=rows)
+
+
+def replay_standup_hip(episodes, steps=400, device=0, **env_kw):
+    """All standup episodes of the record as one RexBatchEnv.  -> list of (obs, None, reward, fell) per episode, as replay_standup_oracle returns."""
+    import torch
+    from rex_gym_amd import RexBatchEnv
+    n = len(episodes)
+    kw = dict(task="standup", signal_type="ol", device=device, range_normalize=True, max_episode_steps=1000, check_actions=False)
+    kw.update(env_kw)
+    env = RexBatchEnv(n, **kw)
+    act = torch.as_tensor(np.stack([ep["action"][:steps] for ep in episodes], 1).astype(np.float32), device=env.device)    # [steps, n, 1]
+    obs = [env.reset().double().cpu().numpy() * OBS_HI]
+    rew, fell = [], np.full(n, -1)
+    for t in range(steps):
+        o, r, d, _ = env.step(act[t])
+        obs.append(o.double().cpu().numpy() * OBS_HI)
+        rew.append(r.double().cpu().numpy())
+        dn = d.cpu().numpy().astype(bool)
+        fell[(fell < 0) & dn] = t + 1
+    env.close()
+    obs, rew = np.stack(obs, 1), np.stack(rew, 1)
+    out = []
+    for k in range(n):
+        end = steps if fell[k] < 0 else int(fell[k])
+        out.append((obs[k, :end + 1], None, rew[k, :end], int(fell[k]) if fell[k] >= 0 else None))
+    return out
