@@ -160,6 +160,35 @@ def joint_rmse_vs_oracle(workload, kwargs, n=256, steps=200, seed=11):
     return rec
 
 
+def vs_pybullet_record(device):
+    """The other half of BASELINE.json's metric against PyBullet itself, as far as the reference holds PyBullet data: its shipped turn / ol and
+    standup / ol checkpoints carry recorded episodes of their envs on real PyBullet (tests/golden/make_pybullet_golden.py; observations, not joint
+    angles: base roll / pitch and their rates).  The recorded actions replayed on the HIP path (tests/pybullet_replay.py: checker code, after the
+    timed region, like the oracle legs)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
+    import numpy as np
+    import pybullet_replay as pr
+    eps = pr.load()
+    s = pr.summarize(eps, pr.HipReplayer(eps, steps=120, device=device), steps=120, windows=(25, 50, 100))
+    st = pr.load_standup()
+    shipped = pr.replay_standup_hip(st, device=device)
+    low = pr.replay_standup_hip(st, device=device, friction_range=(0.25, 0.25))
+    ev = s["event_peaks"]
+    return {
+        "what": "recorded PyBullet episodes of the reference's RexTurnEnv / RexStandupEnv (its shipped checkpoints' episode memory) replayed on the HIP "
+                "path: RMS error of base roll and pitch [rad] over the first 25 / 50 / 100 control steps, gait events on the record's control step, "
+                "standup outcome",
+        "turn_episodes": s["episodes"], "turn_roll_pitch_rmse_rad": {str(k): v["rp_rmse"] for k, v in s["windows"].items()},
+        "turn_roll_pitch_record_rms_rad": {str(k): v["rp_ref_rms"] for k, v in s["windows"].items()},
+        "turn_rate_profile_correlation": s["rate_profile_correlation"],
+        "turn_gait_events_on_the_records_step": f"{sum(1 for e in ev.values() if e['record'] == e['replay'])} of {len(ev)}",
+        "within_1e-3_rad": bool(s["windows"][25]["rp_rmse"] <= 1e-3),
+        "standup_episodes": len(st), "standup_record_return_mean": float(np.mean([e["reward"].sum() for e in st])),
+        "standup_default_friction": {"fell": int(sum(r[3] is not None for r in shipped)), "return_mean": float(np.mean([r[2].sum() for r in shipped]))},
+        "standup_friction_0.25": {"fell": int(sum(r[3] is not None for r in low)), "return_mean": float(np.mean([r[2].sum() for r in low]))},
+    }
+
+
 class Rollout:
     """An env shard stepped the way the timed region steps it: every step writes observation / reward / done straight into slice t
     of a rollout segment [T, n, ...] (RexBatchEnv.step(out=...), no copies); every T steps the finished segment is all-gathered to
@@ -739,6 +768,11 @@ def main():
                 out["joint_rmse_vs_oracle"] = joint_rmse_vs_oracle(f"{task_name}-{args.signal}/{args.terrain}/{args.mark}", env_kw)
             except Exception as e:
                 out["joint_rmse_vs_oracle"] = {"failed": str(e)}
+            if (task_name, args.signal, args.terrain, args.mark) == ("walk", "ik", "plane", "base"):     # the default line only
+                try:
+                    out["vs_pybullet_record"] = vs_pybullet_record(local_rank)
+                except Exception as e:
+                    out["vs_pybullet_record"] = {"failed": f"{type(e).__name__}: {e}"}
         # compact copies of the secondary measurements inside `config` / `roofline` (flat scalars: the part of the line a record keeper that
         # reduces unknown top-level keys to their names still carries); the full blocks stay at the top level
         cfgd, rl = out["config"], out["roofline"]
@@ -763,6 +797,13 @@ def main():
             rl["joint_rmse_share_envs_with_the_oracles_events"] = tol.get("share_envs_with_the_oracles_event_sequence")
             rl["joint_rmse_p99_rad_on_them"] = tol.get("p99_rad_on_them")
             rl["joint_rmse_within_1e-3_rad"] = tol.get("within_1e-3_rad_absolute")
+        pb = out.get("vs_pybullet_record") or {}
+        if "turn_roll_pitch_rmse_rad" in pb:
+            rl["pybullet_record_turn_roll_pitch_rmse_25_steps_rad"] = pb["turn_roll_pitch_rmse_rad"]["25"]
+            rl["pybullet_record_turn_gait_events_on_the_records_step"] = pb["turn_gait_events_on_the_records_step"]
+            rl["pybullet_record_within_1e-3_rad"] = pb["within_1e-3_rad"]
+            rl["pybullet_record_standup_fell_default_friction"] = f"{pb['standup_default_friction']['fell']} of {pb['standup_episodes']}"
+            rl["pybullet_record_standup_return_friction_0.25_vs_record"] = f"{pb['standup_friction_0.25']['return_mean']:.0f} vs {pb['standup_record_return_mean']:.0f}"
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
