@@ -138,7 +138,7 @@ def summarize(episodes, replay, steps=200, windows=(25, 50, 100, 200), **kw):
         rate_profile_correlation=float(np.corrcoef(ref[1:], ours[1:])[0, 1]),
         event_peaks={f"{lo}-{hi}": dict(record=int(lo + np.argmax(ref[lo:hi])), replay=int(lo + np.argmax(ours[lo:hi])),
                                         record_rad_s=float(ref[lo:hi].max()), replay_rad_s=float(ours[lo:hi].max())) for lo, hi in EVENT_WINDOWS},
-        per_episode=[{k: (v if not isinstance(v, dict) or not isinstance(k, int) else v) for k, v in r.items() if not isinstance(k, int)} for r in rows])
+        per_episode=[{k: v for k, v in r.items() if not isinstance(k, int)} for r in rows])      # (without the per-window blocks)
 
 
 class HipReplayer:
