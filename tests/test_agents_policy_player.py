@@ -293,3 +293,26 @@ def test_rewritten_shipped_checkpoints_are_byte_identical(rel, tmp_path):
     for ext in (".index", ".data-00000-of-00001"):
         with open(prefix + ext, "rb") as f, open(out + ext, "rb") as g:
             assert f.read() == g.read(), ext
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REFERENCE, "rex_gym", "policies")), reason="reference tree not present")
+def test_restored_network_reproduces_the_reference_graphs_recorded_outputs():
+    """Outputs of the reference's own TensorFlow graph to hold the restored network and filter to: the turn / ol checkpoint was saved between two
+    PPO updates, so its episode memory (`memory/Variable_1` observ, `_3` mean, `_4` logstd; agents/ppo/algorithm.py:66-78,126-133) holds what
+    `perform()` computed for the episodes collected since the last update -- with the very weights the checkpoint stores (episodes whose recorded
+    logstd is the checkpoint's; the others are leftovers of an earlier cycle).  The observ filter kept streaming while they were collected
+    (1e6 samples seen, so it barely moved): the recomputed mean action agrees to 2e-3 where the leftovers are 1e-1 off."""
+    ck = Checkpoint(os.path.join(REFERENCE, "rex_gym", "policies", "turn", "ol", "model.ckpt-2000000"))
+    net = policy_player.restore_network(ck).eval()
+    filt = policy_player.restore_normalizer(ck, "normalize_observ", clip=5.0)
+    length, observ = ck.tensor("memory/Variable"), ck.tensor("memory/Variable_1")
+    mean, logstd = ck.tensor("memory/Variable_3"), ck.tensor("memory/Variable_4")
+    current = ck.tensor("network/rnn/policy/logstd").reshape(-1)
+    fresh = [k for k in range(len(length)) if length[k] > 0 and np.array_equal(logstd[k, 0], current)]
+    stale = [k for k in range(len(length)) if length[k] > 0 and k not in fresh]
+    assert len(fresh) >= 2 and len(stale) >= 10
+    with torch.no_grad():
+        err = lambda k: float((net(filt.transform(torch.from_numpy(observ[k, :length[k]])))[0].numpy() - mean[k, :length[k]]).__abs__().max())   # noqa: E731
+        assert max(err(k) for k in fresh) < 2e-3, [err(k) for k in fresh]
+        assert min(err(k) for k in stale) > 2e-2
+        assert all(np.array_equal(logstd[k, :length[k]], np.broadcast_to(current, (length[k], 2))) for k in fresh)
