@@ -24,6 +24,9 @@ ROWS = [
     ("friction mu 1.0", dict(mu=1.0), {}),
     ("friction mu 100 (if <contact_coefficients mu> were honoured)", dict(mu=100.0), {}),
     ("friction cone instead of pyramid", dict(cone=1), {}),
+    ("friction cone, mu 0.35", dict(cone=1, mu=0.35), {}),
+    ("friction cone, mu 0.3", dict(cone=1, mu=0.3), {}),
+    ("friction mu 0.35 (pyramid)", dict(mu=0.35), {}),
     ("one friction direction", dict(friction_dirs=1), {}),
     ("contact ERP 0.08", dict(erp=0.08), {}),
     ("multibody damping 0 / 0", dict(lin_damping=0.0, ang_damping=0.0), {}),
@@ -54,6 +57,9 @@ STANDUP_ROWS = [
     ("friction mu 0.3", dict(mu=0.3), {}), ("friction mu 0.35", dict(mu=0.35), {}), ("friction mu 0.4", dict(mu=0.4), {}),
     ("friction mu 1.0", dict(mu=1.0), {}),
     ("friction cone instead of pyramid", dict(cone=1), {}),
+    ("friction cone, mu 0.4", dict(cone=1, mu=0.4), {}),
+    ("friction cone, mu 0.35", dict(cone=1, mu=0.35), {}),
+    ("friction cone, mu 0.3", dict(cone=1, mu=0.3), {}),
     ("6 substeps per control step", {}, dict(action_repeat=6, solver_iterations=50)),
     ("multibody damping 0.4 / 0.4", dict(lin_damping=0.4, ang_damping=0.4), {}),
     ("link inertias x 2", dict(inertia_scale=2.0), {}),
