@@ -6,9 +6,11 @@ policy's action and the reward of the reference's RexTurnEnv (signal 'ol') on re
   0.1 s of sim time -- sit 16.7 steps apart, and the first toe touch-down after the reset's teleport comes at step 6 = 36 ms; with the
   5 substeps of today's constructor default both come late);
 * the turning direction (`_solve_direction`, :313-322) -- both are played, the one whose roll / pitch fit is kept;
-* the start yaw (`reset`, :139-143: U(0.2, 6)) -- on the flat plane the dynamics do not depend on it, only the world-frame rates
-  (`GetBaseRollPitchYawRate`, rex.py:530-537) and |x| + |y| of the reward do: the rotation about z that maps this run's rates onto the
-  recorded ones (closed-form least squares over the first steps);
+* the start yaw (`reset`, :139-143: U(0.2, 6)) -- the world-frame rates (`GetBaseRollPitchYawRate`, rex.py:530-537) and |x| + |y| of the
+  reward turn with it: the rotation about z that maps this run's rates onto the recorded ones (closed-form least squares over the first
+  steps).  The dynamics themselves depend on it only through the friction pyramid, whose two directions are world axes (btPlaneSpace1 of
+  the ground normal) in Bullet and here: `summarize(at_fitted_yaw=True)` replays every episode a second time from its fitted yaw
+  (roll / pitch error 10-17 % smaller); the default, and what the tests and the bench line use, is one yaw per turning direction;
 * the target yaw -- not needed before the goal is reached; the replay's target is placed 3 rad away in the turning direction.
 
 Observation 0 of the record is exactly zero: the training-time env read the pose back after `resetBasePositionAndOrientation`
@@ -119,13 +121,28 @@ def rate_profile(episodes, replay, steps=120, **kw):
     return np.nanmedian(ref, 0), np.nanmedian(ours, 0), names
 
 
-def summarize(episodes, replay, steps=200, windows=(25, 50, 100, 200), **kw):
+def direction_at(yaw, ccw):
+    """(init_orient, target_orient) that starts at `yaw` and turns the given way with the target 2.5 rad off (`_solve_direction`)."""
+    yaw = float(min(max(yaw % (2 * np.pi), 0.05), 6.2))
+    t = yaw + 2.5 if ccw else yaw - 2.5
+    if ccw and t > 6.2:
+        t -= 2 * np.pi            # init > target, diff > 3.14: clockwise False
+    if not ccw and t < 0.1:
+        t += 2 * np.pi            # init < target, diff > 3.14: clockwise True
+    return yaw, float(t)
+
+
+def summarize(episodes, replay, steps=200, windows=(25, 50, 100, 200), at_fitted_yaw=False, **kw):
     """The record of a replay of every episode: per-window errors averaged over the episodes + the event timing."""
     rows = []
     for ep in episodes:
         name, d, fits = best_direction(ep, replay, **kw)
         obs, xy, ended = replay(ep["action"], d, min(steps, ep["length"] - 1), **kw)
         c = compare(ep, obs, xy, d[0], windows)
+        for _ in range(2 if at_fitted_yaw else 0):      # (the world-aligned friction pyramid: replay from the episode's own start yaw)
+            d = direction_at(c["start_yaw"], name == "ccw")
+            obs, xy, ended = replay(ep["action"], d, min(steps, ep["length"] - 1), **kw)
+            c = compare(ep, obs, xy, d[0], windows)
         c.update(direction=name, direction_fit_rmse=fits, ended=ended)
         rows.append(c)
     ref, ours, _ = rate_profile(episodes, replay, **kw)

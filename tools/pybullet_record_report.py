@@ -19,6 +19,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 ROWS = [
     ("restatement as shipped (6 substeps per control step, recovered from the record)", {}, {}),
+    ("as shipped, every episode replayed from its fitted start yaw (the friction pyramid's directions are world axes)", {}, dict(at_fitted_yaw=True)),
     ("5 substeps per control step (today's constructor default)", {}, dict(action_repeat=5, solver_iterations=60)),
     ("friction mu 0.25", dict(mu=0.25), {}),
     ("friction mu 1.0", dict(mu=1.0), {}),
@@ -81,7 +82,9 @@ def work_standup(row):
 def work(row):
     import pybullet_replay as pr
     name, probes, kw = row
-    s = pr.summarize(pr.load(), pr.replay_oracle, steps=120, windows=(25, 50, 100), probes=probes or None, **kw)
+    kw = dict(kw)
+    fitted = kw.pop("at_fitted_yaw", False)
+    s = pr.summarize(pr.load(), pr.replay_oracle, steps=120, windows=(25, 50, 100), at_fitted_yaw=fitted, probes=probes or None, **kw)
     return name, s
 
 
