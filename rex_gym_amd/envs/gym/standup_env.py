@@ -2,7 +2,10 @@
 
 The episode starts crouched: reset() runs the reset motion towards INIT_POSES['rest_position'] (standup_env.py:108-110;
 its foot target of 6 rad is held at the URDF bound 2.59 by the joint-limit rows), then the env commands the 'stand' pose
-with a short 'brake' overshoot (standup_env.py:113-120)."""
+with a short 'brake' overshoot (standup_env.py:113-120).
+
+Known discrepancy with PyBullet: on recorded PyBullet episodes of this env the robot stays up after standing; here, at the
+default toe friction 0.5, it tips over its front feet at control step ~100.  `RexStandupEnv(friction_range=(0.25, 0.25))` reproduces the record."""
 from .walk_env import _SingleEnv
 
 
