@@ -586,13 +586,16 @@ if __name__ == "__main__":   # python -m rex_gym_amd.agents.ppo --task walk --en
                     help="segments: the actor inside the launch, one launch per --segment steps (train_segments); steps: perform() in PyTorch, "
                          "one launch and three host synchronisations per step (train, the reference's loop shape)")
     ap.add_argument("--segment", type=int, default=25)
+    ap.add_argument("--toe-friction", type=float, default=None, help="pin the toe friction (RexBatchEnv(friction_range=(f, f))); the standup task matches its "
+                                                                     "PyBullet record at 0.25 (DESIGN.md section 2)")
     ap.add_argument("--logdir", default=None, help="write the trained policy there as a TensorFlow-1 checkpoint the reference's policy player "
                                                    "restores (model.ckpt-<env steps>.index / .data-00000-of-00001 + checkpoint: policy_player.save_policy)")
     a = ap.parse_args()
     import time
     # the reference trains through RangeNormalize + ClipAction (playground/trainer.py:48-52): actions in [-1, 1]
     env = RexBatchEnv(a.envs, task=a.task, signal_type=a.signal, seed=a.seed, max_episode_steps=a.max_length, range_normalize=True,
-                      gait_clock_scale=a.gait_clock_scale, auto_reset=a.loop == "segments", check_actions=False)
+                      gait_clock_scale=a.gait_clock_scale, auto_reset=a.loop == "segments", check_actions=False,
+                      **({"friction_range": (a.toe_friction, a.toe_friction)} if a.toe_friction is not None else {}))
     agent = PPOAgent(a.envs, env.obs_dim, env.action_dim, PPOConfig(update_every=a.envs, max_length=a.max_length), seed=a.seed)
     actor = None
     if a.loop == "segments":
