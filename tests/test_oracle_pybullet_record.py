@@ -92,10 +92,12 @@ def test_standup_outcome_of_the_record(standup):
 def test_standup_outcome_with_low_toe_friction(standup):
     """The same replay with the toe friction at 0.25 (a probe of the oracle, not a product setting): nobody falls, the episode return and
     the pitch trace over all 400 steps are the record's -- what the xfail above would have to look like."""
-    s = pr.summarize_standup(standup[:4], pr.replay_standup_oracle, steps=400, probes=dict(mu=0.25))["summary"]
     import ctypes
     import orclib
-    lib = orclib.Oracle().lib
-    lib.orc_set_probe.argtypes = [ctypes.c_char_p, ctypes.c_double]
-    lib.orc_set_probe(b"mu", 0.5)                                    # (process-wide static of the oracle: back to the shipped value)
+    try:
+        s = pr.summarize_standup(standup[:4], pr.replay_standup_oracle, steps=400, probes=dict(mu=0.25))["summary"]
+    finally:                                                         # (the probe is a process-wide static of the oracle: back to the shipped value)
+        lib = orclib.Oracle().lib
+        lib.orc_set_probe.argtypes = [ctypes.c_char_p, ctypes.c_double]
+        lib.orc_set_probe(b"mu", 0.5)
     assert s["fell"] == 0 and s["return_replay"] > 0.9 * s["return_record_400"] and s["pitch_rmse_all"] < 0.04, s
