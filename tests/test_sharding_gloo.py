@@ -131,3 +131,47 @@ def test_ppo_ranks_stay_in_step_when_gradients_are_averaged():
         assert p.exitcode == 0
     assert res[0][1] == res[1][1] >= 2
     np.testing.assert_array_equal(res[0][0], res[1][0])
+
+
+def _gather_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT); sys.path.insert(0, HERE)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rex_gym_amd.sharding import gather_rollout, shard_from_env
+    sh = shard_from_env(2 * world)                                   # two envs per rank
+    g = torch.arange(sh.env_index_base, sh.env_index_base + sh.num_envs, dtype=torch.float32)
+    t = torch.arange(3, dtype=torch.float32)
+    seg = {"obs": (100 * t[:, None, None] + g[None, :, None] + 0.25 * torch.arange(4)[None, None, :]).contiguous(),     # [T, n, 4]: value = f(step, GLOBAL env, word)
+           "done": ((t[:, None] + g[None, :]) % 3 == 0)}                                                                 # bool travels as bytes
+    a = gather_rollout(seg, async_op=True, slot=0)                    # two segments in flight, as the bench keeps them
+    b = gather_rollout({k: (v + 1000 if v.dtype != torch.bool else ~v) for k, v in seg.items()}, async_op=True, slot=1)
+    a, b = a.wait(), b.wait()
+    q.put((rank, a["obs"].numpy(), a["done"].numpy(), b["obs"].numpy(), b["done"].numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_rollout_on_four_ranks_keeps_the_global_env_order():
+    """The hand-off at the world sizes a SCALE run uses beyond two: four gloo ranks, two segments in flight on two buffer slots; every rank
+    receives [T, 4 * n, ...] in global env order, bool blocks included."""
+    world = 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29400 + (os.getpid() % 150)
+    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = np.arange(2 * world, dtype=np.float32)
+    t = np.arange(3, dtype=np.float32)
+    obs = 100 * t[:, None, None] + g[None, :, None] + 0.25 * np.arange(4, dtype=np.float32)[None, None, :]
+    done = (t[:, None] + g[None, :]) % 3 == 0
+    for rank, a_obs, a_done, b_obs, b_done in res:
+        np.testing.assert_array_equal(a_obs, obs, err_msg=f"rank {rank}")
+        np.testing.assert_array_equal(a_done, done)
+        np.testing.assert_array_equal(b_obs, obs + 1000)
+        np.testing.assert_array_equal(b_done, ~done)
