@@ -60,6 +60,7 @@ def test_hip_path_on_the_standup_record(torch):
     rec = np.array([ep["reward"].sum() for ep in episodes])
     ret_low = np.array([r[2].sum() for r in low])
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "pybullet_standup_record_hip.json")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
     with open(out, "w") as f:
         json.dump(dict(record_return_mean=float(rec.mean()), default_friction=dict(fell=int(sum(r[3] is not None for r in shipped)),
                                                                                      fell_at_median=float(np.median([r[3] for r in shipped if r[3] is not None] or [0])),
